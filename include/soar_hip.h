@@ -1,0 +1,169 @@
+/*
+ * include/soar_hip.h -- C ABI of libsoar_hip.so, the MI355X (gfx950) implementation of SOAR's
+ * per-frame avatar path: Gaussian-surfel rasterizer forward/backward, SMPL-X LBS warp, 3-NN distance.
+ *
+ * Every entry point replaces one interface of the reference (hangg7/soar); citations are file:line
+ * relative to the reference root, DGR/ = submodules/diff-gaussian-rasterization/,
+ * TS/ = soar/threestudio-soar/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / STL types cross the boundary;
+ *  - pointers named *_dev (and all array arguments unless stated otherwise) are DEVICE pointers;
+ *    they may be NULL exactly where the reference accepts an empty tensor;
+ *  - `stream` is a hipStream_t passed as void* (PyTorch-ROCm: torch.cuda.current_stream().cuda_stream);
+ *  - every function returns 0 on success and non-zero on failure; soar_last_error() then holds a
+ *    message (thread-local).  Nothing throws across the ABI;
+ *  - outputs and gradient arrays are fully written (or zero-filled) by the callee, so the caller
+ *    may pass uninitialised memory (the reference zero-fills in DGR/rasterize_points.cu:61-66,133-147);
+ *  - the three scratch buffers (geometry / binning / image) are opaque, caller-owned byte arrays, as in
+ *    the reference (DGR/rasterize_points.cu:68-75): sizes come from soar_rast_*_bytes(), the same
+ *    buffers must be handed to soar_rast_backward().  Base pointers must be 256-byte aligned.
+ */
+#ifndef SOAR_HIP_H
+#define SOAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOAR_HIP_ABI_VERSION 1
+
+/* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
+ * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
+typedef struct SoarRastParams {
+    int32_t P;                 /* number of Gaussians (means3D.size(0)) */
+    int32_t W, H;              /* image_width, image_height */
+    int32_t sh_degree;         /* active SH degree D */
+    int32_t M;                 /* SH coefficients per Gaussian (sh.size(1)), 0 with colors_precomp */
+    int32_t prefiltered;
+    int32_t render_front;
+    int32_t sort_descending;
+    int32_t debug;             /* 1: synchronise + check after every stage (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:419-426) */
+    /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
+    int32_t cfg_surface;       /* config[0] */
+    int32_t cfg_normalize_depth; /* config[1] */
+    int32_t cfg_perpix_depth;  /* config[2] */
+    int32_t cfg_lrn_cam;       /* config[3] */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    const float *bg_dev;         /* [3]  */
+    const float *viewmatrix_dev; /* [16] row-vector (transposed) world->view, element 12..14 = translation */
+    const float *projmatrix_dev; /* [16] full projection, same convention */
+    const float *prcppoint_dev;  /* [2]  principal point (cx/W, cy/H) */
+    const float *patchbbox_dev;  /* [4]  (h0, w0, h1, w1) */
+    const float *campos_dev;     /* [3]  */
+} SoarRastParams;
+
+/* ---- scratch sizing: replaces required<GeometryState/ImageState/BinningState>()
+ *      (DGR/cuda_rasterizer/rasterizer_impl.h:77-84, rasterizer_impl.cu:134-184) ---- */
+int soar_rast_geometry_bytes(int32_t P, int32_t M, size_t *bytes);
+int soar_rast_image_bytes(int32_t W, int32_t H, size_t *bytes);
+int soar_rast_binning_bytes(int64_t num_rendered, size_t *bytes);
+
+/* ---- forward, replaces CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer_impl.cu:188-312)
+ *      split at its one host synchronisation point (the D2H copy of num_rendered, :250-257), because the
+ *      binning buffer is sized by the caller from that number (resizeFunctional, DGR/rasterize_points.cu:27-33).
+ *
+ * stage 1: preprocess (forward.cu:205-385) + inclusive scan (:242-245) + blocking read-back of num_rendered.
+ *   means3D [P,3]; opacities [P]; exactly one of shs [P,M,3] / colors_precomp [P,3];
+ *   exactly one of (scales [P,3], rotations [P,4]) / cov3D_precomp [P,6].
+ *   radii_out [P] int32 (API output).  *num_rendered_host receives R. */
+int soar_rast_forward_geometry(const SoarRastParams *prm,
+                               const float *means3D, const float *shs, const float *colors_precomp,
+                               const float *opacities, const float *scales, const float *rotations,
+                               const float *cov3D_precomp,
+                               void *geom_buffer, int32_t *radii_out, int64_t *num_rendered_host,
+                               void *stream);
+
+/* stage 2: duplicateWithKeys (:66-99) + radix sort on bits [0,32+bit) (:266-285) + identifyTileRanges
+ *   (:104-124,287-295) + per-tile blend (forward.cu:390-692).
+ *   out_color [3,H,W], out_normal [3,H,W], out_depth [1,H,W], out_opac [1,H,W]. */
+int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii,
+                             void *geom_buffer, void *binning_buffer, void *image_buffer,
+                             int64_t num_rendered,
+                             float *out_color, float *out_normal, float *out_depth, float *out_opac,
+                             void *stream);
+
+/* ---- backward, replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer_impl.cu:316-379)
+ *      and the gradient allocation of RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:107-187).
+ *   dL_dout_* are the four image gradients.  Outputs (all fully written):
+ *   dL_dmeans2D [P,3], dL_dcolors [P,3], dL_dopacity [P], dL_dmeans3D [P,3], dL_dcov3D [P,6],
+ *   dL_dsh [P,M,3] (may be NULL when M == 0), dL_dscales [P,3], dL_drotations [P,4],
+ *   dL_dviewmat [16], dL_dprojmat [16], dL_dcampos [3]. */
+int soar_rast_backward(const SoarRastParams *prm,
+                       const float *means3D, const int32_t *radii, const float *shs,
+                       const float *colors_precomp, const float *scales, const float *rotations,
+                       const float *cov3D_precomp,
+                       const void *geom_buffer, const void *binning_buffer, const void *image_buffer,
+                       int64_t num_rendered,
+                       const float *dL_dout_color, const float *dL_dout_normal,
+                       const float *dL_dout_depth, const float *dL_dout_opac,
+                       float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D,
+                       float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                       float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos,
+                       void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* bytes of `workspace` needed by soar_rast_backward (per-Gaussian accumulation rows) */
+int soar_rast_backward_workspace_bytes(int32_t P, size_t *bytes);
+
+/* ---- markVisible (DGR/rasterize_points.cu:189-205): the reference kernel body is commented out
+ *      (DGR/cuda_rasterizer/rasterizer_impl.cu:52-62), so `present` [P] (bool/uint8) is all false. */
+int soar_rast_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                           uint8_t *present, void *stream);
+
+/* ---- debugging / parity: copy intermediates out of the opaque buffers into caller arrays (any may be NULL).
+ *   means2D [P,2], depths [P], conic_opacity [P,4], normal [P,3], depth_plane [P,2] (the two per-pixel-depth
+ *   coefficients folded from Jinv), rgb [P,3], cov3D [P,6], tiles_touched [P], point_offsets [P],
+ *   keys_unsorted/keys_sorted [R] uint64, vals_unsorted/point_list [R] uint32, ranges [T,2] uint32,
+ *   final_T [H*W], final_D [H*W], n_contrib [H*W] uint32. */
+int soar_rast_export_state(const SoarRastParams *prm, const void *geom_buffer, const void *binning_buffer,
+                           const void *image_buffer, int64_t num_rendered,
+                           float *means2D, float *depths, float *conic_opacity, float *normal,
+                           float *depth_plane, float *rgb, float *cov3D,
+                           uint32_t *tiles_touched, uint32_t *point_offsets,
+                           uint64_t *keys_unsorted, uint32_t *vals_unsorted,
+                           uint64_t *keys_sorted, uint32_t *point_list, uint32_t *ranges,
+                           float *final_T, float *final_D, uint32_t *n_contrib, void *stream);
+
+/* ---- SMPL-X linear-blend skinning of canonical Gaussians ----
+ * soar_lbs_knn_weights: SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637).
+ *   xyz [P,3] canonical points, verts [V,3] canonical SMPL-X vertices, vert_weights [V,J] skinning weights;
+ *   K nearest vertices (the reference hard-codes 30), d = clamp(sqrt(d2), 1e-4, 1), ws = (1/d)/sum(1/d),
+ *   weights_out [P,J] = sum_k ws_k * vert_weights[idx_k].  knn_idx_out [P,K] int32 optional (may be NULL). */
+int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V,
+                         const float *vert_weights, int32_t J, int32_t K,
+                         float *weights_out, int32_t *knn_idx_out, void *stream);
+
+/* soar_lbs_warp_forward: blend + apply, i.e. SMPL_Guidance.__call__ line TS/utils/smpl.py:613
+ *   (pt_mats = einsum("bnj,bjxy->bnxy", w, cano2live)) fused with DiffGaussian.forward's warp
+ *   (TS/renderer/diff_gaussian_rasterizer.py:103-114 / :138-149):
+ *     p' = M3 p + t ; R' = M3 R(q) ; optionally p' <- p' T, R' <- T^T R' (axis_perm, row-major 3x3, may be NULL);
+ *     q' = normalize(matrix_to_quaternion(R')).
+ *   weights [P,J]; joint_mats [J,16] row-major 4x4 (cano2live = A_live @ inv(A_cano));
+ *   offsets [P,3] optional additive offsets applied after the warp (cfg.offset, :107-108), may be NULL.
+ *   xyz_out [P,3], rot_out [P,4]; pt_mats_out [P,16] optional (may be NULL). */
+int soar_lbs_warp_forward(const float *xyz, const float *rot, const float *weights, const float *joint_mats,
+                          const float *offsets, const float *axis_perm, int32_t P, int32_t J,
+                          float *xyz_out, float *rot_out, float *pt_mats_out, void *stream);
+
+/* soar_lbs_warp_backward: gradient of the above w.r.t. xyz and rot (weights and joint matrices are
+ *   constants in the reference: TS/utils/smpl.py:611 detaches, :543-545 plain tensors). */
+int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weights, const float *joint_mats,
+                           const float *axis_perm, int32_t P, int32_t J,
+                           const float *dL_dxyz_out, const float *dL_drot_out,
+                           float *dL_dxyz, float *dL_drot, void *stream);
+
+/* ---- simple-knn distCUDA2 (call sites TS/geometry/surfel_base.py:499-503, gaussian_base.py:585-588):
+ *   out[i] = mean of the 3 smallest squared distances from point i to the other points. */
+int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
+
+const char *soar_last_error(void);
+int soar_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOAR_HIP_H */

@@ -1,0 +1,115 @@
+/*
+ * oracle/rasterizer_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement (plain C, gcc -ffp-contract=off) of the Gaussian-surfel
+ * rasterizer of hangg7/soar (submodules/diff-gaussian-rasterization, "DGR" below).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY STATUS: *parity unpinned*.  The reference ships no tests, golden vectors or
+ * fixtures for this path and its CUDA sources cannot be built in
+ * this image without writing stand-ins for the CUDA toolkit headers (cuda_runtime.h,
+ * cooperative_groups.h, cub) -- which the build rules forbid -- so every function
+ * below is a line-by-line restatement of the cited reference lines, evaluated in
+ * IEEE fp32 without FMA contraction, and is NOT cross-checked against an executed
+ * reference binary.
+ */
+#ifndef SOAR_RASTERIZER_ORACLE_H
+#define SOAR_RASTERIZER_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284)
+ * plus the sizes the C++ glue derives (DGR/rasterize_points.cu:54-84). */
+typedef struct OracleParams {
+    int32_t P;               /* number of Gaussians */
+    int32_t W, H;            /* image size */
+    int32_t sh_degree;       /* D */
+    int32_t M;               /* SH coefficients per Gaussian (0 when colors_precomp is used) */
+    int32_t prefiltered;
+    int32_t render_front;
+    int32_t sort_descending;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    float bg[3];
+    float viewmatrix[16];    /* row-vector convention, element [12..14] = translation */
+    float projmatrix[16];
+    float prcppoint[2];
+    float patchbbox[4];      /* (h0, w0, h1, w1) */
+    float campos[3];
+    float config[4];         /* surface, normalize_depth, perpix_depth, lrn_cam */
+} OracleParams;
+
+/* Per-Gaussian forward state (the useful part of GeometryState, DGR/cuda_rasterizer/rasterizer_impl.h:30-51).
+ * All arrays are caller-allocated with P entries (times the stated width) and are zero-filled by the oracle
+ * before use (the reference leaves its scratch uninitialised; entries of culled Gaussians are unspecified there). */
+typedef struct OracleGeom {
+    int32_t  *radii;          /* [P]    */
+    float    *means2D;        /* [P,2]  */
+    float    *depths;         /* [P]    */
+    float    *cov3D;          /* [P,6]  */
+    float    *conic_opacity;  /* [P,4]  */
+    float    *rgb;            /* [P,3]  (SH path only) */
+    uint8_t  *clamped;        /* [P,3]  (SH path only) */
+    float    *normal;         /* [P,3]  */
+    float    *Jinv;           /* [P,10] */
+    float    *viewCos;        /* [P]    */
+    uint32_t *tiles_touched;  /* [P]    */
+    uint32_t *point_offsets;  /* [P]    inclusive scan of tiles_touched */
+} OracleGeom;
+
+uint32_t oracle_get_higher_msb(uint32_t n);
+
+/* forward stage 1+2: preprocess + inclusive scan; returns num_rendered (R). */
+int64_t oracle_preprocess(const OracleParams *prm,
+                          const float *means3D, const float *scales, const float *rotations,
+                          const float *opacities, const float *shs, const float *cov3D_precomp,
+                          const float *colors_precomp, OracleGeom *g);
+
+/* forward stage 3-5: key emit, stable radix sort on bits [0,32+bit), tile ranges.
+ * keys_unsorted/vals_unsorted/keys_sorted/vals_sorted have R entries, ranges has 2*T. */
+void oracle_bin(const OracleParams *prm, const OracleGeom *g, int64_t R,
+                uint64_t *keys_unsorted, uint32_t *vals_unsorted,
+                uint64_t *keys_sorted, uint32_t *vals_sorted, uint32_t *ranges);
+
+/* forward stage 6: per-tile blend.  features = colors_precomp or g->rgb.
+ * n_threads <= 1: sequential, deterministic.  */
+void oracle_render_forward(const OracleParams *prm, const OracleGeom *g, const float *features,
+                           const uint32_t *point_list, const uint32_t *ranges,
+                           float *final_T, float *final_D, uint32_t *n_contrib,
+                           float *out_color, float *out_normal, float *out_depth, float *out_opac,
+                           int n_threads);
+
+/* backward stage 1: per-tile reverse walk; the 13 per-pair atomicAdd targets are accumulated in double
+ * (any order of the reference's float atomics is within rounding of this) and rounded to float once.
+ * dL_dmean2D [P,3] (z unused), dL_dconic [P,4] (slots x,y,w), dL_dopacity[P], dL_dcolors[P,3],
+ * dL_dnormal[P,3], dL_ddepth[P]. */
+void oracle_render_backward(const OracleParams *prm, const OracleGeom *g, const float *features,
+                            const uint32_t *point_list, const uint32_t *ranges,
+                            const float *final_T, const float *final_D, const uint32_t *n_contrib,
+                            const float *dL_dpixcolor, const float *dL_dpixnormal,
+                            const float *dL_dpixdepth, const float *dL_dpixopac,
+                            float *dL_dmean2D, float *dL_dconic, float *dL_dopacity,
+                            float *dL_dcolors, float *dL_dnormal, float *dL_ddepth,
+                            int n_threads);
+
+/* backward stage 2+3: computeCov2DCUDA + preprocessCUDA(backward).
+ * Outputs: dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drots[P,4],
+ * dL_dviewmat[16], dL_dprojmat[16], dL_dcampos[3]; all must be zero-filled by the caller
+ * (DGR/rasterize_points.cu:133-147). cov3D is cov3D_precomp or g->cov3D. */
+void oracle_preprocess_backward(const OracleParams *prm, const int32_t *radii,
+                                const float *means3D, const float *scales, const float *rotations,
+                                const float *shs, const uint8_t *clamped, const float *cov3D,
+                                const float *dL_dmean2D, const float *dL_dconic,
+                                float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth,
+                                float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+                                float *dL_dscales, float *dL_drots,
+                                float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""Build libsoar_hip.so (the C-ABI library declared in include/soar_hip.h) with hipcc for gfx950.
+
+``python -m soar_amd.build`` or ``soar_amd.build.build()``.  hipcc cross-compiles without a GPU, so this also
+runs in the CPU-only build container.  The library is written in-tree (``soar_amd/_lib/``) so that it travels
+with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+from typing import List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OUT_DIR = os.path.join(_HERE, "_lib")
+OBJ_DIR = os.path.join(OUT_DIR, "obj")
+LIB_PATH = os.path.join(OUT_DIR, "libsoar_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON_FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
+]
+# per-file extra flags.  rast_preprocess / rast_binning feed integer decisions (radii, tile rectangles, sort keys):
+# no FMA contraction there, so they evaluate exactly like an IEEE evaluation of the reference expressions.
+EXTRA_FLAGS = {
+    "rast_preprocess.hip": ["-ffp-contract=off"],
+    "rast_binning.hip": ["-ffp-contract=off"],
+}
+SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
+           "rast_geom_bwd.hip", "lbs.hip"]
+HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
+
+
+def _digest(paths: List[str], flags: List[str]) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
+def _compile_one(src: str, verbose: bool) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    flags = COMMON_FLAGS + EXTRA_FLAGS.get(src, [])
+    stamp = obj + ".sha"
+    dig = _digest([path] + HEADERS, flags)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj
+    cmd = [HIPCC] + flags + ["-c", path, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return obj
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile_one(s, verbose), SOURCES))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))

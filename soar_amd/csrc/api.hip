@@ -1,0 +1,351 @@
+// api.hip -- C-ABI entry points of libsoar_hip.so (declared in include/soar_hip.h) and the opaque scratch
+// buffer layouts.  Host-side orchestration only; kernels live in the rast_*.hip / lbs_*.hip units.
+#include "soar_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace soar {
+
+static thread_local char g_error[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what, const char *file, int line)
+{
+    if (e == hipSuccess) return 0;
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return 1;
+}
+
+int post_launch(const char *what, hipStream_t stream, int debug)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) return 0;
+    set_error("stage '%s' failed: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
+    return 1;
+}
+
+// ---- scratch carving (bump allocation, 256-byte aligned; same idea as obtain(), rasterizer_impl.h:22-28) ----
+template <typename T>
+static void take(char *&p, T *&ptr, size_t count)
+{
+    p = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(p)));
+    ptr = reinterpret_cast<T *>(p);
+    p += sizeof(T) * count;
+}
+
+int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
+{
+    char *p = static_cast<char *>(base);
+    const size_t n = P > 0 ? (size_t)P : 1;
+    take(p, out->header, 64);
+    take(p, out->rec, n);
+    take(p, out->cov3D, n * 6);
+    take(p, out->tiles_touched, n);
+    take(p, out->point_offsets, n);
+    take(p, out->clamped, M > 0 ? n * 3 : 1);
+    out->scan_temp_bytes = scan_temp_bytes(P);
+    char *tmp;
+    take(p, tmp, out->scan_temp_bytes);
+    out->scan_temp = tmp;
+    out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
+    return 0;
+}
+
+int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
+{
+    char *p = static_cast<char *>(base);
+    const size_t pix = (size_t)W * H;
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    take(p, out->ranges, tiles > 0 ? tiles : 1);
+    take(p, out->final_T, pix > 0 ? pix : 1);
+    take(p, out->n_contrib, pix > 0 ? pix : 1);
+    take(p, out->final_D, pix > 0 ? pix : 1);
+    out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
+    return 0;
+}
+
+int carve_binning(void *base, int64_t R, BinBuf *out)
+{
+    char *p = static_cast<char *>(base);
+    const size_t n = R > 0 ? (size_t)R : 1;
+    take(p, out->keys_unsorted, n);
+    take(p, out->keys_sorted, n);
+    take(p, out->vals_unsorted, n);
+    take(p, out->vals_sorted, n);
+    out->sort_temp_bytes = sort_temp_bytes(R);
+    char *tmp;
+    take(p, tmp, out->sort_temp_bytes);
+    out->sort_temp = tmp;
+    out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
+    return 0;
+}
+
+static int check_params(const SoarRastParams *prm)
+{
+    if (!prm) { set_error("SoarRastParams is NULL"); return 1; }
+    if (prm->P < 0 || prm->W <= 0 || prm->H <= 0) { set_error("invalid sizes P=%d W=%d H=%d", prm->P, prm->W, prm->H); return 1; }
+    if (!prm->bg_dev || !prm->viewmatrix_dev || !prm->projmatrix_dev || !prm->prcppoint_dev || !prm->patchbbox_dev ||
+        !prm->campos_dev) {
+        set_error("a camera/background device pointer in SoarRastParams is NULL");
+        return 1;
+    }
+    return 0;
+}
+
+static int check_aligned(const void *p, const char *name)
+{
+    if (!p) { set_error("%s is NULL", name); return 1; }
+    if (reinterpret_cast<size_t>(p) % ALIGN) { set_error("%s must be %zu-byte aligned", name, ALIGN); return 1; }
+    return 0;
+}
+
+}  // namespace soar
+
+using namespace soar;
+
+extern "C" {
+
+const char *soar_last_error(void) { return g_error; }
+int soar_abi_version(void) { return SOAR_HIP_ABI_VERSION; }
+
+int soar_rast_geometry_bytes(int32_t P, int32_t M, size_t *bytes)
+{
+    if (!bytes || P < 0) { set_error("soar_rast_geometry_bytes: bad arguments"); return 1; }
+    GeomBuf g;
+    carve_geom(nullptr, P, M, &g);
+    *bytes = g.total_bytes;
+    return 0;
+}
+
+int soar_rast_image_bytes(int32_t W, int32_t H, size_t *bytes)
+{
+    if (!bytes || W <= 0 || H <= 0) { set_error("soar_rast_image_bytes: bad arguments"); return 1; }
+    ImageBuf b;
+    carve_image(nullptr, W, H, &b);
+    *bytes = b.total_bytes;
+    return 0;
+}
+
+int soar_rast_binning_bytes(int64_t num_rendered, size_t *bytes)
+{
+    if (!bytes || num_rendered < 0) { set_error("soar_rast_binning_bytes: bad arguments"); return 1; }
+    BinBuf b;
+    carve_binning(nullptr, num_rendered, &b);
+    *bytes = b.total_bytes;
+    return 0;
+}
+
+int soar_rast_backward_workspace_bytes(int32_t P, size_t *bytes)
+{
+    if (!bytes || P < 0) { set_error("soar_rast_backward_workspace_bytes: bad arguments"); return 1; }
+    *bytes = align_up(sizeof(float) * ACC_STRIDE * (size_t)(P > 0 ? P : 1)) + ALIGN;
+    return 0;
+}
+
+int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, const float *shs,
+                               const float *colors_precomp, const float *opacities, const float *scales,
+                               const float *rotations, const float *cov3D_precomp, void *geom_buffer,
+                               int32_t *radii_out, int64_t *num_rendered_host, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return 1; }
+    *num_rendered_host = 0;
+    if (prm->P == 0) return 0;                                     // rasterize_points.cu:78
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    if (!means3D || !opacities || !radii_out) { set_error("means3D / opacities / radii_out must not be NULL"); return 1; }
+    if ((shs == nullptr) == (colors_precomp == nullptr)) {
+        set_error("Please provide excatly one of either SHs or precomputed colors!");   // __init__.py:316-321
+        return 1;
+    }
+    if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
+        ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
+        set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");   // :323-328
+        return 1;
+    }
+    if (shs && prm->M <= 0) { set_error("SH path needs M > 0"); return 1; }
+    if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) { set_error("sh_degree %d needs more than M=%d coefficients", prm->sh_degree, prm->M); return 1; }
+
+    GeomBuf g;
+    carve_geom(geom_buffer, prm->P, prm->M, &g);
+    if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
+        return 1;
+    if (launch_scan(*prm, g, stream)) return 1;
+    // the one host synchronisation of the forward pass (rasterizer_impl.cu:250-252)
+    uint32_t r = 0;
+    SOAR_HIP_OK(hipMemcpyAsync(&r, g.point_offsets + (prm->P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SOAR_HIP_OK(hipStreamSynchronize(stream));
+    *num_rendered_host = (int64_t)r;
+    return 0;
+}
+
+int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                             void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
+                             float *out_depth, float *out_opac, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (!out_color || !out_normal || !out_depth || !out_opac) { set_error("output image pointers must not be NULL"); return 1; }
+    const size_t pix = (size_t)prm->W * prm->H;
+    if (prm->P == 0) {                                             // outputs are zeros (rasterize_points.cu:61-66)
+        SOAR_HIP_OK(hipMemsetAsync(out_color, 0, 3 * pix * sizeof(float), stream));
+        SOAR_HIP_OK(hipMemsetAsync(out_normal, 0, 3 * pix * sizeof(float), stream));
+        SOAR_HIP_OK(hipMemsetAsync(out_depth, 0, pix * sizeof(float), stream));
+        SOAR_HIP_OK(hipMemsetAsync(out_opac, 0, pix * sizeof(float), stream));
+        return 0;
+    }
+    if (check_aligned(geom_buffer, "geom_buffer") || check_aligned(image_buffer, "image_buffer")) return 1;
+    if (num_rendered > 0 && check_aligned(binning_buffer, "binning_buffer")) return 1;
+    if (!radii) { set_error("radii is NULL"); return 1; }
+    GeomBuf g;
+    ImageBuf img;
+    BinBuf b;
+    carve_geom(geom_buffer, prm->P, prm->M, &g);
+    carve_image(image_buffer, prm->W, prm->H, &img);
+    carve_binning(binning_buffer, num_rendered, &b);
+    if (launch_binning(*prm, radii, g, b, img, num_rendered, stream)) return 1;
+    if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, stream)) return 1;
+    return 0;
+}
+
+int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
+                       const float *colors_precomp, const float *scales, const float *rotations,
+                       const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
+                       const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
+                       const float *dL_dout_normal, const float *dL_dout_depth, const float *dL_dout_opac,
+                       float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D,
+                       float *dL_dsh, float *dL_dscales, float *dL_drotations, float *dL_dviewmat, float *dL_dprojmat,
+                       float *dL_dcampos, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (!dL_dviewmat || !dL_dprojmat || !dL_dcampos) { set_error("camera gradient pointers must not be NULL"); return 1; }
+    if (prm->P == 0) {
+        SOAR_HIP_OK(hipMemsetAsync(dL_dviewmat, 0, 16 * sizeof(float), stream));
+        SOAR_HIP_OK(hipMemsetAsync(dL_dprojmat, 0, 16 * sizeof(float), stream));
+        SOAR_HIP_OK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+        return 0;
+    }
+    if (check_aligned(geom_buffer, "geom_buffer") || check_aligned(image_buffer, "image_buffer") ||
+        check_aligned(workspace, "workspace"))
+        return 1;
+    if (num_rendered > 0 && check_aligned(binning_buffer, "binning_buffer")) return 1;
+    size_t need = 0;
+    soar_rast_backward_workspace_bytes(prm->P, &need);
+    if (workspace_bytes < need - ALIGN) { set_error("workspace too small: %zu < %zu", workspace_bytes, need); return 1; }
+    if (!means3D || !radii || !dL_dout_color || !dL_dout_normal || !dL_dout_depth || !dL_dout_opac || !dL_dmeans2D ||
+        !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations) {
+        set_error("soar_rast_backward: a required pointer is NULL");
+        return 1;
+    }
+    if (prm->M > 0 && shs && !dL_dsh) { set_error("dL_dsh is NULL but SHs are in use"); return 1; }
+    (void)colors_precomp;   // colours are read from the forward's records
+
+    GeomBuf g;
+    ImageBuf img;
+    BinBuf b;
+    carve_geom(const_cast<void *>(geom_buffer), prm->P, prm->M, &g);
+    carve_image(const_cast<void *>(image_buffer), prm->W, prm->H, &img);
+    carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
+    float *acc = static_cast<float *>(workspace);
+    SOAR_HIP_OK(hipMemsetAsync(acc, 0, sizeof(float) * ACC_STRIDE * (size_t)prm->P, stream));
+    if (num_rendered > 0) {
+        if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, acc, stream))
+            return 1;
+    }
+    if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
+                                 dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat,
+                                 dL_dprojmat, dL_dcampos, stream))
+        return 1;
+    return 0;
+}
+
+int soar_rast_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                           uint8_t *present, void *stream_)
+{
+    (void)means3D; (void)viewmatrix; (void)projmatrix;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0) { set_error("P < 0"); return 1; }
+    if (P == 0) return 0;
+    if (!present) { set_error("present is NULL"); return 1; }
+    // checkFrustum's body is commented out in the reference (rasterizer_impl.cu:52-62): nothing is ever marked
+    SOAR_HIP_OK(hipMemsetAsync(present, 0, (size_t)P, stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- state export (parity tests) ---------------------------------------------------------------
+namespace soar {
+namespace {
+__global__ void export_records_kernel(int P, const GaussRec *rec, float *means2D, float *depths, float *conic_opacity,
+                                      float *normal, float *depth_plane, float *rgb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const GaussRec r = rec[i];
+    if (means2D) { means2D[2 * i] = r.q0.x; means2D[2 * i + 1] = r.q0.y; }
+    if (depths) depths[i] = r.q1.z;
+    if (conic_opacity) {
+        conic_opacity[4 * i] = r.q0.z; conic_opacity[4 * i + 1] = r.q0.w; conic_opacity[4 * i + 2] = r.q1.x;
+        conic_opacity[4 * i + 3] = r.q1.y;
+    }
+    if (normal) { normal[3 * i] = r.q3.x; normal[3 * i + 1] = r.q3.y; normal[3 * i + 2] = r.q3.z; }
+    if (depth_plane) { depth_plane[2 * i] = r.q1.w; depth_plane[2 * i + 1] = r.q2.x; }
+    if (rgb) { rgb[3 * i] = r.q2.y; rgb[3 * i + 1] = r.q2.z; rgb[3 * i + 2] = r.q2.w; }
+}
+}  // namespace
+}  // namespace soar
+
+extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geom_buffer, const void *binning_buffer,
+                                      const void *image_buffer, int64_t num_rendered, float *means2D, float *depths,
+                                      float *conic_opacity, float *normal, float *depth_plane, float *rgb, float *cov3D,
+                                      uint32_t *tiles_touched, uint32_t *point_offsets, uint64_t *keys_unsorted,
+                                      uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list,
+                                      uint32_t *ranges, float *final_T, float *final_D, uint32_t *n_contrib, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (prm->P == 0) return 0;
+    GeomBuf g;
+    ImageBuf img;
+    BinBuf b;
+    carve_geom(const_cast<void *>(geom_buffer), prm->P, prm->M, &g);
+    const size_t P = (size_t)prm->P, pix = (size_t)prm->W * prm->H;
+    const size_t tiles = (size_t)((prm->W + TILE - 1) / TILE) * ((prm->H + TILE - 1) / TILE);
+    hipLaunchKernelGGL(soar::export_records_kernel, dim3((prm->P + 255) / 256), dim3(256), 0, stream, prm->P, g.rec, means2D,
+                       depths, conic_opacity, normal, depth_plane, rgb);
+    SOAR_LAUNCH_OK("export_records", stream, prm->debug);
+#define COPY(dst, src, bytes) \
+    if (dst) SOAR_HIP_OK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, stream))
+    COPY(cov3D, g.cov3D, P * 6 * sizeof(float));
+    COPY(tiles_touched, g.tiles_touched, P * sizeof(uint32_t));
+    COPY(point_offsets, g.point_offsets, P * sizeof(uint32_t));
+    if (image_buffer) {
+        carve_image(const_cast<void *>(image_buffer), prm->W, prm->H, &img);
+        COPY(ranges, img.ranges, tiles * sizeof(uint2));
+        COPY(final_T, img.final_T, pix * sizeof(float));
+        COPY(final_D, img.final_D, pix * sizeof(float));
+        COPY(n_contrib, img.n_contrib, pix * sizeof(uint32_t));
+    }
+    if (binning_buffer && num_rendered > 0) {
+        carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
+        const size_t R = (size_t)num_rendered;
+        COPY(keys_unsorted, b.keys_unsorted, R * sizeof(uint64_t));
+        COPY(vals_unsorted, b.vals_unsorted, R * sizeof(uint32_t));
+        COPY(keys_sorted, b.keys_sorted, R * sizeof(uint64_t));
+        COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
+    }
+#undef COPY
+    return 0;
+}

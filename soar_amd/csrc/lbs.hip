@@ -1,0 +1,466 @@
+// lbs.hip -- SMPL-X linear-blend skinning of canonical Gaussian surfels and nearest-neighbour helpers, gfx950.
+//
+//  * knn_weights_kernel   : SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637): brute-force K-NN over the
+//                           canonical SMPL-X vertices staged through LDS, inverse-distance blend of skinning rows.
+//  * warp_forward_kernel  : blend (TS/utils/smpl.py:613) fused with the apply step of DiffGaussian.forward
+//                           (TS/renderer/diff_gaussian_rasterizer.py:103-114, :138-149): one kernel instead of an
+//                           einsum + ~8 small torch kernels; weight rows are staged through LDS with coalesced loads,
+//                           joint matrices are wave-uniform (scalar loads).
+//  * warp_backward_kernel : analytic gradient w.r.t. canonical xyz and quaternion.
+//  * dist2_knn3_kernel    : simple-knn distCUDA2 semantics (mean of the 3 smallest squared distances, self excluded).
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_MAXK = 32;
+constexpr int KNN_TILE = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// K nearest canonical vertices + inverse-distance skinning weights
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(KNN_THREADS)
+knn_weights_kernel(const float *__restrict__ xyz, int P, const float *__restrict__ verts, int V,
+                   const float *__restrict__ vert_weights, int J, int K, float *__restrict__ weights_out,
+                   int32_t *__restrict__ knn_idx_out)
+{
+    __shared__ float tile[KNN_TILE * 3];
+    __shared__ float best_d[KNN_MAXK][KNN_THREADS];     // [k][thread]: bank = thread, conflict-free
+    __shared__ int best_i[KNN_MAXK][KNN_THREADS];
+
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x * KNN_THREADS + tid;
+    const bool valid = p < P;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) { x = xyz[3 * p]; y = xyz[3 * p + 1]; z = xyz[3 * p + 2]; }
+
+    for (int k = 0; k < K; k++) { best_d[k][tid] = 3.0e38f; best_i[k][tid] = -1; }
+    float worst = 3.0e38f;       // current K-th best distance of this thread
+    int worst_slot = 0;
+
+    for (int base = 0; base < V; base += KNN_TILE) {
+        const int n = min(KNN_TILE, V - base);
+        __syncthreads();
+        for (int t = tid; t < n * 3; t += KNN_THREADS) tile[t] = verts[(size_t)base * 3 + t];
+        __syncthreads();
+        if (!valid) continue;
+        for (int v = 0; v < n; v++) {
+            const float ddx = x - tile[3 * v], ddy = y - tile[3 * v + 1], ddz = z - tile[3 * v + 2];
+            const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            if (d2 < worst) {
+                best_d[worst_slot][tid] = d2;
+                best_i[worst_slot][tid] = base + v;
+                // find the new worst
+                float w = -1.f;
+                int ws = 0;
+                for (int k = 0; k < K; k++) {
+                    const float dk = best_d[k][tid];
+                    if (dk > w) { w = dk; ws = k; }
+                }
+                worst = w;
+                worst_slot = ws;
+            }
+        }
+    }
+    if (!valid) return;
+
+    // order the K hits by (distance, index): insertion sort in LDS (K <= 32)
+    for (int i = 1; i < K; i++) {
+        const float d = best_d[i][tid];
+        const int id = best_i[i][tid];
+        int j = i - 1;
+        while (j >= 0 && (best_d[j][tid] > d || (best_d[j][tid] == d && best_i[j][tid] > id))) {
+            best_d[j + 1][tid] = best_d[j][tid];
+            best_i[j + 1][tid] = best_i[j][tid];
+            j--;
+        }
+        best_d[j + 1][tid] = d;
+        best_i[j + 1][tid] = id;
+    }
+
+    // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1)   (smpl.py:630-634)
+    float norm = 0.f;
+    for (int k = 0; k < K; k++) {
+        const float d = fminf(fmaxf(sqrtf(best_d[k][tid]), 0.0001f), 1.0f);
+        const float w = 1.0f / d;
+        best_d[k][tid] = w;
+        norm += w;
+    }
+    if (knn_idx_out)
+        for (int k = 0; k < K; k++) knn_idx_out[(size_t)p * K + k] = best_i[k][tid];
+
+    // weights[p, :] = sum_k ws_k * vert_weights[idx_k, :]   (smpl.py:632-635)
+    float *out = weights_out + (size_t)p * J;
+    for (int j0 = 0; j0 < J; j0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; k++) {
+            const int id = best_i[k][tid];
+            if (id < 0) continue;
+            const float w = best_d[k][tid] / norm;
+            const float *row = vert_weights + (size_t)id * J + j0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < J) acc[u] += w * row[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (j0 + u < J) out[j0 + u] = acc[u];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// quaternion <-> matrix helpers (row-major 3x3, m[r*3+c]); public pytorch3d conventions, real part first
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_mat(const float q[4], float m[9])
+{
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    m[0] = 1 - two_s * (j * j + k * k); m[1] = two_s * (i * j - k * r); m[2] = two_s * (i * k + j * r);
+    m[3] = two_s * (i * j + k * r); m[4] = 1 - two_s * (i * i + k * k); m[5] = two_s * (j * k - i * r);
+    m[6] = two_s * (i * k - j * r); m[7] = two_s * (j * k + i * r); m[8] = 1 - two_s * (i * i + j * j);
+}
+
+// candidate table of matrix_to_quaternion: returns best index, fills cand[4] and a = q_abs[best]
+__device__ __forceinline__ int mat_to_quat_candidates(const float m[9], float cand[4], float &a_best, float &x_best)
+{
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const float xs[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+    float qa[4];
+    int best = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) qa[t] = xs[t] > 0.f ? sqrtf(xs[t]) : 0.f;
+#pragma unroll
+    for (int t = 1; t < 4; t++)
+        if (qa[t] > qa[best]) best = t;
+    a_best = qa[best];
+    x_best = xs[best];
+    const float sq = a_best * a_best;
+    if (best == 0) { cand[0] = sq; cand[1] = m21 - m12; cand[2] = m02 - m20; cand[3] = m10 - m01; }
+    else if (best == 1) { cand[0] = m21 - m12; cand[1] = sq; cand[2] = m10 + m01; cand[3] = m02 + m20; }
+    else if (best == 2) { cand[0] = m02 - m20; cand[1] = m10 + m01; cand[2] = sq; cand[3] = m12 + m21; }
+    else { cand[0] = m10 - m01; cand[1] = m20 + m02; cand[2] = m21 + m12; cand[3] = sq; }
+    return best;
+}
+
+struct WarpArgs {
+    int P, J;
+    const float *xyz, *rot, *weights, *joint_mats, *offsets, *axis_perm;
+    float *xyz_out, *rot_out, *pt_mats_out;
+    const float *g_xyz_out, *g_rot_out;
+    float *g_xyz, *g_rot;
+};
+
+constexpr int WARP_THREADS = 256;
+constexpr int WARP_MAXJ = 64;
+
+// blended 3x4 transform of one Gaussian: M[r*4+c] = sum_j w_j * A_j[r][c]; weights via LDS (coalesced tile load)
+__device__ __forceinline__ void blend_matrix(const WarpArgs &a, float *wtile, int p0, int tid, float M[12])
+{
+    const int J = a.J;
+    const int nrows = min(WARP_THREADS, a.P - p0);
+    __syncthreads();
+    for (int t = tid; t < nrows * J; t += WARP_THREADS) wtile[t] = a.weights[(size_t)p0 * J + t];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 12; c++) M[c] = 0.f;
+    if (tid < nrows) {
+        const float *wrow = wtile + tid * J;           // stride J = 55 floats: odd => conflict-free
+        for (int j = 0; j < J; j++) {
+            const float w = wrow[j];
+            const float *A = a.joint_mats + 16 * j;    // wave-uniform address -> scalar loads
+#pragma unroll
+            for (int c = 0; c < 12; c++) M[c] += w * A[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
+{
+    extern __shared__ float wtile[];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * WARP_THREADS;
+    const int p = p0 + tid;
+    float M[12];
+    blend_matrix(a, wtile, p0, tid, M);
+    if (p >= a.P) return;
+
+    if (a.pt_mats_out) {
+        float4 *o = reinterpret_cast<float4 *>(a.pt_mats_out + (size_t)p * 16);
+        // bottom row is the blend of the joints' [0,0,0,1] rows = sum of weights
+        float wsum = 0.f;
+        const float *wrow = wtile + tid * a.J;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int j = 0; j < a.J; j++) {
+            const float *A = a.joint_mats + 16 * j + 12;
+            b0 += wrow[j] * A[0]; b1 += wrow[j] * A[1]; b2 += wrow[j] * A[2]; wsum += wrow[j] * A[3];
+        }
+        o[0] = make_float4(M[0], M[1], M[2], M[3]);
+        o[1] = make_float4(M[4], M[5], M[6], M[7]);
+        o[2] = make_float4(M[8], M[9], M[10], M[11]);
+        o[3] = make_float4(b0, b1, b2, wsum);
+    }
+
+    // position: p' = M3 p + t (+ offsets), then optional axis permutation p' <- p' T
+    const float x = a.xyz[3 * p], y = a.xyz[3 * p + 1], z = a.xyz[3 * p + 2];
+    float px = M[0] * x + M[1] * y + M[2] * z + M[3];
+    float py = M[4] * x + M[5] * y + M[6] * z + M[7];
+    float pz = M[8] * x + M[9] * y + M[10] * z + M[11];
+    if (a.offsets) { px += a.offsets[3 * p]; py += a.offsets[3 * p + 1]; pz += a.offsets[3 * p + 2]; }
+
+    // rotation: R' = M3 R(q)
+    const float4 qv = reinterpret_cast<const float4 *>(a.rot)[p];
+    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    float R[9], Rp[9];
+    quat_to_mat(q, R);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Rp[r * 3 + c] = M[r * 4 + 0] * R[c] + M[r * 4 + 1] * R[3 + c] + M[r * 4 + 2] * R[6 + c];
+
+    if (a.axis_perm) {
+        const float *T = a.axis_perm;                      // row-major 3x3
+        const float tx = px * T[0] + py * T[3] + pz * T[6];
+        const float ty = px * T[1] + py * T[4] + pz * T[7];
+        const float tz = px * T[2] + py * T[5] + pz * T[8];
+        px = tx; py = ty; pz = tz;
+        float Rt[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Rt[r * 3 + c] = T[0 * 3 + r] * Rp[c] + T[1 * 3 + r] * Rp[3 + c] + T[2 * 3 + r] * Rp[6 + c];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rp[k] = Rt[k];
+    }
+    a.xyz_out[3 * p] = px; a.xyz_out[3 * p + 1] = py; a.xyz_out[3 * p + 2] = pz;
+
+    // q' = normalize(standardize(matrix_to_quaternion(R')))
+    float cand[4], a_best, x_best;
+    mat_to_quat_candidates(Rp, cand, a_best, x_best);
+    const float inv = 1.0f / (2.0f * fmaxf(a_best, 0.1f));
+    float o[4] = {cand[0] * inv, cand[1] * inv, cand[2] * inv, cand[3] * inv};
+    if (o[0] < 0.f) { o[0] = -o[0]; o[1] = -o[1]; o[2] = -o[2]; o[3] = -o[3]; }
+    const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]), 1e-12f);
+    reinterpret_cast<float4 *>(a.rot_out)[p] = make_float4(o[0] / nrm, o[1] / nrm, o[2] / nrm, o[3] / nrm);
+}
+
+__global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
+{
+    extern __shared__ float wtile[];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * WARP_THREADS;
+    const int p = p0 + tid;
+    float M[12];
+    blend_matrix(a, wtile, p0, tid, M);
+    if (p >= a.P) return;
+
+    const float *T = a.axis_perm;
+    // ---- position: dL/dp = M3^T (T g)
+    float gx = a.g_xyz_out[3 * p], gy = a.g_xyz_out[3 * p + 1], gz = a.g_xyz_out[3 * p + 2];
+    if (T) {
+        const float tx = T[0] * gx + T[1] * gy + T[2] * gz;
+        const float ty = T[3] * gx + T[4] * gy + T[5] * gz;
+        const float tz = T[6] * gx + T[7] * gy + T[8] * gz;
+        gx = tx; gy = ty; gz = tz;
+    }
+    a.g_xyz[3 * p + 0] = M[0] * gx + M[4] * gy + M[8] * gz;
+    a.g_xyz[3 * p + 1] = M[1] * gx + M[5] * gy + M[9] * gz;
+    a.g_xyz[3 * p + 2] = M[2] * gx + M[6] * gy + M[10] * gz;
+
+    // ---- rotation: recompute the forward
+    const float4 qv = reinterpret_cast<const float4 *>(a.rot)[p];
+    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    float R[9], B[9], Rp[9];
+    quat_to_mat(q, R);
+    // B = T^T M3 (or M3): R' = B R
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            B[r * 3 + c] = T ? (T[0 * 3 + r] * M[0 * 4 + c] + T[1 * 3 + r] * M[1 * 4 + c] + T[2 * 3 + r] * M[2 * 4 + c]) : M[r * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Rp[r * 3 + c] = B[r * 3 + 0] * R[c] + B[r * 3 + 1] * R[3 + c] + B[r * 3 + 2] * R[6 + c];
+
+    float cand[4], a_best, x_best;
+    const int best = mat_to_quat_candidates(Rp, cand, a_best, x_best);
+    const float Dn = 2.0f * fmaxf(a_best, 0.1f);
+    float o[4] = {cand[0] / Dn, cand[1] / Dn, cand[2] / Dn, cand[3] / Dn};
+    const float sgn = (o[0] < 0.f) ? -1.f : 1.f;
+    float u[4] = {sgn * o[0], sgn * o[1], sgn * o[2], sgn * o[3]};
+    const float un = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+    const float4 gq = reinterpret_cast<const float4 *>(a.g_rot_out)[p];
+    float g[4] = {gq.x, gq.y, gq.z, gq.w};
+    // through F.normalize: g_u = (g - (g.n) n) / |u|   (eps branch: plain scale)
+    float gu[4];
+    if (un > 1e-12f) {
+        const float n[4] = {u[0] / un, u[1] / un, u[2] / un, u[3] / un};
+        const float gn = g[0] * n[0] + g[1] * n[1] + g[2] * n[2] + g[3] * n[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) gu[k] = (g[k] - gn * n[k]) / un;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) gu[k] = g[k] / 1e-12f;
+    }
+    // through standardize and the division by D = 2 max(a, 0.1)
+    float gc[4];
+    float gD = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float go = sgn * gu[k];
+        gc[k] = go / Dn;
+        gD -= go * cand[k] / (Dn * Dn);
+    }
+    // cand[best] = a^2 = x (x > 0), D = 2a when a > 0.1:  dL/dx = gc[best] + gD * 2 * (1 / (2a))
+    float gxb = (x_best > 0.f) ? gc[best] : 0.f;
+    if (a_best > 0.1f && x_best > 0.f) gxb += gD / a_best;
+    // scatter to dL/dR' (row-major); x_best = 1 +- m00 +- m11 +- m22
+    float gR[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gR[k] = 0.f;
+    const float s00 = (best == 0 || best == 1) ? 1.f : -1.f;
+    const float s11 = (best == 0 || best == 2) ? 1.f : -1.f;
+    const float s22 = (best == 0 || best == 3) ? 1.f : -1.f;
+    gR[0] = s00 * gxb; gR[4] = s11 * gxb; gR[8] = s22 * gxb;
+    // off-diagonal linear terms (m[r*3+c]): m01=1 m02=2 m10=3 m12=5 m20=6 m21=7
+    if (best == 0) {
+        gR[7] += gc[1]; gR[5] -= gc[1]; gR[2] += gc[2]; gR[6] -= gc[2]; gR[3] += gc[3]; gR[1] -= gc[3];
+    } else if (best == 1) {
+        gR[7] += gc[0]; gR[5] -= gc[0]; gR[3] += gc[2]; gR[1] += gc[2]; gR[2] += gc[3]; gR[6] += gc[3];
+    } else if (best == 2) {
+        gR[2] += gc[0]; gR[6] -= gc[0]; gR[3] += gc[1]; gR[1] += gc[1]; gR[5] += gc[3]; gR[7] += gc[3];
+    } else {
+        gR[3] += gc[0]; gR[1] -= gc[0]; gR[6] += gc[1]; gR[2] += gc[1]; gR[7] += gc[2]; gR[5] += gc[2];
+    }
+    // dL/dR(q) = B^T dL/dR'
+    float G[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) G[r * 3 + c] = B[0 * 3 + r] * gR[c] + B[1 * 3 + r] * gR[3 + c] + B[2 * 3 + r] * gR[6 + c];
+    // R = I + s Q(q), s = 2/|q|^2:  dL/dq_m = s <G, dQ/dq_m> - s^2 q_m <G, Q>
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float nn = r * r + i * i + j * j + k * k;
+    const float s = 2.0f / nn;
+    const float Q[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k), j * k - i * r,
+                        i * k - j * r, j * k + i * r, -(i * i + j * j)};
+    float GQ = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; t++) GQ += G[t] * Q[t];
+    const float dr = -k * G[1] + j * G[2] + k * G[3] - i * G[5] - j * G[6] + i * G[7];
+    const float di = j * G[1] + k * G[2] + j * G[3] - 2 * i * G[4] - r * G[5] + k * G[6] + r * G[7] - 2 * i * G[8];
+    const float dj = -2 * j * G[0] + i * G[1] + r * G[2] + i * G[3] + k * G[5] - r * G[6] + k * G[7] - 2 * j * G[8];
+    const float dk = -2 * k * G[0] - r * G[1] + i * G[2] + r * G[3] - 2 * k * G[4] + j * G[5] + i * G[6] + j * G[7];
+    reinterpret_cast<float4 *>(a.g_rot)[p] =
+        make_float4(s * dr - s * s * r * GQ, s * di - s * s * i * GQ, s * dj - s * s * j * GQ, s * dk - s * s * k * GQ);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mean squared distance to the 3 nearest other points
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dist2_knn3_kernel(const float *__restrict__ pts, int N, float *__restrict__ out)
+{
+    __shared__ float tile[KNN_TILE * 3];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x * 256 + tid;
+    const bool valid = p < N;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) { x = pts[3 * p]; y = pts[3 * p + 1]; z = pts[3 * p + 2]; }
+    float b0 = 3.402823466e+38f, b1 = b0, b2 = b0;            // FLT_MAX, ascending
+    for (int base = 0; base < N; base += KNN_TILE) {
+        const int n = min(KNN_TILE, N - base);
+        __syncthreads();
+        for (int t = tid; t < n * 3; t += 256) tile[t] = pts[(size_t)base * 3 + t];
+        __syncthreads();
+        if (!valid) continue;
+        for (int v = 0; v < n; v++) {
+            const float ddx = x - tile[3 * v], ddy = y - tile[3 * v + 1], ddz = z - tile[3 * v + 2];
+            float d = ddx * ddx + ddy * ddy + ddz * ddz;
+            if (base + v == p) continue;
+            if (d < b2) {
+                b2 = d;
+                if (b2 < b1) { const float t = b1; b1 = b2; b2 = t; }
+                if (b1 < b0) { const float t = b0; b0 = b1; b1 = t; }
+            }
+        }
+    }
+    if (valid) out[p] = (b0 + b1 + b2) / 3.0f;
+}
+
+}  // namespace
+
+}  // namespace soar
+
+using namespace soar;
+
+extern "C" {
+
+int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights, int32_t J,
+                         int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0 || V <= 0 || J <= 0 || K <= 0) { set_error("soar_lbs_knn_weights: bad sizes P=%d V=%d J=%d K=%d", P, V, J, K); return 1; }
+    if (K > KNN_MAXK || K > V) { set_error("soar_lbs_knn_weights: K=%d unsupported (max %d, V=%d)", K, KNN_MAXK, V); return 1; }
+    if (P == 0) return 0;
+    if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
+    hipLaunchKernelGGL(knn_weights_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P,
+                       verts, V, vert_weights, J, K, weights_out, knn_idx_out);
+    SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
+    return 0;
+}
+
+static int warp_check(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t P, int32_t J)
+{
+    if (P < 0 || J <= 0 || J > WARP_MAXJ) { set_error("soar_lbs_warp: bad sizes P=%d J=%d (max J %d)", P, J, WARP_MAXJ); return 1; }
+    if (P > 0 && (!xyz || !rot || !weights || !joint_mats)) { set_error("soar_lbs_warp: NULL pointer"); return 1; }
+    return 0;
+}
+
+int soar_lbs_warp_forward(const float *xyz, const float *rot, const float *weights, const float *joint_mats,
+                          const float *offsets, const float *axis_perm, int32_t P, int32_t J, float *xyz_out,
+                          float *rot_out, float *pt_mats_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!xyz_out || !rot_out) { set_error("soar_lbs_warp_forward: NULL output"); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.offsets = offsets;
+    a.axis_perm = axis_perm; a.xyz_out = xyz_out; a.rot_out = rot_out; a.pt_mats_out = pt_mats_out;
+    const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    hipLaunchKernelGGL(warp_forward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
+    SOAR_LAUNCH_OK("lbs_warp_forward", stream, 0);
+    return 0;
+}
+
+int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weights, const float *joint_mats,
+                           const float *axis_perm, int32_t P, int32_t J, const float *dL_dxyz_out,
+                           const float *dL_drot_out, float *dL_dxyz, float *dL_drot, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!dL_dxyz_out || !dL_drot_out || !dL_dxyz || !dL_drot) { set_error("soar_lbs_warp_backward: NULL pointer"); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.axis_perm = axis_perm;
+    a.g_xyz_out = dL_dxyz_out; a.g_rot_out = dL_drot_out; a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
+    const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    hipLaunchKernelGGL(warp_backward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
+    SOAR_LAUNCH_OK("lbs_warp_backward", stream, 0);
+    return 0;
+}
+
+int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N < 0) { set_error("soar_dist2_knn3: N < 0"); return 1; }
+    if (N == 0) return 0;
+    if (!points || !out) { set_error("soar_dist2_knn3: NULL pointer"); return 1; }
+    hipLaunchKernelGGL(dist2_knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, points, N, out);
+    SOAR_LAUNCH_OK("dist2_knn3", stream, 0);
+    return 0;
+}
+
+}  // extern "C"

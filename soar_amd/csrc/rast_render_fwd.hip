@@ -1,0 +1,146 @@
+// rast_render_fwd.hip -- per-tile front-to-back alpha blend for gfx950.
+//
+// Replaces renderCUDA<3> forward (DGR/cuda_rasterizer/forward.cu:390-692) and depth_differencing
+// (auxiliary.h:390-397).
+//
+// CDNA4 mapping (not the reference's 256-thread lock-step block):
+//  * a 16x16 tile is owned by one 256-thread workgroup, but each of its four wavefronts owns an 8x8
+//    pixel quad and walks the tile's depth-sorted list on its own: no workgroup barrier anywhere, a wave
+//    leaves as soon as its 64 pixels are saturated (wave-level vote = one s_cbranch on the exec mask);
+//  * the list is consumed in chunks of 64: lane l gathers the 64-byte record of entry l (four 16-byte
+//    loads, one cache-line half) and parks it in the wave's private 4 KiB LDS slab; the blend loop then
+//    reads records with wave-uniform (broadcast) ds_read_b128 -- two for the alpha test, two more only if
+//    some lane survives it;
+//  * workgroup -> tile mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+struct FwdArgs {
+    int W, H, gx, gy, ntiles;
+    int normalize_depth;
+    const uint2 *ranges;
+    const uint32_t *point_list;
+    const GaussRec *rec;
+    const float *bg;
+    float *final_T;
+    float *final_D;
+    uint32_t *n_contrib;
+    float *out_color, *out_normal, *out_depth, *out_opac;
+};
+
+// blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of tiles
+__device__ __forceinline__ int xcd_tile(int bid, int n)
+{
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, within = bid >> 3;
+    return xcd * q + min(xcd, r) + within;
+}
+
+__global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
+{
+    __shared__ GaussRec slab[4][WAVE];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float fx = (float)px, fy = (float)py;
+
+    const uint2 range = a.ranges[tile];
+
+    float T = 1.0f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
+    uint32_t last_contributor = 0;
+    bool done = !inside;
+
+    GaussRec *my = slab[wave];
+    const float4 *myq = reinterpret_cast<const float4 *>(my);
+
+    for (uint32_t base = range.x; base < range.y; base += WAVE) {
+        if (__ballot(!done) == 0ull) break;                 // whole quad saturated
+        const int n = min((uint32_t)WAVE, range.y - base);
+        if (lane < n) {
+            const uint32_t id = a.point_list[base + lane];
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
+            float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+            float4 *dst = reinterpret_cast<float4 *>(my + lane);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const uint32_t contrib0 = base - range.x;           // entries before this chunk
+        for (int j = 0; j < n; j++) {
+            const float4 q0 = myq[4 * j + 0];               // x, y, A, B
+            const float4 q1 = myq[4 * j + 1];               // C, opacity, depth, plane_a
+            const float dx = q0.x - fx, dy = q0.y - fy;
+            // forward.cu:507-508
+            const float power = -0.5f * ((q0.z * dx * dx + q1.x * dy * dy) + 2.f * q0.w * dx * dy);
+            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            // skip rules :512,:545 ; a saturated pixel stops before blending (:549-552)
+            bool live = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float test_T = T * (1.f - alpha);
+            if (live && test_T < 0.0001f) {
+                done = true;
+                live = false;
+            }
+            if (__ballot(live) == 0ull) continue;
+            const float4 q2 = myq[4 * j + 2];               // plane_b, r, g, b
+            const float4 q3 = myq[4 * j + 3];               // nx, ny, nz, radius
+            if (live) {
+                const float w = alpha * T;
+                const float depth = q1.z - (dx * q1.w + dy * q2.x);   // per-pixel depth on the surfel plane
+                D += depth * w;
+                C0 += q2.y * w; C1 += q2.z * w; C2 += q2.w * w;
+                N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                T = test_T;
+                last_contributor = contrib0 + (uint32_t)j + 1u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // slab is overwritten by the next chunk
+    }
+
+    if (inside) {
+        // epilogue, forward.cu:618-633
+        T = fminf((float)(1 - 0.000001), T);
+        const size_t pix = (size_t)a.W * py + px;
+        const size_t hw = (size_t)a.H * a.W;
+        a.final_T[pix] = T;
+        a.n_contrib[pix] = last_contributor;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[hw + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * hw + pix] = C2 + T * a.bg[2];
+        a.out_normal[pix] = N0;
+        a.out_normal[hw + pix] = N1;
+        a.out_normal[2 * hw + pix] = N2;
+        a.out_depth[pix] = a.normalize_depth ? D / (1.f - T) : D + T * 10.f;
+        a.out_opac[pix] = 1.f - T;
+        if (a.normalize_depth) a.final_D[pix] = D;
+    }
+}
+
+}  // namespace
+
+int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
+                          float *out_color, float *out_normal, float *out_depth, float *out_opac, hipStream_t stream)
+{
+    FwdArgs a;
+    a.W = prm.W; a.H = prm.H;
+    a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
+    a.ntiles = a.gx * a.gy;
+    a.normalize_depth = prm.cfg_normalize_depth;
+    a.ranges = img.ranges; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
+    a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
+    a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
+    hipLaunchKernelGGL(render_forward_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
+    return 0;
+}
+
+}  // namespace soar

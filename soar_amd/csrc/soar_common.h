@@ -1,0 +1,105 @@
+// soar_common.h -- internal declarations shared by the HIP translation units of libsoar_hip.so.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, 16x16 pixel tiles are processed as four 8x8 wave quads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/soar_hip.h"
+
+namespace soar {
+
+constexpr int TILE = 16;              // BLOCK_X = BLOCK_Y = 16 (DGR/cuda_rasterizer/config.h:14-16)
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int WAVE = 64;
+constexpr size_t ALIGN = 256;
+
+// ---- error plumbing (never throw across the C ABI) -------------------------------------------
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what, const char *file, int line);
+#define SOAR_HIP_OK(expr)                                                         \
+    do {                                                                          \
+        if (::soar::check_hip((expr), #expr, __FILE__, __LINE__)) return 1;       \
+    } while (0)
+// after a kernel launch: always catch launch errors; in debug mode also synchronise (CHECK_CUDA semantics)
+int post_launch(const char *what, hipStream_t stream, int debug);
+#define SOAR_LAUNCH_OK(what, stream, debug)                                       \
+    do {                                                                          \
+        if (::soar::post_launch((what), (stream), (debug))) return 1;             \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+// ---- per-Gaussian render record: 64 bytes, one gather granule --------------------------------
+// q0 = {mean2D.x, mean2D.y, conic.x (A), conic.y (B)}
+// q1 = {conic.z (C), opacity, view depth, depth-plane a}
+// q2 = {depth-plane b, colour r, g, b}
+// q3 = {view normal x, y, z, radius (int bits)}
+// depth-plane (a, b): the only two combinations of Jinv[10] that the renderers consume,
+//   a = J6*J0 + J9*J2, b = J6*J1 + J9*J3  (auxiliary.h:390-397, backward.cu:839-840).
+struct alignas(16) GaussRec {
+    float4 q0, q1, q2, q3;
+};
+static_assert(sizeof(GaussRec) == 64, "record must be 64 bytes");
+
+// ---- opaque scratch buffers -------------------------------------------------------------------
+struct GeomBuf {
+    uint32_t *header;        // [64]: [0] num_rendered
+    GaussRec *rec;           // [P]
+    float *cov3D;            // [P,6]
+    uint32_t *tiles_touched; // [P]
+    uint32_t *point_offsets; // [P] inclusive scan
+    uint8_t *clamped;        // [P,3] (SH path)
+    void *scan_temp;
+    size_t scan_temp_bytes;
+    size_t total_bytes;
+};
+struct ImageBuf {
+    uint2 *ranges;           // [T]
+    float *final_T;          // [pix]
+    uint32_t *n_contrib;     // [pix]
+    float *final_D;          // [pix]
+    size_t total_bytes;
+};
+struct BinBuf {
+    uint64_t *keys_unsorted; // [R]
+    uint64_t *keys_sorted;   // [R]
+    uint32_t *vals_unsorted; // [R]
+    uint32_t *vals_sorted;   // [R]  (point_list)
+    void *sort_temp;
+    size_t sort_temp_bytes;
+    size_t total_bytes;
+};
+int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out);
+int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out);
+int carve_binning(void *base, int64_t R, BinBuf *out);
+
+// per-Gaussian accumulation row written by the backward blend (one 64-byte atomic granule)
+// [0,1] dL_dmean2D.xy  [2,3,4] dL_dconic (x,y,w)  [5] dL_dopacity  [6..8] dL_dcolor
+// [9..11] dL_dnormal  [12] dL_ddepth  [13..15] unused
+constexpr int ACC_STRIDE = 16;
+
+uint32_t higher_msb(uint32_t n);   // getHigherMsb, rasterizer_impl.cu:35-48
+size_t scan_temp_bytes(int32_t P);
+size_t sort_temp_bytes(int64_t R);
+
+// ---- stage launchers (each returns 0 on success) ------------------------------------------------
+int launch_preprocess(const SoarRastParams &prm, const float *means3D, const float *shs, const float *colors_precomp,
+                      const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
+                      GeomBuf &g, int32_t *radii, hipStream_t stream);
+int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
+int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
+                   hipStream_t stream);
+int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
+                          float *out_color, float *out_normal, float *out_depth, float *out_opac, hipStream_t stream);
+int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
+                           const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
+                           float *acc, hipStream_t stream);
+int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, const int32_t *radii, const float *shs,
+                             const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
+                             const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                             float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, hipStream_t stream);
+
+}  // namespace soar

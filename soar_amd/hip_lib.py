@@ -1,0 +1,91 @@
+"""ctypes binding of libsoar_hip.so (include/soar_hip.h).
+
+There is no CPU fallback: if the library is missing the import of a symbol fails loudly with a build hint.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libsoar_hip.so")
+
+c_f32p = C.c_void_p
+_vp = C.c_void_p
+
+
+class SoarRastParams(C.Structure):
+    """Mirror of ``struct SoarRastParams`` (include/soar_hip.h)."""
+    _fields_ = [
+        ("P", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32),
+        ("prefiltered", C.c_int32), ("render_front", C.c_int32), ("sort_descending", C.c_int32), ("debug", C.c_int32),
+        ("cfg_surface", C.c_int32), ("cfg_normalize_depth", C.c_int32), ("cfg_perpix_depth", C.c_int32),
+        ("cfg_lrn_cam", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("bg_dev", _vp), ("viewmatrix_dev", _vp), ("projmatrix_dev", _vp), ("prcppoint_dev", _vp),
+        ("patchbbox_dev", _vp), ("campos_dev", _vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/soar_hip.h declares
+SIGNATURES = {
+    "soar_last_error": (C.c_char_p, []),
+    "soar_abi_version": (C.c_int, []),
+    "soar_rast_geometry_bytes": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_rast_image_bytes": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_rast_binning_bytes": (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
+    "soar_rast_backward_workspace_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_rast_forward_geometry": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, C.POINTER(C.c_int64), _vp]),
+    "soar_rast_forward_render": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "soar_rast_backward": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 4
+                           + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
+    "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "soar_rast_export_state": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64] + [_vp] * 17 + [_vp]),
+    "soar_lbs_knn_weights": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
+    "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
+    "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class SoarHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libsoar_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SoarHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m soar_amd.build` "
+                "(hipcc --offload-arch=gfx950). soar_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.soar_abi_version() != 1:
+            raise SoarHipError("libsoar_hip.so ABI version mismatch; rebuild with `python -m soar_amd.build --force`")
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().soar_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SoarHipError(f"{what} failed: {last_error()}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device/host pointer of a torch tensor (None for an empty / missing tensor, like the reference's nullptr)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()

@@ -1,0 +1,336 @@
+"""Drop-in replacement of ``diff_gaussian_rasterization`` (the Gaussian-surfel variant shipped with hangg7/soar)
+running on hand-written HIP kernels for MI355X (gfx950) through the C ABI of ``libsoar_hip.so``.
+
+Public surface kept identical to the reference
+(``submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py``):
+
+* ``GaussianRasterizationSettings`` -- same 17 fields, same order (:267-284);
+* ``GaussianRasterizer(raster_settings).forward(means3D, means2D, opacities, shs=None, colors_precomp=None,
+  scales=None, rotations=None, cov3D_precomp=None)`` -> ``(color, normal, depth, opac, radii)`` (:287-356) and
+  ``.markVisible(positions)`` (:292-300);
+* ``rasterize_gaussians(...)`` functional form (:28-55);
+* ``_C.rasterize_gaussians / rasterize_gaussians_backward / mark_visible`` with the positional signatures and return
+  tuples of the pybind module (``ext.cpp:15-19``, ``rasterize_points.h:17-53``).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only.  There is no CPU or eager fallback: every
+call goes to the HIP library and raises if it is missing or if a tensor is not on a ``cuda`` (= HIP) device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip_lib
+from .hip_lib import SoarRastParams, check, ptr
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    patch_bbox: torch.Tensor
+    prcppoint: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    render_front: bool
+    sort_descending: bool
+    debug: bool
+    config: torch.Tensor
+
+
+# ---------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------
+_config_cache = {}
+
+
+def _config_flags(config: torch.Tensor) -> Tuple[int, int, int, int]:
+    """``config[i] > 0`` for i < 4 as host ints.  The reference reads the float tensor inside its kernels
+    (forward.cu:275,464; backward.cu:285,475,581); here the four switches travel by value, so the tensor is
+    read back once per (storage, version) and cached."""
+    key = (config.data_ptr(), config._version, str(config.device), config.numel())
+    hit = _config_cache.get(key)
+    if hit is None:
+        vals = config.detach().float().reshape(-1).cpu().tolist()
+        vals = vals + [0.0] * (4 - len(vals))
+        hit = tuple(int(v > 0) for v in vals[:4])
+        if len(_config_cache) > 64:
+            _config_cache.clear()
+        _config_cache[key] = hit
+    return hit
+
+
+def _dev_f32(t: torch.Tensor, device: torch.device, name: str) -> torch.Tensor:
+    """fp32, contiguous, on `device` (the reference calls .contiguous().data<float>() on every argument)."""
+    if t is None:
+        raise ValueError(f"{name} is None")
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _opt_f32(t: Optional[torch.Tensor], device: torch.device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    return _dev_f32(t, device, "tensor")
+
+
+def _require_hip(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on '{t.device}': soar_amd runs on HIP devices only (torch device type 'cuda' on ROCm); "
+            "there is no CPU fallback")
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _scratch(nbytes: int, device: torch.device) -> torch.Tensor:
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if buf.data_ptr() % 256:
+        raise RuntimeError("device allocation is not 256-byte aligned")
+    return buf
+
+
+class _Ctx:
+    """Per-call bundle: the C parameter block plus the tensors whose device pointers it holds (kept alive)."""
+
+    def __init__(self, P, M, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, prefiltered, render_front,
+                 sort_descending, debug, bg, viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device):
+        self.keep = [
+            _dev_f32(bg, device, "bg"), _dev_f32(viewmatrix, device, "viewmatrix"),
+            _dev_f32(projmatrix, device, "projmatrix"), _dev_f32(prcppoint, device, "prcppoint"),
+            _dev_f32(patchbbox, device, "patch_bbox"), _dev_f32(campos, device, "campos"),
+        ]
+        for t, n, name in zip(self.keep, (3, 16, 16, 2, 4, 3), ("bg", "viewmatrix", "projmatrix", "prcppoint",
+                                                                "patch_bbox", "campos")):
+            if t.numel() < n:
+                raise ValueError(f"{name} must have at least {n} elements, got {t.numel()}")
+        surface, norm_depth, pix_depth, lrn_cam = _config_flags(config)
+        p = SoarRastParams()
+        p.P, p.W, p.H = int(P), int(W), int(H)
+        p.sh_degree, p.M = int(sh_degree), int(M)
+        p.prefiltered, p.render_front, p.sort_descending, p.debug = int(bool(prefiltered)), int(bool(render_front)), \
+            int(bool(sort_descending)), int(bool(debug))
+        p.cfg_surface, p.cfg_normalize_depth, p.cfg_perpix_depth, p.cfg_lrn_cam = surface, norm_depth, pix_depth, lrn_cam
+        p.tanfovx, p.tanfovy, p.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+        (p.bg_dev, p.viewmatrix_dev, p.projmatrix_dev, p.prcppoint_dev, p.patchbbox_dev, p.campos_dev) = \
+            [t.data_ptr() for t in self.keep]
+        self.params = p
+
+
+# ---------------------------------------------------------------------------------------------------
+# the `_C` extension surface
+# ---------------------------------------------------------------------------------------------------
+class _NativeOps:
+    """Same entry points, positional signatures and return tuples as the reference's pybind module ``_C``."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, image_height, image_width,
+                            sh, degree, campos, prefiltered, render_front, sort_descending, debug, config):
+        """-> (num_rendered, color[3,H,W], normal[3,H,W], depth[1,H,W], opac[1,H,W], radii[P] int32,
+        geomBuffer, binningBuffer, imgBuffer)   (rasterize_points.cu:35-105)"""
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")      # rasterize_points.cu:50-52
+        _require_hip(means3D, "means3D")
+        L = hip_lib.lib()
+        device = means3D.device
+        P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+        out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        out_normal = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        out_depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+        out_opac = torch.empty((1, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        empty = torch.empty((0,), dtype=torch.uint8, device=device)
+        sh_t = _opt_f32(sh, device)
+        M = int(sh_t.size(1)) if sh_t is not None else 0
+        ctx = _Ctx(P, M, H, W, tan_fovx, tan_fovy, scale_modifier, degree, prefiltered, render_front, sort_descending,
+                   debug, background, viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device)
+        prm = C.byref(ctx.params)
+        stream = _stream(device)
+        with torch.cuda.device(device):
+            if P == 0:
+                check(L.soar_rast_forward_render(prm, None, None, None, None, 0, out_color.data_ptr(), out_normal.data_ptr(),
+                                                 out_depth.data_ptr(), out_opac.data_ptr(), stream), "rasterize_gaussians")
+                return 0, out_color, out_normal, out_depth, out_opac, radii, empty, empty.clone(), empty.clone()
+            means = _dev_f32(means3D, device, "means3D")
+            opac = _dev_f32(opacity, device, "opacity")
+            cols, scl, rot, cov = (_opt_f32(colors, device), _opt_f32(scales, device), _opt_f32(rotations, device),
+                                   _opt_f32(cov3D_precomp, device))
+            nbytes = C.c_size_t(0)
+            check(L.soar_rast_geometry_bytes(P, M, C.byref(nbytes)), "geometry_bytes")
+            geom = _scratch(nbytes.value, device)
+            check(L.soar_rast_image_bytes(W, H, C.byref(nbytes)), "image_bytes")
+            img = _scratch(nbytes.value, device)
+            R = C.c_int64(0)
+            check(L.soar_rast_forward_geometry(prm, means.data_ptr(), ptr(sh_t), ptr(cols), opac.data_ptr(), ptr(scl),
+                                               ptr(rot), ptr(cov), geom.data_ptr(), radii.data_ptr(), C.byref(R), stream),
+                  "rasterize_gaussians (geometry stage)")
+            num_rendered = int(R.value)
+            check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
+            binning = _scratch(nbytes.value, device)
+            check(L.soar_rast_forward_render(prm, radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
+                                             num_rendered, out_color.data_ptr(), out_normal.data_ptr(),
+                                             out_depth.data_ptr(), out_opac.data_ptr(), stream),
+                  "rasterize_gaussians (render stage)")
+        return num_rendered, out_color, out_normal, out_depth, out_opac, radii, geom, binning, img
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                     viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, dL_dout_color,
+                                     dL_dout_normal, dL_dout_depth, dL_dout_opac, sh, degree, campos, geomBuffer, R,
+                                     binningBuffer, imageBuffer, debug, config):
+        """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+        dL_dscales[P,3], dL_drotations[P,4], dL_dviewmat[4,4], dL_dprojmat[4,4], dL_dcampos[3])
+        (rasterize_points.cu:107-187)"""
+        _require_hip(means3D, "means3D")
+        L = hip_lib.lib()
+        device = means3D.device
+        P = int(means3D.size(0))
+        H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+        sh_t = _opt_f32(sh, device)
+        M = int(sh_t.size(1)) if sh_t is not None else 0
+        f = dict(dtype=torch.float32, device=device)
+        g_means2D = torch.empty((P, 3), **f)
+        g_colors = torch.empty((P, 3), **f)
+        g_opacity = torch.empty((P, 1), **f)
+        g_means3D = torch.empty((P, 3), **f)
+        g_cov3D = torch.empty((P, 6), **f)
+        g_sh = torch.empty((P, M, 3), **f)
+        g_scales = torch.empty((P, 3), **f)
+        g_rot = torch.empty((P, 4), **f)
+        g_view = torch.empty((4, 4), **f)
+        g_proj = torch.empty((4, 4), **f)
+        g_campos = torch.empty((3,), **f)
+        # render_front / sort_descending / prefiltered do not enter the backward pass
+        ctx = _Ctx(P, M, H, W, tan_fovx, tan_fovy, scale_modifier, degree, False, False, False, debug, background,
+                   viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device)
+        stream = _stream(device)
+        with torch.cuda.device(device):
+            if P > 0:
+                nbytes = C.c_size_t(0)
+                check(L.soar_rast_backward_workspace_bytes(P, C.byref(nbytes)), "backward_workspace_bytes")
+                work = _scratch(nbytes.value, device)
+                means = _dev_f32(means3D, device, "means3D")
+                dC, dN, dD, dO = (_dev_f32(dL_dout_color, device, "dL_dout_color"),
+                                  _dev_f32(dL_dout_normal, device, "dL_dout_normal"),
+                                  _dev_f32(dL_dout_depth, device, "dL_dout_depth"),
+                                  _dev_f32(dL_dout_opac, device, "dL_dout_opac"))
+                cols, scl, rot, cov = (_opt_f32(colors, device), _opt_f32(scales, device), _opt_f32(rotations, device),
+                                       _opt_f32(cov3D_precomp, device))
+                radii_i = radii if radii.dtype == torch.int32 else radii.int()
+                work_ptr, work_n = work.data_ptr(), work.numel()
+            else:
+                means = dC = dN = dD = dO = None
+                cols = scl = rot = cov = radii_i = None
+                work_ptr, work_n = None, 0
+            check(L.soar_rast_backward(
+                C.byref(ctx.params), ptr(means), ptr(radii_i), ptr(sh_t), ptr(cols), ptr(scl), ptr(rot), ptr(cov),
+                ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), int(R),
+                ptr(dC), ptr(dN), ptr(dD), ptr(dO),
+                ptr(g_means2D), ptr(g_colors), ptr(g_opacity), ptr(g_means3D), ptr(g_cov3D), ptr(g_sh), ptr(g_scales),
+                ptr(g_rot), g_view.data_ptr(), g_proj.data_ptr(), g_campos.data_ptr(), work_ptr, work_n, stream),
+                "rasterize_gaussians_backward")
+        return (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_view, g_proj, g_campos)
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        """-> bool[P]; all False, as in the reference whose checkFrustum body is commented out
+        (rasterizer_impl.cu:52-62, rasterize_points.cu:189-205)."""
+        _require_hip(means3D, "means3D")
+        L = hip_lib.lib()
+        P = int(means3D.size(0))
+        present = torch.empty((P,), dtype=torch.bool, device=means3D.device)
+        with torch.cuda.device(means3D.device):
+            check(L.soar_rast_mark_visible(P, ptr(means3D), ptr(viewmatrix), ptr(projmatrix), ptr(present),
+                                           _stream(means3D.device)), "mark_visible")
+        return present
+
+
+_C = _NativeOps()
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd op and module
+# ---------------------------------------------------------------------------------------------------
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                projmatrix, campos, raster_settings):
+        rs = raster_settings
+        (num_rendered, color, normal, depth, opac, radii, geom, binning, img) = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, viewmatrix,
+            projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+            rs.sh_degree, campos, rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.opac_shape = opacities.shape
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, normal, depth, opac, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_normal, g_depth, g_opac, _g_radii):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_view, g_proj,
+         g_campos) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
+            rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, rs.config)
+        # gradients in input order: means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, view, proj,
+        # campos, settings (__init__.py:249-262).  Empty placeholder inputs receive correspondingly empty gradients.
+        def like(g, ref):
+            return g if ref.numel() > 0 else None
+        return (g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors_precomp), g_opacities.reshape(ctx.opac_shape),
+                like(g_scales, scales), like(g_rot, rotations), like(g_cov3D, cov3Ds_precomp), g_view, g_proj, g_campos,
+                None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                        projmatrix, campos, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     viewmatrix, projmatrix, campos, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   rs.viewmatrix, rs.projmatrix, rs.campos, rs)
