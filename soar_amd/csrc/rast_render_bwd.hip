@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(BwdArgs a)
             const float4 q0 = myq[4 * j + 0];
             const float4 q1 = myq[4 * j + 1];
             const float dx = q0.x - fx, dy = q0.y - fy;
-            const float power = -0.5f * ((q0.z * dx * dx + q1.x * dy * dy) + 2.f * q0.w * dx * dy);
-            const float G = __expf(power);
+            const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
+            const float G = exp_nonpositive(power);
             const float alpha = fminf(0.99f, q1.y * G);
             const bool live = (pos < last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);   // :653-680
             if (__ballot(live) == 0ull) continue;

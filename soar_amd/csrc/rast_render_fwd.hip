@@ -81,11 +81,11 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
             const float4 q1 = myq[4 * j + 1];               // C, opacity, depth, plane_a
             const float dx = q0.x - fx, dy = q0.y - fy;
             // forward.cu:507-508
-            const float power = -0.5f * ((q0.z * dx * dx + q1.x * dy * dy) + 2.f * q0.w * dx * dy);
-            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
+            const float alpha = fminf(0.99f, q1.y * exp_nonpositive(power));
             // skip rules :512,:545 ; a saturated pixel stops before blending (:549-552)
             bool live = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const float test_T = T * (1.f - alpha);
+            const float test_T = mul_one_minus(T, alpha);
             if (live && test_T < 0.0001f) {
                 done = true;
                 live = false;

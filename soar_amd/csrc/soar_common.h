@@ -80,6 +80,36 @@ int carve_binning(void *base, int64_t R, BinBuf *out);
 // [9..11] dL_dnormal  [12] dL_ddepth  [13..15] unused
 constexpr int ACC_STRIDE = 16;
 
+#if defined(__HIPCC__)
+// exp(x) for x <= 0 to ~1 ulp: v_exp_f32 on the rounded product x*log2(e), corrected for the product's rounding
+// error.  (The hardware exp2 alone leaves up to 4e-7 relative error at |x| ~ 6, which the blend amplifies by
+// 1/(1-alpha) <= 100; the reference's expf is a <= 2 ulp routine.)
+__device__ __forceinline__ float exp_nonpositive(float x)
+{
+    const float L2E_HI = 1.44269502162933349609375f;   // 0x3fb8aa3b
+    const float L2E_LO = 1.925963033500011e-08f;        // 0x32a5705f
+    const float t = x * L2E_HI;
+    float lo = __builtin_fmaf(x, L2E_HI, -t);
+    lo = __builtin_fmaf(x, L2E_LO, lo);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, lo * 0.693147180559945309f, e);
+}
+
+// Gaussian falloff exponent exactly as the reference writes it (forward.cu:507-508, backward.cu:663-664), evaluated
+// without FMA contraction so that the skip / saturation decisions see the same value as an IEEE evaluation.
+__device__ __forceinline__ float falloff_power(float A, float B, float Cc, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    const float dist = (A * dx * dx + Cc * dy * dy) + 2 * B * dx * dy;
+    return -0.5f * dist;
+}
+__device__ __forceinline__ float mul_one_minus(float T, float alpha)
+{
+#pragma clang fp contract(off)
+    return T * (1.f - alpha);
+}
+#endif
+
 uint32_t higher_msb(uint32_t n);   // getHigherMsb, rasterizer_impl.cu:35-48
 size_t scan_temp_bytes(int32_t P);
 size_t sort_temp_bytes(int64_t R);

@@ -52,23 +52,21 @@ class GaussianRasterizationSettings(NamedTuple):
 # ---------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------
-_config_cache = {}
-
-
 def _config_flags(config: torch.Tensor) -> Tuple[int, int, int, int]:
     """``config[i] > 0`` for i < 4 as host ints.  The reference reads the float tensor inside its kernels
-    (forward.cu:275,464; backward.cu:285,475,581); here the four switches travel by value, so the tensor is
-    read back once per (storage, version) and cached."""
-    key = (config.data_ptr(), config._version, str(config.device), config.numel())
-    hit = _config_cache.get(key)
-    if hit is None:
-        vals = config.detach().float().reshape(-1).cpu().tolist()
-        vals = vals + [0.0] * (4 - len(vals))
-        hit = tuple(int(v > 0) for v in vals[:4])
-        if len(_config_cache) > 64:
-            _config_cache.clear()
-        _config_cache[key] = hit
-    return hit
+    (forward.cu:275,464; backward.cu:285,475,581); here the four switches travel by value, so the tensor is read back
+    once and the result is remembered ON the tensor object (invalidated by in-place writes through ``_version``)."""
+    memo = getattr(config, "_soar_flags", None)
+    if memo is not None and memo[0] == config._version:
+        return memo[1]
+    vals = config.detach().float().reshape(-1).cpu().tolist()
+    vals = vals + [0.0] * (4 - len(vals))
+    flags = tuple(int(v > 0) for v in vals[:4])
+    try:
+        config._soar_flags = (config._version, flags)
+    except Exception:
+        pass
+    return flags
 
 
 def _dev_f32(t: torch.Tensor, device: torch.device, name: str) -> torch.Tensor:
