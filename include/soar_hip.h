@@ -160,6 +160,16 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
  *   out[i] = mean of the 3 smallest squared distances from point i to the other points. */
 int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
 
+/* ---- per-stage timing (no reference counterpart; used by bench.py for the roofline figure) ----
+ * When enabled, every kernel stage is bracketed by two hipEvents recorded on the launch stream.
+ * soar_prof_read synchronises the pending events and returns the accumulated device time and launch count of
+ * one stage (ids/names via soar_prof_stage_count / soar_prof_stage_name). */
+int soar_prof_enable(int on);
+int soar_prof_reset(void);
+int soar_prof_stage_count(void);
+const char *soar_prof_stage_name(int stage);
+int soar_prof_read(int stage, double *total_ms, int64_t *launches);
+
 const char *soar_last_error(void);
 int soar_abi_version(void);
 

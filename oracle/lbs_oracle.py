@@ -1,0 +1,175 @@
+"""oracle/lbs_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (torch fp32 on the CPU, autograd for gradients) of the LBS half of SOAR's per-frame path.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+What follows which reference lines (relative to /root/reference/soar/threestudio-soar/, "TS/"):
+
+* ``batch_rodrigues`` / ``batch_rigid_transform`` / ``joint_transforms``: TS/utils/smplx/lbs.py:293-396 and the ``A``
+  part of ``lbs()`` (:197-226) + ``A[..., :3, 3] += transl`` (TS/utils/smplx/body_models.py:1383).
+  PINNED: tests/golden/smplx_joint_transforms.npz holds outputs of the reference's own ``lbs(...,
+  return_affine_mat=True)`` imported from /root/reference in the build container (tests/golden/make_lbs_golden.py).
+* ``quaternion_to_matrix``: pytorch3d semantics; an in-tree copy exists at TS/data/uncond_multiview.py:2422-2450.
+  PINNED against that copy's outputs (same golden script, function extracted and executed from the reference file).
+* ``matrix_to_quaternion``: pytorch3d (unpinned HEAD, setup.py:146) is NOT vendored in the reference: restated from the
+  published algorithm (4 candidates, argmax of q_abs, divide by 2*max(q_abs, 0.1), standardize to non-negative real part).
+  PARITY UNPINNED for this function (quaternion sign is irrelevant downstream: the rasterizer only uses R(q)).
+* ``query_weights`` : SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637); knn_points (pytorch3d, not vendored)
+  restated as exact brute-force K-NN on squared distances, ascending.  PARITY UNPINNED (TS/utils/smpl.py is not
+  importable here: needs threestudio / pytorch3d / trimesh).
+* ``warp``: TS/utils/smpl.py:609-613 (cano2live, einsum blend) + TS/renderer/diff_gaussian_rasterizer.py:103-114 /
+  :138-149 (apply, optional axis permutation from transform_point_cloud :321-352).  ``transform_point_cloud`` is PINNED
+  (golden script executes the reference function); the rest is a restatement.
+* ``dist2_knn3``: simple-knn distCUDA2 (submodule empty, no SHA: PARITY UNPINNED), published semantics: mean of the
+  three smallest squared distances to OTHER points.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---- SMPL-X joint transforms (lbs.py) ---------------------------------------------------------
+def batch_rodrigues(rot_vecs: torch.Tensor) -> torch.Tensor:
+    batch_size = rot_vecs.shape[0]
+    dtype = rot_vecs.dtype
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)              # lbs.py:311
+    rot_dir = rot_vecs / angle
+    cos = torch.unsqueeze(torch.cos(angle), dim=1)
+    sin = torch.unsqueeze(torch.sin(angle), dim=1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((batch_size, 1), dtype=dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view((batch_size, 3, 3))
+    ident = torch.eye(3, dtype=dtype).unsqueeze(dim=0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def batch_rigid_transform(rot_mats, joints, parents):
+    """lbs.py:343-396, including the serial chain over the kinematic tree."""
+    joints = torch.unsqueeze(joints, dim=-1)
+    rel_joints = joints.clone()
+    rel_joints[:, 1:] -= joints[:, parents[1:]]
+    R = rot_mats.reshape(-1, 3, 3)
+    t = rel_joints.reshape(-1, 3, 1)
+    transforms_mat = torch.cat([F.pad(R, [0, 0, 0, 1]), F.pad(t, [0, 0, 0, 1], value=1)], dim=2).reshape(
+        -1, joints.shape[1], 4, 4)
+    chain = [transforms_mat[:, 0]]
+    for i in range(1, parents.shape[0]):
+        chain.append(torch.matmul(chain[parents[i]], transforms_mat[:, i]))
+    transforms = torch.stack(chain, dim=1)
+    joints_homogen = F.pad(joints, [0, 0, 0, 1])
+    rel_transforms = transforms - F.pad(torch.matmul(transforms, joints_homogen), [3, 0, 0, 0, 0, 0, 0, 0])
+    return transforms[:, :, :3, 3], rel_transforms
+
+
+def joint_transforms(betas, full_pose, v_template, shapedirs, J_regressor, parents, transl=None):
+    """``A`` of lbs() (lbs.py:197-226) with transl added (body_models.py:1383).  betas [B,NB], full_pose [B,J*3]."""
+    batch_size = max(betas.shape[0], full_pose.shape[0])
+    v_shaped = v_template + torch.einsum("bl,mkl->bmk", [betas, shapedirs])
+    J = torch.einsum("bik,ji->bjk", [v_shaped, J_regressor])
+    rot_mats = batch_rodrigues(full_pose.reshape(-1, 3)).view([batch_size, -1, 3, 3])
+    _, A = batch_rigid_transform(rot_mats, J, parents)
+    if transl is not None:
+        A = A.clone()
+        A[:, :, :3, 3] += transl.unsqueeze(dim=1)
+    return A
+
+
+# ---- rotation conversions (pytorch3d semantics) -------------------------------------------------
+def quaternion_to_matrix(quaternions: torch.Tensor) -> torch.Tensor:
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def _sqrt_positive_part(x: torch.Tensor) -> torch.Tensor:
+    ret = torch.zeros_like(x)
+    positive_mask = x > 0
+    ret = torch.where(positive_mask, torch.sqrt(torch.where(positive_mask, x, torch.ones_like(x))), ret)
+    return ret
+
+
+def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:
+    batch_dim = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch_dim + (9,)), dim=-1)
+    q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
+                                             1.0 - m00 - m11 + m22], dim=-1))
+    quat_by_rijk = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    flr = torch.tensor(0.1).to(dtype=q_abs.dtype)
+    quat_candidates = quat_by_rijk / (2.0 * q_abs[..., None].max(flr))
+    best = F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5
+    out = quat_candidates[best, :].reshape(batch_dim + (4,))
+    return torch.where(out[..., 0:1] < 0, -out, out)          # standardize_quaternion
+
+
+# ---- blend weights (smpl.py:618-637) ------------------------------------------------------------
+def knn_brute(x: torch.Tensor, verts: torch.Tensor, K: int = 30, chunk: int = 2048):
+    """Exact K nearest vertices on squared distances, ascending -> (d2 [P,K], idx [P,K])."""
+    d_out, i_out = [], []
+    for s in range(0, x.shape[0], chunk):
+        xs = x[s:s + chunk]
+        diff = xs[:, None, :] - verts[None, :, :]
+        d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        d, i = torch.topk(d2, K, dim=1, largest=False, sorted=True)
+        d_out.append(d)
+        i_out.append(i)
+    return torch.cat(d_out), torch.cat(i_out)
+
+
+def query_weights(x: torch.Tensor, smpl_verts: torch.Tensor, smpl_weights: torch.Tensor, K: int = 30, knn=None):
+    my_dist, my_idx = knn if knn is not None else knn_brute(x, smpl_verts, K)
+    my_dist = my_dist.sqrt().clamp(0.0001, 1.0)
+    weights = smpl_weights[my_idx]
+    ws = 1.0 / my_dist
+    ws = ws / (ws.sum(-1)[..., None])
+    return (ws[..., None] * weights).sum(-2)
+
+
+# ---- warp (smpl.py:609-613 + diff_gaussian_rasterizer.py:103-114,138-149) ---------------------------
+def axis_perm_matrix(dirs: str = "+z,+x,+y") -> torch.Tensor:
+    """transform_point_cloud's T (diff_gaussian_rasterizer.py:321-352): column i is the direction vector of dirs[i]."""
+    dir2vec = {"+x": [1, 0, 0], "+y": [0, 1, 0], "+z": [0, 0, 1], "-x": [-1, 0, 0], "-y": [0, -1, 0], "-z": [0, 0, -1]}
+    T = np.zeros((3, 3))
+    for i, d in enumerate(dirs.split(",")):
+        T[:, i] = dir2vec[d]
+    return torch.from_numpy(T).float()
+
+
+def warp(points: torch.Tensor, rot: torch.Tensor, weights: torch.Tensor, cano2live: torch.Tensor,
+         offsets: Optional[torch.Tensor] = None, T: Optional[torch.Tensor] = None):
+    """points [P,3], rot [P,4], weights [P,J], cano2live [J,4,4] -> (points', rot', pt_mats[1,P,4,4])."""
+    mat = torch.einsum("bnj,bjxy->bnxy", weights[None], cano2live[None])                       # smpl.py:613
+    pts = (torch.einsum("bnxy,bny->bnx", mat[..., :3, :3], points[None]) + mat[..., :3, 3])[0]  # :103-106
+    if offsets is not None:
+        pts = pts + offsets
+    rot_mat = quaternion_to_matrix(rot)
+    rot_mat = torch.matmul(mat[..., :3, :3], rot_mat)
+    if T is not None:
+        pts = torch.matmul(pts, T)
+        rot_mat = torch.matmul(T.T, rot_mat)
+    q = matrix_to_quaternion(rot_mat)
+    q = F.normalize(q, p=2, dim=-1)[0]
+    return pts, q, mat
+
+
+def dist2_knn3(points: np.ndarray) -> np.ndarray:
+    p = torch.as_tensor(points, dtype=torch.float32)
+    out = torch.empty(p.shape[0])
+    for s in range(0, p.shape[0], 1024):
+        diff = p[s:s + 1024, None, :] - p[None, :, :]
+        d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        idx = torch.arange(s, min(s + 1024, p.shape[0]))
+        d2[torch.arange(idx.numel()), idx] = float("inf")          # exclude the point itself (by index)
+        b, _ = torch.topk(d2, 3, dim=1, largest=False, sorted=True)
+        out[s:s + 1024] = ((b[:, 0] + b[:, 1]) + b[:, 2]) / 3.0
+    return out.numpy()

@@ -34,6 +34,49 @@ int post_launch(const char *what, hipStream_t stream, int debug)
     return 1;
 }
 
+// ---- per-stage event timing -----------------------------------------------------------------------
+namespace {
+struct ProfSlot { hipEvent_t a, b; int stage; bool open; };
+constexpr int PROF_SLOTS = 4096;
+bool g_prof_on = false;
+ProfSlot g_slots[PROF_SLOTS];
+int g_slot_used = 0;
+bool g_slots_init = false;
+double g_stage_ms[ST_COUNT];
+long long g_stage_n[ST_COUNT];
+const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "emit_keys", "sort", "tile_ranges", "render_forward",
+                                       "render_backward", "geometry_backward", "lbs_knn_weights", "lbs_warp_forward",
+                                       "lbs_warp_backward", "dist2_knn3"};
+void prof_drain()
+{
+    for (int i = 0; i < g_slot_used; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_slots[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_slots[i].a, g_slots[i].b) == hipSuccess) {
+            g_stage_ms[g_slots[i].stage] += ms;
+            g_stage_n[g_slots[i].stage] += 1;
+        }
+    }
+    g_slot_used = 0;
+}
+}  // namespace
+
+StageTimer::StageTimer(int stage, hipStream_t s) : slot(-1), stream(s)
+{
+    if (!g_prof_on) return;
+    if (!g_slots_init) {
+        for (int i = 0; i < PROF_SLOTS; i++) { (void)hipEventCreate(&g_slots[i].a); (void)hipEventCreate(&g_slots[i].b); }
+        g_slots_init = true;
+    }
+    if (g_slot_used == PROF_SLOTS) prof_drain();
+    slot = g_slot_used++;
+    g_slots[slot].stage = stage;
+    (void)hipEventRecord(g_slots[slot].a, stream);
+}
+StageTimer::~StageTimer()
+{
+    if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, stream);
+}
+
 // ---- scratch carving (bump allocation, 256-byte aligned; same idea as obtain(), rasterizer_impl.h:22-28) ----
 template <typename T>
 static void take(char *&p, T *&ptr, size_t count)
@@ -116,6 +159,24 @@ using namespace soar;
 extern "C" {
 
 const char *soar_last_error(void) { return g_error; }
+
+int soar_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+int soar_prof_reset(void)
+{
+    prof_drain();
+    for (int i = 0; i < ST_COUNT; i++) { g_stage_ms[i] = 0.0; g_stage_n[i] = 0; }
+    return 0;
+}
+int soar_prof_stage_count(void) { return ST_COUNT; }
+const char *soar_prof_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? g_stage_names[stage] : ""; }
+int soar_prof_read(int stage, double *total_ms, int64_t *launches)
+{
+    if (stage < 0 || stage >= ST_COUNT || !total_ms || !launches) { set_error("soar_prof_read: bad arguments"); return 1; }
+    prof_drain();
+    *total_ms = g_stage_ms[stage];
+    *launches = g_stage_n[stage];
+    return 0;
+}
 int soar_abi_version(void) { return SOAR_HIP_ABI_VERSION; }
 
 int soar_rast_geometry_bytes(int32_t P, int32_t M, size_t *bytes)

@@ -405,6 +405,7 @@ int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_
     if (K > KNN_MAXK || K > V) { set_error("soar_lbs_knn_weights: K=%d unsupported (max %d, V=%d)", K, KNN_MAXK, V); return 1; }
     if (P == 0) return 0;
     if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
+    StageTimer timer(ST_LBS_KNN, stream);
     hipLaunchKernelGGL(knn_weights_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P,
                        verts, V, vert_weights, J, K, weights_out, knn_idx_out);
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
@@ -430,6 +431,7 @@ int soar_lbs_warp_forward(const float *xyz, const float *rot, const float *weigh
     a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.offsets = offsets;
     a.axis_perm = axis_perm; a.xyz_out = xyz_out; a.rot_out = rot_out; a.pt_mats_out = pt_mats_out;
     const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    StageTimer timer(ST_LBS_WARP_FWD, stream);
     hipLaunchKernelGGL(warp_forward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
     SOAR_LAUNCH_OK("lbs_warp_forward", stream, 0);
     return 0;
@@ -447,6 +449,7 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
     a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.axis_perm = axis_perm;
     a.g_xyz_out = dL_dxyz_out; a.g_rot_out = dL_drot_out; a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
     const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    StageTimer timer(ST_LBS_WARP_BWD, stream);
     hipLaunchKernelGGL(warp_backward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
     SOAR_LAUNCH_OK("lbs_warp_backward", stream, 0);
     return 0;
@@ -458,6 +461,7 @@ int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream_)
     if (N < 0) { set_error("soar_dist2_knn3: N < 0"); return 1; }
     if (N == 0) return 0;
     if (!points || !out) { set_error("soar_dist2_knn3: NULL pointer"); return 1; }
+    StageTimer timer(ST_DIST2, stream);
     hipLaunchKernelGGL(dist2_knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, points, N, out);
     SOAR_LAUNCH_OK("dist2_knn3", stream, 0);
     return 0;

@@ -49,6 +49,7 @@ size_t sort_temp_bytes(int64_t R)
 
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream)
 {
+    StageTimer timer(ST_SCAN, stream);
     size_t bytes = g.scan_temp_bytes;
     SOAR_HIP_OK(rocprim::inclusive_scan(g.scan_temp, bytes, g.tiles_touched, g.point_offsets, (size_t)prm.P,
                                         rocprim::plus<uint32_t>(), stream));
@@ -116,12 +117,17 @@ int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, 
     SOAR_HIP_OK(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, stream));
     if (R <= 0) return 0;
 
+    {
+    StageTimer timer(ST_EMIT_KEYS, stream);
     hipLaunchKernelGGL(emit_keys_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, prm.P, g.rec, g.point_offsets,
                        radii, b.keys_unsorted, b.vals_unsorted, gx, gy);
+    }
     SOAR_LAUNCH_OK("emit_keys", stream, prm.debug);
 
     const unsigned end_bit = 32u + higher_msb((uint32_t)(gx * gy));
     size_t bytes = b.sort_temp_bytes;
+    {
+    StageTimer timer(ST_SORT, stream);
     if (!prm.sort_descending) {
         SOAR_HIP_OK(rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys_sorted, b.vals_unsorted,
                                               b.vals_sorted, (size_t)R, 0u, end_bit, stream));
@@ -129,10 +135,14 @@ int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, 
         SOAR_HIP_OK(rocprim::radix_sort_pairs_desc(b.sort_temp, bytes, b.keys_unsorted, b.keys_sorted, b.vals_unsorted,
                                                    b.vals_sorted, (size_t)R, 0u, end_bit, stream));
     }
+    }
     SOAR_LAUNCH_OK("radix_sort_pairs", stream, prm.debug);
 
+    {
+    StageTimer timer(ST_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_sorted,
                        img.ranges);
+    }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
     return 0;
 }

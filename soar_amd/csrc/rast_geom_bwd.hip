@@ -369,6 +369,7 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
     SOAR_HIP_OK(hipMemsetAsync(dL_dviewmat, 0, 16 * sizeof(float), stream));
     SOAR_HIP_OK(hipMemsetAsync(dL_dprojmat, 0, 16 * sizeof(float), stream));
     SOAR_HIP_OK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+    StageTimer timer(ST_GEOM_BWD, stream);
     hipLaunchKernelGGL(geometry_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("geometry_backward", stream, prm.debug);
     return 0;

@@ -335,6 +335,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
     a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.radii = radii;
     const int threads = 256;
     const int blocks = (prm.P + threads - 1) / threads;
+    StageTimer timer(ST_PREPROCESS, stream);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, stream, a);
     SOAR_LAUNCH_OK("preprocess", stream, prm.debug);
     return 0;

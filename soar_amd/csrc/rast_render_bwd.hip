@@ -213,6 +213,7 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc;
+    StageTimer timer(ST_RENDER_BWD, stream);
     hipLaunchKernelGGL(render_backward_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_backward", stream, prm.debug);
     return 0;

@@ -138,6 +138,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.ranges = img.ranges; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
+    StageTimer timer(ST_RENDER_FWD, stream);
     hipLaunchKernelGGL(render_forward_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
     return 0;

@@ -1,0 +1,130 @@
+"""SMPL-X linear-blend-skinning of canonical Gaussian surfels on MI355X (host side of ``soar_lbs_*``).
+
+* ``knn_blend_weights``  == ``SMPL_Guidance.query_weights_smpl``            (TS/utils/smpl.py:618-637)
+* ``lbs_warp``           == blend (TS/utils/smpl.py:613) + apply (TS/renderer/diff_gaussian_rasterizer.py:103-114 and
+  :138-149) as ONE fused HIP kernel with an analytic backward (autograd.Function); gradients flow to the canonical
+  ``xyz`` and ``rot`` only -- weights and joint matrices are constants in the reference as well (smpl.py:611,543-545).
+* ``dist2_knn3``         == simple-knn ``distCUDA2``                          (TS/geometry/surfel_base.py:499-503)
+
+No CPU fallback: tensors must live on a HIP (``cuda``) device.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip_lib
+from .hip_lib import check, ptr
+
+KNN_K = 30      # hard-coded in the reference (the K argument is ignored, smpl.py:618,628)
+
+
+def _need_hip(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on '{t.device}': soar_amd runs on HIP devices only; there is no CPU fallback")
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def knn_blend_weights(xyz: torch.Tensor, verts: torch.Tensor, vert_weights: torch.Tensor, K: int = KNN_K,
+                      return_idx: bool = False):
+    """xyz [P,3], verts [V,3], vert_weights [V,J] -> weights [P,J] (detached), optionally the K-NN indices [P,K]."""
+    _need_hip(xyz, "xyz")
+    L = hip_lib.lib()
+    x, v, w = _f32(xyz), _f32(verts.to(xyz.device)), _f32(vert_weights.to(xyz.device))
+    P, V, J = x.shape[0], v.shape[0], w.shape[-1]
+    w = w.reshape(V, J)
+    out = torch.empty((P, J), dtype=torch.float32, device=x.device)
+    idx = torch.empty((P, K), dtype=torch.int32, device=x.device) if return_idx else None
+    with torch.cuda.device(x.device):
+        check(L.soar_lbs_knn_weights(ptr(x), P, ptr(v), V, ptr(w), J, K, ptr(out), ptr(idx), _stream(x.device)),
+              "soar_lbs_knn_weights")
+    return (out, idx) if return_idx else out
+
+
+class _LbsWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, rot, weights, joint_mats, offsets, axis_perm):
+        _need_hip(xyz, "xyz")
+        L = hip_lib.lib()
+        dev = xyz.device
+        x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
+        off = _f32(offsets) if offsets is not None else None
+        T = _f32(axis_perm.to(dev)) if axis_perm is not None else None
+        P, J = x.shape[0], A.shape[0]
+        if w.shape != (P, J):
+            raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
+        xyz_out = torch.empty_like(x)
+        rot_out = torch.empty_like(q)
+        with torch.cuda.device(dev):
+            check(L.soar_lbs_warp_forward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(off), ptr(T), P, J, ptr(xyz_out),
+                                          ptr(rot_out), None, _stream(dev)), "soar_lbs_warp_forward")
+        ctx.save_for_backward(x, q, w, A, T if T is not None else torch.empty(0, device=dev))
+        ctx.has_offsets = offsets is not None and offsets.requires_grad
+        return xyz_out, rot_out
+
+    @staticmethod
+    def backward(ctx, g_xyz_out, g_rot_out):
+        L = hip_lib.lib()
+        x, q, w, A, T = ctx.saved_tensors
+        dev = x.device
+        P, J = x.shape[0], A.shape[0]
+        gx = _f32(g_xyz_out) if g_xyz_out is not None else torch.zeros_like(x)
+        gq = _f32(g_rot_out) if g_rot_out is not None else torch.zeros_like(q)
+        g_xyz = torch.empty_like(x)
+        g_rot = torch.empty_like(q)
+        with torch.cuda.device(dev):
+            check(L.soar_lbs_warp_backward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(T), P, J, ptr(gx), ptr(gq), ptr(g_xyz),
+                                           ptr(g_rot), _stream(dev)), "soar_lbs_warp_backward")
+        g_off = None
+        if ctx.has_offsets:
+            # p'' = (p' + offsets) T  ->  dL/doffsets = T g
+            g_off = gx if T.numel() == 0 else gx @ T.t()
+        return g_xyz, g_rot, None, None, g_off, None
+
+
+def lbs_warp(xyz: torch.Tensor, rot: torch.Tensor, weights: torch.Tensor, joint_mats: torch.Tensor,
+             offsets: Optional[torch.Tensor] = None, axis_perm: Optional[torch.Tensor] = None
+             ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Warp canonical surfels into a posed frame.
+
+    xyz [P,3], rot [P,4] (r,x,y,z), weights [P,J], joint_mats [J,4,4] (cano2live = A_live @ inv(A_cano)),
+    offsets [P,3] optional, axis_perm [3,3] optional (the "+z,+x,+y" matrix T of transform_point_cloud,
+    diff_gaussian_rasterizer.py:321-352) -> (xyz' [P,3], rot' [P,4] unit quaternions)."""
+    return _LbsWarp.apply(xyz, rot, weights, joint_mats, offsets, axis_perm)
+
+
+def point_transforms(xyz: torch.Tensor, rot: torch.Tensor, weights: torch.Tensor, joint_mats: torch.Tensor) -> torch.Tensor:
+    """pt_mats [P,4,4] = sum_j w[p,j] joint_mats[j]  (the tensor SMPL_Guidance.__call__ returns, smpl.py:613)."""
+    _need_hip(xyz, "xyz")
+    L = hip_lib.lib()
+    dev = xyz.device
+    x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
+    P, J = x.shape[0], A.shape[0]
+    mats = torch.empty((P, 4, 4), dtype=torch.float32, device=dev)
+    xo, qo = torch.empty_like(x), torch.empty_like(q)
+    with torch.cuda.device(dev):
+        check(L.soar_lbs_warp_forward(ptr(x), ptr(q), ptr(w), ptr(A), None, None, P, J, ptr(xo), ptr(qo), ptr(mats),
+                                      _stream(dev)), "soar_lbs_warp_forward")
+    return mats
+
+
+def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
+    """simple-knn ``distCUDA2``: mean squared distance of every point to its 3 nearest other points."""
+    _need_hip(points, "points")
+    L = hip_lib.lib()
+    p = _f32(points).reshape(-1, 3)
+    out = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        check(L.soar_dist2_knn3(ptr(p), p.shape[0], ptr(out), _stream(p.device)), "soar_dist2_knn3")
+    return out
+
+
+distCUDA2 = dist2_knn3      # the name the reference imports from simple_knn._C

@@ -1,0 +1,115 @@
+"""GPU parity tests of the LBS kernels (through the C ABI) against oracle/lbs_oracle.py (torch CPU + autograd)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lbs_oracle as lo
+from soar_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(P=4000, seed=0, V=syn.SMPLX_NUM_VERTS):
+    s = syn.make_surfels(P, seed)
+    bm = syn.make_body_model(seed, V=V)
+    poses = syn.make_pose_sequence(8, seed)
+    betas = torch.cat([poses["betas"], poses["expression"][:1]], dim=1)
+    A_cano = lo.joint_transforms(betas, torch.zeros(1, 165), bm.v_template[None], bm.shapedirs, bm.J_regressor, bm.parents,
+                                 torch.tensor([[0.0, 0.3, 0.0]]))
+    A_live = lo.joint_transforms(betas, poses["full_pose"][3:4], bm.v_template[None], bm.shapedirs, bm.J_regressor,
+                                 bm.parents, poses["transl"][3:4])
+    cano2live = torch.matmul(A_live, torch.linalg.inv(A_cano))[0]
+    return s, bm, cano2live
+
+
+def test_knn_blend_weights_match_oracle():
+    from soar_amd import lbs
+    s, bm, _ = _setup(P=3000)
+    w_ref = lo.query_weights(s.xyz, bm.v_template, bm.lbs_weights)
+    d_ref, i_ref = lo.knn_brute(s.xyz, bm.v_template, 30)
+    w, idx = lbs.knn_blend_weights(s.xyz.to(DEV), bm.v_template.to(DEV), bm.lbs_weights.to(DEV), return_idx=True)
+    idx = idx.cpu().numpy()
+    # index sets are exact except where two candidates tie within fp32 rounding of d2 at the K-th place
+    same_rows = (np.sort(idx, 1) == np.sort(i_ref.numpy(), 1)).all(1)
+    assert same_rows.mean() > 0.995
+    np.testing.assert_allclose(w.cpu().numpy()[same_rows], w_ref.numpy()[same_rows], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("use_T,use_off", [(False, False), (True, False), (True, True)])
+def test_warp_forward_backward_match_oracle(use_T, use_off):
+    from soar_amd import lbs
+    s, bm, cano2live = _setup(P=3000, seed=1)
+    w = lo.query_weights(s.xyz, bm.v_template, bm.lbs_weights)
+    T = lo.axis_perm_matrix("+z,+x,+y") if use_T else None
+    gen = torch.Generator().manual_seed(5)
+    off = 0.01 * torch.randn(s.xyz.shape, generator=gen) if use_off else None
+    # un-normalised quaternions on purpose: quaternion_to_matrix divides by |q|^2
+    rot0 = s.rot * (0.5 + torch.rand(s.rot.shape[0], 1, generator=gen))
+    xyz_c = s.xyz.clone().requires_grad_(True)
+    rot_c = rot0.clone().requires_grad_(True)
+    p_ref, q_ref, mats_ref = lo.warp(xyz_c, rot_c, w, cano2live, off, T)
+    gp = torch.randn(p_ref.shape, generator=gen)
+    gq = torch.randn(q_ref.shape, generator=gen)
+    ((p_ref * gp).sum() + (q_ref * gq).sum()).backward()
+
+    xyz_g = s.xyz.to(DEV).requires_grad_(True)
+    rot_g = rot0.to(DEV).requires_grad_(True)
+    p, q = lbs.lbs_warp(xyz_g, rot_g, w.to(DEV), cano2live.to(DEV), off.to(DEV) if use_off else None,
+                        T.to(DEV) if use_T else None)
+    ((p * gp.to(DEV)).sum() + (q * gq.to(DEV)).sum()).backward()
+    np.testing.assert_allclose(p.detach().cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    # quaternion sign is standardised (non-negative real part) on both sides
+    np.testing.assert_allclose(q.detach().cpu().numpy(), q_ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(xyz_g.grad.cpu().numpy(), xyz_c.grad.numpy(), rtol=1e-4, atol=1e-5)
+    scale = rot_c.grad.abs().max().item()
+    assert (rot_g.grad.cpu() - rot_c.grad).abs().max().item() <= 1e-4 * scale
+    if not use_T and not use_off:
+        mats = lbs.point_transforms(s.xyz.to(DEV), rot0.to(DEV), w.to(DEV), cano2live.to(DEV))
+        np.testing.assert_allclose(mats.cpu().numpy(), mats_ref[0].detach().numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_warp_ragged_and_empty():
+    from soar_amd import lbs
+    s, bm, cano2live = _setup(P=300, seed=2, V=512)
+    w = lo.query_weights(s.xyz, bm.v_template, bm.lbs_weights)
+    for P in (1, 255, 257):
+        p, q = lbs.lbs_warp(s.xyz[:P].to(DEV), s.rot[:P].to(DEV), w[:P].to(DEV), cano2live.to(DEV))
+        p_ref, q_ref, _ = lo.warp(s.xyz[:P], s.rot[:P], w[:P], cano2live)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=2e-5)
+    p, q = lbs.lbs_warp(s.xyz[:0].to(DEV), s.rot[:0].to(DEV), w[:0].to(DEV), cano2live.to(DEV))
+    assert p.shape == (0, 3) and q.shape == (0, 4)
+
+
+def test_dist2_knn3_matches_oracle():
+    from soar_amd import lbs
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.randn(2500, 3, generator=gen)
+    pts[10] = pts[11]                                   # duplicate point: distance 0 counts (self excluded by index)
+    ref = lo.dist2_knn3(pts.numpy())
+    got = lbs.dist2_knn3(pts.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9)
+    assert got[10] < ref.mean() and lbs.distCUDA2 is lbs.dist2_knn3
+
+
+def test_full_size_properties_C1():
+    """10k canonical Gaussians, SMPL-X-sized vertex set: identity joints leave the cloud unchanged; weights are a
+    partition of unity; a rigid global transform moves every point rigidly."""
+    from soar_amd import lbs
+    s = syn.make_surfels(10000, 4)
+    bm = syn.make_body_model(4)
+    w = lbs.knn_blend_weights(s.xyz.to(DEV), bm.v_template.to(DEV), bm.lbs_weights.to(DEV))
+    assert torch.allclose(w.sum(1), torch.ones(10000, device=DEV), atol=1e-5) and (w >= 0).all()
+    eye = torch.eye(4, device=DEV)[None].repeat(55, 1, 1)
+    p, q = lbs.lbs_warp(s.xyz.to(DEV), s.rot.to(DEV), w, eye)
+    assert torch.allclose(p.cpu(), s.xyz, atol=1e-6)
+    assert torch.allclose(lo.quaternion_to_matrix(q.cpu()), lo.quaternion_to_matrix(s.rot), atol=1e-5)
+    Rg = lo.batch_rodrigues(torch.tensor([[0.3, -0.2, 0.5]]))[0]
+    G = torch.eye(4)
+    G[:3, :3] = Rg
+    G[:3, 3] = torch.tensor([0.1, 0.2, 0.3])
+    p, q = lbs.lbs_warp(s.xyz.to(DEV), s.rot.to(DEV), w, G.to(DEV)[None].repeat(55, 1, 1))
+    assert torch.allclose(p.cpu(), s.xyz @ Rg.T + G[:3, 3], atol=2e-6)
+    assert torch.allclose(lo.quaternion_to_matrix(q.cpu()), Rg @ lo.quaternion_to_matrix(s.rot), atol=1e-5)
