@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd frames/s of SOAR's per-frame avatar path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One STEP = one pass of the hot path over one batch of `--frames-per-step` (default 4) synthetic video frames per GPU:
+KNN blend weights once, then per frame  LBS warp -> main rasterize fwd -> occlusion rasterize fwd (no grad) ->
+backward through the main rasterizer and the warp, gradients of the shared Gaussians accumulating in one flat buffer;
+with N > 1 the step ends with ONE RCCL all-reduce of that buffer (frame data-parallel, weak scaling).
+Workload (default): BASELINE config C3 -- 100k Gaussians, 1080x1920, 400-frame sequence, batch = 4 frames.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (P, W, H, frames)
+    "C2": (50_000, 960, 540, 1),
+    "C3": (100_000, 1920, 1080, 400),
+    "C5": (300_000, 3840, 2160, 400),
+    "tiny": (5_000, 256, 192, 8),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(P, R, W, H):
+    """compulsory bytes per launch of every stage (passes = 6)."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    pix = W * H
+    passes = 6
+    return {
+        "preprocess": 160 * P, "scan": 8 * P, "emit_keys": 20 * P + 12 * R, "sort": 24 * passes * R,
+        "tile_ranges": 8 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix,
+        "render_backward": 44 * pix + 96 * R + 60 * P, "geometry_backward": (92 + 148) * P,
+        "lbs_warp_forward": 276 * P, "lbs_warp_backward": 304 * P,
+        "lbs_knn_weights": 232 * P + 232 * 10475,
+    }
+
+
+def frame_bytes(P, R_main, R_occ, W, H):
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    pix = W * H
+    b_rast = 488 * P + 356 * R_main + 16 * T + 88 * pix
+    b_occ = 188 * P + 260 * R_occ + 16 * T + 44 * pix
+    b_lbs = 580 * P
+    return b_rast + b_occ + b_lbs
+
+
+def build_sequence(workload, device, seed=0):
+    from soar_amd import synthetic as syn
+    from soar_amd.frame_step import AvatarSequence
+    P, W, H, F = WORKLOADS[workload]
+    surfels = syn.make_surfels(P, seed)
+    body = syn.make_body_model(seed)
+    poses = syn.make_pose_sequence(max(F, 4), seed)
+    cam = syn.make_camera(W, H)
+    seq = AvatarSequence(surfels, body, poses, cam, device)
+    targets = {k: v.to(device) for k, v in syn.make_loss_targets(H, W, seed).items()}
+    return seq, targets, (surfels, body, poses, cam)
+
+
+def synthetic_loss(out, targets):
+    """L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth)   """
+    return ((out.render - targets["color"]).abs().mean() + (out.mask - targets["mask"]).abs().mean()
+            + 0.1 * (out.normal * targets["normal"]).mean() + 0.01 * out.depth.mean())
+
+
+def run_step(seq, targets, flat, frames, bg):
+    flat.zero()
+    seq.refresh_blend_weights()
+    for f in frames:
+        out = seq.render_frame(f, bg, with_occ=True)
+        synthetic_loss(out, targets).backward()
+    return flat.all_reduce()
+
+
+def cpu_baseline(workload, parts, n_frames=2, seed=0):
+    """The CPU oracle ("port": plain-C restatement, OpenMP over tiles) + torch-CPU LBS on a bounded sample of the
+    same workload: `n_frames` full frames (LBS warp + main fwd+bwd + occlusion fwd) after one KNN-weights pass."""
+    from oracle import cpu_oracle as co
+    from oracle import lbs_oracle as lo
+    from scipy.spatial import cKDTree
+    from soar_amd import synthetic as syn
+    surfels, body, poses, cam = parts
+    P, W, H, F = WORKLOADS[workload]
+    threads = min(os.cpu_count() or 1, 32)          # beyond ~32 threads the tile loop stops scaling (atomics, dynamic schedule)
+    torch.set_num_threads(threads)
+    betas = torch.cat([poses["betas"], poses["expression"][:1]], dim=1)
+    cano_pose = torch.zeros(1, 165)
+    cano_pose[:, 5], cano_pose[:, 8] = 30 / 180 * np.pi, -30 / 180 * np.pi
+    A_cano = lo.joint_transforms(betas, cano_pose, body.v_template[None], body.shapedirs, body.J_regressor, body.parents,
+                                 torch.tensor([[0.0, 0.3, 0.0]]))
+    tg = syn.make_loss_targets(H, W, seed)
+    bg = np.array([0.2, 0.5, 0.7], np.float32)
+    st = lambda front: co.Settings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.world_view_transform.numpy(),
+                                   cam.full_proj_transform.numpy(), np.array([0, 0, H, W], np.float32),
+                                   cam.prcppoint.numpy(), 0, cam.camera_center.numpy(), render_front=front)
+    t0 = time.perf_counter()
+    # KNN blend weights once (kd-tree instead of brute force: fastest exact CPU form)
+    d, i = cKDTree(body.v_template.numpy()).query(surfels.xyz.numpy(), k=30, workers=threads)
+    w = lo.query_weights(surfels.xyz, body.v_template, body.lbs_weights,
+                         knn=(torch.from_numpy((d * d).astype(np.float32)), torch.from_numpy(i.astype(np.int64))))
+    for f in range(n_frames):
+        fp = poses["full_pose"][f:f + 1]
+        A_live = lo.joint_transforms(torch.cat([poses["betas"], poses["expression"][f:f + 1]], 1), fp, body.v_template[None],
+                                     body.shapedirs, body.J_regressor, body.parents, poses["transl"][f:f + 1])
+        c2l = torch.matmul(A_live, torch.linalg.inv(A_cano))[0]
+        xyz = surfels.xyz.clone().requires_grad_(True)
+        rot = surfels.rot.clone().requires_grad_(True)
+        p, q, _ = lo.warp(xyz, rot, w, c2l)
+        fw = co.rasterize_forward(st(False), p.detach().numpy(), surfels.opacity.numpy(), colors_precomp=surfels.colors.numpy(),
+                                  scales=surfels.scales.numpy(), rotations=q.detach().numpy(), n_threads=threads)
+        co.rasterize_forward(st(True), p.detach().numpy(), surfels.opacity.numpy(),
+                             colors_precomp=np.repeat(surfels.occ.numpy(), 3, 1), scales=surfels.scales.numpy(),
+                             rotations=q.detach().numpy(), n_threads=threads)
+        _, dC, dN, dD, dO = syn.loss_and_pixel_grads(*[torch.from_numpy(x) for x in (fw.out_color, fw.out_normal,
+                                                                                       fw.out_depth, fw.out_opac)], tg)
+        bw = co.rasterize_backward(fw, dC.numpy(), dN.numpy(), dD.numpy(), dO.numpy(), n_threads=threads)
+        (p * torch.from_numpy(bw.dL_dmeans3D)).sum().add((q * torch.from_numpy(bw.dL_drotations)).sum()).backward()
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_frames} full frames of {workload} ({P} Gaussians, {H}x{W}): KNN weights (kd-tree) once, then "
+                      f"per frame LBS warp fwd+bwd (torch CPU), main rasterize fwd+bwd and occlusion fwd "
+                      f"(oracle/rasterizer_oracle.c, OpenMP {threads} threads); {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-step", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from soar_amd import build, hip_lib, rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer, global_batch, shard_frames
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    L = hip_lib.lib()
+
+    seq, targets, parts = build_sequence(args.workload, device)
+    P, W, H, F = WORKLOADS[args.workload]
+    flat = FlatGradBuffer(seq.leaves())
+    bg = torch.tensor([0.2, 0.5, 0.7], device=device)
+    fps_per_rank = args.frames_per_step
+
+    def frames_of(step):
+        return shard_frames(global_batch(step, fps_per_rank, world, seq.num_frames), rank, world)
+
+    for s in range(args.warmup):
+        run_step(seq, targets, flat, frames_of(s), bg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    for k in rasterizer.stats:
+        rasterizer.stats[k] = 0
+    if not args.no_stage_timers:
+        L.soar_prof_reset()
+        L.soar_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(seq, targets, flat, frames_of(args.warmup + s), bg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.soar_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = args.steps * fps_per_rank * world
+    value = total_frames / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream during the timed region ----
+    roof = None
+    stages = {}
+    if not args.no_stage_timers:
+        for i in range(L.soar_prof_stage_count()):
+            ms, n = C.c_double(0), C.c_int64(0)
+            L.soar_prof_read(i, C.byref(ms), C.byref(n))
+            if n.value:
+                stages[L.soar_prof_stage_name(i).decode()] = (ms.value, n.value)
+        # main passes (fwd+bwd) vs occlusion passes (fwd only): half of the forward launches each
+        n_fwd = max(rasterizer.stats["forward_calls"], 1)
+        R_all = rasterizer.stats["num_rendered"] / n_fwd
+        R_main = rasterizer.stats["num_rendered_bwd"] / max(rasterizer.stats["backward_calls"], 1)
+        R_occ = 2 * R_all - R_main if n_fwd >= 2 else R_all
+        dom = max(stages, key=lambda k: stages[k][0]) if stages else None
+        if dom:
+            ms, n = stages[dom]
+            R_for = R_main if dom in ("render_backward", "geometry_backward") else R_all
+            bytes_per_launch = algorithmic_bytes(P, R_for, W, H).get(dom)
+            if bytes_per_launch:
+                avg_s = ms / n / 1e3
+                achieved = bytes_per_launch / avg_s / 1e9
+                traffic = None
+                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(pmc):
+                    try:
+                        traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                    except Exception:
+                        traffic = None
+                roof = {"bound": "hbm", "kernel": dom, "stage_total_ms": {k: round(v[0], 3) for k, v in stages.items()}, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_launch_us": round(1e3 * ms / n, 2), "launches": n,
+                        "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                        "whole_frame": {"algorithmic_bytes_per_frame": int(frame_bytes(P, R_main, R_occ, W, H)),
+                                        "achieved_GBs": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9, 2),
+                                        "frac": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+                        "stage_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in stages.items()}}
+
+    result = {
+        "metric": "fwd+bwd frames/sec @100k Gaussians, 1080p; achieved HBM GB/s vs roofline",
+        "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
+                               f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
+                               f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}",
+                   "num_rendered_main": int(rasterizer.stats["num_rendered_bwd"] / max(rasterizer.stats["backward_calls"], 1))},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.workload, parts)
+            except Exception as ex:          # the baseline must never hide the GPU number
+                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {ex!r}"}
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

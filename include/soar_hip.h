@@ -143,6 +143,8 @@ int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_
  *     p' = M3 p + t ; R' = M3 R(q) ; optionally p' <- p' T, R' <- T^T R' (axis_perm, row-major 3x3, may be NULL);
  *     q' = normalize(matrix_to_quaternion(R')).
  *   weights [P,J]; joint_mats [J,16] row-major 4x4 (cano2live = A_live @ inv(A_cano));
+ *   alternatively weights == NULL and joint_mats = one ready-made row-major 4x4 per Gaussian [P,16] (the pt_mats
+ *   tensor SMPL_Guidance.__call__ returns, TS/utils/smpl.py:613-615; J is ignored);
  *   offsets [P,3] optional additive offsets applied after the warp (cfg.offset, :107-108), may be NULL.
  *   xyz_out [P,3], rot_out [P,4]; pt_mats_out [P,16] optional (may be NULL). */
 int soar_lbs_warp_forward(const float *xyz, const float *rot, const float *weights, const float *joint_mats,

@@ -155,16 +155,28 @@ struct WarpArgs {
 constexpr int WARP_THREADS = 256;
 constexpr int WARP_MAXJ = 64;
 
-// blended 3x4 transform of one Gaussian: M[r*4+c] = sum_j w_j * A_j[r][c]; weights via LDS (coalesced tile load)
+// blended 3x4 transform of one Gaussian: M[r*4+c] = sum_j w_j * A_j[r][c]; weights via LDS (coalesced tile load).
+// With a.weights == nullptr, a.joint_mats holds one ready-made 4x4 per Gaussian (the pt_mats tensor that
+// SMPL_Guidance.__call__ returns) and is simply loaded.
 __device__ __forceinline__ void blend_matrix(const WarpArgs &a, float *wtile, int p0, int tid, float M[12])
 {
     const int J = a.J;
     const int nrows = min(WARP_THREADS, a.P - p0);
+#pragma unroll
+    for (int c = 0; c < 12; c++) M[c] = 0.f;
+    if (a.weights == nullptr) {
+        if (tid < nrows) {
+            const float4 *m = reinterpret_cast<const float4 *>(a.joint_mats + (size_t)(p0 + tid) * 16);
+            const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+            M[0] = r0.x; M[1] = r0.y; M[2] = r0.z; M[3] = r0.w;
+            M[4] = r1.x; M[5] = r1.y; M[6] = r1.z; M[7] = r1.w;
+            M[8] = r2.x; M[9] = r2.y; M[10] = r2.z; M[11] = r2.w;
+        }
+        return;
+    }
     __syncthreads();
     for (int t = tid; t < nrows * J; t += WARP_THREADS) wtile[t] = a.weights[(size_t)p0 * J + t];
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 12; c++) M[c] = 0.f;
     if (tid < nrows) {
         const float *wrow = wtile + tid * J;           // stride J = 55 floats: odd => conflict-free
         for (int j = 0; j < J; j++) {
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
     blend_matrix(a, wtile, p0, tid, M);
     if (p >= a.P) return;
 
-    if (a.pt_mats_out) {
+    if (a.pt_mats_out && a.weights) {
         float4 *o = reinterpret_cast<float4 *>(a.pt_mats_out + (size_t)p * 16);
         // bottom row is the blend of the joints' [0,0,0,1] rows = sum of weights
         float wsum = 0.f;
@@ -414,8 +426,8 @@ int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_
 
 static int warp_check(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t P, int32_t J)
 {
-    if (P < 0 || J <= 0 || J > WARP_MAXJ) { set_error("soar_lbs_warp: bad sizes P=%d J=%d (max J %d)", P, J, WARP_MAXJ); return 1; }
-    if (P > 0 && (!xyz || !rot || !weights || !joint_mats)) { set_error("soar_lbs_warp: NULL pointer"); return 1; }
+    if (P < 0 || (weights && (J <= 0 || J > WARP_MAXJ))) { set_error("soar_lbs_warp: bad sizes P=%d J=%d (max J %d)", P, J, WARP_MAXJ); return 1; }
+    if (P > 0 && (!xyz || !rot || !joint_mats)) { set_error("soar_lbs_warp: NULL pointer"); return 1; }
     return 0;
 }
 
@@ -430,7 +442,7 @@ int soar_lbs_warp_forward(const float *xyz, const float *rot, const float *weigh
     WarpArgs a{};
     a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.offsets = offsets;
     a.axis_perm = axis_perm; a.xyz_out = xyz_out; a.rot_out = rot_out; a.pt_mats_out = pt_mats_out;
-    const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    const size_t lds = weights ? sizeof(float) * WARP_THREADS * (size_t)J : 0;
     StageTimer timer(ST_LBS_WARP_FWD, stream);
     hipLaunchKernelGGL(warp_forward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
     SOAR_LAUNCH_OK("lbs_warp_forward", stream, 0);
@@ -448,7 +460,7 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
     WarpArgs a{};
     a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats; a.axis_perm = axis_perm;
     a.g_xyz_out = dL_dxyz_out; a.g_rot_out = dL_drot_out; a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
-    const size_t lds = sizeof(float) * WARP_THREADS * (size_t)J;
+    const size_t lds = weights ? sizeof(float) * WARP_THREADS * (size_t)J : 0;
     StageTimer timer(ST_LBS_WARP_BWD, stream);
     hipLaunchKernelGGL(warp_backward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
     SOAR_LAUNCH_OK("lbs_warp_backward", stream, 0);

@@ -55,18 +55,26 @@ class _LbsWarp(torch.autograd.Function):
         _need_hip(xyz, "xyz")
         L = hip_lib.lib()
         dev = xyz.device
-        x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
+        x, q, A = _f32(xyz), _f32(rot), _f32(joint_mats).reshape(-1, 16)
         off = _f32(offsets) if offsets is not None else None
         T = _f32(axis_perm.to(dev)) if axis_perm is not None else None
-        P, J = x.shape[0], A.shape[0]
-        if w.shape != (P, J):
-            raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
+        P = x.shape[0]
+        if weights is None:                       # per-Gaussian matrices (pt_mats) instead of weights x joints
+            w, J = None, 0
+            if A.shape[0] != P:
+                raise ValueError(f"per-point matrices must be [{P},4,4], got {tuple(joint_mats.shape)}")
+        else:
+            w, J = _f32(weights), A.shape[0]
+            if w.shape != (P, J):
+                raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
         xyz_out = torch.empty_like(x)
         rot_out = torch.empty_like(q)
         with torch.cuda.device(dev):
             check(L.soar_lbs_warp_forward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(off), ptr(T), P, J, ptr(xyz_out),
                                           ptr(rot_out), None, _stream(dev)), "soar_lbs_warp_forward")
-        ctx.save_for_backward(x, q, w, A, T if T is not None else torch.empty(0, device=dev))
+        ctx.J = J
+        ctx.save_for_backward(x, q, w if w is not None else torch.empty(0, device=dev), A,
+                              T if T is not None else torch.empty(0, device=dev))
         ctx.has_offsets = offsets is not None and offsets.requires_grad
         return xyz_out, rot_out
 
@@ -75,7 +83,7 @@ class _LbsWarp(torch.autograd.Function):
         L = hip_lib.lib()
         x, q, w, A, T = ctx.saved_tensors
         dev = x.device
-        P, J = x.shape[0], A.shape[0]
+        P, J = x.shape[0], ctx.J
         gx = _f32(g_xyz_out) if g_xyz_out is not None else torch.zeros_like(x)
         gq = _f32(g_rot_out) if g_rot_out is not None else torch.zeros_like(q)
         g_xyz = torch.empty_like(x)
@@ -95,7 +103,8 @@ def lbs_warp(xyz: torch.Tensor, rot: torch.Tensor, weights: torch.Tensor, joint_
              ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Warp canonical surfels into a posed frame.
 
-    xyz [P,3], rot [P,4] (r,x,y,z), weights [P,J], joint_mats [J,4,4] (cano2live = A_live @ inv(A_cano)),
+    xyz [P,3], rot [P,4] (r,x,y,z), weights [P,J], joint_mats [J,4,4] (cano2live = A_live @ inv(A_cano)) -- or
+    weights=None and joint_mats = per-Gaussian matrices [P,4,4] (what SMPL_Guidance.__call__ returns) --,
     offsets [P,3] optional, axis_perm [3,3] optional (the "+z,+x,+y" matrix T of transform_point_cloud,
     diff_gaussian_rasterizer.py:321-352) -> (xyz' [P,3], rot' [P,4] unit quaternions)."""
     return _LbsWarp.apply(xyz, rot, weights, joint_mats, offsets, axis_perm)

@@ -28,6 +28,9 @@ from .hip_lib import SoarRastParams, check, ptr
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C"]
 
+# running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
+stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
+
 
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
@@ -180,6 +183,8 @@ class _NativeOps:
                                                ptr(rot), ptr(cov), geom.data_ptr(), radii.data_ptr(), C.byref(R), stream),
                   "rasterize_gaussians (geometry stage)")
             num_rendered = int(R.value)
+            stats["forward_calls"] += 1
+            stats["num_rendered"] += num_rendered
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             binning = _scratch(nbytes.value, device)
             check(L.soar_rast_forward_render(prm, radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
@@ -219,6 +224,8 @@ class _NativeOps:
         ctx = _Ctx(P, M, H, W, tan_fovx, tan_fovy, scale_modifier, degree, False, False, False, debug, background,
                    viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device)
         stream = _stream(device)
+        stats["backward_calls"] += 1
+        stats["num_rendered_bwd"] += int(R)
         with torch.cuda.device(device):
             if P > 0:
                 nbytes = C.c_size_t(0)

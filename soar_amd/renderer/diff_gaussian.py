@@ -1,0 +1,169 @@
+"""``"gaussiansurfel-rasterizer"``: the threestudio-soar renderer plugin on the MI355X kernels.
+
+Mirror of ``DiffGaussian`` (TS/renderer/diff_gaussian_rasterizer.py:26-318): same registry name, ``Config`` fields,
+``configure(geometry, material, background)``, ``forward(viewpoint_camera, bg_color, patch_size, scaling_modifier,
+override_color, gt, render_front, stage, **kwargs)`` with kwargs ``gt_index`` / ``gt_a_smpl`` and the same ten output
+keys.  The geometry object is duck-typed exactly as in the reference (``get_xyz, get_rotation, get_opacity, get_occ,
+get_scaling, get_colors, attribute_field, smpl_guidance, active_sh_degree, config``; minimal example
+TS/test/render_rot.py:16-51).
+
+What differs is the execution: the LBS blend + apply (+ quaternion re-extraction) is ONE fused HIP kernel with an
+analytic backward when ``smpl_guidance`` exposes ``joint_mats``/``blend_weights`` (``soar_amd.smpl_guidance``); with a
+guidance object that only implements the reference call ``(root, mat[1,P,4,4], scale)`` the same kernel consumes the
+per-Gaussian matrices.  Both rasterizations run through ``soar_amd.rasterizer``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from .. import lbs
+from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from . import registry
+from .batch import GaussianBatchRenderer
+from .postops import depth2normal, normal2curv
+
+_DIR2VEC = {"+x": (1, 0, 0), "+y": (0, 1, 0), "+z": (0, 0, 1), "-x": (-1, 0, 0), "-y": (0, -1, 0), "-z": (0, 0, -1)}
+
+
+def axis_permutation(dirs: str, device) -> torch.Tensor:
+    """The 3x3 matrix T of ``transform_point_cloud`` (:321-352): column i is the direction named by dirs[i]."""
+    T = np.zeros((3, 3))
+    for i, d in enumerate(dirs.split(",")):
+        if d not in _DIR2VEC:
+            raise ValueError(f"Invalid direction: {d}")
+        T[:, i] = _DIR2VEC[d]
+    return torch.from_numpy(T).float().to(device)
+
+
+def transform_point_cloud(xyz: torch.Tensor, dirs: str):
+    T = axis_permutation(dirs, xyz.device)
+    return torch.matmul(xyz, T), T
+
+
+class _RendererBase(registry.BaseObject):
+    """What threestudio's ``Rasterizer`` base contributes to this plugin: it stores the three sub-modules."""
+
+    @dataclass
+    class Config(registry.BaseObject.Config):
+        pass
+
+    def configure(self, geometry=None, material=None, background=None) -> None:
+        self.geometry, self.material, self.background = geometry, material, background
+        self.training = True
+
+
+@registry.register("gaussiansurfel-rasterizer")
+class DiffGaussian(_RendererBase, GaussianBatchRenderer):
+    @dataclass
+    class Config(_RendererBase.Config):
+        debug: bool = False
+        invert_bg_prob: float = 1.0
+        back_ground_color: Tuple[float, float, float] = (1, 1, 1)
+        offset: bool = False
+        use_explicit: bool = False
+
+    cfg: Config
+
+    def configure(self, geometry=None, material=None, background=None) -> None:
+        registry.info("[Note] Gaussian Splatting doesn't support material and background now.")
+        super().configure(geometry, material, background)
+        self.background_tensor = torch.tensor(self.cfg.back_ground_color, dtype=torch.float32, device="cuda")
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def _warp(self, pc, points, rot, offsets, axis_perm, zero_out, kwargs):
+        """LBS warp of the canonical surfels: fused kernel; gradients reach `points` and `rot` only."""
+        guide = pc.smpl_guidance
+        idx = kwargs.get("gt_index")
+        a_smpl = kwargs.get("gt_a_smpl")
+        if hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights"):
+            with torch.no_grad():
+                mats = guide.joint_mats(smpl_parms_in=a_smpl, idx=None if a_smpl is not None else idx, zero_out=zero_out)
+                w = guide.blend_weights(points)
+            return lbs.lbs_warp(points, rot, w, mats, offsets, axis_perm)
+        # reference-style guidance: (root, mat[1,P,4,4], scale)
+        if a_smpl is not None:
+            with torch.no_grad():
+                _, mat, _ = guide(points, smpl_parms=a_smpl, zero_out=zero_out) if zero_out else guide(points, smpl_parms=a_smpl)
+        else:
+            _, mat, _ = guide(points, idx=idx, zero_out=True) if zero_out else guide(points, idx=idx)
+        return lbs.lbs_warp(points, rot, None, mat[0].detach(), offsets, axis_perm)
+
+    def forward(self, viewpoint_camera, bg_color: torch.Tensor, patch_size: list = [float("inf"), float("inf")],
+                scaling_modifier=1.0, override_color=None, gt=False, render_front=True, stage=0, **kwargs):
+        """Render one view.  Background tensor (bg_color) must be on the GPU."""
+        pc = self.geometry
+        points = pc.get_xyz
+        rot = pc.get_rotation
+
+        fields = pc.attribute_field(points.detach()) if not gt else pc.attribute_field(points.detach(), z=None)
+        attribute_color, attribute_scale, attribute_offsets = fields["shs"], fields["scales"], fields["offsets"]
+        offsets = attribute_offsets if self.cfg.offset else None
+        if not gt:
+            # SDS pose views: global orientation / translation zeroed and the "+z,+x,+y" axis permutation (:77-114)
+            T = axis_permutation("+z,+x,+y", points.device)
+            points, rot = self._warp(pc, points, rot, offsets, T, True, kwargs)
+        else:
+            points, rot = self._warp(pc, points, rot, offsets, None, False, kwargs)     # video frame (:116-149)
+            if not self.training:
+                bg_color = torch.ones_like(bg_color)
+
+        # zero tensor whose gradient is the screen-space mean gradient used by densification (:155-164)
+        screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device="cuda") + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+
+        tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+        tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+
+        def settings(front: bool, descending: bool):
+            return GaussianRasterizationSettings(
+                image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+                tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+                viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+                patch_bbox=viewpoint_camera.random_patch(patch_size[0], patch_size[1]),
+                prcppoint=viewpoint_camera.prcppoint, sh_degree=pc.active_sh_degree,
+                campos=viewpoint_camera.camera_center, prefiltered=False, render_front=front,
+                sort_descending=descending, debug=False, config=pc.config)
+
+        rasterizer = GaussianRasterizer(raster_settings=settings(False, not render_front))      # :173-191
+        rasterizer_occ = GaussianRasterizer(raster_settings=settings(True, False))             # :193-211
+
+        opacity = pc.get_opacity
+        scales = (pc.get_scaling if self.cfg.use_explicit else attribute_scale).repeat(1, 3)
+        scales[..., -1] = -1e10                                                                 # :234
+        colors_precomp = pc.get_colors if self.cfg.use_explicit else attribute_color
+        ones = torch.ones_like(opacity)
+
+        rendered_image, rendered_normal, rendered_depth, rendered_opac, radii = rasterizer(
+            means3D=points, means2D=screenspace_points, shs=None, colors_precomp=colors_precomp, opacities=ones,
+            scales=scales, rotations=rot, cov3D_precomp=None)
+        occ = pc.get_occ.repeat(1, 3)
+        rendered_occ = rasterizer_occ(
+            means3D=points.detach(), means2D=screenspace_points.detach(), shs=None, colors_precomp=occ, opacities=ones,
+            scales=scales.detach(), rotations=rot.detach(), cov3D_precomp=None)[0]
+
+        # image-space post-ops (:292-303)
+        mask = rendered_opac > 1e-5
+        normal_mask = mask.repeat(3, 1, 1)
+        rendered_normal = torch.where(normal_mask, rendered_normal, rendered_normal.detach())
+        rendered_normal = rendered_normal * torch.tensor([1.0, -1.0, -1.0], device=rendered_normal.device)[:, None, None]
+        curv = normal2curv(rendered_normal, rendered_opac.detach() > 1e-5)
+        rendered_normal = (rendered_normal + 1) / 2
+        depth_normal = depth2normal(rendered_depth, rendered_opac.detach() > 1e-5, viewpoint_camera)
+        depth_normal = depth_normal * torch.tensor([1.0, -1.0, -1.0], device=depth_normal.device)[:, None, None]
+        depth_normal = (depth_normal + 1) / 2
+
+        return {
+            "render": rendered_image, "normal": rendered_normal, "depth": rendered_depth, "pred_normal": depth_normal,
+            "mask": rendered_opac, "occ": rendered_occ, "curv": curv, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii,
+        }
+
+    __call__ = forward
