@@ -1,7 +1,6 @@
 // lbs.hip -- SMPL-X linear-blend skinning of canonical Gaussian surfels and nearest-neighbour helpers, gfx950.
 //
-//  * knn_weights_kernel   : SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637): brute-force K-NN over the
-//                           canonical SMPL-X vertices staged through LDS, inverse-distance blend of skinning rows.
+//  (the K-NN blend-weight kernel lives in lbs_knn.hip)
 //  * warp_forward_kernel  : blend (TS/utils/smpl.py:613) fused with the apply step of DiffGaussian.forward
 //                           (TS/renderer/diff_gaussian_rasterizer.py:103-114, :138-149): one kernel instead of an
 //                           einsum + ~8 small torch kernels; weight rows are staged through LDS with coalesced loads,
@@ -14,101 +13,7 @@ namespace soar {
 
 namespace {
 
-constexpr int KNN_THREADS = 256;
-constexpr int KNN_MAXK = 32;
 constexpr int KNN_TILE = 1024;
-
-// ------------------------------------------------------------------------------------------------
-// K nearest canonical vertices + inverse-distance skinning weights
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(KNN_THREADS)
-knn_weights_kernel(const float *__restrict__ xyz, int P, const float *__restrict__ verts, int V,
-                   const float *__restrict__ vert_weights, int J, int K, float *__restrict__ weights_out,
-                   int32_t *__restrict__ knn_idx_out)
-{
-    __shared__ float tile[KNN_TILE * 3];
-    __shared__ float best_d[KNN_MAXK][KNN_THREADS];     // [k][thread]: bank = thread, conflict-free
-    __shared__ int best_i[KNN_MAXK][KNN_THREADS];
-
-    const int tid = threadIdx.x;
-    const int p = blockIdx.x * KNN_THREADS + tid;
-    const bool valid = p < P;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (valid) { x = xyz[3 * p]; y = xyz[3 * p + 1]; z = xyz[3 * p + 2]; }
-
-    for (int k = 0; k < K; k++) { best_d[k][tid] = 3.0e38f; best_i[k][tid] = -1; }
-    float worst = 3.0e38f;       // current K-th best distance of this thread
-    int worst_slot = 0;
-
-    for (int base = 0; base < V; base += KNN_TILE) {
-        const int n = min(KNN_TILE, V - base);
-        __syncthreads();
-        for (int t = tid; t < n * 3; t += KNN_THREADS) tile[t] = verts[(size_t)base * 3 + t];
-        __syncthreads();
-        if (!valid) continue;
-        for (int v = 0; v < n; v++) {
-            const float ddx = x - tile[3 * v], ddy = y - tile[3 * v + 1], ddz = z - tile[3 * v + 2];
-            const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-            if (d2 < worst) {
-                best_d[worst_slot][tid] = d2;
-                best_i[worst_slot][tid] = base + v;
-                // find the new worst
-                float w = -1.f;
-                int ws = 0;
-                for (int k = 0; k < K; k++) {
-                    const float dk = best_d[k][tid];
-                    if (dk > w) { w = dk; ws = k; }
-                }
-                worst = w;
-                worst_slot = ws;
-            }
-        }
-    }
-    if (!valid) return;
-
-    // order the K hits by (distance, index): insertion sort in LDS (K <= 32)
-    for (int i = 1; i < K; i++) {
-        const float d = best_d[i][tid];
-        const int id = best_i[i][tid];
-        int j = i - 1;
-        while (j >= 0 && (best_d[j][tid] > d || (best_d[j][tid] == d && best_i[j][tid] > id))) {
-            best_d[j + 1][tid] = best_d[j][tid];
-            best_i[j + 1][tid] = best_i[j][tid];
-            j--;
-        }
-        best_d[j + 1][tid] = d;
-        best_i[j + 1][tid] = id;
-    }
-
-    // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1)   (smpl.py:630-634)
-    float norm = 0.f;
-    for (int k = 0; k < K; k++) {
-        const float d = fminf(fmaxf(sqrtf(best_d[k][tid]), 0.0001f), 1.0f);
-        const float w = 1.0f / d;
-        best_d[k][tid] = w;
-        norm += w;
-    }
-    if (knn_idx_out)
-        for (int k = 0; k < K; k++) knn_idx_out[(size_t)p * K + k] = best_i[k][tid];
-
-    // weights[p, :] = sum_k ws_k * vert_weights[idx_k, :]   (smpl.py:632-635)
-    float *out = weights_out + (size_t)p * J;
-    for (int j0 = 0; j0 < J; j0 += 8) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < K; k++) {
-            const int id = best_i[k][tid];
-            if (id < 0) continue;
-            const float w = best_d[k][tid] / norm;
-            const float *row = vert_weights + (size_t)id * J + j0;
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (j0 + u < J) acc[u] += w * row[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (j0 + u < J) out[j0 + u] = acc[u];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // quaternion <-> matrix helpers (row-major 3x3, m[r*3+c]); public pytorch3d conventions, real part first
@@ -408,21 +313,6 @@ __global__ void __launch_bounds__(256) dist2_knn3_kernel(const float *__restrict
 using namespace soar;
 
 extern "C" {
-
-int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights, int32_t J,
-                         int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
-{
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (P < 0 || V <= 0 || J <= 0 || K <= 0) { set_error("soar_lbs_knn_weights: bad sizes P=%d V=%d J=%d K=%d", P, V, J, K); return 1; }
-    if (K > KNN_MAXK || K > V) { set_error("soar_lbs_knn_weights: K=%d unsupported (max %d, V=%d)", K, KNN_MAXK, V); return 1; }
-    if (P == 0) return 0;
-    if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
-    StageTimer timer(ST_LBS_KNN, stream);
-    hipLaunchKernelGGL(knn_weights_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P,
-                       verts, V, vert_weights, J, K, weights_out, knn_idx_out);
-    SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
-    return 0;
-}
 
 static int warp_check(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t P, int32_t J)
 {

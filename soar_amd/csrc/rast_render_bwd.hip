@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(BwdArgs a)
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, ld = 0.f;     // last_* (:617-618)
     float ac0 = 0.f, ac1 = 0.f, ac2 = 0.f, an0 = 0.f, an1 = 0.f, an2 = 0.f, ad = 0.f;     // accum_rec* (:607)
 
+    const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
     GaussRec *my = slab[wave];
     uint32_t *my_id = slab_id[wave];
     const float4 *myq = reinterpret_cast<const float4 *>(my);
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(BwdArgs a)
     // positions [0, deepest) of the tile list, walked from the back in 64-entry chunks
     for (int cbase = (int)((deepest - 1u) & ~63u); cbase >= 0; cbase -= WAVE) {
         const int n = min(WAVE, (int)deepest - cbase);
+        bool relevant = false;
         if (lane < n) {
             const uint32_t id = a.point_list[range.x + cbase + lane];
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
@@ -127,12 +129,16 @@ __global__ void __launch_bounds__(256) render_backward_kernel(BwdArgs a)
             float4 *dst = reinterpret_cast<float4 *>(my + lane);
             dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
             my_id[lane] = id;
+            relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
         }
+        unsigned long long todo = __ballot(relevant);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        for (int j = n - 1; j >= 0; j--) {
+        while (todo != 0ull) {
+            const int j = 63 - __builtin_clzll(todo);       // back to front
+            todo &= ~(1ull << j);
             const uint32_t pos = (uint32_t)(cbase + j);
             const float4 q0 = myq[4 * j + 0];
             const float4 q1 = myq[4 * j + 1];

@@ -11,6 +11,9 @@
 //    loads, one cache-line half) and parks it in the wave's private 4 KiB LDS slab; the blend loop then
 //    reads records with wave-uniform (broadcast) ds_read_b128 -- two for the alpha test, two more only if
 //    some lane survives it;
+//  * before that loop the SAME 64 lanes, still holding one record each, evaluate a conservative bound of the splat's
+//    alpha over the quad (splat_may_touch_quad): a ballot yields the 64-bit set of entries that can matter, and the
+//    blend loop visits only those bits (s_ff1) -- entries that every pixel would skip cost nothing;
 //  * workgroup -> tile mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
 #include "soar_common.h"
 
@@ -61,22 +64,32 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     GaussRec *my = slab[wave];
     const float4 *myq = reinterpret_cast<const float4 *>(my);
 
+    const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
+
     for (uint32_t base = range.x; base < range.y; base += WAVE) {
         if (__ballot(!done) == 0ull) break;                 // whole quad saturated
         const int n = min((uint32_t)WAVE, range.y - base);
+        // phase A -- lanes = list entries: gather the record, park it in the slab, and vote whether the splat can
+        // reach the 1/255 alpha floor anywhere in this quad
+        bool relevant = false;
         if (lane < n) {
             const uint32_t id = a.point_list[base + lane];
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
             float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
             float4 *dst = reinterpret_cast<float4 *>(my + lane);
             dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+            relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
         }
+        unsigned long long todo = __ballot(relevant);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        // phase B -- lanes = pixels: walk the surviving entries in list order
         const uint32_t contrib0 = base - range.x;           // entries before this chunk
-        for (int j = 0; j < n; j++) {
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
             const float4 q0 = myq[4 * j + 0];               // x, y, A, B
             const float4 q1 = myq[4 * j + 1];               // C, opacity, depth, plane_a
             const float dx = q0.x - fx, dy = q0.y - fy;
@@ -90,7 +103,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                 done = true;
                 live = false;
             }
-            if (__ballot(live) == 0ull) continue;
+            if (__ballot(live) == 0ull) {
+                if (__ballot(!done) == 0ull) break;
+                continue;
+            }
             const float4 q2 = myq[4 * j + 2];               // plane_b, r, g, b
             const float4 q3 = myq[4 * j + 3];               // nx, ny, nz, radius
             if (live) {

@@ -115,6 +115,35 @@ __device__ __forceinline__ float falloff_power(float A, float B, float Cc, float
     const float dist = (A * dx * dx + Cc * dy * dy) + 2 * B * dx * dy;
     return -0.5f * dist;
 }
+// Conservative wave-level culling: can a splat reach alpha >= 1/255 at ANY pixel centre of the 8x8 quad whose pixels
+// span [x0, x0+7] x [y0, y0+7]?  Minimises the (positive-definite) falloff form over the quad's rectangle -- a lower
+// bound of its value at every pixel -- and compares the implied alpha bound with the 1/255 skip threshold of the blend
+// (forward.cu:545, backward.cu:680) with a safety margin, so dropping a splat never changes a result: splats that
+// fail are exactly those every lane would have skipped.  Returns true when in doubt (non-PD conic, NaN).
+__device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A, float B, float Cc, float opacity,
+                                                     float x0, float y0)
+{
+    const float dx_hi = gx - x0, dx_lo = dx_hi - 7.f;
+    const float dy_hi = gy - y0, dy_lo = dy_hi - 7.f;
+    const bool pd = (A > 0.f) && (Cc > 0.f) && (A * Cc - B * B > 0.f);
+    const float nx = dx_lo > 0.f ? dx_lo : (dx_hi < 0.f ? dx_hi : 0.f);
+    const float ny = dy_lo > 0.f ? dy_lo : (dy_hi < 0.f ? dy_hi : 0.f);
+    float qmin = 3.0e38f;
+    if (nx != 0.f) {
+        const float t = fminf(fmaxf(-B * nx / Cc, dy_lo), dy_hi);
+        qmin = fminf(qmin, A * nx * nx + 2.f * B * nx * t + Cc * t * t);
+    }
+    if (ny != 0.f) {
+        const float t = fminf(fmaxf(-B * ny / A, dx_lo), dx_hi);
+        qmin = fminf(qmin, A * t * t + 2.f * B * t * ny + Cc * ny * ny);
+    }
+    if (nx == 0.f && ny == 0.f) qmin = 0.f;
+    // alpha_max = opacity * exp(-qmin/2) < (1/255)(1 - 1e-3)  <=>  qmin > 2 ln(255 opacity) + 2e-3
+    const float thr = 2.f * __logf(255.f * opacity) + 2.0e-3f;
+    const bool certainly_invisible = (qmin * 0.9999f - 1.0e-3f > thr) || (255.f * opacity < 0.999f);
+    return !(pd && certainly_invisible);
+}
+
 __device__ __forceinline__ float mul_one_minus(float T, float alpha)
 {
 #pragma clang fp contract(off)
