@@ -31,6 +31,9 @@ COMMON_FLAGS = [
 EXTRA_FLAGS = {
     "rast_preprocess.hip": ["-ffp-contract=off"],
     "rast_binning.hip": ["-ffp-contract=off"],
+    # the per-Gaussian backward has cancellation-prone expressions (quaternion gradient): keep the reference's
+    # operation order un-contracted so that rounding follows an IEEE evaluation of the reference source
+    "rast_geom_bwd.hip": ["-ffp-contract=off"],
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
            "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip"]

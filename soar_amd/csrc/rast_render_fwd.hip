@@ -66,19 +66,27 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 
     const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
 
+    // software pipeline over chunks: the records of chunk k+1 are requested before the blend loop of chunk k runs,
+    // so the dependent (list entry -> record) gather latency stays off the critical path of long tile lists
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    if (range.x + lane < range.y) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[range.x + lane]);
+        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+    }
     for (uint32_t base = range.x; base < range.y; base += WAVE) {
         if (__ballot(!done) == 0ull) break;                 // whole quad saturated
         const int n = min((uint32_t)WAVE, range.y - base);
-        // phase A -- lanes = list entries: gather the record, park it in the slab, and vote whether the splat can
-        // reach the 1/255 alpha floor anywhere in this quad
+        // phase A -- lanes = list entries: park the record in the slab and vote whether the splat can reach the
+        // 1/255 alpha floor anywhere in this quad
         bool relevant = false;
         if (lane < n) {
-            const uint32_t id = a.point_list[base + lane];
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
-            float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
             float4 *dst = reinterpret_cast<float4 *>(my + lane);
             dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
             relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
+        }
+        if (base + WAVE + lane < range.y) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[base + WAVE + lane]);
+            r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         }
         unsigned long long todo = __ballot(relevant);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
