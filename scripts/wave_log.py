@@ -1,0 +1,16 @@
+"""Diagnostic: summarise a SOAR_WAVE_LOG dump (per-wave {t_start, t_end, list length, blend iterations}, 100 MHz wall clock)."""
+import sys
+import numpy as np
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 4)
+t0 = a[..., 0][a[..., 0] > 0].min()
+start = (a[..., 0].astype(np.int64) - int(t0)) / 100.0      # us
+end = (a[..., 1].astype(np.int64) - int(t0)) / 100.0
+dur = end - start
+print("waves", dur.size, "kernel span us", end.max(), "first start", start.min(), "last start", start.max())
+print("wave duration us: mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % (dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+order = np.argsort(dur.ravel())[::-1][:15]
+for o in order:
+    t, w = divmod(o, 4)
+    print(f"tile {t} wave {w}: start {start.ravel()[o]:8.1f} end {end.ravel()[o]:8.1f} dur {dur.ravel()[o]:8.1f} us  list {a[t, w, 2]}  iters {a[t, w, 3]}")
+for cut in (25, 50, 100, 150, 200, 250, 300):
+    print(f"waves still running at {cut} us:", int(((start < cut) & (end > cut)).sum()))

@@ -409,19 +409,30 @@ __global__ void __launch_bounds__(256) render_backward_dpp_kernel(BwdArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        while (todo != 0ull) {
-            const int j = 63 - __builtin_clzll(todo);       // back to front
-            todo &= ~(1ull << j);
-            const float4 q0 = myq[4 * j + 0];
-            const float4 q1 = myq[4 * j + 1];
+        // software pipeline over the surviving entries (back to front): the next record's four LDS reads are in
+        // flight while the current entry is processed
+        float4 n0, n1, n2, n3;
+        int jn = -1;
+        if (todo != 0ull) {
+            jn = 63 - __builtin_clzll(todo);
+            todo &= ~(1ull << jn);
+            n0 = myq[4 * jn + 0]; n1 = myq[4 * jn + 1]; n2 = myq[4 * jn + 2]; n3 = myq[4 * jn + 3];
+        }
+        while (jn >= 0) {
+            const int j = jn;
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            jn = -1;
+            if (todo != 0ull) {
+                jn = 63 - __builtin_clzll(todo);
+                todo &= ~(1ull << jn);
+                n0 = myq[4 * jn + 0]; n1 = myq[4 * jn + 1]; n2 = myq[4 * jn + 2]; n3 = myq[4 * jn + 3];
+            }
             const float dx = q0.x - c.fx, dy = q0.y - c.fy;
             const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
             const float G = exp_nonpositive(power);
             const float alpha = fminf(0.99f, q1.y * G);
             const bool live = ((uint32_t)(cbase + j) < c.last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(live) == 0ull) continue;
-            const float4 q2 = myq[4 * j + 2];
-            const float4 q3 = myq[4 * j + 3];
             float v[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = 0.f;

@@ -17,6 +17,9 @@
 //  * workgroup -> tile mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
 #include "soar_common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace soar {
 
 namespace {
@@ -32,6 +35,7 @@ struct FwdArgs {
     float *final_D;
     uint32_t *n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opac;
+    unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
 };
 
 // blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of tiles
@@ -42,9 +46,12 @@ __device__ __forceinline__ int xcd_tile(int bid, int n)
     return xcd * q + min(xcd, r) + within;
 }
 
+template <bool LOG>
 __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 {
-    __shared__ GaussRec slab[4][WAVE];
+    __shared__ GaussRec slab[4][WAVE + 1];             // +1: an all-zero record
+    unsigned long long t_start = 0, n_iter = 0;
+    if (LOG) t_start = wall_clock64();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = xcd_tile(blockIdx.x, a.ntiles);
@@ -63,6 +70,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 
     GaussRec *my = slab[wave];
     const float4 *myq = reinterpret_cast<const float4 *>(my);
+    if (lane < 4) reinterpret_cast<float4 *>(my + WAVE)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
 
@@ -95,37 +103,56 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 
         // phase B -- lanes = pixels: walk the surviving entries in list order
         const uint32_t contrib0 = base - range.x;           // entries before this chunk
+        // surviving entries are taken FOUR at a time: their 16 LDS reads are issued together and the four alpha
+        // evaluations (falloff + exp: the long dependent chains) are independent, so they interleave in the single
+        // wave that is left on a SIMD at the tail of the launch; only the short transmittance chain stays serial.
+        // Missing group members point at the all-zero record (alpha = 0: never live).
         while (todo != 0ull) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const float4 q0 = myq[4 * j + 0];               // x, y, A, B
-            const float4 q1 = myq[4 * j + 1];               // C, opacity, depth, plane_a
-            const float dx = q0.x - fx, dy = q0.y - fy;
-            // forward.cu:507-508
-            const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
-            const float alpha = fminf(0.99f, q1.y * exp_nonpositive(power));
-            // skip rules :512,:545 ; a saturated pixel stops before blending (:549-552)
-            bool live = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const float test_T = mul_one_minus(T, alpha);
-            if (live && test_T < 0.0001f) {
-                done = true;
-                live = false;
+            if (LOG) n_iter++;
+            int jj[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                jj[k] = todo ? __builtin_ctzll(todo) : WAVE;
+                todo = todo ? (todo & (todo - 1ull)) : 0ull;
             }
-            if (__ballot(live) == 0ull) {
-                if (__ballot(!done) == 0ull) break;
-                continue;
+            float4 q0[4], q1[4], q2[4], q3[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                q0[k] = myq[4 * jj[k] + 0]; q1[k] = myq[4 * jj[k] + 1];     // x,y,A,B | C,opacity,depth,plane_a
+                q2[k] = myq[4 * jj[k] + 2]; q3[k] = myq[4 * jj[k] + 3];     // plane_b,r,g,b | nx,ny,nz,-
             }
-            const float4 q2 = myq[4 * j + 2];               // plane_b, r, g, b
-            const float4 q3 = myq[4 * j + 3];               // nx, ny, nz, radius
-            if (live) {
-                const float w = alpha * T;
-                const float depth = q1.z - (dx * q1.w + dy * q2.x);   // per-pixel depth on the surfel plane
-                D += depth * w;
-                C0 += q2.y * w; C1 += q2.z * w; C2 += q2.w * w;
-                N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                T = test_T;
-                last_contributor = contrib0 + (uint32_t)j + 1u;
+            float dx[4], dy[4], power[4], alpha[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                dx[k] = q0[k].x - fx; dy[k] = q0[k].y - fy;
+                power[k] = falloff_power(q0[k].z, q0[k].w, q1[k].x, dx[k], dy[k]);          // forward.cu:507-508
+                alpha[k] = fminf(0.99f, q1[k].y * exp_nonpositive(power[k]));
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // Branch-free (selects only: no exec-mask juggling in the serial part).  Skip rules :512,:545 zero the
+                // effective alpha; a pixel saturates BEFORE blending the entry that would drop T below 1e-4 (:549-552).
+                // Invariant: T >= 1e-4 for every lane, so test_T < 1e-4 can only happen on a live lane.
+                float a_eff = (power[k] > 0.0f) ? 0.f : alpha[k];
+                a_eff = (alpha[k] < 1.0f / 255.0f) ? 0.f : a_eff;
+                a_eff = done ? 0.f : a_eff;
+                const float test_T = mul_one_minus(T, a_eff);
+                const bool stop = test_T < 0.0001f;
+                done = stop ? true : done;
+                const float w = stop ? 0.f : a_eff * T;
+                const bool blend = w != 0.f;
+                const float depth = q1[k].z - (dx[k] * q1[k].w + dy[k] * q2[k].x);         // depth on the surfel plane
+                D = blend ? __builtin_fmaf(depth, w, D) : D;
+                C0 = blend ? __builtin_fmaf(q2[k].y, w, C0) : C0;
+                C1 = blend ? __builtin_fmaf(q2[k].z, w, C1) : C1;
+                C2 = blend ? __builtin_fmaf(q2[k].w, w, C2) : C2;
+                N0 = blend ? __builtin_fmaf(q3[k].x, w, N0) : N0;
+                N1 = blend ? __builtin_fmaf(q3[k].y, w, N1) : N1;
+                N2 = blend ? __builtin_fmaf(q3[k].z, w, N2) : N2;
+                T = blend ? test_T : T;
+                last_contributor = blend ? contrib0 + (uint32_t)jj[k] + 1u : last_contributor;
+            }
+            if (__ballot(!done) == 0ull) break;              // wave-uniform: whole quad saturated
         }
         __builtin_amdgcn_wave_barrier();                     // slab is overwritten by the next chunk
     }
@@ -147,6 +174,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
         a.out_opac[pix] = 1.f - T;
         if (a.normalize_depth) a.final_D[pix] = D;
     }
+    if (LOG && (threadIdx.x & 63) == 0) {
+        unsigned long long *w = a.wave_log + ((size_t)tile * 4 + (threadIdx.x >> 6)) * 4;
+        w[0] = t_start; w[1] = wall_clock64(); w[2] = range.y - range.x; w[3] = n_iter;
+    }
 }
 
 }  // namespace
@@ -163,7 +194,25 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     StageTimer timer(ST_RENDER_FWD, stream);
-    hipLaunchKernelGGL(render_forward_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
+    a.wave_log = nullptr;
+    const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
+    static int logged = 0;
+    if (log_path && !logged && prm.render_front == 0) {
+        logged = 1;
+        const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)a.ntiles;
+        SOAR_HIP_OK(hipMalloc(&a.wave_log, nbytes));
+        SOAR_HIP_OK(hipMemsetAsync(a.wave_log, 0, nbytes, stream));
+        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(a.ntiles), dim3(256), 0, stream, a);
+        SOAR_HIP_OK(hipStreamSynchronize(stream));
+        unsigned long long *host = (unsigned long long *)malloc(nbytes);
+        SOAR_HIP_OK(hipMemcpy(host, a.wave_log, nbytes, hipMemcpyDeviceToHost));
+        FILE *f = fopen(log_path, "wb");
+        if (f) { fwrite(host, 1, nbytes, f); fclose(f); }
+        free(host);
+        (void)hipFree(a.wave_log);
+        return 0;
+    }
+    hipLaunchKernelGGL(render_forward_kernel<false>, dim3(a.ntiles), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
     return 0;
 }
