@@ -451,14 +451,191 @@ __global__ void __launch_bounds__(256) render_backward_dpp_kernel(BwdArgs a)
     }
 }
 
-bool use_dpp_variant()
+// ================================================================================================
+// variant "slots" (default): lane = (pixel, slot) -- four list entries per pixel and step
+// ================================================================================================
+// Same decomposition as the forward kernel: workgroup = 8x8 quad of a tile, wavefront = 4x4 pixel block, the four
+// lanes of a pixel take the four deepest remaining surviving entries.  Per step:
+//   * every lane evaluates alpha / liveness of ITS entry for ITS pixel (backward.cu:653-680);
+//   * the transmittance in front of each entry follows by dividing back to front through the four slots (quad
+//     broadcasts, reference order T = T / (1 - alpha), :683);
+//   * the "colour behind" recurrences (:701, :719, :766) are linear, and the gradient only needs their dot product
+//     with the pixel's upstream gradient: ONE scalar recurrence P' = alpha (c.d) + (1 - alpha) P replaces seven;
+//   * each lane forms the 13 gradient terms of its (pixel, entry) pair; the 16 pixels of the wavefront are summed
+//     with the transpose-reduce (v_permlane32/16_swap + DPP) which leaves, in the 16 pixel-lanes of slot s, the 13 totals
+//     of entry s: the whole step leaves as ONE global_atomic_add_f32 wave-instruction = four 52-byte row segments.
+constexpr int BCHUNK = 256;
+constexpr int DPP_Q_BCAST0 = 0x00, DPP_Q_BCAST1 = 0x55, DPP_Q_BCAST2 = 0xAA, DPP_Q_BCAST3 = 0xFF;
+
+// 16 values x 16 pixel-lanes (lane bits 2..5) -> lane (q, slot) holds the total of value q = 8*b5 + 4*b4 + 2*b3 + b2
+__device__ __forceinline__ float pixel_reduce16(float v[16], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = swap32_add(v[k], v[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = swap16_add(v[k], v[k + 4]);
+    const bool b3 = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float keep = b3 ? v[k + 2] : v[k];
+        const float send = b3 ? v[k] : v[k + 2];
+        v[k] = keep + dpp_move<DPP_ROW_ROR8>(send);
+    }
+    const bool b2 = (lane & 4) != 0;
+    const float keep = b2 ? v[1] : v[0];
+    const float send = b2 ? v[0] : v[1];
+    return keep + dpp_move<DPP_QUAD_XOR3>(dpp_move<DPP_ROW_HALF_MIRROR>(send));     // partner lane ^ 4
+}
+__device__ __forceinline__ int pixel_reduce16_slot(int lane)
+{
+    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
+__global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
+{
+    __shared__ float4 sq0[BCHUNK + 1], sq1[BCHUNK + 1], sq2[BCHUNK + 1], sq3[BCHUNK + 1];   // +1: all-zero record
+    __shared__ uint32_t sid[BCHUNK + 1];
+    __shared__ uint32_t wave_deep[4];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int seq = xcd_tile(blockIdx.x, 4 * a.ntiles);
+    const int tile = seq >> 2, quad = seq & 3;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
+    const int pxl = lane >> 2, slot = lane & 3;
+    const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
+    const bool inside = px < a.W && py < a.H;
+
+    const uint2 range = a.ranges[tile];
+    PixelConsts c;
+    PixelState s;
+    load_pixel(a, px, py, inside, c, s);
+    float T = s.T;                               // replicated in the four lanes of the pixel
+    float P = 0.f;                               // (blend of everything behind) . (upstream gradient), replicated
+    const uint32_t deepest_wave = wave_max_u32(c.last);
+    if (lane == 0) wave_deep[wave] = deepest_wave;
+    if (tid == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        sq0[BCHUNK] = z; sq1[BCHUNK] = z; sq2[BCHUNK] = z; sq3[BCHUNK] = z;
+        sid[BCHUNK] = 0u;
+    }
+    __syncthreads();
+    const uint32_t deepest = max(max(wave_deep[0], wave_deep[1]), max(wave_deep[2], wave_deep[3]));   // block-uniform
+    if (deepest == 0u) return;
+
+    const int qslot = pixel_reduce16_slot(lane);
+
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    uint32_t rid = 0;
+    const int cfirst = (int)((deepest - 1u) / BCHUNK) * BCHUNK;
+    if (cfirst + tid < (int)deepest) {
+        rid = a.point_list[range.x + cfirst + tid];
+        const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
+        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+    }
+    for (int cbase = cfirst; cbase >= 0; cbase -= BCHUNK) {
+        const int n = min(BCHUNK, (int)deepest - cbase);
+        if (tid < n) { sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3; sid[tid] = rid; }
+        if (cbase >= BCHUNK) {
+            rid = a.point_list[range.x + cbase - BCHUNK + tid];
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
+            r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+        }
+        __syncthreads();
+
+        if (cbase < (int)deepest_wave) {
+            for (int sub = ((n - 1) / WAVE) * WAVE; sub >= 0; sub -= WAVE) {
+                // phase A -- lanes = entries: conservative test against this wave's 4x4 block
+                bool relevant = false;
+                const int e = sub + lane;
+                if (e < n && (uint32_t)(cbase + e) < deepest_wave) {
+                    const float4 e0 = sq0[e], e1 = sq1[e];
+                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, (float)bx0, (float)by0, 3.f);
+                }
+                unsigned long long todo = __ballot(relevant);
+
+                // phase B -- lanes = (pixel, slot): the four deepest remaining entries per step, slot 3 = deepest
+                while (todo != 0ull) {
+                    int jj[4];
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) {
+                        const int b = todo ? 63 - (int)__builtin_clzll(todo) : -1;
+                        jj[k] = b >= 0 ? sub + b : BCHUNK;                         // BCHUNK: the zero record
+                        todo = b >= 0 ? (todo & ~(1ull << b)) : 0ull;
+                    }
+                    const int j = slot == 0 ? jj[0] : slot == 1 ? jj[1] : slot == 2 ? jj[2] : jj[3];
+                    const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+                    const uint32_t gid = sid[j];
+                    Splat g;
+                    g.x = q0.x; g.y = q0.y; g.A = q0.z; g.B = q0.w; g.C = q1.x; g.opacity = q1.y; g.depth = q1.z;
+                    g.plane_a = q1.w; g.plane_b = q2.x; g.r = q2.y; g.g = q2.z; g.b = q2.w; g.nx = q3.x; g.ny = q3.y; g.nz = q3.z;
+                    const float dx = g.x - c.fx, dy = g.y - c.fy;
+                    const float power = falloff_power(g.A, g.B, g.C, dx, dy);
+                    const float G = exp_nonpositive(power);
+                    const float alpha = fminf(0.99f, g.opacity * G);
+                    const bool live = (j < BCHUNK) && ((uint32_t)(cbase + j) < c.last) && !(power > 0.0f) &&
+                                      !(alpha < 1.0f / 255.0f);                    // :653-680
+                    const unsigned long long live_mask = __ballot(live);
+                    if (live_mask == 0ull) continue;
+                    const float a_eff = live ? alpha : 0.f;
+                    const float om = 1.f - a_eff;
+                    const float om0 = dpp_move<DPP_Q_BCAST0>(om), om1 = dpp_move<DPP_Q_BCAST1>(om),
+                                om2 = dpp_move<DPP_Q_BCAST2>(om), om3 = dpp_move<DPP_Q_BCAST3>(om);
+                    // transmittance in front of each slot's entry, back to front (:683); om == 1 for dead entries
+                    const float T3 = T / om3, T2 = T3 / om2, T1 = T2 / om1, T0 = T1 / om0;
+                    const float T_mine = slot == 0 ? T0 : slot == 1 ? T1 : slot == 2 ? T2 : T3;
+                    T = T0;
+                    // u = (this entry's colour / normal / depth) . (upstream gradient of the pixel)
+                    const float d_cur = g.depth - (dx * g.plane_a + dy * g.plane_b);
+                    const float u = g.r * c.dC0 + g.g * c.dC1 + g.b * c.dC2 + g.nx * c.dN0 + g.ny * c.dN1 + g.nz * c.dN2 +
+                                    d_cur * c.dD_ch;
+                    // P before each slot: P3 = P, P2 = om3 P3 + a3 u3, ...   (:701, :719, :766 folded into one scalar)
+                    const float t = a_eff * u;
+                    const float t0 = dpp_move<DPP_Q_BCAST0>(t), t1 = dpp_move<DPP_Q_BCAST1>(t),
+                                t2 = dpp_move<DPP_Q_BCAST2>(t), t3 = dpp_move<DPP_Q_BCAST3>(t);
+                    const float P3 = P, P2 = __builtin_fmaf(om3, P3, t3), P1 = __builtin_fmaf(om2, P2, t2),
+                                P0 = __builtin_fmaf(om1, P1, t1);
+                    const float P_mine = slot == 0 ? P0 : slot == 1 ? P1 : slot == 2 ? P2 : P3;
+                    P = __builtin_fmaf(om0, P0, t0);
+
+                    float v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) v[k] = 0.f;
+                    if (live) {
+                        const float wgt = alpha * T_mine;                                       // dchannel_dcolor
+                        v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;             // :711
+                        v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;   // :727
+                        v[12] = wgt * c.dD_ch;                                                  // :782
+                        float dL_dalpha = (u - P_mine) + c.norm_depth_k / om / T_mine;          // :706,:723,:773,:776
+                        dL_dalpha *= T_mine;                                                    // :788
+                        dL_dalpha += c.tail / om;                                               // :791-802
+                        const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;               // :823
+                        v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - c.dD * g.plane_a;   // :828, :839
+                        v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - c.dD * g.plane_b;   // :829, :840
+                        v[2] = dL_ddist * (dx * dx);                                            // :831-835
+                        v[3] = dL_ddist * (dx * dy);
+                        v[4] = dL_ddist * (dy * dy);
+                        v[5] = G * dL_dalpha;                                                   // :854
+                    }
+                    const float total = pixel_reduce16(v, lane);
+                    // entries of this step with at least one live pixel: bits slot, slot+4, ... of the ballot
+                    const bool entry_live = ((live_mask >> slot) & 0x1111111111111111ull) != 0ull;
+                    if (entry_live && qslot < 13) atomicAdd(a.acc + (size_t)gid * ACC_STRIDE + qslot, total);
+                }
+            }
+        }
+        __syncthreads();                              // LDS arrays are overwritten by the next chunk
+    }
+}
+
+int bwd_variant()     // 0 = slots (default), 1 = dpp, 2 = lanes
 {
     static int cached = -1;
     if (cached < 0) {
         const char *v = getenv("SOAR_BWD_VARIANT");
-        cached = (v && !strcmp(v, "lanes")) ? 0 : 1;
+        cached = (v && !strcmp(v, "lanes")) ? 2 : (v && !strcmp(v, "dpp")) ? 1 : 0;
     }
-    return cached == 1;
+    return cached;
 }
 
 }  // namespace
@@ -477,7 +654,10 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc;
     StageTimer timer(ST_RENDER_BWD, stream);
-    if (use_dpp_variant())
+    const int variant = bwd_variant();
+    if (variant == 0)
+        hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * a.ntiles), dim3(256), 0, stream, a);
+    else if (variant == 1)
         hipLaunchKernelGGL(render_backward_dpp_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(render_backward_lanes_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);

@@ -3,18 +3,23 @@
 // Replaces renderCUDA<3> forward (DGR/cuda_rasterizer/forward.cu:390-692) and depth_differencing
 // (auxiliary.h:390-397).
 //
-// CDNA4 mapping (not the reference's 256-thread lock-step block):
-//  * a 16x16 tile is owned by one 256-thread workgroup, but each of its four wavefronts owns an 8x8
-//    pixel quad and walks the tile's depth-sorted list on its own: no workgroup barrier anywhere, a wave
-//    leaves as soon as its 64 pixels are saturated (wave-level vote = one s_cbranch on the exec mask);
-//  * the list is consumed in chunks of 64: lane l gathers the 64-byte record of entry l (four 16-byte
-//    loads, one cache-line half) and parks it in the wave's private 4 KiB LDS slab; the blend loop then
-//    reads records with wave-uniform (broadcast) ds_read_b128 -- two for the alpha test, two more only if
-//    some lane survives it;
-//  * before that loop the SAME 64 lanes, still holding one record each, evaluate a conservative bound of the splat's
-//    alpha over the quad (splat_may_touch_quad): a ballot yields the 64-bit set of entries that can matter, and the
-//    blend loop visits only those bits (s_ff1) -- entries that every pixel would skip cost nothing;
-//  * workgroup -> tile mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
+// The reference runs one thread per pixel and one entry of the tile list per step: on a tile whose list has
+// thousands of entries that is thousands of dependent steps, and on MI355X (256 CUs) only ~1000 tiles of a 1080p
+// frame have any work -- the launch ends as a long tail of single wavefronts.  This kernel spreads the SAME sequential
+// semantics over 4x more wavefronts and 4x shorter dependent chains:
+//
+//  * workgroup = one 8x8 pixel quad of a 16x16 tile (4 workgroups per tile), wavefront = one 4x4 pixel block;
+//  * lane = (pixel p = lane >> 2, slot s = lane & 3): the four lanes of a pixel take FOUR consecutive surviving
+//    entries of the list at once.  Each lane evaluates its own alpha (falloff + exp: the long part), then the
+//    running transmittance is carried through the four slots with wavefront-level quad broadcasts (DPP quad_perm), in
+//    exactly the reference's order of multiplications -- including "stop before the entry that would drop T below
+//    1e-4" -- so T, n_contrib and the set of blended entries are those of the sequential loop.  Colour / normal /
+//    depth sums are kept per slot and folded once per pixel at the end;
+//  * the list is staged per workgroup in chunks of 256 entries: thread t gathers the 64-byte record of entry t
+//    (software-pipelined one chunk ahead) into LDS as four float4 arrays; every wavefront then tests its 64-entry
+//    sub-chunks against ITS 4x4 block (lanes = entries, conservative bound splat_may_touch_rect) and only walks the
+//    set bits of the resulting ballot;
+//  * workgroup -> (tile, quad) mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
 #include "soar_common.h"
 
 #include <cstdio>
@@ -23,6 +28,8 @@
 namespace soar {
 
 namespace {
+
+constexpr int CHUNK = 256;          // list entries staged per workgroup iteration (one per thread)
 
 struct FwdArgs {
     int W, H, gx, gy, ntiles;
@@ -38,126 +45,157 @@ struct FwdArgs {
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
 };
 
-// blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of tiles
-__device__ __forceinline__ int xcd_tile(int bid, int n)
+// blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of the (tile, quad) sequence
+__device__ __forceinline__ int xcd_sequence(int bid, int n)
 {
     const int q = n >> 3, r = n & 7;
     const int xcd = bid & 7, within = bid >> 3;
     return xcd * q + min(xcd, r) + within;
 }
 
+constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST1 = 0x55, DPP_QUAD_BCAST2 = 0xAA, DPP_QUAD_BCAST3 = 0xFF;
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
+
+template <int CTRL>
+__device__ __forceinline__ float quad_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_move_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
 template <bool LOG>
 __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 {
-    __shared__ GaussRec slab[4][WAVE + 1];             // +1: an all-zero record
+    __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     unsigned long long t_start = 0, n_iter = 0;
     if (LOG) t_start = wall_clock64();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int seq = xcd_sequence(blockIdx.x, 4 * a.ntiles);
+    const int tile = seq >> 2, quad = seq & 3;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    // 4x4 pixel block of this wave inside the 8x8 quad of this workgroup inside the 16x16 tile
+    const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
+    const int pxl = lane >> 2, slot = lane & 3;
+    const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
     const bool inside = px < a.W && py < a.H;
     const float fx = (float)px, fy = (float)py;
 
     const uint2 range = a.ranges[tile];
 
-    float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
-    uint32_t last_contributor = 0;
-    bool done = !inside;
+    float T = 1.0f;                                  // replicated in the four lanes of a pixel
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
+    uint32_t last_contributor = 0;                   // per-slot, folded with max at the end
+    bool done = !inside;                             // replicated
+    bool wave_done = (__ballot(!done) == 0ull);
 
-    GaussRec *my = slab[wave];
-    const float4 *myq = reinterpret_cast<const float4 *>(my);
-    if (lane < 4) reinterpret_cast<float4 *>(my + WAVE)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        sq0[CHUNK] = z; sq1[CHUNK] = z; sq2[CHUNK] = z; sq3[CHUNK] = z;
+    }
 
-    const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
-
-    // software pipeline over chunks: the records of chunk k+1 are requested before the blend loop of chunk k runs,
-    // so the dependent (list entry -> record) gather latency stays off the critical path of long tile lists
+    // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    if (range.x + lane < range.y) {
-        const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[range.x + lane]);
+    if (range.x + tid < range.y) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[range.x + tid]);
         r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
     }
-    for (uint32_t base = range.x; base < range.y; base += WAVE) {
-        if (__ballot(!done) == 0ull) break;                 // whole quad saturated
-        const int n = min((uint32_t)WAVE, range.y - base);
-        // phase A -- lanes = list entries: park the record in the slab and vote whether the splat can reach the
-        // 1/255 alpha floor anywhere in this quad
-        bool relevant = false;
-        if (lane < n) {
-            float4 *dst = reinterpret_cast<float4 *>(my + lane);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-            relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
-        }
-        if (base + WAVE + lane < range.y) {
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[base + WAVE + lane]);
+    for (uint32_t base = range.x; base < range.y; base += CHUNK) {
+        const int n = min((uint32_t)CHUNK, range.y - base);
+        if (tid < n) { sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3; }
+        if (base + CHUNK + tid < range.y) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[base + CHUNK + tid]);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         }
-        unsigned long long todo = __ballot(relevant);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
 
-        // phase B -- lanes = pixels: walk the surviving entries in list order
-        const uint32_t contrib0 = base - range.x;           // entries before this chunk
-        // surviving entries are taken FOUR at a time: their 16 LDS reads are issued together and the four alpha
-        // evaluations (falloff + exp: the long dependent chains) are independent, so they interleave in the single
-        // wave that is left on a SIMD at the tail of the launch; only the short transmittance chain stays serial.
-        // Missing group members point at the all-zero record (alpha = 0: never live).
-        while (todo != 0ull) {
-            if (LOG) n_iter++;
-            int jj[4];
+        if (!wave_done) {
+            for (int sub = 0; sub < n; sub += WAVE) {
+                // phase A -- lanes = entries of this 64-entry sub-chunk: conservative test against the 4x4 block
+                bool relevant = false;
+                if (sub + lane < n) {
+                    const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
+                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, (float)bx0, (float)by0, 3.f);
+                }
+                unsigned long long todo = __ballot(relevant);
+                const uint32_t contrib0 = base - range.x + (uint32_t)sub;       // list entries before this sub-chunk
+
+                // phase B -- lanes = (pixel, slot): four surviving entries per step, in list order
+                while (todo != 0ull) {
+                    if (LOG) n_iter++;
+                    int jj[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                jj[k] = todo ? __builtin_ctzll(todo) : WAVE;
-                todo = todo ? (todo & (todo - 1ull)) : 0ull;
+                    for (int k = 0; k < 4; k++) {
+                        jj[k] = todo ? (sub + (int)__builtin_ctzll(todo)) : CHUNK;      // CHUNK: the zero record
+                        todo = todo ? (todo & (todo - 1ull)) : 0ull;
+                    }
+                    const int j = slot == 0 ? jj[0] : slot == 1 ? jj[1] : slot == 2 ? jj[2] : jj[3];
+                    const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+                    // x,y,A,B | C,opacity,depth,plane_a | plane_b,r,g,b | nx,ny,nz,-
+                    const float dx = q0.x - fx, dy = q0.y - fy;
+                    const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);          // forward.cu:507-508
+                    const float alpha = fminf(0.99f, q1.y * exp_nonpositive(power));
+                    // skip rules (:512, :545) zero the effective alpha of this lane's entry
+                    float a_eff = (power > 0.0f) ? 0.f : alpha;
+                    a_eff = (alpha < 1.0f / 255.0f) ? 0.f : a_eff;
+                    a_eff = done ? 0.f : a_eff;
+                    // running transmittance through the four slots, reference order (:548-553, :602).
+                    // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
+                    const float om = 1.f - a_eff;
+                    const float om0 = quad_move<DPP_QUAD_BCAST0>(om), om1 = quad_move<DPP_QUAD_BCAST1>(om),
+                                om2 = quad_move<DPP_QUAD_BCAST2>(om), om3 = quad_move<DPP_QUAD_BCAST3>(om);
+                    const float t0 = mul_keep(T, om0);
+                    const bool s0 = t0 < 0.0001f;
+                    const float T1 = s0 ? T : t0;
+                    const float t1 = mul_keep(T1, om1);
+                    const bool s1 = s0 || (t1 < 0.0001f);
+                    const float T2 = s1 ? T1 : t1;
+                    const float t2 = mul_keep(T2, om2);
+                    const bool s2 = s1 || (t2 < 0.0001f);
+                    const float T3 = s2 ? T2 : t2;
+                    const float t3 = mul_keep(T3, om3);
+                    const bool s3 = s2 || (t3 < 0.0001f);
+                    // transmittance in front of MY entry, and whether the pixel had stopped at or before it
+                    const float T_mine = slot == 0 ? T : slot == 1 ? T1 : slot == 2 ? T2 : T3;
+                    const bool stopped = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
+                    const float w = stopped ? 0.f : a_eff * T_mine;
+                    const bool blend = w != 0.f;
+                    const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
+                    D = blend ? __builtin_fmaf(depth, w, D) : D;
+                    C0 = blend ? __builtin_fmaf(q2.y, w, C0) : C0;
+                    C1 = blend ? __builtin_fmaf(q2.z, w, C1) : C1;
+                    C2 = blend ? __builtin_fmaf(q2.w, w, C2) : C2;
+                    N0 = blend ? __builtin_fmaf(q3.x, w, N0) : N0;
+                    N1 = blend ? __builtin_fmaf(q3.y, w, N1) : N1;
+                    N2 = blend ? __builtin_fmaf(q3.z, w, N2) : N2;
+                    last_contributor = blend ? contrib0 + (uint32_t)(j - sub) + 1u : last_contributor;
+                    T = s3 ? T3 : t3;
+                    done = done || s3;
+                    if (__ballot(!done) == 0ull) { wave_done = true; break; }
+                }
+                if (wave_done) break;
             }
-            float4 q0[4], q1[4], q2[4], q3[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                q0[k] = myq[4 * jj[k] + 0]; q1[k] = myq[4 * jj[k] + 1];     // x,y,A,B | C,opacity,depth,plane_a
-                q2[k] = myq[4 * jj[k] + 2]; q3[k] = myq[4 * jj[k] + 3];     // plane_b,r,g,b | nx,ny,nz,-
-            }
-            float dx[4], dy[4], power[4], alpha[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                dx[k] = q0[k].x - fx; dy[k] = q0[k].y - fy;
-                power[k] = falloff_power(q0[k].z, q0[k].w, q1[k].x, dx[k], dy[k]);          // forward.cu:507-508
-                alpha[k] = fminf(0.99f, q1[k].y * exp_nonpositive(power[k]));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // Branch-free (selects only: no exec-mask juggling in the serial part).  Skip rules :512,:545 zero the
-                // effective alpha; a pixel saturates BEFORE blending the entry that would drop T below 1e-4 (:549-552).
-                // Invariant: T >= 1e-4 for every lane, so test_T < 1e-4 can only happen on a live lane.
-                float a_eff = (power[k] > 0.0f) ? 0.f : alpha[k];
-                a_eff = (alpha[k] < 1.0f / 255.0f) ? 0.f : a_eff;
-                a_eff = done ? 0.f : a_eff;
-                const float test_T = mul_one_minus(T, a_eff);
-                const bool stop = test_T < 0.0001f;
-                done = stop ? true : done;
-                const float w = stop ? 0.f : a_eff * T;
-                const bool blend = w != 0.f;
-                const float depth = q1[k].z - (dx[k] * q1[k].w + dy[k] * q2[k].x);         // depth on the surfel plane
-                D = blend ? __builtin_fmaf(depth, w, D) : D;
-                C0 = blend ? __builtin_fmaf(q2[k].y, w, C0) : C0;
-                C1 = blend ? __builtin_fmaf(q2[k].z, w, C1) : C1;
-                C2 = blend ? __builtin_fmaf(q2[k].w, w, C2) : C2;
-                N0 = blend ? __builtin_fmaf(q3[k].x, w, N0) : N0;
-                N1 = blend ? __builtin_fmaf(q3[k].y, w, N1) : N1;
-                N2 = blend ? __builtin_fmaf(q3[k].z, w, N2) : N2;
-                T = blend ? test_T : T;
-                last_contributor = blend ? contrib0 + (uint32_t)jj[k] + 1u : last_contributor;
-            }
-            if (__ballot(!done) == 0ull) break;              // wave-uniform: whole quad saturated
         }
-        __builtin_amdgcn_wave_barrier();                     // slab is overwritten by the next chunk
+        // also the barrier that protects the LDS arrays before the next chunk overwrites them
+        if (!__syncthreads_or(wave_done ? 0 : 1)) break;
     }
 
-    if (inside) {
+    // fold the four slots of every pixel
+    D += quad_move<DPP_QUAD_XOR1>(D); D += quad_move<DPP_QUAD_XOR2>(D);
+    C0 += quad_move<DPP_QUAD_XOR1>(C0); C0 += quad_move<DPP_QUAD_XOR2>(C0);
+    C1 += quad_move<DPP_QUAD_XOR1>(C1); C1 += quad_move<DPP_QUAD_XOR2>(C1);
+    C2 += quad_move<DPP_QUAD_XOR1>(C2); C2 += quad_move<DPP_QUAD_XOR2>(C2);
+    N0 += quad_move<DPP_QUAD_XOR1>(N0); N0 += quad_move<DPP_QUAD_XOR2>(N0);
+    N1 += quad_move<DPP_QUAD_XOR1>(N1); N1 += quad_move<DPP_QUAD_XOR2>(N1);
+    N2 += quad_move<DPP_QUAD_XOR1>(N2); N2 += quad_move<DPP_QUAD_XOR2>(N2);
+    last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR1>(last_contributor));
+    last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR2>(last_contributor));
+
+    if (inside && slot == 0) {
         // epilogue, forward.cu:618-633
         T = fminf((float)(1 - 0.000001), T);
         const size_t pix = (size_t)a.W * py + px;
@@ -174,8 +212,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
         a.out_opac[pix] = 1.f - T;
         if (a.normalize_depth) a.final_D[pix] = D;
     }
-    if (LOG && (threadIdx.x & 63) == 0) {
-        unsigned long long *w = a.wave_log + ((size_t)tile * 4 + (threadIdx.x >> 6)) * 4;
+    if (LOG && lane == 0) {
+        unsigned long long *w = a.wave_log + ((size_t)seq * 4 + wave) * 4;
         w[0] = t_start; w[1] = wall_clock64(); w[2] = range.y - range.x; w[3] = n_iter;
     }
 }
@@ -193,16 +231,17 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.ranges = img.ranges; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
-    StageTimer timer(ST_RENDER_FWD, stream);
     a.wave_log = nullptr;
+    const int nblocks = 4 * a.ntiles;
+    StageTimer timer(ST_RENDER_FWD, stream);
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     static int logged = 0;
     if (log_path && !logged && prm.render_front == 0) {
         logged = 1;
-        const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)a.ntiles;
+        const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)nblocks;
         SOAR_HIP_OK(hipMalloc(&a.wave_log, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(a.wave_log, 0, nbytes, stream));
-        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(a.ntiles), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(nblocks), dim3(256), 0, stream, a);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, a.wave_log, nbytes, hipMemcpyDeviceToHost));
@@ -212,7 +251,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
         (void)hipFree(a.wave_log);
         return 0;
     }
-    hipLaunchKernelGGL(render_forward_kernel<false>, dim3(a.ntiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(render_forward_kernel<false>, dim3(nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
     return 0;
 }

@@ -115,16 +115,17 @@ __device__ __forceinline__ float falloff_power(float A, float B, float Cc, float
     const float dist = (A * dx * dx + Cc * dy * dy) + 2 * B * dx * dy;
     return -0.5f * dist;
 }
-// Conservative wave-level culling: can a splat reach alpha >= 1/255 at ANY pixel centre of the 8x8 quad whose pixels
-// span [x0, x0+7] x [y0, y0+7]?  Minimises the (positive-definite) falloff form over the quad's rectangle -- a lower
+// Conservative wave-level culling: can a splat reach alpha >= 1/255 at ANY pixel centre of the pixel block whose
+// pixels span [x0, x0+extent] x [y0, y0+extent]?  Minimises the (positive-definite) falloff form over the quad's rectangle -- a lower
 // bound of its value at every pixel -- and compares the implied alpha bound with the 1/255 skip threshold of the blend
 // (forward.cu:545, backward.cu:680) with a safety margin, so dropping a splat never changes a result: splats that
 // fail are exactly those every lane would have skipped.  Returns true when in doubt (non-PD conic, NaN).
-__device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A, float B, float Cc, float opacity,
-                                                     float x0, float y0)
+__device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A, float B, float Cc, float opacity,
+                                                     float x0, float y0, float extent)
 {
-    const float dx_hi = gx - x0, dx_lo = dx_hi - 7.f;
-    const float dy_hi = gy - y0, dy_lo = dy_hi - 7.f;
+    // pixel centres of the block span [x0, x0+extent] x [y0, y0+extent]
+    const float dx_hi = gx - x0, dx_lo = dx_hi - extent;
+    const float dy_hi = gy - y0, dy_lo = dy_hi - extent;
     const bool pd = (A > 0.f) && (Cc > 0.f) && (A * Cc - B * B > 0.f);
     const float nx = dx_lo > 0.f ? dx_lo : (dx_hi < 0.f ? dx_hi : 0.f);
     const float ny = dy_lo > 0.f ? dy_lo : (dy_hi < 0.f ? dy_hi : 0.f);
@@ -143,6 +144,13 @@ __device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A
     const bool certainly_invisible = (qmin * 0.9999f - 1.0e-3f > thr) || (255.f * opacity < 0.999f);
     return !(pd && certainly_invisible);
 }
+
+__device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A, float B, float Cc, float opacity,
+                                                     float x0, float y0)
+{
+    return splat_may_touch_rect(gx, gy, A, B, Cc, opacity, x0, y0, 7.f);
+}
+__device__ __forceinline__ float mul_keep(float a, float b) { return a * b; }
 
 __device__ __forceinline__ float mul_one_minus(float T, float alpha)
 {
