@@ -113,6 +113,7 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->final_T, pix > 0 ? pix : 1);
     take(p, out->n_contrib, pix > 0 ? pix : 1);
     take(p, out->final_D, pix > 0 ? pix : 1);
+    take(p, out->tile_order, (tiles + 7) / 8 * 8 + 8);
     out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
     return 0;
 }

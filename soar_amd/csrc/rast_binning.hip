@@ -108,14 +108,51 @@ tile_ranges_kernel(int64_t L, const uint64_t *__restrict__ keys, uint2 *__restri
     if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
+// Longest-list-first order of the tiles (16 length classes, counting sort in one workgroup).  The blend kernels map
+// workgroup i to the i-th tile of this order, so the hardware dispatcher starts the few long tiles first and back-fills
+// with the thousands of short / empty ones instead of discovering a 4000-entry tile in the middle of the launch.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int T, int Tpad, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t count[16], cursor[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) count[tid] = 0u;
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        const int cls = 15 - min(15, 32 - __clz((int)len));       // class 0: >= 16384 entries ... class 15: empty
+        atomicAdd(&count[cls], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 16; k++) { cursor[k] = acc; acc += count[k]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        const int cls = 15 - min(15, 32 - __clz((int)len));
+        order[atomicAdd(&cursor[cls], 1u)] = (uint32_t)t;
+    }
+    for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
+}
+
 }  // namespace
+
+int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream)
+{
+    const int T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
+    const int Tpad = (T + 7) / 8 * 8;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, T, Tpad, img.ranges, img.tile_order);
+    SOAR_LAUNCH_OK("tile_order", stream, prm.debug);
+    return 0;
+}
 
 int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream)
 {
     const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
     SOAR_HIP_OK(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, stream));
-    if (R <= 0) return 0;
+    if (R <= 0) return launch_tile_order(prm, img, stream);
 
     {
     StageTimer timer(ST_EMIT_KEYS, stream);
@@ -144,7 +181,7 @@ int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, 
                        img.ranges);
     }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
-    return 0;
+    return launch_tile_order(prm, img, stream);
 }
 
 }  // namespace soar

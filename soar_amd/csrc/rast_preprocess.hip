@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
         rec.q0 = make_float4(pix_x, pix_y, conic[0], conic[1]);
         rec.q1 = make_float4(conic[2], a.opacities[idx], vz, plane_a);
         rec.q2 = make_float4(plane_b, rgb[0], rgb[1], rgb[2]);
-        rec.q3 = make_float4(nview[0], nview[1], nview[2], __int_as_float(out_radius));
+        rec.q3 = make_float4(nview[0], nview[1], nview[2], splat_cull_threshold(a.opacities[idx]));
     }
     a.rec[idx] = rec;
     a.radii[idx] = out_radius;

@@ -39,6 +39,7 @@ struct BwdArgs {
     int W, H, gx, gy, ntiles;
     int normalize_depth;
     const uint2 *ranges;
+    const uint32_t *tile_order;
     const uint32_t *point_list;
     const GaussRec *rec;
     const float *bg;
@@ -498,8 +499,11 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     __shared__ uint32_t wave_deep[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int seq = xcd_tile(blockIdx.x, 4 * a.ntiles);
-    const int tile = seq >> 2, quad = seq & 3;
+    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;         // same longest-first mapping as the forward kernel
+    const int rank = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    const uint32_t tile_u = a.tile_order[rank];
+    if (tile_u == 0xFFFFFFFFu) return;
+    const int tile = (int)tile_u;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
     const int pxl = lane >> 2, slot = lane & 3;
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                 const int e = sub + lane;
                 if (e < n && (uint32_t)(cbase + e) < deepest_wave) {
                     const float4 e0 = sq0[e], e1 = sq1[e];
-                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, (float)bx0, (float)by0, 3.f);
+                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[e].w, (float)bx0, (float)by0, 3.f);
                 }
                 unsigned long long todo = __ballot(relevant);
 
@@ -649,14 +653,14 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
     a.ntiles = a.gx * a.gy;
     a.normalize_depth = prm.cfg_normalize_depth;
-    a.ranges = img.ranges; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
+    a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc;
     StageTimer timer(ST_RENDER_BWD, stream);
     const int variant = bwd_variant();
     if (variant == 0)
-        hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * a.ntiles), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * ((a.ntiles + 7) / 8 * 8)), dim3(256), 0, stream, a);
     else if (variant == 1)
         hipLaunchKernelGGL(render_backward_dpp_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
     else

@@ -19,7 +19,8 @@
 //    (software-pipelined one chunk ahead) into LDS as four float4 arrays; every wavefront then tests its 64-entry
 //    sub-chunks against ITS 4x4 block (lanes = entries, conservative bound splat_may_touch_rect) and only walks the
 //    set bits of the resulting ballot;
-//  * workgroup -> (tile, quad) mapping is XCD-aware: consecutive tiles (which share Gaussians) stay on one XCD's L2.
+//  * workgroups follow the longest-list-first tile order built by tile_order_kernel (rast_binning.hip), dealt
+//    round-robin to the XCDs with the four quads of a tile on one XCD: the long tiles start first, everywhere.
 #include "soar_common.h"
 
 #include <cstdio>
@@ -35,6 +36,7 @@ struct FwdArgs {
     int W, H, gx, gy, ntiles;
     int normalize_depth;
     const uint2 *ranges;
+    const uint32_t *tile_order;
     const uint32_t *point_list;
     const GaussRec *rec;
     const float *bg;
@@ -44,14 +46,6 @@ struct FwdArgs {
     float *out_color, *out_normal, *out_depth, *out_opac;
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
 };
-
-// blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of the (tile, quad) sequence
-__device__ __forceinline__ int xcd_sequence(int bid, int n)
-{
-    const int q = n >> 3, r = n & 7;
-    const int xcd = bid & 7, within = bid >> 3;
-    return xcd * q + min(xcd, r) + within;
-}
 
 constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST1 = 0x55, DPP_QUAD_BCAST2 = 0xAA, DPP_QUAD_BCAST3 = 0xFF;
 constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
@@ -75,8 +69,13 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     if (LOG) t_start = wall_clock64();
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int seq = xcd_sequence(blockIdx.x, 4 * a.ntiles);
-    const int tile = seq >> 2, quad = seq & 3;
+    // workgroups are dealt round-robin over the 8 XCDs: XCD x takes the tiles of rank x, x+8, ... of the longest-first
+    // order, four consecutive workgroups of an XCD = the four quads of one tile (one L2 serves the tile's records)
+    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    const int rank = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    const uint32_t tile_u = a.tile_order[rank];
+    if (tile_u == 0xFFFFFFFFu) return;
+    const int tile = (int)tile_u, seq = rank * 4 + quad;
     const int tx = tile % a.gx, ty = tile / a.gx;
     // 4x4 pixel block of this wave inside the 8x8 quad of this workgroup inside the 16x16 tile
     const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                 bool relevant = false;
                 if (sub + lane < n) {
                     const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
-                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, (float)bx0, (float)by0, 3.f);
+                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[sub + lane].w, (float)bx0, (float)by0, 3.f);
                 }
                 unsigned long long todo = __ballot(relevant);
                 const uint32_t contrib0 = base - range.x + (uint32_t)sub;       // list entries before this sub-chunk
@@ -228,11 +227,11 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
     a.ntiles = a.gx * a.gy;
     a.normalize_depth = prm.cfg_normalize_depth;
-    a.ranges = img.ranges; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
+    a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     a.wave_log = nullptr;
-    const int nblocks = 4 * a.ntiles;
+    const int nblocks = 4 * ((a.ntiles + 7) / 8 * 8);
     StageTimer timer(ST_RENDER_FWD, stream);
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     static int logged = 0;

@@ -47,7 +47,7 @@ inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a;
 // q0 = {mean2D.x, mean2D.y, conic.x (A), conic.y (B)}
 // q1 = {conic.z (C), opacity, view depth, depth-plane a}
 // q2 = {depth-plane b, colour r, g, b}
-// q3 = {view normal x, y, z, radius (int bits)}
+// q3 = {view normal x, y, z, cull threshold 2 ln(255 opacity) + margin (see splat_may_touch_rect)}
 // depth-plane (a, b): the only two combinations of Jinv[10] that the renderers consume,
 //   a = J6*J0 + J9*J2, b = J6*J1 + J9*J3  (auxiliary.h:390-397, backward.cu:839-840).
 struct alignas(16) GaussRec {
@@ -72,6 +72,7 @@ struct ImageBuf {
     float *final_T;          // [pix]
     uint32_t *n_contrib;     // [pix]
     float *final_D;          // [pix]
+    uint32_t *tile_order;    // [T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding)
     size_t total_bytes;
 };
 struct BinBuf {
@@ -120,7 +121,7 @@ __device__ __forceinline__ float falloff_power(float A, float B, float Cc, float
 // bound of its value at every pixel -- and compares the implied alpha bound with the 1/255 skip threshold of the blend
 // (forward.cu:545, backward.cu:680) with a safety margin, so dropping a splat never changes a result: splats that
 // fail are exactly those every lane would have skipped.  Returns true when in doubt (non-PD conic, NaN).
-__device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A, float B, float Cc, float opacity,
+__device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A, float B, float Cc, float thr,
                                                      float x0, float y0, float extent)
 {
     // pixel centres of the block span [x0, x0+extent] x [y0, y0+extent]
@@ -130,25 +131,29 @@ __device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A
     const float nx = dx_lo > 0.f ? dx_lo : (dx_hi < 0.f ? dx_hi : 0.f);
     const float ny = dy_lo > 0.f ? dy_lo : (dy_hi < 0.f ? dy_hi : 0.f);
     float qmin = 3.0e38f;
+    // the edge minimiser only has to be approximately right (q is stationary there): hardware reciprocal is enough
     if (nx != 0.f) {
-        const float t = fminf(fmaxf(-B * nx / Cc, dy_lo), dy_hi);
+        const float t = fminf(fmaxf(-B * nx * __builtin_amdgcn_rcpf(Cc), dy_lo), dy_hi);
         qmin = fminf(qmin, A * nx * nx + 2.f * B * nx * t + Cc * t * t);
     }
     if (ny != 0.f) {
-        const float t = fminf(fmaxf(-B * ny / A, dx_lo), dx_hi);
+        const float t = fminf(fmaxf(-B * ny * __builtin_amdgcn_rcpf(A), dx_lo), dx_hi);
         qmin = fminf(qmin, A * t * t + 2.f * B * t * ny + Cc * ny * ny);
     }
     if (nx == 0.f && ny == 0.f) qmin = 0.f;
-    // alpha_max = opacity * exp(-qmin/2) < (1/255)(1 - 1e-3)  <=>  qmin > 2 ln(255 opacity) + 2e-3
-    const float thr = 2.f * __logf(255.f * opacity) + 2.0e-3f;
-    const bool certainly_invisible = (qmin * 0.9999f - 1.0e-3f > thr) || (255.f * opacity < 0.999f);
+    // alpha_max = opacity * exp(-qmin/2) < (1/255)(1 - 1e-3)  <=>  qmin > thr = 2 ln(255 opacity) + 2e-3
+    // (thr is precomputed per splat by the preprocess kernel; -3e38 when 255*opacity < 0.999, NaN stays "visible")
+    const bool certainly_invisible = (qmin * 0.9999f - 1.0e-3f > thr);
     return !(pd && certainly_invisible);
 }
-
+__device__ __forceinline__ float splat_cull_threshold(float opacity)
+{
+    return (255.f * opacity < 0.999f) ? -3.0e38f : 2.f * __logf(255.f * opacity) + 2.0e-3f;
+}
 __device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A, float B, float Cc, float opacity,
                                                      float x0, float y0)
 {
-    return splat_may_touch_rect(gx, gy, A, B, Cc, opacity, x0, y0, 7.f);
+    return splat_may_touch_rect(gx, gy, A, B, Cc, splat_cull_threshold(opacity), x0, y0, 7.f);
 }
 __device__ __forceinline__ float mul_keep(float a, float b) { return a * b; }
 
@@ -168,6 +173,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
                       const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
                       GeomBuf &g, int32_t *radii, hipStream_t stream);
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
+int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream);
 int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream);
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
