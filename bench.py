@@ -82,9 +82,11 @@ def synthetic_loss(out, targets):
 def run_step(seq, targets, flat, frames, bg):
     flat.zero()
     seq.refresh_blend_weights()
-    for f in frames:
-        out = seq.render_frame(f, bg, with_occ=True)
-        synthetic_loss(out, targets).backward()
+    outs = seq.render_frames(frames, bg, with_occ=True)        # one host sync for the whole batch of frames
+    loss = synthetic_loss(outs[0], targets)
+    for out in outs[1:]:
+        loss = loss + synthetic_loss(out, targets)
+    loss.backward()
     return flat.all_reduce()
 
 

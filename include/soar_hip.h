@@ -70,13 +70,18 @@ int soar_rast_binning_bytes(int64_t num_rendered, size_t *bytes);
  * stage 1: preprocess (forward.cu:205-385) + inclusive scan (:242-245) + blocking read-back of num_rendered.
  *   means3D [P,3]; opacities [P]; exactly one of shs [P,M,3] / colors_precomp [P,3];
  *   exactly one of (scales [P,3], rotations [P,4]) / cov3D_precomp [P,6].
- *   radii_out [P] int32 (API output).  *num_rendered_host receives R. */
+ *   radii_out [P] int32 (API output).  *num_rendered_host receives R (NULL: asynchronous form, see below). */
 int soar_rast_forward_geometry(const SoarRastParams *prm,
                                const float *means3D, const float *shs, const float *colors_precomp,
                                const float *opacities, const float *scales, const float *rotations,
                                const float *cov3D_precomp,
                                void *geom_buffer, int32_t *radii_out, int64_t *num_rendered_host,
                                void *stream);
+
+/* Asynchronous form of stage 1: pass num_rendered_host == NULL to soar_rast_forward_geometry (no host synchronisation),
+ * enqueue the geometry stage of several views / frames, then read each R with this call (it synchronises `stream`
+ * once; later calls return immediately).  One sync per batch of views instead of one per view. */
+int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_t *num_rendered_host, void *stream);
 
 /* stage 2: duplicateWithKeys (:66-99) + radix sort on bits [0,32+bit) (:266-285) + identifyTileRanges
  *   (:104-124,287-295) + per-tile blend (forward.cu:390-692).

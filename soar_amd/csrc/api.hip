@@ -221,8 +221,7 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
-    if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return 1; }
-    *num_rendered_host = 0;
+    if (num_rendered_host) *num_rendered_host = 0;
     if (prm->P == 0) return 0;                                     // rasterize_points.cu:78
     if (check_aligned(geom_buffer, "geom_buffer")) return 1;
     if (!means3D || !opacities || !radii_out) { set_error("means3D / opacities / radii_out must not be NULL"); return 1; }
@@ -243,9 +242,26 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
     if (launch_scan(*prm, g, stream)) return 1;
+    if (!num_rendered_host) return 0;             // asynchronous form: read R later with soar_rast_num_rendered()
     // the one host synchronisation of the forward pass (rasterizer_impl.cu:250-252)
     uint32_t r = 0;
     SOAR_HIP_OK(hipMemcpyAsync(&r, g.point_offsets + (prm->P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SOAR_HIP_OK(hipStreamSynchronize(stream));
+    *num_rendered_host = (int64_t)r;
+    return 0;
+}
+
+int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_t *num_rendered_host, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!num_rendered_host || P < 0) { set_error("soar_rast_num_rendered: bad arguments"); return 1; }
+    *num_rendered_host = 0;
+    if (P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    GeomBuf g;
+    carve_geom(const_cast<void *>(geom_buffer), P, M, &g);
+    uint32_t r = 0;
+    SOAR_HIP_OK(hipMemcpyAsync(&r, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SOAR_HIP_OK(hipStreamSynchronize(stream));
     *num_rendered_host = (int64_t)r;
     return 0;

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import lbs
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
 from .smplx_joints import JointTransformer
 from .synthetic import BodyModel, CameraSpec, Surfels
 
@@ -107,3 +107,33 @@ class AvatarSequence:
                                 colors_precomp=self.occ.repeat(1, 3), scales=self.scales.detach(),
                                 rotations=rot_p.detach())[0]
         return FrameOutputs(render, normal, depth, mask, occ_img, radii, means2D)
+
+    # ---- several frames of one optimizer step at once ----
+    def render_frames(self, frames: List[int], bg: torch.Tensor, with_occ: bool = True) -> List[FrameOutputs]:
+        """Same results as ``[render_frame(f, bg) for f in frames]`` with ONE host synchronisation for the whole batch:
+        all LBS warps and geometry stages are enqueued first (``rasterize_views``)."""
+        if self.blend_weights is None:
+            self.refresh_blend_weights()
+        ones = torch.ones_like(self.opacity)
+        main_rs = self.settings(bg, render_front=False, sort_descending=False)
+        occ_rs = self.settings(bg, render_front=True, sort_descending=False)
+        warped, taps, settings, inputs = [], [], [], []
+        for f in frames:
+            xyz_p, rot_p = lbs.lbs_warp(self.xyz, self.rot, self.blend_weights, self.cano2live[f % self.num_frames])
+            tap = torch.zeros_like(xyz_p, requires_grad=True)
+            warped.append((xyz_p, rot_p))
+            taps.append(tap)
+            settings.append(main_rs)
+            inputs.append(dict(means3D=xyz_p, means2D=tap, opacities=ones, colors_precomp=self.colors, scales=self.scales,
+                               rotations=rot_p))
+        n = len(frames)
+        if with_occ:
+            occ_col = self.occ.repeat(1, 3)
+            for (x, r), t in zip(warped, taps):
+                settings.append(occ_rs)
+                inputs.append(dict(means3D=x.detach(), means2D=t.detach(), opacities=ones, colors_precomp=occ_col,
+                                   scales=self.scales.detach(), rotations=r.detach()))
+        views = rasterize_views(settings, inputs)
+        main = views[:n]
+        occ = [v[0].detach() for v in views[n:]] if with_occ else [None] * n
+        return [FrameOutputs(m[0], m[1], m[2], m[3], o, m[4], t) for m, o, t in zip(main, occ, taps)]

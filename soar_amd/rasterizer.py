@@ -26,7 +26,7 @@ import torch.nn as nn
 from . import hip_lib
 from .hip_lib import SoarRastParams, check, ptr
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_views", "_C"]
 
 # running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
 stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
@@ -141,57 +141,89 @@ class _NativeOps:
     """Same entry points, positional signatures and return tuples as the reference's pybind module ``_C``."""
 
     @staticmethod
-    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                            viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, image_height, image_width,
-                            sh, degree, campos, prefiltered, render_front, sort_descending, debug, config):
-        """-> (num_rendered, color[3,H,W], normal[3,H,W], depth[1,H,W], opac[1,H,W], radii[P] int32,
-        geomBuffer, binningBuffer, imgBuffer)   (rasterize_points.cu:35-105)"""
+    def _geometry_stage(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, image_height, image_width,
+                        sh, degree, campos, prefiltered, render_front, sort_descending, debug, config):
+        """Allocate outputs / scratch and enqueue preprocess + scan WITHOUT a host synchronisation.  Returns a state
+        dict for `_render_stage`."""
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")      # rasterize_points.cu:50-52
         _require_hip(means3D, "means3D")
         L = hip_lib.lib()
         device = means3D.device
         P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-        out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-        out_normal = torch.empty((3, H, W), dtype=torch.float32, device=device)
-        out_depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
-        out_opac = torch.empty((1, H, W), dtype=torch.float32, device=device)
-        radii = torch.empty((P,), dtype=torch.int32, device=device)
-        empty = torch.empty((0,), dtype=torch.uint8, device=device)
+        st = {"device": device, "P": P, "H": W and H, "W": W}
+        st["out"] = [torch.empty((3, H, W), dtype=torch.float32, device=device),
+                     torch.empty((3, H, W), dtype=torch.float32, device=device),
+                     torch.empty((1, H, W), dtype=torch.float32, device=device),
+                     torch.empty((1, H, W), dtype=torch.float32, device=device)]
+        st["radii"] = torch.empty((P,), dtype=torch.int32, device=device)
         sh_t = _opt_f32(sh, device)
         M = int(sh_t.size(1)) if sh_t is not None else 0
+        st["M"] = M
         ctx = _Ctx(P, M, H, W, tan_fovx, tan_fovy, scale_modifier, degree, prefiltered, render_front, sort_descending,
                    debug, background, viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device)
-        prm = C.byref(ctx.params)
-        stream = _stream(device)
+        st["ctx"] = ctx
+        st["geom"] = st["img"] = st["binning"] = torch.empty((0,), dtype=torch.uint8, device=device)
+        if P == 0:
+            return st
         with torch.cuda.device(device):
-            if P == 0:
-                check(L.soar_rast_forward_render(prm, None, None, None, None, 0, out_color.data_ptr(), out_normal.data_ptr(),
-                                                 out_depth.data_ptr(), out_opac.data_ptr(), stream), "rasterize_gaussians")
-                return 0, out_color, out_normal, out_depth, out_opac, radii, empty, empty.clone(), empty.clone()
             means = _dev_f32(means3D, device, "means3D")
             opac = _dev_f32(opacity, device, "opacity")
             cols, scl, rot, cov = (_opt_f32(colors, device), _opt_f32(scales, device), _opt_f32(rotations, device),
                                    _opt_f32(cov3D_precomp, device))
+            st["keep"] = (means, opac, cols, scl, rot, cov, sh_t)
             nbytes = C.c_size_t(0)
             check(L.soar_rast_geometry_bytes(P, M, C.byref(nbytes)), "geometry_bytes")
-            geom = _scratch(nbytes.value, device)
+            st["geom"] = _scratch(nbytes.value, device)
             check(L.soar_rast_image_bytes(W, H, C.byref(nbytes)), "image_bytes")
-            img = _scratch(nbytes.value, device)
+            st["img"] = _scratch(nbytes.value, device)
+            check(L.soar_rast_forward_geometry(C.byref(ctx.params), means.data_ptr(), ptr(sh_t), ptr(cols), opac.data_ptr(),
+                                               ptr(scl), ptr(rot), ptr(cov), st["geom"].data_ptr(), st["radii"].data_ptr(),
+                                               None, _stream(device)), "rasterize_gaussians (geometry stage)")
+        return st
+
+    @staticmethod
+    def _render_stage(st):
+        """Read num_rendered (synchronises the stream unless an earlier view of the batch already did), size the binning
+        buffer, enqueue key emission + sort + ranges + blend."""
+        L = hip_lib.lib()
+        device, P = st["device"], st["P"]
+        out = st["out"]
+        prm = C.byref(st["ctx"].params)
+        stream = _stream(device)
+        with torch.cuda.device(device):
+            if P == 0:
+                check(L.soar_rast_forward_render(prm, None, None, None, None, 0, out[0].data_ptr(), out[1].data_ptr(),
+                                                 out[2].data_ptr(), out[3].data_ptr(), stream), "rasterize_gaussians")
+                return 0
             R = C.c_int64(0)
-            check(L.soar_rast_forward_geometry(prm, means.data_ptr(), ptr(sh_t), ptr(cols), opac.data_ptr(), ptr(scl),
-                                               ptr(rot), ptr(cov), geom.data_ptr(), radii.data_ptr(), C.byref(R), stream),
-                  "rasterize_gaussians (geometry stage)")
+            check(L.soar_rast_num_rendered(st["geom"].data_ptr(), P, st["M"], C.byref(R), stream), "num_rendered")
             num_rendered = int(R.value)
             stats["forward_calls"] += 1
             stats["num_rendered"] += num_rendered
+            nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
-            binning = _scratch(nbytes.value, device)
-            check(L.soar_rast_forward_render(prm, radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
-                                             num_rendered, out_color.data_ptr(), out_normal.data_ptr(),
-                                             out_depth.data_ptr(), out_opac.data_ptr(), stream),
+            st["binning"] = _scratch(nbytes.value, device)
+            check(L.soar_rast_forward_render(prm, st["radii"].data_ptr(), st["geom"].data_ptr(), st["binning"].data_ptr(),
+                                             st["img"].data_ptr(), num_rendered, out[0].data_ptr(), out[1].data_ptr(),
+                                             out[2].data_ptr(), out[3].data_ptr(), stream),
                   "rasterize_gaussians (render stage)")
-        return num_rendered, out_color, out_normal, out_depth, out_opac, radii, geom, binning, img
+        return num_rendered
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, image_height, image_width,
+                            sh, degree, campos, prefiltered, render_front, sort_descending, debug, config):
+        """-> (num_rendered, color[3,H,W], normal[3,H,W], depth[1,H,W], opac[1,H,W], radii[P] int32,
+        geomBuffer, binningBuffer, imgBuffer)   (rasterize_points.cu:35-105)"""
+        st = _NativeOps._geometry_stage(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy,
+                                        image_height, image_width, sh, degree, campos, prefiltered, render_front,
+                                        sort_descending, debug, config)
+        num_rendered = _NativeOps._render_stage(st)
+        o = st["out"]
+        return num_rendered, o[0], o[1], o[2], o[3], st["radii"], st["geom"], st["binning"], st["img"]
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
@@ -305,6 +337,84 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors_precomp), g_opacities.reshape(ctx.opac_shape),
                 like(g_scales, scales), like(g_rot, rotations), like(g_cov3D, cov3Ds_precomp), g_view, g_proj, g_campos,
                 None)
+
+
+class _RasterizeViews(torch.autograd.Function):
+    """Several rasterizations (views / video frames) as ONE autograd node: the geometry stages of all views are
+    enqueued first, the host synchronises once to read every num_rendered, then all binning + blend stages follow.
+    This removes the per-view host round trip of the reference (rasterizer_impl.cu:250) from multi-frame steps."""
+
+    N_IN = 8      # tensors per view: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp
+
+    @staticmethod
+    def forward(ctx, settings_list, *flat):
+        n = _RasterizeViews.N_IN
+        views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
+        states = []
+        for rs, (means3D, means2D, sh, colors, opac, scales, rot, cov) in zip(settings_list, views):
+            states.append(_NativeOps._geometry_stage(
+                rs.bg, means3D, colors, opac, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
+                rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config))
+        ctx.num_rendered = [_NativeOps._render_stage(st) for st in states]
+        ctx.settings_list = settings_list
+        ctx.opac_shapes = [v[4].shape for v in views]
+        saved, outs, nondiff = [], [], []
+        for st, v in zip(states, views):
+            saved += [v[3], v[0], v[5], v[6], v[7], st["radii"], v[2], st["geom"], st["binning"], st["img"]]
+            outs += st["out"] + [st["radii"]]
+            nondiff.append(st["radii"])
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(*nondiff)
+        ctx.set_materialize_grads(False)          # views whose outputs are unused (e.g. occlusion passes) are skipped
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        grads = [None]
+        for i, rs in enumerate(ctx.settings_list):
+            colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = ctx.saved_tensors[i * 10:(i + 1) * 10]
+            g_color, g_normal, g_depth, g_opac, _ = gouts[i * 5:(i + 1) * 5]
+            if g_color is None and g_normal is None and g_depth is None and g_opac is None:
+                grads += [None] * 8
+                continue
+            H, W = int(rs.image_height), int(rs.image_width)
+            dev = means3D.device
+            g_color = g_color if g_color is not None else torch.zeros((3, H, W), device=dev)
+            g_normal = g_normal if g_normal is not None else torch.zeros((3, H, W), device=dev)
+            g_depth = g_depth if g_depth is not None else torch.zeros((1, H, W), device=dev)
+            g_opac = g_opac if g_opac is not None else torch.zeros((1, H, W), device=dev)
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rot, _gv, _gp, _gc) = \
+                _C.rasterize_gaussians_backward(
+                    rs.bg, means3D, radii, colors, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix,
+                    rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
+                    rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config)
+            like = lambda g, ref: g if ref.numel() > 0 else None
+            grads += [g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors), g_opacities.reshape(ctx.opac_shapes[i]),
+                      like(g_scales, scales), like(g_rot, rot), like(g_cov3D, cov)]
+        return tuple(grads)
+
+
+def rasterize_views(settings_list, inputs):
+    """Batched form of ``GaussianRasterizer(rs)(**kw)`` for several views at once.
+
+    settings_list: list of GaussianRasterizationSettings; inputs: list of dicts with the keyword arguments of
+    ``GaussianRasterizer.forward`` (means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
+    cov3D_precomp).  Returns a list of ``(color, normal, depth, opac, radii)`` tuples.  Gradients w.r.t. the camera
+    matrices are not propagated by this batched form (``config[3]`` = lrn_cam callers use the per-view module)."""
+    empty = torch.Tensor([])
+    flat = []
+    for kw in inputs:
+        shs, cols = kw.get("shs"), kw.get("colors_precomp")
+        if (shs is None) == (cols is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        scales, rot, cov = kw.get("scales"), kw.get("rotations"), kw.get("cov3D_precomp")
+        if ((scales is None or rot is None) and cov is None) or ((scales is not None or rot is not None) and cov is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        o = lambda t: empty if t is None else t
+        flat += [kw["means3D"], kw["means2D"], o(shs), o(cols), kw["opacities"], o(scales), o(rot), o(cov)]
+    outs = _RasterizeViews.apply(list(settings_list), *flat)
+    return [tuple(outs[i * 5:(i + 1) * 5]) for i in range(len(settings_list))]
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
