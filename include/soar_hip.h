@@ -92,6 +92,20 @@ int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii,
                              float *out_color, float *out_normal, float *out_depth, float *out_opac,
                              void *stream);
 
+/* stage 2 with the occlusion pass fused in.  threestudio-soar rasterizes every frame twice with the same camera and
+ * geometry: the main pass and an occlusion pass with render_front = 1 and colours = per-Gaussian occlusion values
+ * (TS/renderer/diff_gaussian_rasterizer.py:254-263 and :281-291).  The second pass differs from the first only by the
+ * back-face cull in preprocess (forward.cu:262-266), so its per-pixel blend sequence is a subsequence of the first one:
+ * this entry point walks the tile lists once and returns, next to the four main images, out_occ [3,H,W] =
+ * out_color of that second pass (occ_values [P] broadcast to the three channels, same bg).
+ * Requires prm->render_front == 0 and prm->sort_descending == 0.  occ_values == out_occ == NULL: plain stage 2. */
+int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii,
+                                 void *geom_buffer, void *binning_buffer, void *image_buffer,
+                                 int64_t num_rendered,
+                                 float *out_color, float *out_normal, float *out_depth, float *out_opac,
+                                 const float *occ_values, float *out_occ,
+                                 void *stream);
+
 /* ---- backward, replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer_impl.cu:316-379)
  *      and the gradient allocation of RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:107-187).
  *   dL_dout_* are the four image gradients.  Outputs (all fully written):

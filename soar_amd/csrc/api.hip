@@ -96,6 +96,7 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->tiles_touched, n);
     take(p, out->point_offsets, n);
     take(p, out->clamped, M > 0 ? n * 3 : 1);
+    take(p, out->front, n);
     out->scan_temp_bytes = scan_temp_bytes(P);
     char *tmp;
     take(p, tmp, out->scan_temp_bytes);
@@ -267,15 +268,33 @@ int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_
     return 0;
 }
 
+int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                                 void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
+                                 float *out_depth, float *out_opac, const float *occ_values, float *out_occ, void *stream_);
+
 int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
                              void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
                              float *out_depth, float *out_opac, void *stream_)
+{
+    return soar_rast_forward_render_occ(prm, radii, geom_buffer, binning_buffer, image_buffer, num_rendered, out_color,
+                                        out_normal, out_depth, out_opac, nullptr, nullptr, stream_);
+}
+
+int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                                 void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
+                                 float *out_depth, float *out_opac, const float *occ_values, float *out_occ, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
     if (!out_color || !out_normal || !out_depth || !out_opac) { set_error("output image pointers must not be NULL"); return 1; }
     const size_t pix = (size_t)prm->W * prm->H;
+    if ((occ_values == nullptr) != (out_occ == nullptr)) { set_error("occ_values and out_occ must be given together"); return 1; }
+    if (out_occ && (prm->render_front || prm->sort_descending)) {
+        set_error("the fused occlusion pass needs render_front = 0 and sort_descending = 0 on the main pass");
+        return 1;
+    }
     if (prm->P == 0) {                                             // outputs are zeros (rasterize_points.cu:61-66)
+        if (out_occ) SOAR_HIP_OK(hipMemsetAsync(out_occ, 0, 3 * pix * sizeof(float), stream));
         SOAR_HIP_OK(hipMemsetAsync(out_color, 0, 3 * pix * sizeof(float), stream));
         SOAR_HIP_OK(hipMemsetAsync(out_normal, 0, 3 * pix * sizeof(float), stream));
         SOAR_HIP_OK(hipMemsetAsync(out_depth, 0, pix * sizeof(float), stream));
@@ -292,7 +311,7 @@ int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii, vo
     carve_image(image_buffer, prm->W, prm->H, &img);
     carve_binning(binning_buffer, num_rendered, &b);
     if (launch_binning(*prm, radii, g, b, img, num_rendered, stream)) return 1;
-    if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, stream)) return 1;
+    if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
 }
 

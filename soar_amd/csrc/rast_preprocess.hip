@@ -114,6 +114,7 @@ struct PreArgs {
     float *cov3D;
     uint32_t *tiles_touched;
     uint8_t *clamped;
+    float *front_out;
     int32_t *radii;
 };
 
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
 
     float nview[3] = {0.f, 0.f, 0.f};
     float plane_a = 0.f, plane_b = 0.f;
+    bool faces_camera = true;          // what a render_front pass keeps (all splats when not in surface mode)
     if (alive && a.surface) {
         // surfel normal and tangent axes in view space (forward.cu:283-285)
         float ax0[3], ax1[3];
@@ -184,6 +186,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
         // back-face test (auxiliary.h:173-208): the literal -0.01 is a double
         float dot = vx * nview[0] + vy * nview[1] + vz * nview[2];
         bool front = !((double)dot > -0.01);
+        faces_camera = front;
         if (a.render_front && !front) alive = false;
 
         if (alive && a.pix_depth) {
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
         rec.q3 = make_float4(nview[0], nview[1], nview[2], splat_cull_threshold(a.opacities[idx]));
     }
     a.rec[idx] = rec;
+    a.front_out[idx] = faces_camera ? 1.f : 0.f;
     a.radii[idx] = out_radius;
     a.tiles_touched[idx] = out_tiles;
 }
@@ -332,7 +336,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
     a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
     a.view = prm.viewmatrix_dev; a.proj = prm.projmatrix_dev; a.prcp = prm.prcppoint_dev;
     a.bbox = prm.patchbbox_dev; a.campos = prm.campos_dev;
-    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.radii = radii;
+    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.front_out = g.front; a.radii = radii;
     const int threads = 256;
     const int blocks = (prm.P + threads - 1) / threads;
     StageTimer timer(ST_PREPROCESS, stream);

@@ -44,6 +44,9 @@ struct FwdArgs {
     float *final_D;
     uint32_t *n_contrib;
     float *out_color, *out_normal, *out_depth, *out_opac;
+    const float *occ_values;         // fused occlusion pass: per-Gaussian value blended over the camera-facing splats only
+    const float *front;              // [P] 1 = camera-facing (preprocess)
+    float *out_occ;                  // [3,H,W]
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
 };
 
@@ -61,10 +64,16 @@ __device__ __forceinline__ uint32_t quad_move_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
-template <bool LOG>
+// OCC = true additionally blends, in the same walk of the list, what a second rasterization with render_front = 1 and
+// colours = occ_values would produce (TS/renderer/diff_gaussian_rasterizer.py:281-291): the per-pixel sequence of
+// camera-facing entries is the same subsequence of this list (preprocess differs between the two passes only by the
+// back-face cull, forward.cu:262-266), so a second transmittance chain that ignores the back-facing entries reproduces
+// that pass without a second preprocess / sort / blend.
+template <bool LOG, bool OCC>
 __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
+    __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
     unsigned long long t_start = 0, n_iter = 0;
     if (LOG) t_start = wall_clock64();
 
@@ -90,25 +99,36 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
     uint32_t last_contributor = 0;                   // per-slot, folded with max at the end
     bool done = !inside;                             // replicated
+    float T_o = 1.0f, Co = 0.f;                      // occlusion pass: transmittance (replicated), per-slot sum
+    bool done_o = !inside || !OCC;
     bool wave_done = (__ballot(!done) == 0ull);
 
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         sq0[CHUNK] = z; sq1[CHUNK] = z; sq2[CHUNK] = z; sq3[CHUNK] = z;
+        if (OCC) sq4[CHUNK] = make_float2(0.f, 0.f);
     }
 
     // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    float2 r4 = make_float2(0.f, 0.f);
     if (range.x + tid < range.y) {
-        const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[range.x + tid]);
+        const uint32_t id = a.point_list[range.x + tid];
+        const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
         r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+        if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
     }
     for (uint32_t base = range.x; base < range.y; base += CHUNK) {
         const int n = min((uint32_t)CHUNK, range.y - base);
-        if (tid < n) { sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3; }
+        if (tid < n) {
+            sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3;
+            if (OCC) sq4[tid] = r4;
+        }
         if (base + CHUNK + tid < range.y) {
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + a.point_list[base + CHUNK + tid]);
+            const uint32_t id = a.point_list[base + CHUNK + tid];
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+            if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
         }
         __syncthreads();
 
@@ -139,9 +159,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);          // forward.cu:507-508
                     const float alpha = fminf(0.99f, q1.y * exp_nonpositive(power));
                     // skip rules (:512, :545) zero the effective alpha of this lane's entry
-                    float a_eff = (power > 0.0f) ? 0.f : alpha;
-                    a_eff = (alpha < 1.0f / 255.0f) ? 0.f : a_eff;
-                    a_eff = done ? 0.f : a_eff;
+                    float a_live = (power > 0.0f) ? 0.f : alpha;
+                    a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
+                    const float a_eff = done ? 0.f : a_live;
                     // running transmittance through the four slots, reference order (:548-553, :602).
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
                     const float om = 1.f - a_eff;
@@ -174,7 +194,32 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     last_contributor = blend ? contrib0 + (uint32_t)(j - sub) + 1u : last_contributor;
                     T = s3 ? T3 : t3;
                     done = done || s3;
-                    if (__ballot(!done) == 0ull) { wave_done = true; break; }
+                    if (OCC) {
+                        // the same chain over the camera-facing entries only, with its own transmittance and stop
+                        const float2 e4 = sq4[j];
+                        const float a_o = (done_o || e4.y == 0.f) ? 0.f : a_live;
+                        const float mo = 1.f - a_o;
+                        const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
+                                    mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
+                        const float u0 = mul_keep(T_o, mo0);
+                        const bool z0 = u0 < 0.0001f;
+                        const float U1 = z0 ? T_o : u0;
+                        const float u1 = mul_keep(U1, mo1);
+                        const bool z1 = z0 || (u1 < 0.0001f);
+                        const float U2 = z1 ? U1 : u1;
+                        const float u2 = mul_keep(U2, mo2);
+                        const bool z2 = z1 || (u2 < 0.0001f);
+                        const float U3 = z2 ? U2 : u2;
+                        const float u3 = mul_keep(U3, mo3);
+                        const bool z3 = z2 || (u3 < 0.0001f);
+                        const float U_mine = slot == 0 ? T_o : slot == 1 ? U1 : slot == 2 ? U2 : U3;
+                        const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
+                        const float w_o = stopped_o ? 0.f : a_o * U_mine;
+                        Co = (w_o != 0.f) ? __builtin_fmaf(e4.x, w_o, Co) : Co;
+                        T_o = z3 ? U3 : u3;
+                        done_o = done_o || z3;
+                    }
+                    if (__ballot(!(done && done_o)) == 0ull) { wave_done = true; break; }
                 }
                 if (wave_done) break;
             }
@@ -193,6 +238,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     N2 += quad_move<DPP_QUAD_XOR1>(N2); N2 += quad_move<DPP_QUAD_XOR2>(N2);
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR1>(last_contributor));
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR2>(last_contributor));
+    if (OCC) { Co += quad_move<DPP_QUAD_XOR1>(Co); Co += quad_move<DPP_QUAD_XOR2>(Co); }
 
     if (inside && slot == 0) {
         // epilogue, forward.cu:618-633
@@ -210,6 +256,12 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
         a.out_depth[pix] = a.normalize_depth ? D / (1.f - T) : D + T * 10.f;
         a.out_opac[pix] = 1.f - T;
         if (a.normalize_depth) a.final_D[pix] = D;
+        if (OCC) {
+            T_o = fminf((float)(1 - 0.000001), T_o);
+            a.out_occ[pix] = Co + T_o * a.bg[0];
+            a.out_occ[hw + pix] = Co + T_o * a.bg[1];
+            a.out_occ[2 * hw + pix] = Co + T_o * a.bg[2];
+        }
     }
     if (LOG && lane == 0) {
         unsigned long long *w = a.wave_log + ((size_t)seq * 4 + wave) * 4;
@@ -220,7 +272,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 }  // namespace
 
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
-                          float *out_color, float *out_normal, float *out_depth, float *out_opac, hipStream_t stream)
+                          float *out_color, float *out_normal, float *out_depth, float *out_opac,
+                          const float *occ_values, float *out_occ, hipStream_t stream)
 {
     FwdArgs a;
     a.W = prm.W; a.H = prm.H;
@@ -230,17 +283,18 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
+    a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
     a.wave_log = nullptr;
     const int nblocks = 4 * ((a.ntiles + 7) / 8 * 8);
     StageTimer timer(ST_RENDER_FWD, stream);
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     static int logged = 0;
-    if (log_path && !logged && prm.render_front == 0) {
+    if (log_path && !logged && prm.render_front == 0 && !out_occ) {
         logged = 1;
         const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)nblocks;
         SOAR_HIP_OK(hipMalloc(&a.wave_log, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(a.wave_log, 0, nbytes, stream));
-        hipLaunchKernelGGL(render_forward_kernel<true>, dim3(nblocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, a);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, a.wave_log, nbytes, hipMemcpyDeviceToHost));
@@ -250,7 +304,8 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
         (void)hipFree(a.wave_log);
         return 0;
     }
-    hipLaunchKernelGGL(render_forward_kernel<false>, dim3(nblocks), dim3(256), 0, stream, a);
+    if (out_occ) hipLaunchKernelGGL((render_forward_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
     return 0;
 }

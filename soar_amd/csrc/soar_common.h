@@ -63,6 +63,7 @@ struct GeomBuf {
     uint32_t *tiles_touched; // [P]
     uint32_t *point_offsets; // [P] inclusive scan
     uint8_t *clamped;        // [P,3] (SH path)
+    float *front;            // [P] 1 = faces the camera (what render_front keeps), 0 = back-facing; fused occlusion pass
     void *scan_temp;
     size_t scan_temp_bytes;
     size_t total_bytes;
@@ -177,7 +178,8 @@ int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stre
 int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream);
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
-                          float *out_color, float *out_normal, float *out_depth, float *out_opac, hipStream_t stream);
+                          float *out_color, float *out_normal, float *out_depth, float *out_opac,
+                          const float *occ_values, float *out_occ, hipStream_t stream);
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
                            float *acc, hipStream_t stream);

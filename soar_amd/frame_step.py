@@ -116,7 +116,6 @@ class AvatarSequence:
             self.refresh_blend_weights()
         ones = torch.ones_like(self.opacity)
         main_rs = self.settings(bg, render_front=False, sort_descending=False)
-        occ_rs = self.settings(bg, render_front=True, sort_descending=False)
         warped, taps, settings, inputs = [], [], [], []
         for f in frames:
             xyz_p, rot_p = lbs.lbs_warp(self.xyz, self.rot, self.blend_weights, self.cano2live[f % self.num_frames])
@@ -126,14 +125,7 @@ class AvatarSequence:
             settings.append(main_rs)
             inputs.append(dict(means3D=xyz_p, means2D=tap, opacities=ones, colors_precomp=self.colors, scales=self.scales,
                                rotations=rot_p))
-        n = len(frames)
-        if with_occ:
-            occ_col = self.occ.repeat(1, 3)
-            for (x, r), t in zip(warped, taps):
-                settings.append(occ_rs)
-                inputs.append(dict(means3D=x.detach(), means2D=t.detach(), opacities=ones, colors_precomp=occ_col,
-                                   scales=self.scales.detach(), rotations=r.detach()))
+            if with_occ:
+                inputs[-1]["occ_values"] = self.occ          # occlusion pass fused into the main blend
         views = rasterize_views(settings, inputs)
-        main = views[:n]
-        occ = [v[0].detach() for v in views[n:]] if with_occ else [None] * n
-        return [FrameOutputs(m[0], m[1], m[2], m[3], o, m[4], t) for m, o, t in zip(main, occ, taps)]
+        return [FrameOutputs(m[0], m[1], m[2], m[3], m[5] if with_occ else None, m[4], t) for m, t in zip(views, taps)]

@@ -39,6 +39,8 @@ SIGNATURES = {
     "soar_rast_forward_geometry": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, C.POINTER(C.c_int64), _vp]),
     "soar_rast_num_rendered": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _vp]),
     "soar_rast_forward_render": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "soar_rast_forward_render_occ": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
+                                               _vp, _vp, _vp]),
     "soar_rast_backward": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 4
                            + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),

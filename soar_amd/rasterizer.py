@@ -152,7 +152,7 @@ class _NativeOps:
         L = hip_lib.lib()
         device = means3D.device
         P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-        st = {"device": device, "P": P, "H": W and H, "W": W}
+        st = {"device": device, "P": P, "H": H, "W": W}
         st["out"] = [torch.empty((3, H, W), dtype=torch.float32, device=device),
                      torch.empty((3, H, W), dtype=torch.float32, device=device),
                      torch.empty((1, H, W), dtype=torch.float32, device=device),
@@ -184,12 +184,24 @@ class _NativeOps:
         return st
 
     @staticmethod
-    def _render_stage(st):
+    def _render_stage(st, occ_values=None):
         """Read num_rendered (synchronises the stream unless an earlier view of the batch already did), size the binning
-        buffer, enqueue key emission + sort + ranges + blend."""
+        buffer, enqueue key emission + sort + ranges + blend.  With `occ_values` [P] the blend also produces
+        st["occ"] [3,H,W]: the colour image of a render_front=True pass with colours = occ_values (fused occlusion pass)."""
         L = hip_lib.lib()
         device, P = st["device"], st["P"]
         out = st["out"]
+        occ_ptr = occ_out_ptr = None
+        if occ_values is not None:
+            _require_hip(occ_values, "occ_values")
+            if occ_values.numel() != P:
+                raise ValueError(f"occ_values must have one value per Gaussian ({P}), got {occ_values.numel()}")
+            occ_values = _dev_f32(occ_values.detach().reshape(-1), device, "occ_values")
+            st["occ"] = torch.empty((3, st["H"], st["W"]), dtype=torch.float32, device=device)
+            occ_ptr, occ_out_ptr = ptr(occ_values) if P else None, st["occ"].data_ptr()
+            if P == 0:
+                st["occ"].zero_()
+                occ_out_ptr = None
         prm = C.byref(st["ctx"].params)
         stream = _stream(device)
         with torch.cuda.device(device):
@@ -205,9 +217,10 @@ class _NativeOps:
             nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             st["binning"] = _scratch(nbytes.value, device)
-            check(L.soar_rast_forward_render(prm, st["radii"].data_ptr(), st["geom"].data_ptr(), st["binning"].data_ptr(),
-                                             st["img"].data_ptr(), num_rendered, out[0].data_ptr(), out[1].data_ptr(),
-                                             out[2].data_ptr(), out[3].data_ptr(), stream),
+            check(L.soar_rast_forward_render_occ(prm, st["radii"].data_ptr(), st["geom"].data_ptr(),
+                                                 st["binning"].data_ptr(), st["img"].data_ptr(), num_rendered,
+                                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                                 occ_ptr, occ_out_ptr, stream),
                   "rasterize_gaussians (render stage)")
         return num_rendered
 
@@ -344,26 +357,31 @@ class _RasterizeViews(torch.autograd.Function):
     enqueued first, the host synchronises once to read every num_rendered, then all binning + blend stages follow.
     This removes the per-view host round trip of the reference (rasterizer_impl.cu:250) from multi-frame steps."""
 
-    N_IN = 8      # tensors per view: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp
+    # tensors per view: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, occ_values
+    N_IN = 9
+    N_OUT = 6     # color, normal, depth, opac, radii, occ (empty unless occ_values was given)
 
     @staticmethod
     def forward(ctx, settings_list, *flat):
         n = _RasterizeViews.N_IN
         views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
         states = []
-        for rs, (means3D, means2D, sh, colors, opac, scales, rot, cov) in zip(settings_list, views):
+        for rs, (means3D, means2D, sh, colors, opac, scales, rot, cov, _occ) in zip(settings_list, views):
             states.append(_NativeOps._geometry_stage(
                 rs.bg, means3D, colors, opac, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
                 rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
                 rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config))
-        ctx.num_rendered = [_NativeOps._render_stage(st) for st in states]
+        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None) for st, v in zip(states, views)]
         ctx.settings_list = settings_list
         ctx.opac_shapes = [v[4].shape for v in views]
         saved, outs, nondiff = [], [], []
         for st, v in zip(states, views):
             saved += [v[3], v[0], v[5], v[6], v[7], st["radii"], v[2], st["geom"], st["binning"], st["img"]]
-            outs += st["out"] + [st["radii"]]
-            nondiff.append(st["radii"])
+            occ = st.get("occ")
+            if occ is None:
+                occ = torch.empty((0,), dtype=torch.float32, device=st["device"])
+            outs += st["out"] + [st["radii"], occ]
+            nondiff += [st["radii"], occ]
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)          # views whose outputs are unused (e.g. occlusion passes) are skipped
@@ -374,9 +392,9 @@ class _RasterizeViews(torch.autograd.Function):
         grads = [None]
         for i, rs in enumerate(ctx.settings_list):
             colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = ctx.saved_tensors[i * 10:(i + 1) * 10]
-            g_color, g_normal, g_depth, g_opac, _ = gouts[i * 5:(i + 1) * 5]
+            g_color, g_normal, g_depth, g_opac, _, _ = gouts[i * 6:(i + 1) * 6]
             if g_color is None and g_normal is None and g_depth is None and g_opac is None:
-                grads += [None] * 8
+                grads += [None] * 9
                 continue
             H, W = int(rs.image_height), int(rs.image_width)
             dev = means3D.device
@@ -391,7 +409,7 @@ class _RasterizeViews(torch.autograd.Function):
                     rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config)
             like = lambda g, ref: g if ref.numel() > 0 else None
             grads += [g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors), g_opacities.reshape(ctx.opac_shapes[i]),
-                      like(g_scales, scales), like(g_rot, rot), like(g_cov3D, cov)]
+                      like(g_scales, scales), like(g_rot, rot), like(g_cov3D, cov), None]
         return tuple(grads)
 
 
@@ -401,7 +419,12 @@ def rasterize_views(settings_list, inputs):
     settings_list: list of GaussianRasterizationSettings; inputs: list of dicts with the keyword arguments of
     ``GaussianRasterizer.forward`` (means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
     cov3D_precomp).  Returns a list of ``(color, normal, depth, opac, radii)`` tuples.  Gradients w.r.t. the camera
-    matrices are not propagated by this batched form (``config[3]`` = lrn_cam callers use the per-view module)."""
+    matrices are not propagated by this batched form (``config[3]`` = lrn_cam callers use the per-view module).
+
+    A view may carry ``occ_values`` ([P] or [P,1], no gradient): its tuple then gets a sixth element, the [3,H,W] image
+    that a second pass with ``render_front=True`` and ``colors_precomp=occ_values.repeat(1,3)`` would return
+    (TS/renderer/diff_gaussian_rasterizer.py:281-291), blended in the same kernel launch as the main view.  The main
+    view must then have ``render_front=False`` and ``sort_descending=False``."""
     empty = torch.Tensor([])
     flat = []
     for kw in inputs:
@@ -412,9 +435,14 @@ def rasterize_views(settings_list, inputs):
         if ((scales is None or rot is None) and cov is None) or ((scales is not None or rot is not None) and cov is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         o = lambda t: empty if t is None else t
-        flat += [kw["means3D"], kw["means2D"], o(shs), o(cols), kw["opacities"], o(scales), o(rot), o(cov)]
+        flat += [kw["means3D"], kw["means2D"], o(shs), o(cols), kw["opacities"], o(scales), o(rot), o(cov),
+                 o(kw.get("occ_values"))]
     outs = _RasterizeViews.apply(list(settings_list), *flat)
-    return [tuple(outs[i * 5:(i + 1) * 5]) for i in range(len(settings_list))]
+    res = []
+    for i, kw in enumerate(inputs):
+        v = tuple(outs[i * 6:(i + 1) * 6])
+        res.append(v if kw.get("occ_values") is not None else v[:5])
+    return res
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
