@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import lbs
-from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
 from . import registry
 from .batch import GaussianBatchRenderer
 from .postops import depth2normal, normal2curv
@@ -132,22 +132,33 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
                 campos=viewpoint_camera.camera_center, prefiltered=False, render_front=front,
                 sort_descending=descending, debug=False, config=pc.config)
 
-        rasterizer = GaussianRasterizer(raster_settings=settings(False, not render_front))      # :173-191
-        rasterizer_occ = GaussianRasterizer(raster_settings=settings(True, False))             # :193-211
-
         opacity = pc.get_opacity
         scales = (pc.get_scaling if self.cfg.use_explicit else attribute_scale).repeat(1, 3)
         scales[..., -1] = -1e10                                                                 # :234
         colors_precomp = pc.get_colors if self.cfg.use_explicit else attribute_color
         ones = torch.ones_like(opacity)
 
-        rendered_image, rendered_normal, rendered_depth, rendered_opac, radii = rasterizer(
-            means3D=points, means2D=screenspace_points, shs=None, colors_precomp=colors_precomp, opacities=ones,
-            scales=scales, rotations=rot, cov3D_precomp=None)
-        occ = pc.get_occ.repeat(1, 3)
-        rendered_occ = rasterizer_occ(
-            means3D=points.detach(), means2D=screenspace_points.detach(), shs=None, colors_precomp=occ, opacities=ones,
-            scales=scales.detach(), rotations=rot.detach(), cov3D_precomp=None)[0]
+        full_patch = patch_size[0] >= viewpoint_camera.image_height and patch_size[1] >= viewpoint_camera.image_width
+        cam_leaf = any(getattr(t, "requires_grad", False) for t in (viewpoint_camera.world_view_transform,
+                                                                    viewpoint_camera.full_proj_transform,
+                                                                    viewpoint_camera.camera_center))
+        if render_front and full_patch and not cam_leaf:
+            # main pass sorted front-to-back and both passes on the same (full) patch: the occlusion pass (:193-211,
+            # :281-291) is a subsequence of the main one and is blended in the same kernel launch
+            (rendered_image, rendered_normal, rendered_depth, rendered_opac, radii, rendered_occ) = rasterize_views(
+                [settings(False, False)],
+                [dict(means3D=points, means2D=screenspace_points, colors_precomp=colors_precomp, opacities=ones,
+                      scales=scales, rotations=rot, occ_values=pc.get_occ)])[0]
+        else:
+            rasterizer = GaussianRasterizer(raster_settings=settings(False, not render_front))      # :173-191
+            rasterizer_occ = GaussianRasterizer(raster_settings=settings(True, False))             # :193-211
+            rendered_image, rendered_normal, rendered_depth, rendered_opac, radii = rasterizer(
+                means3D=points, means2D=screenspace_points, shs=None, colors_precomp=colors_precomp, opacities=ones,
+                scales=scales, rotations=rot, cov3D_precomp=None)
+            occ = pc.get_occ.repeat(1, 3)
+            rendered_occ = rasterizer_occ(
+                means3D=points.detach(), means2D=screenspace_points.detach(), shs=None, colors_precomp=occ, opacities=ones,
+                scales=scales.detach(), rotations=rot.detach(), cov3D_precomp=None)[0]
 
         # image-space post-ops (:292-303)
         mask = rendered_opac > 1e-5

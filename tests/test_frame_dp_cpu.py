@@ -1,0 +1,92 @@
+"""Frame data-parallel path on CPU with the gloo backend, world_size 2: round-robin frame
+shards cover a global batch exactly once, the ONE flat gradient all-reduce gives every rank the single-process
+gradient, and the densification statistics are summed identically."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from soar_amd import frame_dp
+
+
+def test_shard_frames_partition():
+    for world in (1, 2, 3, 8):
+        for step in (0, 1, 7):
+            batch = frame_dp.global_batch(step, 4, world, num_frames=400)
+            assert len(batch) == 4 * world
+            shards = [frame_dp.shard_frames(batch, r, world) for r in range(world)]
+            assert all(len(s) == 4 for s in shards)
+            assert sorted(f for s in shards for f in s) == sorted(batch)
+    # consecutive steps walk the sequence and wrap
+    assert frame_dp.global_batch(0, 2, 2, 6) == [0, 1, 2, 3] and frame_dp.global_batch(1, 2, 2, 6) == [4, 5, 0, 1]
+    assert frame_dp.shard_frames([], 0, 2) == []
+
+
+def test_flat_buffer_views_are_the_grads():
+    P = 7
+    leaves = {n: torch.randn(P, w, requires_grad=True) for n, w in frame_dp.LEAVES[:4]}
+    buf = frame_dp.FlatGradBuffer(leaves)
+    assert buf.flat.numel() == P * frame_dp.FLOATS_PER_GAUSSIAN
+    loss = sum((t * (i + 1)).sum() for i, t in enumerate(leaves.values()))
+    loss.backward()
+    for i, (n, t) in enumerate(leaves.items()):
+        assert t.grad.data_ptr() == buf.views[n].data_ptr() and t.grad.is_contiguous()
+        assert torch.equal(buf.views[n], torch.full_like(t, float(i + 1)))
+    assert buf.all_reduce() is None                 # no process group: no-op
+    buf.zero()
+    assert float(buf.flat.abs().sum()) == 0.0
+    with pytest.raises(ValueError, match="must be"):
+        frame_dp.FlatGradBuffer({"xyz": torch.zeros(P, 4)})
+
+
+def _frame_loss(leaves, frame):
+    """Stand-in for one frame's render + loss: any differentiable function of the shared leaves and the frame id."""
+    g = torch.Generator().manual_seed(1000 + frame)
+    w = {n: torch.randn(t.shape, generator=g) for n, t in leaves.items()}
+    return sum((torch.sin(t * (1 + 0.1 * frame)) * w[n]).sum() for n, t in leaves.items())
+
+
+def _make_leaves(P):
+    g = torch.Generator().manual_seed(0)
+    return {n: torch.randn(P, w, generator=g).requires_grad_(True) for n, w in frame_dp.LEAVES[:4]}
+
+
+def _worker(rank, world, port, P, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        leaves = _make_leaves(P)
+        buf = frame_dp.FlatGradBuffer(leaves)
+        batch = frame_dp.global_batch(3, 2, world, num_frames=50)
+        for f in frame_dp.shard_frames(batch, rank, world):
+            _frame_loss(leaves, f).backward()
+        work = buf.all_reduce(async_op=True)
+        work.wait()
+        acc, den = torch.full((P, 1), float(rank + 1)), torch.full((P, 1), 1.0)
+        frame_dp.all_reduce_densification_stats(acc, den)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=buf.flat.numpy(), acc=acc.numpy(), den=den.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
+    P, world = 33, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, P, str(tmp_path)), nprocs=world, join=True)
+    # single-process reference: all frames of the same global batch on one set of leaves
+    leaves = _make_leaves(P)
+    buf = frame_dp.FlatGradBuffer(leaves)
+    for f in frame_dp.global_batch(3, 2, world, num_frames=50):
+        _frame_loss(leaves, f).backward()
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    np.testing.assert_array_equal(r0["flat"], r1["flat"])                       # every rank holds the same sum
+    np.testing.assert_allclose(r0["flat"], buf.flat.numpy(), rtol=1e-5, atol=1e-5)
+    assert np.abs(buf.flat.numpy()[P * 13:]).sum() == 0                          # leaves not registered stay zero
+    np.testing.assert_array_equal(r0["acc"], np.full((P, 1), 3.0, np.float32))
+    np.testing.assert_array_equal(r1["den"], np.full((P, 1), 2.0, np.float32))
