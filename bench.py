@@ -37,14 +37,36 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def algorithmic_bytes(P, R, W, H):
-    """compulsory bytes per launch of every stage (passes = 6)."""
+# stage timer name -> kernel name in the rocprofv3 summaries / HBM counter file under profiles/
+STAGE_KERNEL = {"preprocess": "preprocess_kernel", "emit_keys": "emit_keys_kernel", "tile_ranges": "tile_ranges_kernel",
+                "render_forward": "render_forward_kernel", "render_backward": "render_backward_slots_kernel",
+                "geometry_backward": "geometry_backward_kernel", "lbs_knn_weights": "knn_grid_kernel",
+                "lbs_warp_forward": "warp_forward_kernel", "lbs_warp_backward": "warp_backward_kernel"}
+
+
+def measured_traffic(stage):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*_hbm_traffic.json; collected with
+    scripts/profile_round.sh, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, gfx950 correction applied there)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files or stage not in STAGE_KERNEL:
+        return None
+    try:
+        return json.load(open(files[-1]))["kernels"][STAGE_KERNEL[stage]]["traffic_bytes"]
+    except Exception:
+        return None
+
+
+def algorithmic_bytes(P, R, W, H, R_occ=None):
+    """compulsory bytes per launch of every stage (passes = 6).  R_occ: the forward blend also
+    does the occlusion pass (render_front instances) in the same launch -> both passes' bytes."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     pix = W * H
     passes = 6
+    fused_occ = 0 if R_occ is None else 8 * T + 96 * R_occ + 44 * pix
     return {
         "preprocess": 160 * P, "scan": 8 * P, "emit_keys": 20 * P + 12 * R, "sort": 24 * passes * R,
-        "tile_ranges": 8 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix,
+        "tile_ranges": 8 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix + fused_occ,
         "render_backward": 44 * pix + 96 * R + 60 * P, "geometry_backward": (92 + 148) * P,
         "lbs_warp_forward": 276 * P, "lbs_warp_backward": 304 * P,
         "lbs_knn_weights": 232 * P + 232 * 10475,
@@ -90,7 +112,7 @@ def run_step(seq, targets, flat, frames, bg):
     return flat.all_reduce()
 
 
-def cpu_baseline(workload, parts, n_frames=2, seed=0):
+def cpu_baseline(workload, parts, n_frames=8, seed=0):
     """The CPU oracle ("port": plain-C restatement, OpenMP over tiles) + torch-CPU LBS on a bounded sample of the
     same workload: `n_frames` full frames (LBS warp + main fwd+bwd + occlusion fwd) after one KNN-weights pass."""
     from oracle import cpu_oracle as co
@@ -181,6 +203,11 @@ def main():
     def frames_of(step):
         return shard_frames(global_batch(step, fps_per_rank, world, seq.num_frames), rank, world)
 
+    # instances the occlusion pass renders (camera-facing surfels only): measured once with the unfused two-call form,
+    # outside the timed region, to price B_occ of SURVEY 8(d) with the real R
+    with torch.no_grad():
+        seq.render_frame(frames_of(0)[0], bg, with_occ=True)
+    R_occ = rasterizer.last_num_rendered
     for s in range(args.warmup):
         run_step(seq, targets, flat, frames_of(s), bg)
     torch.cuda.synchronize()
@@ -218,26 +245,16 @@ def main():
             L.soar_prof_read(i, C.byref(ms), C.byref(n))
             if n.value:
                 stages[L.soar_prof_stage_name(i).decode()] = (ms.value, n.value)
-        # main passes (fwd+bwd) vs occlusion passes (fwd only): half of the forward launches each
-        n_fwd = max(rasterizer.stats["forward_calls"], 1)
-        R_all = rasterizer.stats["num_rendered"] / n_fwd
-        R_main = rasterizer.stats["num_rendered_bwd"] / max(rasterizer.stats["backward_calls"], 1)
-        R_occ = 2 * R_all - R_main if n_fwd >= 2 else R_all
+        # every timed forward launch is a main pass with the occlusion pass fused in
+        R_main = rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)
         dom = max(stages, key=lambda k: stages[k][0]) if stages else None
         if dom:
             ms, n = stages[dom]
-            R_for = R_main if dom in ("render_backward", "geometry_backward") else R_all
-            bytes_per_launch = algorithmic_bytes(P, R_for, W, H).get(dom)
+            bytes_per_launch = algorithmic_bytes(P, R_main, W, H, R_occ).get(dom)
             if bytes_per_launch:
                 avg_s = ms / n / 1e3
                 achieved = bytes_per_launch / avg_s / 1e9
-                traffic = None
-                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(pmc):
-                    try:
-                        traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
-                    except Exception:
-                        traffic = None
+                traffic = measured_traffic(dom) if args.workload == "C3" else None
                 roof = {"bound": "hbm", "kernel": dom, "stage_total_ms": {k: round(v[0], 3) for k, v in stages.items()}, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_us": round(1e3 * ms / n, 2), "launches": n,
@@ -255,7 +272,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
                                f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
                                f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}",
-                   "num_rendered_main": int(rasterizer.stats["num_rendered_bwd"] / max(rasterizer.stats["backward_calls"], 1))},
+                   "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
+                   "num_rendered_occ": int(R_occ)},
         "roofline": roof,
     }
     if rank == 0:

@@ -30,6 +30,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
 
 # running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
 stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
+last_num_rendered = 0        # num_rendered of the most recent forward call
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -212,6 +213,8 @@ class _NativeOps:
             R = C.c_int64(0)
             check(L.soar_rast_num_rendered(st["geom"].data_ptr(), P, st["M"], C.byref(R), stream), "num_rendered")
             num_rendered = int(R.value)
+            global last_num_rendered
+            last_num_rendered = num_rendered
             stats["forward_calls"] += 1
             stats["num_rendered"] += num_rendered
             nbytes = C.c_size_t(0)
