@@ -3,12 +3,22 @@
 // Replaces SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637): pytorch3d's brute-force knn_points (K = 30 over
 // V = 10475 vertices for every Gaussian, 1e9 distance evaluations per call) followed by a gather of [30,55] rows.
 //
-// Here the (static) vertex set is bucketed into a uniform grid (cell ids -> stable radix sort -> per-cell ranges) and
-// each query walks cube shells around its cell until the K-th best distance is provably final: the search is exact,
-// visits ~300 vertices instead of 10475, and every step is deterministic (stable sort keeps vertex order in a cell).
-// Per-thread top-K lists live in LDS as [k][thread] (bank = thread, conflict-free).
+// Here the vertex set is bucketed into a uniform grid (cell ids -> stable radix sort -> per-cell ranges), the queries
+// are sorted by cell too, and one wavefront takes 64 consecutive sorted queries (lane = query).  All lanes of a cell
+// share the candidate set -- the box of cells around their cell -- so the walk over candidates is UNIFORM: candidate
+// positions and skinning rows are wave-uniform (scalar) loads, there is no divergence and no per-lane gather.
+//   pass 1: every lane keeps the K smallest squared distances in registers (median-of-3 insertion chain, no
+//           indices); the four wavefronts of a workgroup each scan a quarter of the LDS-staged candidates and merge
+//           their lists; the box grows until, for every lane, the K-th distance is provably final (distance to the
+//           nearest open face of the box) -- the search is exact;
+//   pass 2: one query at a time per wavefront: lanes = candidates pick those below the query's K-th distance (ties at
+//           the K-th place in list order until K are reached), then lanes = joints blend their skinning rows, so row
+//           reads and the 220-byte result row are coalesced.
+// A generic one-thread-per-query kernel (any K <= 32, any J) is kept for non-default K / J.
 #include "soar_common.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -19,7 +29,9 @@ namespace {
 constexpr int KNN_THREADS = 128;
 constexpr int KNN_MAXK = 32;
 constexpr int GRID_MAX = 64;             // cells per axis (upper bound)
-constexpr int GRID_RES = 48;             // cells along the longest extent
+constexpr int GRID_RES = 28;             // cells along the longest extent: a 3x3x3 box holds the K = 30 nearest for SMPL-X density
+constexpr int KNN_K = 30;                // the only K the path uses (smpl.py:627: K=30)
+constexpr int KNN_JMAX = 56;             // joints held in registers by the fast kernel (J = 55)
 constexpr int GRID_CELLS = GRID_MAX * GRID_MAX * GRID_MAX;
 
 struct GridMeta {
@@ -212,6 +224,311 @@ knn_grid_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
     }
 }
 
+
+// cell key of every query (clamped into the grid) for the query sort
+__global__ void __launch_bounds__(256)
+query_cells_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restrict__ meta, uint32_t *__restrict__ keys,
+                   uint32_t *__restrict__ vals)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const GridMeta m = *meta;
+    const int cx = cell_coord(xyz[3 * p], m.minx, m.inv_h, m.nx);
+    const int cy = cell_coord(xyz[3 * p + 1], m.miny, m.inv_h, m.ny);
+    const int cz = cell_coord(xyz[3 * p + 2], m.minz, m.inv_h, m.nz);
+    keys[p] = (uint32_t)((cz * GRID_MAX + cy) * GRID_MAX + cx);
+    vals[p] = (uint32_t)p;
+}
+
+__device__ __forceinline__ float dist2_exact(float x, float y, float z, float4 v)
+{
+#pragma clang fp contract(off)            // both passes must see the same bits
+    const float dx = x - v.x, dy = y - v.y, dz = z - v.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// skinning rows in sorted-vertex order, padded to KNN_JMAX floats (16-byte aligned rows -> wide uniform loads)
+__global__ void __launch_bounds__(256)
+pad_rows_kernel(const float *__restrict__ vert_weights, int V, int J, const float4 *__restrict__ sorted_verts,
+                float *__restrict__ rows)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= V * KNN_JMAX) return;
+    const int i = e / KNN_JMAX, j = e % KNN_JMAX;
+    const uint32_t v = __float_as_uint(sorted_verts[i].w);
+    rows[e] = j < J ? vert_weights[(size_t)v * J + j] : 0.f;
+}
+
+constexpr int KNN_SLOTS = 4;             // wavefronts that share the cell segments of one 64-query chunk
+constexpr int KNN_CAND = 768;            // candidates staged in LDS at a time (12 KB)
+constexpr int KNN_RMAX = 3;              // beyond this box radius the search falls back to all vertices
+constexpr int KNN_ROWS = (2 * KNN_RMAX + 1) * (2 * KNN_RMAX + 1);
+
+constexpr int KNN_WAVES = 4;             // wavefronts per workgroup: they split the candidates (pass 1) and the queries (pass 2)
+
+// First wavefront of the workgroup: list the contiguous sorted-vertex ranges covered by the box of radius r around
+// (cx,cy,cz) (the cells of one grid row are adjacent keys) as prefix offsets; info[0] = number of candidates,
+// info[1] = number of rows.
+__device__ __forceinline__ void box_rows(const uint2 *__restrict__ cell_range, const GridMeta &m, int cx, int cy, int cz,
+                                         int r, int V, uint32_t *row_start, uint32_t *row_prefix, int *info, int lane)
+{
+    if (r > KNN_RMAX) {                                      // brute force over all vertices
+        if (lane == 0) { row_start[0] = 0u; row_prefix[0] = 0u; row_prefix[1] = (uint32_t)V; info[0] = V; info[1] = 1; }
+        return;
+    }
+    const int side = 2 * r + 1;
+    const int n_rows = side * side;                          // <= 49 <= 64: one row per lane
+    uint32_t s = 0, e = 0;
+    if (lane < n_rows) {
+        const int gz = cz + lane / side - r, gy = cy + lane % side - r;
+        if (gz >= 0 && gz < m.nz && gy >= 0 && gy < m.ny) {
+            const int base = (gz * GRID_MAX + gy) * GRID_MAX;
+            bool any = false;
+            for (int gx = max(cx - r, 0); gx <= min(cx + r, m.nx - 1); gx++) {
+                const uint2 rg = cell_range[base + gx];
+                if (rg.y > rg.x) {
+                    if (!any) s = rg.x;
+                    e = rg.y;
+                    any = true;
+                }
+            }
+        }
+    }
+    // inclusive scan of the row lengths over the lanes
+    uint32_t incl = e - s;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane < n_rows) { row_start[lane] = s; row_prefix[lane + 1] = incl; }
+    if (lane == 0) { row_prefix[0] = 0u; info[1] = n_rows; }
+    if (lane == n_rows - 1) info[0] = (int)incl;
+}
+
+// Workgroup-cooperative: stage candidates [base, base + n) of the flattened box list into LDS (one coalesced 16-byte
+// load per thread).  Caller synchronises.
+__device__ __forceinline__ void stage_candidates(const float4 *__restrict__ sorted_verts, const uint32_t *row_start,
+                                                 const uint32_t *row_prefix, int n_rows, int base, int n, float4 *cand)
+{
+    for (int t = threadIdx.x; t < n; t += KNN_WAVES * WAVE) {
+        const uint32_t g = (uint32_t)(base + t);
+        int row = 0;
+        while (row + 1 < n_rows && row_prefix[row + 1] <= g) row++;
+        const uint32_t pos = row_start[row] + (g - row_prefix[row]);
+        float4 v = sorted_verts[pos];
+        v.w = __uint_as_float(pos);
+        cand[t] = v;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void chain_insert(float (&best)[K], float d)
+{
+    // sorted insertion, one op per slot: new b[k] = median(b[k-1], d, b[k])
+#pragma unroll
+    for (int k = K - 1; k > 0; k--) best[k] = __builtin_amdgcn_fmed3f(best[k - 1], d, best[k]);
+    best[0] = fminf(best[0], d);
+}
+
+template <bool WITH_IDX, bool LOG = false>
+__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__restrict__ meta,
+                const uint2 *__restrict__ cell_range, const float4 *__restrict__ sorted_verts,
+                const uint32_t *__restrict__ q_keys, const uint32_t *__restrict__ q_ids,
+                const float *__restrict__ rows_padded, int J, float *__restrict__ weights_out,
+                int32_t *__restrict__ knn_idx_out, unsigned long long *__restrict__ wave_log = nullptr)
+{
+    constexpr int K = KNN_K;
+    __shared__ float4 cand[KNN_CAND];                      // {x, y, z, sorted position}
+    __shared__ uint32_t row_start[KNN_ROWS], row_prefix[KNN_ROWS + 1];
+    __shared__ int info[4];                                // candidates, rows, "box is final"
+    __shared__ float merge[2][K][WAVE];                    // top-K lists handed between wavefronts
+    __shared__ float tau_s[WAVE];
+    __shared__ int need_s[WAVE];
+    __shared__ uint32_t list_pos[KNN_WAVES][WAVE];         // the (<= K) neighbours of the query a wavefront is blending
+    __shared__ float list_w[KNN_WAVES][WAVE];
+    unsigned long long t_start = 0, n_cand = 0, n_blend = 0, n_pairs = 0;
+    if (LOG) t_start = wall_clock64();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * WAVE + lane;
+    const bool valid = q < P;
+    const uint32_t key = valid ? q_keys[q] : 0xFFFFFFFFu;
+    // the chunk's queries are sorted by cell: a segment = the lanes of one cell; this workgroup takes segments
+    // slot, slot + KNN_SLOTS, ... so that a chunk that straddles many sparse cells is shared by several workgroups
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    unsigned long long seg_heads = __ballot(valid && (lane == 0 || key != prev));
+    const int slot = blockIdx.y;
+    if ((int)__builtin_popcountll(seg_heads) <= slot) return;
+
+    const int p = valid ? (int)q_ids[q] : 0;
+    const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
+    const GridMeta m = *meta;
+    const float qx = x - m.minx, qy = y - m.miny, qz = z - m.minz;
+
+    for (int seg = 0; seg_heads != 0ull; seg++) {
+        const int head = (int)__builtin_ctzll(seg_heads);
+        seg_heads &= seg_heads - 1ull;
+        if ((seg % KNN_SLOTS) != slot) continue;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, head);
+        const bool active = valid && key == c;
+        const int cx = (int)(c % GRID_MAX), cy = (int)((c / GRID_MAX) % GRID_MAX), cz = (int)(c / (GRID_MAX * GRID_MAX));
+        if (LOG) n_pairs++;
+
+        // ---- pass 1 (lane = query): the K smallest squared distances of every query; each wavefront scans a quarter
+        //      of the candidates, the four sorted lists are merged through LDS; the box grows until every query is
+        //      certified (its K-th distance is below the distance to the nearest open face of the box)
+        int r = 1, n_rows = 0, N = 0;
+        for (;; r++) {
+            __syncthreads();
+            if (wave == 0) box_rows(cell_range, m, cx, cy, cz, r, V, row_start, row_prefix, info, lane);
+            __syncthreads();
+            N = info[0];
+            n_rows = info[1];
+            if (LOG) n_cand += N;
+            float best[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) best[k] = 3.0e38f;
+            for (int base = 0; base < N; base += KNN_CAND) {
+                const int n = min(KNN_CAND, N - base);
+                if (base > 0) __syncthreads();
+                stage_candidates(sorted_verts, row_start, row_prefix, n_rows, base, n, cand);
+                __syncthreads();
+#pragma unroll 2
+                for (int i = wave; i < n; i += KNN_WAVES) chain_insert<K>(best, dist2_exact(x, y, z, cand[i]));
+            }
+            // merge: waves 2,3 -> waves 0,1 ; wave 1 -> wave 0
+            if (wave >= 2) {
+#pragma unroll
+                for (int k = 0; k < K; k++) merge[wave - 2][k][lane] = best[k];
+            }
+            __syncthreads();
+            if (wave < 2) {
+#pragma unroll 2
+                for (int k = 0; k < K; k++) chain_insert<K>(best, merge[wave][k][lane]);
+            }
+            __syncthreads();
+            if (wave == 1) {
+#pragma unroll
+                for (int k = 0; k < K; k++) merge[0][k][lane] = best[k];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll 2
+                for (int k = 0; k < K; k++) chain_insert<K>(best, merge[0][k][lane]);
+                const float tau = best[K - 1];
+                int need = K;                                         // how many candidates AT tau the query takes
+#pragma unroll
+                for (int k = 0; k < K; k++) need -= (best[k] < tau) ? 1 : 0;
+                tau_s[lane] = tau;
+                need_s[lane] = need;
+                // vertices not visited yet lie beyond an open face of the box: the distance to the nearest one bounds them
+                float bound = 3.0e38f;
+                bool open = false;
+                if (cx - r > 0) { open = true; bound = fminf(bound, qx - (cx - r) * m.h); }
+                if (cx + r < m.nx - 1) { open = true; bound = fminf(bound, (cx + r + 1) * m.h - qx); }
+                if (cy - r > 0) { open = true; bound = fminf(bound, qy - (cy - r) * m.h); }
+                if (cy + r < m.ny - 1) { open = true; bound = fminf(bound, (cy + r + 1) * m.h - qy); }
+                if (cz - r > 0) { open = true; bound = fminf(bound, qz - (cz - r) * m.h); }
+                if (cz + r < m.nz - 1) { open = true; bound = fminf(bound, (cz + r + 1) * m.h - qz); }
+                bound = fmaxf(bound, 0.f) * 0.9999f;                  // rounding slack on the face positions
+                const bool certified = !open || r > KNN_RMAX || tau <= bound * bound;
+                const bool final_box = __ballot(active && !certified) == 0ull;
+                if (lane == 0) info[2] = final_box ? 1 : 0;
+            }
+            __syncthreads();
+            if (info[2]) break;
+        }
+        const float tau = tau_s[lane];
+        const int need = need_s[lane];
+
+        // ---- pass 2 (one query at a time per wavefront; lanes = candidates, then lanes = joints): the neighbours of
+        //      a query are the candidates below its K-th distance (ties at the K-th place in list order until K are
+        //      reached); their skinning rows are blended with lanes = joints: row reads and the result row coalesce.
+        const bool single = N <= KNN_CAND;                            // candidates still staged from pass 1
+        float norm_lane = 0.f;                                        // lane = query: sum of 1/d over all chunks
+        int cnt_lane = 0;
+        uint32_t *lpos = list_pos[wave];
+        float *lw = list_w[wave];
+        for (int base = 0; base < N; base += KNN_CAND) {
+            const int n = min(KNN_CAND, N - base);
+            if (!single) {
+                __syncthreads();
+                stage_candidates(sorted_verts, row_start, row_prefix, n_rows, base, n, cand);
+                __syncthreads();
+            }
+            int ordinal = 0;
+            for (unsigned long long todo = __ballot(active); todo != 0ull; todo &= todo - 1ull, ordinal++) {
+                if ((ordinal % KNN_WAVES) != wave) continue;
+                const int l = (int)__builtin_ctzll(todo);
+                const float ux = __shfl(x, l), uy = __shfl(y, l), uz = __shfl(z, l), utau = __shfl(tau, l);
+                const int pl = __builtin_amdgcn_readlane(p, l);
+                int uneed = __builtin_amdgcn_readlane(need, l);
+                const int taken0 = __builtin_amdgcn_readlane(cnt_lane, l);
+                int cnt = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (int t0 = 0; t0 < n; t0 += WAVE) {
+                    const int g = t0 + lane;
+                    const float4 v = cand[min(g, n - 1)];
+                    const float d = dist2_exact(ux, uy, uz, v);
+                    const bool lt = g < n && d < utau, eq = g < n && d == utau;
+                    const unsigned long long eqm = __ballot(eq);
+                    const int eq_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(eqm >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)eqm, 0u));
+                    const bool take = lt || (eq && eq_rank < uneed);
+                    uneed = max(0, uneed - (int)__builtin_popcountll(eqm));
+                    const unsigned long long tm = __ballot(take);
+                    if (tm == 0ull) continue;
+                    const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+                    if (take && at < WAVE) { lpos[at] = __float_as_uint(v.w); lw[at] = d; }
+                    cnt += (int)__builtin_popcountll(tm);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cnt = min(cnt, WAVE);
+                if (LOG) n_blend += cnt;
+                // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1)   (smpl.py:630-634); normalised at the end
+                if (lane < cnt) lw[lane] = 1.0f / fminf(fmaxf(sqrtf(lw[lane]), 0.0001f), 1.0f);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // blend: lanes = joints
+                float accj = 0.f, norm = 0.f;
+                const int jl = min(lane, KNN_JMAX - 1);
+#pragma unroll 6
+                for (int k = 0; k < cnt; k++) {
+                    const float wk = lw[k];
+                    accj = __builtin_fmaf(wk, rows_padded[(size_t)lpos[k] * KNN_JMAX + jl], accj);
+                    norm += wk;
+                }
+                if (WITH_IDX && lane < cnt && taken0 + lane < K)
+                    knn_idx_out[(size_t)pl * K + taken0 + lane] = (int)__float_as_uint(sorted_verts[lpos[lane]].w);
+                if (lane == l) { norm_lane += norm; cnt_lane += cnt; }
+                if (lane < J) {
+                    float *out = weights_out + (size_t)pl * J + lane;
+                    if (single) *out = accj / norm;
+                    else *out = (base == 0) ? accj : *out + accj;
+                }
+            }
+        }
+        if (!single) {                                                // normalise the rows accumulated over several chunks
+            int ordinal = 0;
+            for (unsigned long long todo = __ballot(active); todo != 0ull; todo &= todo - 1ull, ordinal++) {
+                if ((ordinal % KNN_WAVES) != wave) continue;
+                const int l = (int)__builtin_ctzll(todo);
+                const int pl = __builtin_amdgcn_readlane(p, l);
+                const float nl = __shfl(norm_lane, l);
+                if (lane < J) weights_out[(size_t)pl * J + lane] /= nl;
+            }
+        }
+    }
+    if (LOG && lane == 0) {
+        unsigned long long *w = wave_log + (((size_t)blockIdx.x * KNN_SLOTS + slot) * KNN_WAVES + wave) * 8;
+        w[0] = t_start; w[1] = wall_clock64(); w[2] = n_pairs; w[3] = n_cand; w[4] = n_blend;
+    }
+}
+
 // persistent device workspace of the vertex grid (grown on demand, one per process)
 struct KnnWorkspace {
     void *base = nullptr;
@@ -236,14 +553,20 @@ extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *ve
     if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
 
     // carve the workspace
-    size_t sort_bytes = 0;
+    const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
+    size_t sort_bytes = 0, qsort_bytes = 0;
     SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                           (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)V, 0u, 18u, stream));
+    SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, qsort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                          (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, 0u, 18u, stream));
+    if (qsort_bytes > sort_bytes) sort_bytes = qsort_bytes;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return o; };
     const size_t o_meta = carve(sizeof(GridMeta)), o_k0 = carve(4 * (size_t)V), o_k1 = carve(4 * (size_t)V),
                  o_v0 = carve(4 * (size_t)V), o_v1 = carve(4 * (size_t)V), o_rng = carve(sizeof(uint2) * (size_t)GRID_CELLS),
-                 o_sv = carve(sizeof(float4) * (size_t)V), o_tmp = carve(sort_bytes);
+                 o_sv = carve(sizeof(float4) * (size_t)V), o_tmp = carve(sort_bytes),
+                 o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P), o_qv0 = carve(4 * (size_t)P),
+                 o_qv1 = carve(4 * (size_t)P), o_rows = carve(sizeof(float) * (size_t)V * KNN_JMAX);
     int dev = 0;
     SOAR_HIP_OK(hipGetDevice(&dev));
     if (g_ws.bytes < off || g_ws.device != dev) {
@@ -270,8 +593,42 @@ extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *ve
     SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, sort_bytes, k0, k1, v0, v1, (size_t)V, 0u, 18u, stream));
     SOAR_HIP_OK(hipMemsetAsync(rng, 0, sizeof(uint2) * (size_t)GRID_CELLS, stream));
     hipLaunchKernelGGL(grid_ranges_kernel, dim3((V + 255) / 256), dim3(256), 0, stream, verts, V, k1, v1, rng, sv);
-    hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P, V,
-                       meta, rng, sv, vert_weights, J, K, weights_out, knn_idx_out);
+    if (fast) {
+        uint32_t *qk0 = reinterpret_cast<uint32_t *>(b + o_qk0), *qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
+        uint32_t *qv0 = reinterpret_cast<uint32_t *>(b + o_qv0), *qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
+        hipLaunchKernelGGL(query_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, meta, qk0, qv0);
+        SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, sort_bytes, qk0, qk1, qv0, qv1, (size_t)P, 0u, 18u, stream));
+        float *rows = reinterpret_cast<float *>(b + o_rows);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((V * KNN_JMAX + 255) / 256), dim3(256), 0, stream, vert_weights, V, J, sv, rows);
+        const dim3 grid((P + WAVE - 1) / WAVE, KNN_SLOTS);
+        const float *rows4 = rows;
+        const char *log_path = getenv("SOAR_KNN_LOG");            // diagnostic: per-wave timeline of one launch
+        if (log_path && !knn_idx_out) {
+            unsigned long long *log_dev = nullptr;
+            const size_t nbytes = sizeof(unsigned long long) * 8 * (size_t)grid.x * KNN_SLOTS * KNN_WAVES;
+            SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
+            SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
+            hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1,
+                               rows4, J, weights_out, knn_idx_out, log_dev);
+            SOAR_HIP_OK(hipStreamSynchronize(stream));
+            unsigned long long *host = (unsigned long long *)malloc(nbytes);
+            SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
+            FILE *f = fopen(log_path, "wb");
+            if (f) { fwrite(host, 1, nbytes, f); fclose(f); }
+            free(host);
+            (void)hipFree(log_dev);
+            return 0;
+        }
+        if (knn_idx_out)
+            hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1, rows4,
+                               J, weights_out, knn_idx_out);
+        else
+            hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1, rows4,
+                               J, weights_out, knn_idx_out);
+    } else {
+        hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P,
+                           V, meta, rng, sv, vert_weights, J, K, weights_out, knn_idx_out);
+    }
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
     return 0;
 }
