@@ -96,9 +96,10 @@ def build_sequence(workload, device, seed=0):
 
 
 def synthetic_loss(out, targets):
-    """L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth)   """
-    return ((out.render - targets["color"]).abs().mean() + (out.mask - targets["mask"]).abs().mean()
-            + 0.1 * (out.normal * targets["normal"]).mean() + 0.01 * out.depth.mean())
+    """L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth)   (SURVEY 8d),
+    value and pixel gradients in one HIP kernel (soar_amd/losses.py)."""
+    from soar_amd.losses import frame_loss
+    return frame_loss(out.render, out.normal, out.depth, out.mask, targets)
 
 
 def run_step(seq, targets, flat, frames, bg):

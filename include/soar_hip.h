@@ -181,6 +181,17 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
  *   out[i] = mean of the 3 smallest squared distances from point i to the other points. */
 int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
 
+/* ---- per-frame image loss, value + pixel gradients in one pass (the dense
+ *      four-output loss of section 8(d):  L = wc mean|color - tc| + wm mean|opac - tm| + wn mean(normal . tn) + wd mean(depth);
+ *      same per-pixel structure as the reference's frame losses, TS/system/gaussian_surfel_mvdream.py:311-330,622-630).
+ *   color/normal/target_color/target_normal [3,H,W], depth/opac/target_mask [1,H,W]; W*H must be a multiple of 4.
+ *   loss_out [1], sums4 [4] (scratch: the four un-normalised sums), dL_d* = gradient of L w.r.t. the four images. */
+int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
+                    const float *opac, const float *target_color, const float *target_mask,
+                    const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
+                    float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                    float *dL_dopac, void *stream);
+
 /* ---- per-stage timing (no reference counterpart; used by bench.py for the roofline figure) ----
  * When enabled, every kernel stage is bracketed by two hipEvents recorded on the launch stream.
  * soar_prof_read synchronises the pending events and returns the accumulated device time and launch count of

@@ -1,0 +1,118 @@
+// frame_loss.hip -- per-frame image loss, value and pixel gradients in ONE pass over the rasterizer outputs.
+//
+// L = wc * mean|color - target| + wm * mean|opac - mask| + wn * mean(normal . n_target) + wd * mean(depth)
+// is the dense four-output loss SURVEY.md section 8(d) prescribes for the per-frame benchmark (the reference's
+// per-frame losses -- masked L1, cosine normal loss, TS/system/gaussian_surfel_mvdream.py:311-330,622-630 -- have
+// the same structure: per-pixel terms averaged over the image).  In eager torch this is ~25 full-image kernels per
+// frame; here every pixel is read once and its four gradient planes are written once.
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+struct LossArgs {
+    int n;                       // pixels
+    const float *color, *normal, *depth, *opac;            // [3,n] [3,n] [n] [n]
+    const float *t_color, *t_mask, *t_normal;              // [3,n] [n] [3,n]
+    float wc, wm, wn, wd;
+    float *dcolor, *dnormal, *ddepth, *dopac;
+    float *sums;                 // [4] un-normalised sums of the four terms
+};
+
+__device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
+{
+    const int n4 = a.n >> 2;
+    float s_c = 0.f, s_m = 0.f, s_n = 0.f, s_d = 0.f;
+    const float gc = a.wc / (3.f * a.n), gm = a.wm / a.n, gn = a.wn / (3.f * a.n), gd = a.wd / a.n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        float4 nsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float4 c = reinterpret_cast<const float4 *>(a.color + (size_t)ch * a.n)[i];
+            const float4 t = reinterpret_cast<const float4 *>(a.t_color + (size_t)ch * a.n)[i];
+            const float4 d = make_float4(c.x - t.x, c.y - t.y, c.z - t.z, c.w - t.w);
+            s_c += (fabsf(d.x) + fabsf(d.y)) + (fabsf(d.z) + fabsf(d.w));
+            reinterpret_cast<float4 *>(a.dcolor + (size_t)ch * a.n)[i] =
+                make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w));
+            const float4 nr = reinterpret_cast<const float4 *>(a.normal + (size_t)ch * a.n)[i];
+            const float4 nt = reinterpret_cast<const float4 *>(a.t_normal + (size_t)ch * a.n)[i];
+            nsum.x += nr.x * nt.x; nsum.y += nr.y * nt.y; nsum.z += nr.z * nt.z; nsum.w += nr.w * nt.w;
+            reinterpret_cast<float4 *>(a.dnormal + (size_t)ch * a.n)[i] = make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w);
+        }
+        s_n += (nsum.x + nsum.y) + (nsum.z + nsum.w);
+        const float4 o = reinterpret_cast<const float4 *>(a.opac)[i];
+        const float4 m = reinterpret_cast<const float4 *>(a.t_mask)[i];
+        const float4 e = make_float4(o.x - m.x, o.y - m.y, o.z - m.z, o.w - m.w);
+        s_m += (fabsf(e.x) + fabsf(e.y)) + (fabsf(e.z) + fabsf(e.w));
+        reinterpret_cast<float4 *>(a.dopac)[i] = make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w));
+        const float4 dp = reinterpret_cast<const float4 *>(a.depth)[i];
+        s_d += (dp.x + dp.y) + (dp.z + dp.w);
+        reinterpret_cast<float4 *>(a.ddepth)[i] = make_float4(gd, gd, gd, gd);
+    }
+    __shared__ float part[4][4];
+    s_c = wave_sum(s_c); s_m = wave_sum(s_m); s_n = wave_sum(s_n); s_d = wave_sum(s_d);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { part[wave][0] = s_c; part[wave][1] = s_m; part[wave][2] = s_n; part[wave][3] = s_d; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        atomicAdd(a.sums + threadIdx.x, v);
+    }
+}
+
+// loss = wc*sums[0]/(3n) + wm*sums[1]/n + wn*sums[2]/(3n) + wd*sums[3]/n
+__global__ void frame_loss_finish_kernel(const float *sums, int n, float wc, float wm, float wn, float wd, float *loss)
+{
+    if (threadIdx.x == 0)
+        *loss = (wc * sums[0] / (3.f * n) + wm * sums[1] / n) + (wn * sums[2] / (3.f * n) + wd * sums[3] / n);
+}
+
+}  // namespace
+
+}  // namespace soar
+
+using namespace soar;
+
+extern "C" int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
+                               const float *opac, const float *target_color, const float *target_mask,
+                               const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
+                               float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                               float *dL_dopac, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0) { set_error("soar_frame_loss: bad image size %dx%d", W, H); return 1; }
+    if (!color || !normal || !depth || !opac || !target_color || !target_mask || !target_normal || !loss_out || !sums4 ||
+        !dL_dcolor || !dL_dnormal || !dL_ddepth || !dL_dopac) {
+        set_error("soar_frame_loss: NULL pointer");
+        return 1;
+    }
+    LossArgs a;
+    a.n = W * H;
+    a.color = color; a.normal = normal; a.depth = depth; a.opac = opac;
+    a.t_color = target_color; a.t_mask = target_mask; a.t_normal = target_normal;
+    a.wc = w_color; a.wm = w_mask; a.wn = w_normal; a.wd = w_depth;
+    a.dcolor = dL_dcolor; a.dnormal = dL_dnormal; a.ddepth = dL_ddepth; a.dopac = dL_dopac;
+    a.sums = sums4;
+    if (a.n & 3) {        // planes of a [3,n] tensor are 16-byte aligned only when n % 4 == 0
+        set_error("soar_frame_loss: W*H must be a multiple of 4 (got %d)", a.n);
+        return 1;
+    }
+    SOAR_HIP_OK(hipMemsetAsync(sums4, 0, 4 * sizeof(float), stream));
+    StageTimer timer(ST_FRAME_LOSS, stream);
+    const int blocks = min(2048, max(1, (a.n / 4 + 255) / 256));
+    hipLaunchKernelGGL(frame_loss_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(64), 0, stream, sums4, a.n, w_color, w_mask, w_normal, w_depth,
+                       loss_out);
+    SOAR_LAUNCH_OK("frame_loss", stream, 0);
+    return 0;
+}

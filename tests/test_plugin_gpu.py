@@ -200,3 +200,27 @@ def test_render_frames_equals_per_frame_path():
         assert _rel(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 1e-4, k
     for x, y in zip(ta, tb):
         assert _rel(y.cpu().numpy(), x.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("hw", [(120, 160), (61, 96), (1080, 1920)])
+def test_frame_loss_kernel_matches_torch(hw):
+    """soar_frame_loss (value + four gradient planes in one pass) == the eager torch loss and its autograd gradients."""
+    from soar_amd.losses import frame_loss
+    Hh, Ww = hw
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    color, normal, depth, opac = (mk(3, Hh, Ww).requires_grad_(True), mk(3, Hh, Ww).requires_grad_(True),
+                                  mk(1, Hh, Ww).requires_grad_(True), torch.rand(1, Hh, Ww, generator=g).to(DEV).requires_grad_(True))
+    tg = {k: v.to(DEV) for k, v in syn.make_loss_targets(Hh, Ww, 1).items()}
+    ref = ((color - tg["color"]).abs().mean() + (opac - tg["mask"]).abs().mean() + 0.1 * (normal * tg["normal"]).mean()
+           + 0.01 * depth.mean())
+    g_ref = torch.autograd.grad(ref * 2.5, (color, normal, depth, opac))
+    got = frame_loss(color, normal, depth, opac, tg)
+    g_got = torch.autograd.grad(got * 2.5, (color, normal, depth, opac))
+    assert abs(float(got.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach())))
+    for a, b in zip(g_got, g_ref):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-12)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        frame_loss(color[:, :3, :5], normal[:, :3, :5], depth[:, :3, :5], opac[:, :3, :5],
+                   {k: v[:, :3, :5] for k, v in tg.items()})
