@@ -2,6 +2,8 @@
 // buffer layouts.  Host-side orchestration only; kernels live in the rast_*.hip / lbs_*.hip units.
 #include "soar_common.h"
 
+#include <mutex>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -37,7 +39,8 @@ int post_launch(const char *what, hipStream_t stream, int debug)
 // ---- per-stage event timing -----------------------------------------------------------------------
 namespace {
 struct ProfSlot { hipEvent_t a, b; int stage; bool open; };
-constexpr int PROF_SLOTS = 4096;
+constexpr int PROF_SLOTS = 16384;
+std::mutex g_prof_mutex;                 // stages may be enqueued from several host threads (one per HIP stream)
 bool g_prof_on = false;
 ProfSlot g_slots[PROF_SLOTS];
 int g_slot_used = 0;
@@ -63,13 +66,16 @@ void prof_drain()
 StageTimer::StageTimer(int stage, hipStream_t s) : slot(-1), stream(s)
 {
     if (!g_prof_on) return;
-    if (!g_slots_init) {
-        for (int i = 0; i < PROF_SLOTS; i++) { (void)hipEventCreate(&g_slots[i].a); (void)hipEventCreate(&g_slots[i].b); }
-        g_slots_init = true;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (!g_slots_init) {
+            for (int i = 0; i < PROF_SLOTS; i++) { (void)hipEventCreate(&g_slots[i].a); (void)hipEventCreate(&g_slots[i].b); }
+            g_slots_init = true;
+        }
+        if (g_slot_used == PROF_SLOTS) return;       // full until the next soar_prof_read / soar_prof_reset: stop sampling
+        slot = g_slot_used++;
+        g_slots[slot].stage = stage;
     }
-    if (g_slot_used == PROF_SLOTS) prof_drain();
-    slot = g_slot_used++;
-    g_slots[slot].stage = stage;
     (void)hipEventRecord(g_slots[slot].a, stream);
 }
 StageTimer::~StageTimer()

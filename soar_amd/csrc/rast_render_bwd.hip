@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) render_backward_lanes_kernel(BwdArgs a)
     const bool inside = px < a.W && py < a.H;
 
     const uint2 range = a.ranges[tile];
+    set_wave_priority_by_length(range.y - range.x);
     PixelConsts c;
     PixelState s;
     load_pixel(a, px, py, inside, c, s);
@@ -371,6 +372,7 @@ __global__ void __launch_bounds__(256) render_backward_dpp_kernel(BwdArgs a)
     const bool inside = px < a.W && py < a.H;
 
     const uint2 range = a.ranges[tile];
+    set_wave_priority_by_length(range.y - range.x);
     PixelConsts c;
     PixelState s;
     load_pixel(a, px, py, inside, c, s);
@@ -511,6 +513,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     const bool inside = px < a.W && py < a.H;
 
     const uint2 range = a.ranges[tile];
+    set_wave_priority_by_length(range.y - range.x);
     PixelConsts c;
     PixelState s;
     load_pixel(a, px, py, inside, c, s);

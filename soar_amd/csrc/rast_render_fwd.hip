@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     const float fx = (float)px, fy = (float)py;
 
     const uint2 range = a.ranges[tile];
+    set_wave_priority_by_length(range.y - range.x);
 
     float T = 1.0f;                                  // replicated in the four lanes of a pixel
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
@@ -289,12 +290,13 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     StageTimer timer(ST_RENDER_FWD, stream);
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     static int logged = 0;
-    if (log_path && !logged && prm.render_front == 0 && !out_occ) {
+    if (log_path && !logged && prm.render_front == 0) {
         logged = 1;
         const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)nblocks;
         SOAR_HIP_OK(hipMalloc(&a.wave_log, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(a.wave_log, 0, nbytes, stream));
-        hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, a);
+        if (out_occ) hipLaunchKernelGGL((render_forward_kernel<true, true>), dim3(nblocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, a);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, a.wave_log, nbytes, hipMemcpyDeviceToHost));

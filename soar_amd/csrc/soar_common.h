@@ -109,6 +109,15 @@ __device__ __forceinline__ float exp_nonpositive(float x)
     return __builtin_fmaf(e, lo * 0.693147180559945309f, e);
 }
 
+// Wavefronts of long tile lists are the critical path of a blend launch: give them issue priority over the thousands
+// of short ones sharing their SIMD (the hardware arbiter serves higher s_setprio levels first).
+__device__ __forceinline__ void set_wave_priority_by_length(uint32_t len)
+{
+    if (len > 2048u) __builtin_amdgcn_s_setprio(3);
+    else if (len > 768u) __builtin_amdgcn_s_setprio(2);
+    else if (len > 256u) __builtin_amdgcn_s_setprio(1);
+}
+
 // Gaussian falloff exponent exactly as the reference writes it (forward.cu:507-508, backward.cu:663-664), evaluated
 // without FMA contraction so that the skip / saturation decisions see the same value as an IEEE evaluation.
 __device__ __forceinline__ float falloff_power(float A, float B, float Cc, float dx, float dy)

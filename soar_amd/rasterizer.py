@@ -18,6 +18,7 @@ call goes to the HIP library and raises if it is missing or if a tensor is not o
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -101,6 +102,46 @@ def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- side streams for batched views ---------------------------------------------------------------
+# The binning chain of one view is a sequence of small launch-bound kernels and both blend kernels end in a tail of a
+# few long tiles: one view cannot fill 256 CUs.  `rasterize_views` therefore runs the views of a batch on separate HIP
+# streams (fork after the inputs exist on the caller's stream, join before the outputs are used).  SOAR_STREAMS=1
+# turns this off (single-stream, per-kernel profiling).
+NUM_STREAMS = max(1, int(os.environ.get("SOAR_STREAMS", "4")))
+_side_streams = {}
+
+
+def _view_stream(device: torch.device, i: int):
+    key = (device.index, i % NUM_STREAMS)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def _fork(device: torch.device, side) -> int:
+    """Make `side` wait for everything enqueued so far on the caller's stream (this also covers memory the caching
+    allocator just handed out, which earlier kernels of the caller's stream may still be using); returns its handle."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    side.wait_event(ev)
+    return side.cuda_stream
+
+
+def _run_deferred(device: torch.device, calls) -> None:
+    """Enqueue the deferred C-ABI calls (one per view, each on its own stream).  Measured: issuing them from a thread
+    pool does not help -- the HIP runtime serialises the launches -- so they run in order on the calling thread."""
+    for c in calls:
+        c()
+
+
+def _join(device: torch.device, sides) -> None:
+    cur = torch.cuda.current_stream(device)
+    for s in sides:
+        ev = torch.cuda.Event()
+        ev.record(s)
+        cur.wait_event(ev)
+
+
 def _scratch(nbytes: int, device: torch.device) -> torch.Tensor:
     buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     if buf.data_ptr() % 256:
@@ -144,16 +185,16 @@ class _NativeOps:
     @staticmethod
     def _geometry_stage(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, image_height, image_width,
-                        sh, degree, campos, prefiltered, render_front, sort_descending, debug, config):
+                        sh, degree, campos, prefiltered, render_front, sort_descending, debug, config, side=None):
         """Allocate outputs / scratch and enqueue preprocess + scan WITHOUT a host synchronisation.  Returns a state
-        dict for `_render_stage`."""
+        dict for `_render_stage`.  `side`: torch stream to run this view on (forked from the current stream)."""
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")      # rasterize_points.cu:50-52
         _require_hip(means3D, "means3D")
         L = hip_lib.lib()
         device = means3D.device
         P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-        st = {"device": device, "P": P, "H": H, "W": W}
+        st = {"device": device, "P": P, "H": H, "W": W, "side": side}
         st["out"] = [torch.empty((3, H, W), dtype=torch.float32, device=device),
                      torch.empty((3, H, W), dtype=torch.float32, device=device),
                      torch.empty((1, H, W), dtype=torch.float32, device=device),
@@ -179,19 +220,21 @@ class _NativeOps:
             st["geom"] = _scratch(nbytes.value, device)
             check(L.soar_rast_image_bytes(W, H, C.byref(nbytes)), "image_bytes")
             st["img"] = _scratch(nbytes.value, device)
+            stream = _fork(device, side) if side is not None else _stream(device)
             check(L.soar_rast_forward_geometry(C.byref(ctx.params), means.data_ptr(), ptr(sh_t), ptr(cols), opac.data_ptr(),
                                                ptr(scl), ptr(rot), ptr(cov), st["geom"].data_ptr(), st["radii"].data_ptr(),
-                                               None, _stream(device)), "rasterize_gaussians (geometry stage)")
+                                               None, stream), "rasterize_gaussians (geometry stage)")
         return st
 
     @staticmethod
-    def _render_stage(st, occ_values=None):
+    def _render_stage(st, occ_values=None, defer=None):
         """Read num_rendered (synchronises the stream unless an earlier view of the batch already did), size the binning
         buffer, enqueue key emission + sort + ranges + blend.  With `occ_values` [P] the blend also produces
         st["occ"] [3,H,W]: the colour image of a render_front=True pass with colours = occ_values (fused occlusion pass)."""
         L = hip_lib.lib()
         device, P = st["device"], st["P"]
         out = st["out"]
+        side = st.get("side")
         occ_ptr = occ_out_ptr = None
         if occ_values is not None:
             _require_hip(occ_values, "occ_values")
@@ -204,7 +247,7 @@ class _NativeOps:
                 st["occ"].zero_()
                 occ_out_ptr = None
         prm = C.byref(st["ctx"].params)
-        stream = _stream(device)
+        stream = side.cuda_stream if side is not None else _stream(device)
         with torch.cuda.device(device):
             if P == 0:
                 check(L.soar_rast_forward_render(prm, None, None, None, None, 0, out[0].data_ptr(), out[1].data_ptr(),
@@ -220,11 +263,20 @@ class _NativeOps:
             nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             st["binning"] = _scratch(nbytes.value, device)
-            check(L.soar_rast_forward_render_occ(prm, st["radii"].data_ptr(), st["geom"].data_ptr(),
-                                                 st["binning"].data_ptr(), st["img"].data_ptr(), num_rendered,
-                                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-                                                 occ_ptr, occ_out_ptr, stream),
-                  "rasterize_gaussians (render stage)")
+            if side is not None:
+                stream = _fork(device, side)
+            st["occ_in"] = occ_values            # keep the converted tensor alive until the launch ran
+
+            def launch():
+                check(L.soar_rast_forward_render_occ(prm, st["radii"].data_ptr(), st["geom"].data_ptr(),
+                                                     st["binning"].data_ptr(), st["img"].data_ptr(), num_rendered,
+                                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                                     out[3].data_ptr(), occ_ptr, occ_out_ptr, stream),
+                      "rasterize_gaussians (render stage)")
+            if defer is not None:
+                defer.append(launch)
+            else:
+                launch()
         return num_rendered
 
     @staticmethod
@@ -245,7 +297,7 @@ class _NativeOps:
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                      viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, dL_dout_color,
                                      dL_dout_normal, dL_dout_depth, dL_dout_opac, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imageBuffer, debug, config):
+                                     binningBuffer, imageBuffer, debug, config, side=None, defer=None):
         """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
         dL_dscales[P,3], dL_drotations[P,4], dL_dviewmat[4,4], dL_dprojmat[4,4], dL_dcampos[3])
         (rasterize_points.cu:107-187)"""
@@ -271,7 +323,6 @@ class _NativeOps:
         # render_front / sort_descending / prefiltered do not enter the backward pass
         ctx = _Ctx(P, M, H, W, tan_fovx, tan_fovy, scale_modifier, degree, False, False, False, debug, background,
                    viewmatrix, projmatrix, prcppoint, patchbbox, campos, config, device)
-        stream = _stream(device)
         stats["backward_calls"] += 1
         stats["num_rendered_bwd"] += int(R)
         with torch.cuda.device(device):
@@ -292,13 +343,28 @@ class _NativeOps:
                 means = dC = dN = dD = dO = None
                 cols = scl = rot = cov = radii_i = None
                 work_ptr, work_n = None, 0
-            check(L.soar_rast_backward(
-                C.byref(ctx.params), ptr(means), ptr(radii_i), ptr(sh_t), ptr(cols), ptr(scl), ptr(rot), ptr(cov),
-                ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), int(R),
-                ptr(dC), ptr(dN), ptr(dD), ptr(dO),
-                ptr(g_means2D), ptr(g_colors), ptr(g_opacity), ptr(g_means3D), ptr(g_cov3D), ptr(g_sh), ptr(g_scales),
-                ptr(g_rot), g_view.data_ptr(), g_proj.data_ptr(), g_campos.data_ptr(), work_ptr, work_n, stream),
-                "rasterize_gaussians_backward")
+            stream = _fork(device, side) if side is not None else _stream(device)
+            alive = [ctx, work if P > 0 else None, means, dC, dN, dD, dO, cols, scl, rot, cov, radii_i, sh_t]
+
+            def launch():
+                check(L.soar_rast_backward(
+                    C.byref(ctx.params), ptr(means), ptr(radii_i), ptr(sh_t), ptr(cols), ptr(scl), ptr(rot), ptr(cov),
+                    ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), int(R),
+                    ptr(dC), ptr(dN), ptr(dD), ptr(dO),
+                    ptr(g_means2D), ptr(g_colors), ptr(g_opacity), ptr(g_means3D), ptr(g_cov3D), ptr(g_sh), ptr(g_scales),
+                    ptr(g_rot), g_view.data_ptr(), g_proj.data_ptr(), g_campos.data_ptr(), work_ptr, work_n, stream),
+                    "rasterize_gaussians_backward")
+                del alive[:]
+            if side is not None and P > 0:
+                # temporaries of this call die before the caller joins the side stream: keep the caching allocator
+                # from recycling them while the kernels are still running
+                for t in [*alive[1:], *ctx.keep]:
+                    if t is not None:
+                        t.record_stream(side)
+            if defer is not None:
+                defer.append(launch)
+            else:
+                launch()
         return (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_view, g_proj, g_campos)
 
     @staticmethod
@@ -369,12 +435,20 @@ class _RasterizeViews(torch.autograd.Function):
         n = _RasterizeViews.N_IN
         views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
         states = []
-        for rs, (means3D, means2D, sh, colors, opac, scales, rot, cov, _occ) in zip(settings_list, views):
+        use_sides = NUM_STREAMS > 1 and len(settings_list) > 1 and views[0][0].is_cuda
+        for i, (rs, (means3D, means2D, sh, colors, opac, scales, rot, cov, _occ)) in enumerate(zip(settings_list, views)):
             states.append(_NativeOps._geometry_stage(
                 rs.bg, means3D, colors, opac, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
                 rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
-                rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config))
-        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None) for st, v in zip(states, views)]
+                rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config,
+                side=_view_stream(means3D.device, i) if use_sides else None))
+        calls = [] if use_sides else None
+        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls)
+                            for st, v in zip(states, views)]
+        if use_sides:
+            _run_deferred(states[0]["device"], calls)
+            _join(states[0]["device"], {st["side"] for st in states if st["side"] is not None})
+        ctx.use_sides = use_sides
         ctx.settings_list = settings_list
         ctx.opac_shapes = [v[4].shape for v in views]
         saved, outs, nondiff = [], [], []
@@ -393,6 +467,8 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         grads = [None]
+        used = set()
+        calls = [] if ctx.use_sides else None
         for i, rs in enumerate(ctx.settings_list):
             colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = ctx.saved_tensors[i * 10:(i + 1) * 10]
             g_color, g_normal, g_depth, g_opac, _, _ = gouts[i * 6:(i + 1) * 6]
@@ -409,10 +485,17 @@ class _RasterizeViews(torch.autograd.Function):
                 _C.rasterize_gaussians_backward(
                     rs.bg, means3D, radii, colors, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix,
                     rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
-                    rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config)
+                    rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config,
+                    side=_view_stream(dev, i) if ctx.use_sides else None, defer=calls)
+            if ctx.use_sides:
+                used.add(_view_stream(dev, i))
             like = lambda g, ref: g if ref.numel() > 0 else None
             grads += [g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors), g_opacities.reshape(ctx.opac_shapes[i]),
                       like(g_scales, scales), like(g_rot, rot), like(g_cov3D, cov), None]
+        if used:
+            dev = next(iter(used)).device
+            _run_deferred(dev, calls)
+            _join(dev, used)
         return tuple(grads)
 
 
