@@ -35,7 +35,7 @@ EXTRA_FLAGS = {
     # operation order un-contracted so that rounding follows an IEEE evaluation of the reference source
     "rast_geom_bwd.hip": ["-ffp-contract=off"],
 }
-SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
+SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
            "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip"]
 HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
 

@@ -103,6 +103,15 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->point_offsets, n);
     take(p, out->clamped, M > 0 ? n * 3 : 1);
     take(p, out->front, n);
+    take(p, out->rect, n);
+    take(p, out->rect_sorted, n);
+    take(p, out->depth_key, n);
+    take(p, out->sort_slot, n);
+    take(p, out->sort_pairs, n);
+    take(p, out->ids_sorted, n);
+    take(p, out->bucket_cnt, 8192);
+    take(p, out->bucket_base, 8192 + 1);
+    take(p, out->blk_stats, ((n + 255) / 256) * BLK_STATS);
     out->scan_temp_bytes = scan_temp_bytes(P);
     char *tmp;
     take(p, tmp, out->scan_temp_bytes);
@@ -121,6 +130,7 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->n_contrib, pix > 0 ? pix : 1);
     take(p, out->final_D, pix > 0 ? pix : 1);
     take(p, out->tile_order, (tiles + 7) / 8 * 8 + 8);
+    take(p, out->tile_count, tiles > 0 ? tiles : 1);
     out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
     return 0;
 }
@@ -246,9 +256,13 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
 
     GeomBuf g;
     carve_geom(geom_buffer, prm->P, prm->M, &g);
+    // header (kmin / kmax / n_vis) and the depth-bucket counters start from zero
+    SOAR_HIP_OK(hipMemsetAsync(g.header, 0, 64 * sizeof(uint32_t), stream));
+    SOAR_HIP_OK(hipMemsetAsync(g.bucket_cnt, 0, 8192 * sizeof(uint32_t), stream));
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
     if (launch_scan(*prm, g, stream)) return 1;
+    if (!prm->sort_descending && launch_depth_buckets(*prm, g, stream)) return 1;
     if (!num_rendered_host) return 0;             // asynchronous form: read R later with soar_rast_num_rendered()
     // the one host synchronisation of the forward pass (rasterizer_impl.cu:250-252)
     uint32_t r = 0;
@@ -316,7 +330,13 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
     carve_geom(geom_buffer, prm->P, prm->M, &g);
     carve_image(image_buffer, prm->W, prm->H, &img);
     carve_binning(binning_buffer, num_rendered, &b);
-    if (launch_binning(*prm, radii, g, b, img, num_rendered, stream)) return 1;
+    // ascending sort: per-tile lists straight from the depth-ordered Gaussians (rast_tilebin.hip); the descending sort
+    // of back views keeps the 64-bit key sort (rast_binning.hip)
+    if (num_rendered > 0 && !prm->sort_descending) {
+        if (launch_tile_binning(*prm, g, b, img, stream)) return 1;
+    } else if (launch_binning(*prm, g, b, img, num_rendered, stream)) {
+        return 1;
+    }
     if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
 }
@@ -444,10 +464,15 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
     if (binning_buffer && num_rendered > 0) {
         carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
         const size_t R = (size_t)num_rendered;
+        COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
+        if (!prm->sort_descending && image_buffer && (keys_unsorted || vals_unsorted || keys_sorted)) {
+            // the ascending path never materialises the 64-bit keys: produce them for inspection with the key sort
+            // (point_list and ranges above were copied out first; the key sort rewrites them with its own result)
+            if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
+        }
         COPY(keys_unsorted, b.keys_unsorted, R * sizeof(uint64_t));
         COPY(vals_unsorted, b.vals_unsorted, R * sizeof(uint32_t));
         COPY(keys_sorted, b.keys_sorted, R * sizeof(uint64_t));
-        COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
     }
 #undef COPY
     return 0;

@@ -62,22 +62,16 @@ namespace {
 // One thread per Gaussian walks its tile rectangle row-major (y outer, x inner) and emits
 // key = (tile << 32) | bits(view depth), value = Gaussian index.
 __global__ void __launch_bounds__(256)
-emit_keys_kernel(int P, const GaussRec *__restrict__ rec, const uint32_t *__restrict__ offsets,
-                 const int32_t *__restrict__ radii, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, int gx, int gy)
+emit_keys_kernel(int P, const uint2 *__restrict__ rect, const uint32_t *__restrict__ depth_key,
+                 const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, int gx)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
-    const int rad = radii[idx];
-    if (rad <= 0) return;
+    const uint2 rc = rect[idx];                       // the tile rectangle preprocess computed (getRect, auxiliary.h:53-63)
+    const int x0 = (int)(rc.x & 0xFFFFu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xFFFFu), y1 = (int)(rc.y >> 16);
+    if (x1 <= x0 || y1 <= y0) return;
     uint32_t off = (idx == 0) ? 0u : offsets[idx - 1];
-    const float4 q0 = rec[idx].q0;
-    const float4 q1 = rec[idx].q1;
-    const float px = q0.x, py = q0.y;
-    const int x0 = min(gx, max(0, (int)((px - rad) / TILE)));
-    const int y0 = min(gy, max(0, (int)((py - rad) / TILE)));
-    const int x1 = min(gx, max(0, (int)((px + rad + TILE - 1) / TILE)));
-    const int y1 = min(gy, max(0, (int)((py + rad + TILE - 1) / TILE)));
-    const uint64_t depth_bits = (uint64_t)__float_as_uint(q1.z);
+    const uint64_t depth_bits = (uint64_t)depth_key[idx];
     for (int y = y0; y < y1; y++) {
         for (int x = x0; x < x1; x++) {
             uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
@@ -147,7 +141,7 @@ int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stre
     return 0;
 }
 
-int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
+int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream)
 {
     const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
@@ -156,8 +150,8 @@ int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, 
 
     {
     StageTimer timer(ST_EMIT_KEYS, stream);
-    hipLaunchKernelGGL(emit_keys_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, prm.P, g.rec, g.point_offsets,
-                       radii, b.keys_unsorted, b.vals_unsorted, gx, gy);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, prm.P, g.rect, g.depth_key,
+                       g.point_offsets, b.keys_unsorted, b.vals_unsorted, gx);
     }
     SOAR_LAUNCH_OK("emit_keys", stream, prm.debug);
 

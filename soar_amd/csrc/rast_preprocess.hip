@@ -115,17 +115,23 @@ struct PreArgs {
     uint32_t *tiles_touched;
     uint8_t *clamped;
     float *front_out;
+    uint2 *rect_out;
+    uint32_t *depth_key_out;
+    uint32_t *blk_stats;
     int32_t *radii;
 };
 
 __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P) return;
+    // lanes past the end redo the last Gaussian (identical stores) so that whole wavefronts reach the reduction below
+    const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx_raw < a.P;
+    const int idx = in_range ? idx_raw : a.P - 1;
 
     // culled unless proven otherwise (forward.cu:249-250)
     int out_radius = 0;
     uint32_t out_tiles = 0;
+    uint2 out_rect = make_uint2(0u, 0u);        // empty rectangle: not visible
     GaussRec rec;
     rec.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
     rec.q1 = rec.q0;
@@ -292,6 +298,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
             } else {
                 out_radius = rad;
                 out_tiles = ntiles;
+                out_rect = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
             }
         }
     }
@@ -312,6 +319,27 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
         rec.q3 = make_float4(nview[0], nview[1], nview[2], splat_cull_threshold(a.opacities[idx]));
     }
     a.rec[idx] = rec;
+    a.rect_out[idx] = out_rect;
+    a.depth_key_out[idx] = alive ? __float_as_uint(vz) : 0xFFFFFFFFu;
+    {
+        // per-block maxima for the depth sort and the tile binning: key range and bounding box of the tile rectangles
+        // (no atomics: the next kernel folds the per-block rows)
+        __shared__ uint32_t red[4][BLK_STATS];
+        const bool vis = alive && in_range;
+        const uint32_t key = __float_as_uint(vz);
+        uint32_t v[BLK_STATS] = {vis ? key : 0u, vis ? ~key : 0u, vis ? (out_rect.x >> 16) : 0u, vis ? (out_rect.y >> 16) : 0u,
+                                 vis ? ~(out_rect.x & 0xFFFFu) : 0u, vis ? ~(out_rect.y & 0xFFFFu) : 0u};
+#pragma unroll
+        for (int k = 0; k < BLK_STATS; k++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] = max(v[k], (uint32_t)__shfl_xor((int)v[k], off));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < BLK_STATS)
+            a.blk_stats[blockIdx.x * BLK_STATS + threadIdx.x] =
+                max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+    }
     a.front_out[idx] = faces_camera ? 1.f : 0.f;
     a.radii[idx] = out_radius;
     a.tiles_touched[idx] = out_tiles;
@@ -336,7 +364,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
     a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
     a.view = prm.viewmatrix_dev; a.proj = prm.projmatrix_dev; a.prcp = prm.prcppoint_dev;
     a.bbox = prm.patchbbox_dev; a.campos = prm.campos_dev;
-    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.front_out = g.front; a.radii = radii;
+    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.front_out = g.front; a.rect_out = g.rect; a.depth_key_out = g.depth_key; a.blk_stats = g.blk_stats; a.radii = radii;
     const int threads = 256;
     const int blocks = (prm.P + threads - 1) / threads;
     StageTimer timer(ST_PREPROCESS, stream);

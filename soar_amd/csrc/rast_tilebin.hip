@@ -1,0 +1,542 @@
+// rast_tilebin.hip -- tile binning without a global sort of the (tile | depth) instance keys, gfx950.
+//
+// Produces exactly what duplicateWithKeys + cub::DeviceRadixSort::SortPairs + identifyTileRanges produce for the
+// ascending sort (DGR/cuda_rasterizer/rasterizer_impl.cu:66-124, 266-295): for every tile the list of Gaussians whose
+// rectangle covers it, ordered by view depth, ties by Gaussian index (a stable sort of keys emitted in index order),
+// laid out tile after tile (`point_list`), plus `ranges`.  The reference sorts R = sum(tiles_touched) 64-bit keys
+// (7.6e5 at 100k Gaussians / 1080p); the library sort that does this here is ~20 launch-bound kernels, 180 us.
+//
+// Same result from the structure of the problem instead:
+//   1. depth_sort_pass_kernel x4: stable LSD radix sort of the P (not R) depth keys.  One launch per 8-bit digit and
+//      no inter-workgroup protocol: every workgroup re-histograms ALL keys (P is small: 400 KB from L2) to know how
+//      many keys of each digit precede its own 4096-key block.  The first pass also splats each rectangle's four
+//      corner increments into a 2-D difference grid; the last pass also writes the rectangles in sorted order.
+//   2. tile_prefix_kernel: 2-D prefix sum of the difference grid = instances per tile, exclusive scan = `ranges`.
+//   3. bin_tiles_kernel: one workgroup per 4x4 tiles walks the depth-ordered rectangles, keeps (in order) those that
+//      touch its 4x4 tiles, and appends them to each covered tile's list with ballot-prefix compaction: every list
+//      comes out in depth order with no per-tile sort and no atomics.
+// The descending sort (back views) keeps the library path.
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+__device__ __forceinline__ int prefix_in_mask(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- depth order of the visible Gaussians: monotone buckets + a small sort per bucket ---------------------------------
+// (key, index) pairs are unique, so any sort of the 64-bit value (key << 32 | index) is the stable order the reference
+// gets from its radix sort.  Keys are spread over B buckets by a monotone map of [kmin, kmax] (both reduced by
+// preprocess); a bucket holds a few dozen pairs and is sorted by one wavefront in registers.  Larger buckets are sorted by
+// the whole workgroup in LDS, and the (pathological: thousands of equal depths) ones beyond that in global memory.
+constexpr int BKT_MAX = 8192;            // buckets (upper bound)
+constexpr int BKT_LDS = 2048;            // pairs one workgroup sorts in LDS
+
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float scale, int B)
+{
+    // monotone in key: int->float conversion, a positive multiply and the truncation are all monotone
+    return (uint32_t)min(B - 1, (int)((float)(key - kmin) * scale));
+}
+
+__global__ void __launch_bounds__(256)
+bucket_count_kernel(int P, int B, const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ blk_stats, int nblk,
+                    uint32_t *__restrict__ header, uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ slot)
+{
+    // every workgroup folds the per-block statistics preprocess left behind (max of: key, ~key, x1, y1, ~x0, ~y0)
+    __shared__ uint32_t red[4][BLK_STATS];
+    {
+        uint32_t v[BLK_STATS];
+#pragma unroll
+        for (int k = 0; k < BLK_STATS; k++) v[k] = 0u;
+        for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+            for (int k = 0; k < BLK_STATS; k++) v[k] = max(v[k], blk_stats[b * BLK_STATS + k]);
+#pragma unroll
+        for (int k = 0; k < BLK_STATS; k++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] = max(v[k], (uint32_t)__shfl_xor((int)v[k], off));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < BLK_STATS) {
+            const uint32_t m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+            red[0][threadIdx.x] = m;
+            if (blockIdx.x == 0) header[H_KMAX + threadIdx.x] = m;      // H_KMAX, H_NOT_KMIN, H_X1, H_Y1, H_NOT_X0, H_NOT_Y0
+        }
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t key = depth_key[i];
+    if (key == 0xFFFFFFFFu) { slot[i] = 0xFFFFFFFFu; return; }
+    const uint32_t kmin = ~red[0][1], kmax = red[0][0];
+    const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
+    slot[i] = atomicAdd(&bucket_cnt[bucket_of(key, kmin, scale, B)], 1u);
+}
+
+__global__ void __launch_bounds__(1024)
+bucket_scatter_kernel(int P, int B, const uint32_t *__restrict__ depth_key, uint32_t *__restrict__ header,
+                      const uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ bucket_base,
+                      const uint32_t *__restrict__ slot, uint64_t *__restrict__ pairs)
+{
+    __shared__ uint32_t base[BKT_MAX];
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    // exclusive prefix of the bucket counts (every workgroup recomputes it: 32 KB from L2)
+    const int per = B / 1024 > 0 ? B / 1024 : 1;
+    uint32_t s = 0;
+    for (int k = 0; k < per; k++) {
+        const int b = tid * per + k;
+        if (b < B) s += bucket_cnt[b];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t up = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += up;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int k = 0; k < per; k++) {
+        const int b = tid * per + k;
+        if (b < B) {
+            base[b] = run;
+            if (blockIdx.x == 0) bucket_base[b] = run;
+            run += bucket_cnt[b];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 1023) { bucket_base[B] = part[1023]; header[H_NVIS] = part[1023]; }
+    __syncthreads();
+    const uint32_t kmin = ~header[H_NOT_KMIN], kmax = header[H_KMAX];
+    const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
+    for (int i = blockIdx.x * 1024 + tid; i < P; i += gridDim.x * 1024) {
+        const uint32_t key = depth_key[i];
+        if (key == 0xFFFFFFFFu) continue;
+        pairs[base[bucket_of(key, kmin, scale, B)] + slot[i]] = ((uint64_t)key << 32) | (uint32_t)i;
+    }
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ascending bitonic sort of one value per lane
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t v, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= WAVE; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t o = shfl_xor_u64(v, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            const bool take_min = up == lower;
+            v = take_min ? (v < o ? v : o) : (v < o ? o : v);
+        }
+    }
+    return v;
+}
+
+struct BucketSortArgs {
+    int B;
+    const uint32_t *bucket_base;
+    uint64_t *pairs;
+    const uint2 *rect;
+    uint32_t *ids_sorted;
+    uint2 *rect_sorted;
+};
+
+__device__ __forceinline__ void emit_sorted(const BucketSortArgs &a, uint32_t pos, uint64_t pair)
+{
+    const uint32_t id = (uint32_t)pair;
+    const uint2 rc = a.rect[id];
+    a.ids_sorted[pos] = id;
+    a.rect_sorted[pos] = rc;
+}
+
+// workgroup = 4 wavefronts = 4 consecutive buckets
+__global__ void __launch_bounds__(256) bucket_sort_kernel(BucketSortArgs a)
+{
+    __shared__ uint64_t lds[BKT_LDS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // phase 1: every wavefront sorts its own bucket if it fits one value per lane
+    {
+        const int b = blockIdx.x * 4 + wave;
+        if (b < a.B) {
+            const uint32_t lo = a.bucket_base[b], n = a.bucket_base[b + 1] - lo;
+            if (n > 0u && n <= (uint32_t)WAVE) {
+                uint64_t v = lane < (int)n ? a.pairs[lo + lane] : ~0ull;
+                v = wave_sort64(v, lane);
+                if (lane < (int)n) emit_sorted(a, lo + lane, v);
+            }
+        }
+    }
+    // phase 2: the buckets that did not fit, one after the other, by the whole workgroup: normalised bitonic network
+    // (every comparator ascending, first step of a merge mirrored), which sorts any n when comparators whose upper end
+    // is >= n are skipped -- in LDS, or in global memory for the (pathological: thousands of equal depths) buckets
+    // beyond the LDS capacity
+    for (int w = 0; w < 4; w++) {
+        const int b = blockIdx.x * 4 + w;
+        if (b >= a.B) break;
+        const uint32_t lo = a.bucket_base[b], n = a.bucket_base[b + 1] - lo;
+        if (n <= (uint32_t)WAVE) continue;
+        uint32_t n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        const bool in_lds = n <= (uint32_t)BKT_LDS;
+        uint64_t *p = in_lds ? lds : a.pairs + lo;
+        __syncthreads();
+        if (in_lds) {
+            for (uint32_t i = tid; i < n; i += 256) lds[i] = a.pairs[lo + i];
+            __syncthreads();
+        }
+        for (uint32_t k = 2; k <= n2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < n2 / 2; t += 256) {
+                    uint32_t i, o;
+                    if (j == (k >> 1)) {                   // mirror step
+                        const uint32_t blk = t / j, r = t % j;
+                        i = blk * k + r;
+                        o = blk * k + k - 1 - r;
+                    } else {
+                        i = 2 * t - (t & (j - 1));
+                        o = i + j;
+                    }
+                    if (o < n) {
+                        const uint64_t x = p[i], y = p[o];
+                        if (x > y) { p[i] = y; p[o] = x; }
+                    }
+                }
+                if (!in_lds) __threadfence_block();
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < n; i += 256) emit_sorted(a, lo + i, p[i]);
+    }
+}
+
+constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile: one tile per wavefront
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_WAVES = BIN_THREADS / WAVE;
+constexpr int BIN_UNROLL = 8;           // rectangles per thread and trip (independent loads in flight)
+constexpr int BIN_CHUNK = BIN_THREADS * BIN_UNROLL;
+constexpr int BIN_CAP = 3072;           // survivors buffered between two flushes
+
+struct SuperTile {
+    int tx0, ty0, tx1, ty1;
+};
+__device__ __forceinline__ SuperTile super_tile_of(int block, int gx, int gy)
+{
+    const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER;
+    SuperTile s;
+    s.tx0 = (block % nsx) * BIN_SUPER;
+    s.ty0 = (block / nsx) * BIN_SUPER;
+    s.tx1 = min(gx, s.tx0 + BIN_SUPER);
+    s.ty1 = min(gy, s.ty0 + BIN_SUPER);
+    return s;
+}
+__device__ __forceinline__ bool rect_hits(uint2 rc, const SuperTile &s)
+{
+    const int x0 = (int)(rc.x & 0xFFFFu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xFFFFu), y1 = (int)(rc.y >> 16);
+    return x0 < s.tx1 && x1 > s.tx0 && y0 < s.ty1 && y1 > s.ty0;       // empty rectangles are never stored in the sorted list
+}
+
+// Pass A: instances per tile.  One workgroup per 4x4 tiles walks the depth-ordered rectangles and adds every rectangle
+// that touches its tiles to a 5x5 difference grid in LDS (4 LDS atomics per hit); the grid's 2-D prefix sum is the
+// number of instances of each of its 16 tiles.  Workgroups outside the bounding box of all rectangles leave at once.
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint2 *__restrict__ rect_sorted,
+                 uint32_t *__restrict__ tile_count)
+{
+    __shared__ int diff[BIN_SUPER + 1][BIN_SUPER + 1];
+    const int tid = threadIdx.x;
+    const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
+    const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
+    const int P = (int)header[H_NVIS];
+    const bool inside = P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0;
+    if (tid < (BIN_SUPER + 1) * (BIN_SUPER + 1)) (&diff[0][0])[tid] = 0;
+    lds_barrier();
+    if (inside) {
+        uint2 rc[BIN_UNROLL];
+#pragma unroll
+        for (int j = 0; j < BIN_UNROLL; j++) rc[j] = j * BIN_THREADS + tid < P ? rect_sorted[j * BIN_THREADS + tid] : make_uint2(0u, 0u);
+        for (int base = 0; base < P; base += BIN_CHUNK) {
+            uint2 nx[BIN_UNROLL];                              // next trip's rectangles are in flight while this one is counted
+#pragma unroll
+            for (int j = 0; j < BIN_UNROLL; j++) {
+                const int k = base + BIN_CHUNK + j * BIN_THREADS + tid;
+                nx[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < BIN_UNROLL; j++) {
+                if (rect_hits(rc[j], st)) {
+                    const int x0 = max((int)(rc[j].x & 0xFFFFu), st.tx0) - st.tx0, x1 = min((int)(rc[j].x >> 16), st.tx1) - st.tx0;
+                    const int y0 = max((int)(rc[j].y & 0xFFFFu), st.ty0) - st.ty0, y1 = min((int)(rc[j].y >> 16), st.ty1) - st.ty0;
+                    atomicAdd(&diff[y0][x0], 1);
+                    atomicAdd(&diff[y0][x1], -1);
+                    atomicAdd(&diff[y1][x0], -1);
+                    atomicAdd(&diff[y1][x1], 1);
+                }
+                rc[j] = nx[j];
+            }
+        }
+    }
+    lds_barrier();
+    if (tid == 0) {
+        for (int y = 0; y < BIN_SUPER; y++)
+            for (int x = 1; x < BIN_SUPER; x++) diff[y][x] += diff[y][x - 1];
+        for (int x = 0; x < BIN_SUPER; x++)
+            for (int y = 1; y < BIN_SUPER; y++) diff[y][x] += diff[y - 1][x];
+    }
+    lds_barrier();
+    if (tid < BIN_SUPER * BIN_SUPER) {
+        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + (tid >> 2);
+        if (tx < st.tx1 && ty < st.ty1) tile_count[ty * gx + tx] = (uint32_t)diff[tid >> 2][tid & 3];
+    }
+}
+
+// One workgroup: exclusive scan of the tile counts in tile order = ranges (untouched tiles keep (0,0) like
+// identifyTileRanges, rasterizer_impl.cu:287-295).
+__global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (T + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(T, t0 + per);
+    uint32_t s = 0;
+    for (int t = t0; t < t1; t++) s += tile_count[t];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t up = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += up;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int t = t0; t < t1; t++) {
+        const uint32_t c = tile_count[t];
+        ranges[t] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+        run += c;
+    }
+}
+
+// 16-bit mask of the tiles of the super-tile a rectangle covers (bit 4*y + x)
+__device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
+{
+    const int x0 = max((int)(rc.x & 0xFFFFu), s.tx0) - s.tx0, x1 = min((int)(rc.x >> 16), s.tx1) - s.tx0;
+    const int y0 = max((int)(rc.y & 0xFFFFu), s.ty0) - s.ty0, y1 = min((int)(rc.y >> 16), s.ty1) - s.ty0;
+    const uint32_t row = (1u << x1) - (1u << x0), ym = (1u << y1) - (1u << y0);
+    const uint32_t spread = (ym & 1u) | ((ym & 2u) << 3) | ((ym & 4u) << 6) | ((ym & 8u) << 9);
+    return row * spread;                       // row < 16: no carries between the nibbles
+}
+
+// Pass B: the lists.  Same walk; the rectangles that touch the 4x4 tiles are kept (in order) in LDS with the mask of
+// the tiles they cover.  A flush hands the buffered survivors out in slabs of 64 to the wavefronts; per slab and tile
+// a ballot gives the number of entries, a scan over the slabs gives every slab its place in each tile's list, and
+// the ids are appended with ballot-prefix compaction: every list comes out in depth order, without atomics or sorts.
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint2 *__restrict__ rect_sorted,
+                 const uint32_t *__restrict__ ids_sorted, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list)
+{
+    constexpr int NT = BIN_SUPER * BIN_SUPER;
+    constexpr int MAX_SLABS = BIN_CAP / WAVE;
+    static_assert(MAX_SLABS <= WAVE, "one lane per slab in the scan");
+    __shared__ uint32_t surv_mask[BIN_CAP], surv_id[BIN_CAP];
+    __shared__ uint32_t slab_at[MAX_SLABS][NT];
+    __shared__ uint32_t tile_cursor[NT];
+    __shared__ uint32_t wave_cnt[2][BIN_WAVES];
+    __shared__ int any_s;
+    const int P = (int)header[H_NVIS];            // visible Gaussians = length of the depth-ordered list
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
+
+    if (tid == 0) any_s = 0;
+    lds_barrier();
+    if (tid < NT) {
+        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + (tid >> 2);
+        uint2 rg = make_uint2(0u, 0u);
+        if (tx < st.tx1 && ty < st.ty1) rg = ranges[ty * gx + tx];
+        tile_cursor[tid] = rg.x;
+        if (rg.y != rg.x) any_s = 1;
+    }
+    lds_barrier();
+    if (!any_s) return;                           // no Gaussian touches these 16 tiles
+
+    int nbuf = 0;
+    auto flush = [&]() {
+        lds_barrier();
+        const int nslab = (nbuf + WAVE - 1) / WAVE;
+        // entries per (slab, tile)
+        for (int sl = wave; sl < nslab; sl += BIN_WAVES) {
+            const uint32_t m = sl * WAVE + lane < nbuf ? surv_mask[sl * WAVE + lane] : 0u;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint32_t c = (uint32_t)__builtin_popcountll(__ballot((m >> t) & 1u));
+                mine = lane == t ? c : mine;
+            }
+            if (lane < NT) slab_at[sl][lane] = mine;
+        }
+        lds_barrier();
+        // wavefront t: exclusive scan over the slabs of tile t, starting at the tile's cursor
+        if (wave < NT) {
+            const uint32_t c = lane < nslab ? slab_at[lane][wave] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t cur = tile_cursor[wave];
+            if (lane < nslab) slab_at[lane][wave] = cur + incl - c;
+            if (lane == WAVE - 1) tile_cursor[wave] = cur + incl;
+        }
+        lds_barrier();
+        for (int sl = wave; sl < nslab; sl += BIN_WAVES) {
+            const bool ok = sl * WAVE + lane < nbuf;
+            const uint32_t m = ok ? surv_mask[sl * WAVE + lane] : 0u;
+            const uint32_t id = ok ? surv_id[sl * WAVE + lane] : 0u;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const unsigned long long bal = __ballot((m >> t) & 1u);
+                if ((m >> t) & 1u) point_list[slab_at[sl][t] + (uint32_t)prefix_in_mask(bal)] = id;
+            }
+        }
+        lds_barrier();
+        nbuf = 0;
+    };
+
+    // wavefront w scans the contiguous slice [base + w*512, base + (w+1)*512) of every trip: survivors stay in depth
+    // order when the wavefronts append one after the other.  The next trip's loads are issued before this one is used.
+    uint2 rc[BIN_UNROLL];
+    uint32_t id[BIN_UNROLL];
+    {
+        const int k0 = wave * (WAVE * BIN_UNROLL) + lane;
+#pragma unroll
+        for (int j = 0; j < BIN_UNROLL; j++) {
+            const int k = k0 + j * WAVE;
+            rc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
+            id[j] = k < P ? ids_sorted[k] : 0u;
+        }
+    }
+    auto append = [&](uint32_t at, const unsigned long long (&hits)[BIN_UNROLL]) {
+#pragma unroll
+        for (int j = 0; j < BIN_UNROLL; j++) {
+            if ((hits[j] >> lane) & 1ull) {
+                const uint32_t pos = at + (uint32_t)prefix_in_mask(hits[j]);
+                surv_mask[pos] = cover_mask(rc[j], st);
+                surv_id[pos] = id[j];
+            }
+            at += (uint32_t)__builtin_popcountll(hits[j]);
+        }
+    };
+    int parity = 0;
+    for (int base = 0; base < P; base += BIN_CHUNK, parity ^= 1) {
+        uint2 nrc[BIN_UNROLL];
+        uint32_t nid[BIN_UNROLL];
+        {
+            const int k0 = base + BIN_CHUNK + wave * (WAVE * BIN_UNROLL) + lane;
+#pragma unroll
+            for (int j = 0; j < BIN_UNROLL; j++) {
+                const int k = k0 + j * WAVE;
+                nrc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
+                nid[j] = k < P ? ids_sorted[k] : 0u;
+            }
+        }
+        unsigned long long hits[BIN_UNROLL];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < BIN_UNROLL; j++) {
+            hits[j] = __ballot(rect_hits(rc[j], st));
+            mine += (uint32_t)__builtin_popcountll(hits[j]);
+        }
+        if (lane == 0) wave_cnt[parity][wave] = mine;
+        lds_barrier();
+        uint32_t off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BIN_WAVES; w++) {
+            const uint32_t c = wave_cnt[parity][w];
+            off += w < wave ? c : 0u;
+            total += c;
+        }
+        if (total != 0u) {
+            if (nbuf + (int)total > BIN_CAP) flush();
+            if ((int)total <= BIN_CAP) {
+                append((uint32_t)nbuf + off, hits);
+                nbuf += (int)total;
+            } else {
+                // more hits in one trip than the buffer holds (thousands of huge splats in a row): one wavefront's slice
+                // (<= 512 hits) at a time
+                for (int w = 0; w < BIN_WAVES; w++) {
+                    const int cw = (int)wave_cnt[parity][w];
+                    if (cw == 0) continue;
+                    if (nbuf + cw > BIN_CAP) flush();
+                    if (wave == w) append((uint32_t)nbuf, hits);
+                    nbuf += cw;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BIN_UNROLL; j++) { rc[j] = nrc[j]; id[j] = nid[j]; }
+    }
+    flush();
+}
+
+}  // namespace
+
+static int bucket_count_for(int32_t P)
+{
+    int B = 256;
+    while (B < BKT_MAX && B * 32 < P) B <<= 1;          // ~32 Gaussians per bucket
+    return B;
+}
+
+// geometry stage: bucket counts and the scatter of the (key, index) pairs
+int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream)
+{
+    const int B = bucket_count_for(prm.P);
+    const int nblk = (prm.P + 255) / 256;               // = preprocess grid: one statistics row per block
+    StageTimer timer(ST_SORT, stream);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(256), 0, stream, prm.P, B, g.depth_key, g.blk_stats, nblk, g.header,
+                       g.bucket_cnt, g.sort_slot);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(min(64, (prm.P + 1023) / 1024)), dim3(1024), 0, stream, prm.P, B, g.depth_key,
+                       g.header, g.bucket_cnt, g.bucket_base, g.sort_slot, g.sort_pairs);
+    SOAR_LAUNCH_OK("depth_buckets", stream, prm.debug);
+    return 0;
+}
+
+int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, hipStream_t stream)
+{
+    const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
+    const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, nsy = (gy + BIN_SUPER - 1) / BIN_SUPER;
+    {
+        StageTimer timer(ST_SORT, stream);
+        BucketSortArgs a;
+        a.B = bucket_count_for(prm.P);
+        a.bucket_base = g.bucket_base; a.pairs = g.sort_pairs; a.rect = g.rect; a.ids_sorted = g.ids_sorted;
+        a.rect_sorted = g.rect_sorted;
+        hipLaunchKernelGGL(bucket_sort_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+    }
+    SOAR_LAUNCH_OK("bucket_sort", stream, prm.debug);
+    {
+        StageTimer timer(ST_RANGES, stream);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, g.rect_sorted,
+                           img.tile_count);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges);
+    }
+    SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
+    {
+        StageTimer timer(ST_EMIT_KEYS, stream);
+        hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, g.rect_sorted,
+                           g.ids_sorted, img.ranges, b.vals_sorted);
+    }
+    SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);
+    return launch_tile_order(prm, img, stream);
+}
+
+}  // namespace soar

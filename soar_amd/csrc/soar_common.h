@@ -57,23 +57,42 @@ static_assert(sizeof(GaussRec) == 64, "record must be 64 bytes");
 
 // ---- opaque scratch buffers -------------------------------------------------------------------
 struct GeomBuf {
-    uint32_t *header;        // [64]: [0] num_rendered
+    uint32_t *header;        // [64]: see H_* below
     GaussRec *rec;           // [P]
     float *cov3D;            // [P,6]
     uint32_t *tiles_touched; // [P]
     uint32_t *point_offsets; // [P] inclusive scan
     uint8_t *clamped;        // [P,3] (SH path)
     float *front;            // [P] 1 = faces the camera (what render_front keeps), 0 = back-facing; fused occlusion pass
+    uint2 *rect;             // [P] tile rectangle {x0 | x1 << 16, y0 | y1 << 16}; x1 <= x0: not visible
+    uint2 *rect_sorted;      // [P] the rectangles in depth order (rast_tilebin.hip)
+    uint32_t *depth_key;     // [P] bits of the view depth (> 0), 0xFFFFFFFF when not visible
+    uint32_t *sort_slot;     // [P] slot of each visible Gaussian inside its depth bucket
+    uint64_t *sort_pairs;    // [P] (depth key << 32 | index), bucket after bucket
+    uint32_t *ids_sorted;    // [P] Gaussian ids in depth order (first header[H_NVIS] entries)
+    uint32_t *bucket_cnt;    // [8192] depth buckets
+    uint32_t *bucket_base;   // [8192 + 1]
+    uint32_t *blk_stats;     // [ceil(P/256)][BLK_STATS] per-block maxima written by preprocess
     void *scan_temp;
     size_t scan_temp_bytes;
     size_t total_bytes;
 };
+// words of GeomBuf::header
+constexpr int H_NVIS = 1;       // number of visible Gaussians
+constexpr int H_KMAX = 2;       // max depth_key over the visible Gaussians, then (same order as a blk_stats row):
+constexpr int H_NOT_KMIN = 3;   //   max of ~depth_key  (kmin = ~value)
+constexpr int H_X1 = 4;         //   max x1, max y1, max ~x0, max ~y0 of the tile rectangles = their bounding box
+constexpr int H_Y1 = 5;
+constexpr int H_NOT_X0 = 6;
+constexpr int H_NOT_Y0 = 7;
+constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
     uint2 *ranges;           // [T]
     float *final_T;          // [pix]
     uint32_t *n_contrib;     // [pix]
     float *final_D;          // [pix]
     uint32_t *tile_order;    // [T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding)
+    uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
     size_t total_bytes;
 };
 struct BinBuf {
@@ -107,6 +126,14 @@ __device__ __forceinline__ float exp_nonpositive(float x)
     lo = __builtin_fmaf(x, L2E_LO, lo);
     const float e = __builtin_amdgcn_exp2f(t);
     return __builtin_fmaf(e, lo * 0.693147180559945309f, e);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
+// (s_waitcnt vmcnt(0)) -- which throws away software prefetch across the barrier and charges a full store round trip
+// per barrier.  Use where no global memory is exchanged between the wavefronts of the workgroup.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Wavefronts of long tile lists are the critical path of a blend launch: give them issue priority over the thousands
@@ -184,7 +211,9 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
                       GeomBuf &g, int32_t *radii, hipStream_t stream);
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
 int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream);
-int launch_binning(const SoarRastParams &prm, const int32_t *radii, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
+int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
+int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, hipStream_t stream);
+int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream);
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
                           float *out_color, float *out_normal, float *out_depth, float *out_opac,
