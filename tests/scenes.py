@@ -97,6 +97,46 @@ def blob_scene(P=800, W=97, H=61, seed=1, config=(0, 0, 0, 0), use_sh=False, sh_
                  np.array(cfg, np.float32), sh_degree=sh_degree, seed=seed)
 
 
+def depth_plane_scene(P=6000, W=128, H=96, seed=21, n_spread=120) -> Scene:
+    """Thousands of small Gaussians on ONE plane perpendicular to the view axis (view depths equal up to rounding, many
+    exactly equal) plus a few spread over a wide depth range: the depth sort sees one bucket with thousands of (nearly)
+    equal keys, ties must come out in index order."""
+    rng = np.random.default_rng(seed)
+    cam = syn.make_camera(W, H, distance=3.0, elevation=0.0, azimuth=0.0, target=(0.0, 0.0, 0.0))
+    V = cam.world_view_transform.numpy()                       # row-vector convention: p_view = [p, 1] @ V
+    Rinv = np.linalg.inv(V[:3, :3].astype(np.float64))
+    t = V[3, :3].astype(np.float64)
+    pv = np.zeros((P, 3))
+    pv[:, 0] = rng.uniform(-0.9, 0.9, P)
+    pv[:, 1] = rng.uniform(-0.6, 0.6, P)
+    pv[:, 2] = 3.0
+    pv[:n_spread, 2] = rng.uniform(1.0, 6.0, n_spread)
+    means = ((pv - t) @ Rinv).astype(np.float32)
+    scales = np.full((P, 3), 0.02, np.float32) * rng.uniform(0.5, 1.5, (P, 1)).astype(np.float32)
+    q = np.tile(np.array([[1.0, 0.0, 0.0, 0.0]], np.float32), (P, 1))
+    opac = rng.uniform(0.05, 0.6, (P, 1)).astype(np.float32)
+    colors = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    return Scene(f"depth_plane_P{P}", H, W, means, opac, scales, q, colors, None, None, cam,
+                 np.array([0.1, 0.2, 0.3], np.float32), np.array([0, 0, H, W], np.float32), np.array([0, 0, 0, 0], np.float32),
+                 seed=seed)
+
+
+def big_splats_scene(P=5000, W=160, H=128, seed=22) -> Scene:
+    """Thousands of Gaussians that each cover a large part of the image: every 4x4-tile block of the binning sees more
+    hits in one pass over the list than its survivor buffer holds, and every tile list has thousands of entries."""
+    rng = np.random.default_rng(seed)
+    cam = syn.make_camera(W, H, distance=3.0, elevation=0.1, azimuth=0.2, target=(0.0, 0.0, 0.0))
+    means = rng.normal(0, 0.25, (P, 3)).astype(np.float32)
+    scales = np.exp(rng.normal(-1.6, 0.3, (P, 3))).astype(np.float32)
+    q = rng.normal(0, 1, (P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opac = rng.uniform(0.01, 0.08, (P, 1)).astype(np.float32)
+    colors = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    return Scene(f"big_splats_P{P}", H, W, means, opac, scales, q, colors, None, None, cam,
+                 np.array([0.3, 0.3, 0.3], np.float32), np.array([0, 0, H, W], np.float32), np.array([0, 0, 0, 0], np.float32),
+                 seed=seed)
+
+
 def upstream_grads(scene: Scene, seed_offset=0):
     """Dense pseudo-random image gradients (deterministic)."""
     rng = np.random.default_rng(scene.seed + 991 + seed_offset)
