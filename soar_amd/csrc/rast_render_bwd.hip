@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
         sq0[BCHUNK] = z; sq1[BCHUNK] = z; sq2[BCHUNK] = z; sq3[BCHUNK] = z;
         sid[BCHUNK] = 0u;
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t deepest = max(max(wave_deep[0], wave_deep[1]), max(wave_deep[2], wave_deep[3]));   // block-uniform
     if (deepest == 0u) return;
 
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         }
-        __syncthreads();
+        lds_barrier();          // LDS only: next chunk's gathers and this chunk's atomics stay in flight
 
         if (cbase < (int)deepest_wave) {
             for (int sub = ((n - 1) / WAVE) * WAVE; sub >= 0; sub -= WAVE) {
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                 }
             }
         }
-        __syncthreads();                              // LDS arrays are overwritten by the next chunk
+        lds_barrier();                                // LDS arrays are overwritten by the next chunk
     }
 }
 

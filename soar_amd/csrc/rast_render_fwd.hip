@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
+    __shared__ int wave_alive[2][4];
     unsigned long long t_start = 0, n_iter = 0;
     if (LOG) t_start = wall_clock64();
 
@@ -119,7 +120,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
         r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
     }
-    for (uint32_t base = range.x; base < range.y; base += CHUNK) {
+    int parity = 0;
+    for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
         const int n = min((uint32_t)CHUNK, range.y - base);
         if (tid < n) {
             sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3;
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
             if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
         }
-        __syncthreads();
+        lds_barrier();           // LDS only: the gathers of the next chunk stay in flight while this one is blended
 
         if (!wave_done) {
             for (int sub = 0; sub < n; sub += WAVE) {
@@ -183,15 +185,15 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     const float T_mine = slot == 0 ? T : slot == 1 ? T1 : slot == 2 ? T2 : T3;
                     const bool stopped = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
                     const float w = stopped ? 0.f : a_eff * T_mine;
-                    const bool blend = w != 0.f;
+                    const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
                     const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
-                    D = blend ? __builtin_fmaf(depth, w, D) : D;
-                    C0 = blend ? __builtin_fmaf(q2.y, w, C0) : C0;
-                    C1 = blend ? __builtin_fmaf(q2.z, w, C1) : C1;
-                    C2 = blend ? __builtin_fmaf(q2.w, w, C2) : C2;
-                    N0 = blend ? __builtin_fmaf(q3.x, w, N0) : N0;
-                    N1 = blend ? __builtin_fmaf(q3.y, w, N1) : N1;
-                    N2 = blend ? __builtin_fmaf(q3.z, w, N2) : N2;
+                    D = __builtin_fmaf(depth, w, D);
+                    C0 = __builtin_fmaf(q2.y, w, C0);
+                    C1 = __builtin_fmaf(q2.z, w, C1);
+                    C2 = __builtin_fmaf(q2.w, w, C2);
+                    N0 = __builtin_fmaf(q3.x, w, N0);
+                    N1 = __builtin_fmaf(q3.y, w, N1);
+                    N2 = __builtin_fmaf(q3.z, w, N2);
                     last_contributor = blend ? contrib0 + (uint32_t)(j - sub) + 1u : last_contributor;
                     T = s3 ? T3 : t3;
                     done = done || s3;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                         const float U_mine = slot == 0 ? T_o : slot == 1 ? U1 : slot == 2 ? U2 : U3;
                         const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
                         const float w_o = stopped_o ? 0.f : a_o * U_mine;
-                        Co = (w_o != 0.f) ? __builtin_fmaf(e4.x, w_o, Co) : Co;
+                        Co = __builtin_fmaf(e4.x, w_o, Co);
                         T_o = z3 ? U3 : u3;
                         done_o = done_o || z3;
                     }
@@ -225,8 +227,11 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                 if (wave_done) break;
             }
         }
-        // also the barrier that protects the LDS arrays before the next chunk overwrites them
-        if (!__syncthreads_or(wave_done ? 0 : 1)) break;
+        // "is any wavefront of the workgroup still blending?" -- also the barrier that protects the LDS arrays before
+        // the next chunk overwrites them
+        if (lane == 0) wave_alive[parity][wave] = wave_done ? 0 : 1;
+        lds_barrier();
+        if ((wave_alive[parity][0] | wave_alive[parity][1] | wave_alive[parity][2] | wave_alive[parity][3]) == 0) break;
     }
 
     // fold the four slots of every pixel
