@@ -102,15 +102,48 @@ def synthetic_loss(out, targets):
     return frame_loss(out.render, out.normal, out.depth, out.mask, targets)
 
 
-def run_step(seq, targets, flat, frames, bg):
+def step_body(seq, targets, flat, frames, bg, capacity=None, joint_mats=None):
+    """zero grads -> KNN blend weights -> LBS warp + rasterize (main + fused occlusion) of every frame -> loss -> backward"""
     flat.zero()
     seq.refresh_blend_weights()
-    outs = seq.render_frames(frames, bg, with_occ=True)        # one host sync for the whole batch of frames
+    outs = seq.render_frames(frames, bg, with_occ=True, capacity=capacity, joint_mats=joint_mats)
     loss = synthetic_loss(outs[0], targets)
     for out in outs[1:]:
         loss = loss + synthetic_loss(out, targets)
     loss.backward()
+
+
+def run_step(seq, targets, flat, frames, bg, capacity=None):
+    step_body(seq, targets, flat, frames, bg, capacity)        # synchronous form: one host sync for the batch of frames
     return flat.all_reduce()
+
+
+class GraphStep:
+    """One optimizer step captured as a HIP graph (torch.cuda.CUDAGraph): possible because the sync-free form of the
+    rasterizer has no host read-back and no size that depends on the frame.  The frame's joint transforms are the only
+    per-step input: they are copied into a static buffer before every replay.  The gradient all-reduce stays outside."""
+
+    def __init__(self, seq, targets, flat, bg, n_frames, capacity):
+        self.seq, self.flat = seq, flat
+        self.mats = torch.empty((n_frames, 55, 4, 4), dtype=torch.float32, device=seq.device)
+        frames0 = list(range(n_frames))
+        self.mats.copy_(seq.cano2live[frames0])
+        side = torch.cuda.Stream(device=seq.device)
+        side.wait_stream(torch.cuda.current_stream(seq.device))
+        with torch.cuda.stream(side):                          # warm-up on a side stream, as graph capture requires
+            for _ in range(2):
+                step_body(seq, targets, flat, frames0, bg, capacity, self.mats)
+        torch.cuda.current_stream(seq.device).wait_stream(side)
+        torch.cuda.synchronize(seq.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            step_body(seq, targets, flat, frames0, bg, capacity, self.mats)
+
+    def __call__(self, frames):
+        idx = torch.as_tensor([f % self.seq.num_frames for f in frames], device=self.seq.device)
+        torch.index_select(self.seq.cano2live, 0, idx, out=self.mats)
+        self.graph.replay()
+        return self.flat.all_reduce()
 
 
 def cpu_baseline(workload, parts, n_frames=8, seed=0):
@@ -172,6 +205,9 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--mode", default="graph", choices=["graph", "async", "sync"],
+                    help="graph: each step replayed from a HIP graph (falls back to async if capture fails); async: "
+                         "sync-free rasterizer, eager launches; sync: the reference's blocking num_rendered read-back")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,22 +245,43 @@ def main():
     with torch.no_grad():
         seq.render_frame(frames_of(0)[0], bg, with_occ=True)
     R_occ = rasterizer.last_num_rendered
-    for s in range(args.warmup):
+    # warm-up in the synchronous form; it also measures the instances per frame that bound the binning buffers of the
+    # sync-free forms (2x the largest number seen; the device checks the bound, the host checks the flag after timing)
+    for k in rasterizer.stats:
+        rasterizer.stats[k] = 0
+    r_seen = 0
+    for s in range(max(args.warmup, 1)):
         run_step(seq, targets, flat, frames_of(s), bg)
+        r_seen = max(r_seen, rasterizer.last_num_rendered)
+    torch.cuda.synchronize()
+    stats_warm = dict(rasterizer.stats)
+    capacity = None if args.mode == "sync" else 2 * r_seen
+    mode, stepper = args.mode, None
+    if mode == "graph":
+        try:
+            stepper = GraphStep(seq, targets, flat, bg, len(frames_of(0)), capacity)
+        except Exception as e:                                   # capture not supported here: eager sync-free launches
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); falling back to --mode async", file=sys.stderr)
+            torch.cuda.synchronize()
+            mode = "async"
+    if stepper is None:
+        stepper = lambda frames: run_step(seq, targets, flat, frames, bg, capacity)
+    for s in range(2):                                           # untimed steps in the timed mode
+        stepper(frames_of(s))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    for k in rasterizer.stats:
-        rasterizer.stats[k] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        run_step(seq, targets, flat, frames_of(args.warmup + s), bg)
+        stepper(frames_of(args.warmup + s))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    stats_timed = dict(rasterizer.stats)
+    if capacity is not None:
+        rasterizer.check_binning()                               # raises if a binning buffer of the last step was too small
+    stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
     # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
     #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views
     #      of a step overlap on separate streams and share the GPU).  Not part of `value`.
@@ -287,7 +344,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
                                f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
-                               f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}",
+                               f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}", "mode": mode,
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(R_occ)},
         "roofline": roof,

@@ -83,6 +83,15 @@ int soar_rast_forward_geometry(const SoarRastParams *prm,
  * once; later calls return immediately).  One sync per batch of views instead of one per view. */
 int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_t *num_rendered_host, void *stream);
 
+/* Sync-free form of the forward pass: `num_rendered` passed to stage 2 (and to backward) may be any CAPACITY >= the
+ * actual number of (tile, Gaussian) instances -- it only sizes / carves the caller's binning buffer (ascending sort;
+ * the tile binning of rast_tilebin.hip does not use it otherwise).  The actual number is found on the device; if it
+ * exceeds the capacity nothing is binned or rendered (images = background) and this call reports it, so a caller can
+ * enqueue whole steps without the reference's blocking read-back (rasterizer_impl.cu:250) and check once afterwards.
+ * Synchronises `stream`.  *instances_host = instances found, *overflow_host = 0 or the number that did not fit. */
+int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
+                             void *stream);
+
 /* stage 2: duplicateWithKeys (:66-99) + radix sort on bits [0,32+bit) (:266-285) + identifyTileRanges
  *   (:104-124,287-295) + per-tile blend (forward.cu:390-692).
  *   out_color [3,H,W], out_normal [3,H,W], out_depth [1,H,W], out_opac [1,H,W]. */

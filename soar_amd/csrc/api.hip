@@ -292,6 +292,25 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
                                  void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
                                  float *out_depth, float *out_opac, const float *occ_values, float *out_occ, void *stream_);
 
+int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
+                             void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!instances_host || !overflow_host || P < 0) { set_error("soar_rast_binning_status: bad arguments"); return 1; }
+    *instances_host = 0;
+    *overflow_host = 0;
+    if (P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    GeomBuf g;
+    carve_geom(const_cast<void *>(geom_buffer), P, M, &g);
+    uint32_t w[2] = {0u, 0u};
+    SOAR_HIP_OK(hipMemcpyAsync(w, g.header + H_TOTAL, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SOAR_HIP_OK(hipStreamSynchronize(stream));
+    *instances_host = (int64_t)w[0];
+    *overflow_host = (int64_t)w[1];
+    return 0;
+}
+
 int soar_rast_forward_render(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
                              void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
                              float *out_depth, float *out_opac, void *stream_)
@@ -333,7 +352,7 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
     // ascending sort: per-tile lists straight from the depth-ordered Gaussians (rast_tilebin.hip); the descending sort
     // of back views keeps the 64-bit key sort (rast_binning.hip)
     if (num_rendered > 0 && !prm->sort_descending) {
-        if (launch_tile_binning(*prm, g, b, img, stream)) return 1;
+        if (launch_tile_binning(*prm, g, b, img, num_rendered, stream)) return 1;
     } else if (launch_binning(*prm, g, b, img, num_rendered, stream)) {
         return 1;
     }

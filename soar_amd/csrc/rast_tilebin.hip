@@ -301,7 +301,10 @@ bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint
 
 // One workgroup: exclusive scan of the tile counts in tile order = ranges (untouched tiles keep (0,0) like
 // identifyTileRanges, rasterizer_impl.cu:287-295).
-__global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges)
+// `capacity` = instances the caller's binning buffer holds: when the lists would not fit, every range is left empty
+// (nothing is written or rendered) and header[H_OVERFLOW] reports the number that was needed.
+__global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
+                                                         uint32_t capacity, uint32_t *__restrict__ header)
 {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
@@ -317,10 +320,13 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *
         part[tid] += up;
         __syncthreads();
     }
+    const uint32_t total = part[1023];
+    const bool fits = total <= capacity;
+    if (tid == 0) { header[H_TOTAL] = total; header[H_OVERFLOW] = fits ? 0u : total; }
     uint32_t run = part[tid] - s;
     for (int t = t0; t < t1; t++) {
         const uint32_t c = tile_count[t];
-        ranges[t] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+        ranges[t] = (c && fits) ? make_uint2(run, run + c) : make_uint2(0u, 0u);
         run += c;
     }
 }
@@ -510,7 +516,7 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
     return 0;
 }
 
-int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, hipStream_t stream)
+int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t capacity, hipStream_t stream)
 {
     const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, nsy = (gy + BIN_SUPER - 1) / BIN_SUPER;
@@ -527,7 +533,8 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         StageTimer timer(ST_RANGES, stream);
         hipLaunchKernelGGL(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, g.rect_sorted,
                            img.tile_count);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges,
+                           (uint32_t)(capacity > 0xFFFFFFFFll ? 0xFFFFFFFFll : capacity), g.header);
     }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
     {

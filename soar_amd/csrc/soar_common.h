@@ -85,6 +85,8 @@ constexpr int H_X1 = 4;         //   max x1, max y1, max ~x0, max ~y0 of the til
 constexpr int H_Y1 = 5;
 constexpr int H_NOT_X0 = 6;
 constexpr int H_NOT_Y0 = 7;
+constexpr int H_TOTAL = 8;      // instances (sum of the tile counts) found by the tile binning
+constexpr int H_OVERFLOW = 9;   // 0, or H_TOTAL when it exceeded the capacity of the caller's binning buffer
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
     uint2 *ranges;           // [T]
@@ -212,7 +214,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
 int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream);
 int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
-int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, hipStream_t stream);
+int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t capacity, hipStream_t stream);
 int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
                    hipStream_t stream);
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,

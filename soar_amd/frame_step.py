@@ -109,16 +109,20 @@ class AvatarSequence:
         return FrameOutputs(render, normal, depth, mask, occ_img, radii, means2D)
 
     # ---- several frames of one optimizer step at once ----
-    def render_frames(self, frames: List[int], bg: torch.Tensor, with_occ: bool = True) -> List[FrameOutputs]:
+    def render_frames(self, frames: List[int], bg: torch.Tensor, with_occ: bool = True, capacity: Optional[int] = None,
+                      joint_mats: Optional[torch.Tensor] = None) -> List[FrameOutputs]:
         """Same results as ``[render_frame(f, bg) for f in frames]`` with ONE host synchronisation for the whole batch:
-        all LBS warps and geometry stages are enqueued first (``rasterize_views``)."""
+        all LBS warps and geometry stages are enqueued first (``rasterize_views``).  ``capacity``: sync-free form (see
+        ``rasterize_views``).  ``joint_mats`` [len(frames),55,4,4]: use these transforms instead of indexing the sequence
+        (a static input buffer when the step is replayed from a HIP graph)."""
         if self.blend_weights is None:
             self.refresh_blend_weights()
         ones = torch.ones_like(self.opacity)
         main_rs = self.settings(bg, render_front=False, sort_descending=False)
         warped, taps, settings, inputs = [], [], [], []
-        for f in frames:
-            xyz_p, rot_p = lbs.lbs_warp(self.xyz, self.rot, self.blend_weights, self.cano2live[f % self.num_frames])
+        for i, f in enumerate(frames):
+            mats = joint_mats[i] if joint_mats is not None else self.cano2live[f % self.num_frames]
+            xyz_p, rot_p = lbs.lbs_warp(self.xyz, self.rot, self.blend_weights, mats)
             tap = torch.zeros_like(xyz_p, requires_grad=True)
             warped.append((xyz_p, rot_p))
             taps.append(tap)
@@ -127,5 +131,5 @@ class AvatarSequence:
                                rotations=rot_p))
             if with_occ:
                 inputs[-1]["occ_values"] = self.occ          # occlusion pass fused into the main blend
-        views = rasterize_views(settings, inputs)
+        views = rasterize_views(settings, inputs, capacity=capacity)
         return [FrameOutputs(m[0], m[1], m[2], m[3], m[5] if with_occ else None, m[4], t) for m, t in zip(views, taps)]

@@ -227,7 +227,7 @@ class _NativeOps:
         return st
 
     @staticmethod
-    def _render_stage(st, occ_values=None, defer=None):
+    def _render_stage(st, occ_values=None, defer=None, capacity=None):
         """Read num_rendered (synchronises the stream unless an earlier view of the batch already did), size the binning
         buffer, enqueue key emission + sort + ranges + blend.  With `occ_values` [P] the blend also produces
         st["occ"] [3,H,W]: the colour image of a render_front=True pass with colours = occ_values (fused occlusion pass)."""
@@ -253,13 +253,18 @@ class _NativeOps:
                 check(L.soar_rast_forward_render(prm, None, None, None, None, 0, out[0].data_ptr(), out[1].data_ptr(),
                                                  out[2].data_ptr(), out[3].data_ptr(), stream), "rasterize_gaussians")
                 return 0
-            R = C.c_int64(0)
-            check(L.soar_rast_num_rendered(st["geom"].data_ptr(), P, st["M"], C.byref(R), stream), "num_rendered")
-            num_rendered = int(R.value)
             global last_num_rendered
-            last_num_rendered = num_rendered
-            stats["forward_calls"] += 1
-            stats["num_rendered"] += num_rendered
+            if capacity is not None:
+                # sync-free: the binning buffer is sized by the caller's bound, the device checks that it was enough
+                num_rendered = int(capacity)
+                stats["forward_calls"] += 1
+            else:
+                R = C.c_int64(0)
+                check(L.soar_rast_num_rendered(st["geom"].data_ptr(), P, st["M"], C.byref(R), stream), "num_rendered")
+                num_rendered = int(R.value)
+                last_num_rendered = num_rendered
+                stats["forward_calls"] += 1
+                stats["num_rendered"] += num_rendered
             nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             st["binning"] = _scratch(nbytes.value, device)
@@ -431,7 +436,7 @@ class _RasterizeViews(torch.autograd.Function):
     N_OUT = 6     # color, normal, depth, opac, radii, occ (empty unless occ_values was given)
 
     @staticmethod
-    def forward(ctx, settings_list, *flat):
+    def forward(ctx, settings_list, capacity, *flat):
         n = _RasterizeViews.N_IN
         views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
         states = []
@@ -443,8 +448,12 @@ class _RasterizeViews(torch.autograd.Function):
                 rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config,
                 side=_view_stream(means3D.device, i) if use_sides else None))
         calls = [] if use_sides else None
-        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls)
+        if capacity is not None and any(rs.sort_descending for rs in settings_list):
+            raise ValueError("the sync-free capacity mode needs sort_descending = False on every view")
+        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls, capacity=capacity)
                             for st, v in zip(states, views)]
+        global _last_batch
+        _last_batch = [(st["geom"], st["P"], st["M"], st["device"]) for st in states] if capacity is not None else []
         if use_sides:
             _run_deferred(states[0]["device"], calls)
             _join(states[0]["device"], {st["side"] for st in states if st["side"] is not None})
@@ -466,7 +475,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        grads = [None]
+        grads = [None, None]
         used = set()
         calls = [] if ctx.use_sides else None
         for i, rs in enumerate(ctx.settings_list):
@@ -499,7 +508,26 @@ class _RasterizeViews(torch.autograd.Function):
         return tuple(grads)
 
 
-def rasterize_views(settings_list, inputs):
+_last_batch = []
+
+
+def check_binning():
+    """After sync-free (`capacity=`) calls: synchronise and return [(instances, overflow)] of the views of the last batch;
+    raises if a binning buffer was too small (that view rendered nothing: its images are the background)."""
+    L = hip_lib.lib()
+    out = []
+    for geom, P, M, device in _last_batch:
+        n, o = C.c_int64(0), C.c_int64(0)
+        with torch.cuda.device(device):
+            check(L.soar_rast_binning_status(geom.data_ptr(), P, M, C.byref(n), C.byref(o), _stream(device)), "binning_status")
+        out.append((int(n.value), int(o.value)))
+    bad = [o for _, o in out if o]
+    if bad:
+        raise RuntimeError(f"binning capacity exceeded: {max(bad)} (tile, Gaussian) instances needed; raise `capacity`")
+    return out
+
+
+def rasterize_views(settings_list, inputs, capacity=None):
     """Batched form of ``GaussianRasterizer(rs)(**kw)`` for several views at once.
 
     settings_list: list of GaussianRasterizationSettings; inputs: list of dicts with the keyword arguments of
@@ -510,7 +538,12 @@ def rasterize_views(settings_list, inputs):
     A view may carry ``occ_values`` ([P] or [P,1], no gradient): its tuple then gets a sixth element, the [3,H,W] image
     that a second pass with ``render_front=True`` and ``colors_precomp=occ_values.repeat(1,3)`` would return
     (TS/renderer/diff_gaussian_rasterizer.py:281-291), blended in the same kernel launch as the main view.  The main
-    view must then have ``render_front=False`` and ``sort_descending=False``."""
+    view must then have ``render_front=False`` and ``sort_descending=False``.
+
+    ``capacity``: sync-free form.  The reference blocks the host in every forward call to read ``num_rendered`` and size
+    the binning buffer (rasterizer_impl.cu:250); with ``capacity`` = an upper bound of the (tile, Gaussian) instances of a
+    view the buffers are sized by it, nothing is read back and whole optimizer steps can be enqueued (or captured in a
+    HIP graph).  The device checks the bound; call ``check_binning()`` afterwards (e.g. once per step)."""
     empty = torch.Tensor([])
     flat = []
     for kw in inputs:
@@ -523,7 +556,7 @@ def rasterize_views(settings_list, inputs):
         o = lambda t: empty if t is None else t
         flat += [kw["means3D"], kw["means2D"], o(shs), o(cols), kw["opacities"], o(scales), o(rot), o(cov),
                  o(kw.get("occ_values"))]
-    outs = _RasterizeViews.apply(list(settings_list), *flat)
+    outs = _RasterizeViews.apply(list(settings_list), capacity, *flat)
     res = []
     for i, kw in enumerate(inputs):
         v = tuple(outs[i * 6:(i + 1) * 6])
