@@ -165,6 +165,15 @@ int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_
                          const float *vert_weights, int32_t J, int32_t K,
                          float *weights_out, int32_t *knn_idx_out, void *stream);
 
+/* The same in two steps for a STATIC vertex set (SOAR's canonical SMPL-X vertices and lbs_weights never change during
+ * training, TS/utils/smpl.py:508-511): build the vertex grid once, query it every optimizer step.
+ *   grid_buffer: soar_lbs_knn_grid_bytes(V) bytes of 256-byte aligned device memory, owned by the caller. */
+int soar_lbs_knn_grid_bytes(int32_t V, size_t *bytes);
+int soar_lbs_knn_build_grid(const float *verts, int32_t V, const float *vert_weights, int32_t J, void *grid_buffer,
+                            void *stream);
+int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J,
+                       const float *xyz, int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream);
+
 /* soar_lbs_warp_forward: blend + apply, i.e. SMPL_Guidance.__call__ line TS/utils/smpl.py:613
  *   (pt_mats = einsum("bnj,bjxy->bnxy", w, cano2live)) fused with DiffGaussian.forward's warp
  *   (TS/renderer/diff_gaussian_rasterizer.py:103-114 / :138-149):

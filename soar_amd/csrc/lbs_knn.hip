@@ -543,30 +543,76 @@ KnnWorkspace g_ws;
 
 using namespace soar;
 
-extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights,
-                                    int32_t J, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
-{
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (P < 0 || V <= 0 || J <= 0 || K <= 0) { set_error("soar_lbs_knn_weights: bad sizes P=%d V=%d J=%d K=%d", P, V, J, K); return 1; }
-    if (K > KNN_MAXK || K > V) { set_error("soar_lbs_knn_weights: K=%d unsupported (max %d, V=%d)", K, KNN_MAXK, V); return 1; }
-    if (P == 0) return 0;
-    if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
+namespace {
 
-    // carve the workspace
-    const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
-    size_t sort_bytes = 0, qsort_bytes = 0;
+// the vertex grid: everything that depends on the (static) canonical vertices and their skinning rows only
+struct KnnGrid {
+    GridMeta *meta;
+    uint2 *cell_range;       // [GRID_CELLS]
+    float4 *sorted_verts;    // [V] {x, y, z, vertex id}
+    float *rows;             // [V][KNN_JMAX] skinning rows in sorted order, zero padded
+    uint32_t *k0, *k1, *v0, *v1;   // build temporaries
+    void *sort_tmp;
+    size_t sort_bytes;
+    size_t total;
+};
+
+int carve_knn_grid(void *base, int32_t V, KnnGrid *g, hipStream_t stream)
+{
+    size_t sort_bytes = 0;
     SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                           (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)V, 0u, 18u, stream));
+    char *b = static_cast<char *>(base);
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return b + o; };
+    g->meta = reinterpret_cast<GridMeta *>(carve(sizeof(GridMeta)));
+    g->cell_range = reinterpret_cast<uint2 *>(carve(sizeof(uint2) * (size_t)GRID_CELLS));
+    g->sorted_verts = reinterpret_cast<float4 *>(carve(sizeof(float4) * (size_t)V));
+    g->rows = reinterpret_cast<float *>(carve(sizeof(float) * (size_t)V * KNN_JMAX));
+    g->k0 = reinterpret_cast<uint32_t *>(carve(4 * (size_t)V));
+    g->k1 = reinterpret_cast<uint32_t *>(carve(4 * (size_t)V));
+    g->v0 = reinterpret_cast<uint32_t *>(carve(4 * (size_t)V));
+    g->v1 = reinterpret_cast<uint32_t *>(carve(4 * (size_t)V));
+    g->sort_tmp = carve(sort_bytes);
+    g->sort_bytes = sort_bytes;
+    g->total = off + ALIGN;
+    return 0;
+}
+
+int knn_build(const float *verts, int32_t V, const float *vert_weights, int32_t J, const KnnGrid &g, hipStream_t stream)
+{
+    hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(256), 0, stream, verts, V, g.meta);
+    hipLaunchKernelGGL(grid_cells_kernel, dim3((V + 255) / 256), dim3(256), 0, stream, verts, V, g.meta, g.k0, g.v0);
+    size_t sort_bytes = g.sort_bytes;
+    SOAR_HIP_OK(rocprim::radix_sort_pairs(g.sort_tmp, sort_bytes, g.k0, g.k1, g.v0, g.v1, (size_t)V, 0u, 18u, stream));
+    SOAR_HIP_OK(hipMemsetAsync(g.cell_range, 0, sizeof(uint2) * (size_t)GRID_CELLS, stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3((V + 255) / 256), dim3(256), 0, stream, verts, V, g.k1, g.v1, g.cell_range,
+                       g.sorted_verts);
+    if (J <= KNN_JMAX)
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((V * KNN_JMAX + 255) / 256), dim3(256), 0, stream, vert_weights, V, J,
+                           g.sorted_verts, g.rows);
+    SOAR_LAUNCH_OK("lbs_knn_build_grid", stream, 0);
+    return 0;
+}
+
+int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P, int32_t K,
+              float *weights_out, int32_t *knn_idx_out, hipStream_t stream)
+{
+    const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
+    if (!fast) {
+        hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P, V,
+                           g.meta, g.cell_range, g.sorted_verts, vert_weights, J, K, weights_out, knn_idx_out);
+        SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
+        return 0;
+    }
+    // query-side workspace (keys / ids of the cell sort): persistent, grown on demand
+    size_t qsort_bytes = 0;
     SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, qsort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                           (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, 0u, 18u, stream));
-    if (qsort_bytes > sort_bytes) sort_bytes = qsort_bytes;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return o; };
-    const size_t o_meta = carve(sizeof(GridMeta)), o_k0 = carve(4 * (size_t)V), o_k1 = carve(4 * (size_t)V),
-                 o_v0 = carve(4 * (size_t)V), o_v1 = carve(4 * (size_t)V), o_rng = carve(sizeof(uint2) * (size_t)GRID_CELLS),
-                 o_sv = carve(sizeof(float4) * (size_t)V), o_tmp = carve(sort_bytes),
-                 o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P), o_qv0 = carve(4 * (size_t)P),
-                 o_qv1 = carve(4 * (size_t)P), o_rows = carve(sizeof(float) * (size_t)V * KNN_JMAX);
+    const size_t o_tmp = carve(qsort_bytes), o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P),
+                 o_qv0 = carve(4 * (size_t)P), o_qv1 = carve(4 * (size_t)P);
     int dev = 0;
     SOAR_HIP_OK(hipGetDevice(&dev));
     if (g_ws.bytes < off || g_ws.device != dev) {
@@ -581,54 +627,105 @@ extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *ve
         g_ws.device = dev;
     }
     char *b = static_cast<char *>(g_ws.base);
-    GridMeta *meta = reinterpret_cast<GridMeta *>(b + o_meta);
-    uint32_t *k0 = reinterpret_cast<uint32_t *>(b + o_k0), *k1 = reinterpret_cast<uint32_t *>(b + o_k1);
-    uint32_t *v0 = reinterpret_cast<uint32_t *>(b + o_v0), *v1 = reinterpret_cast<uint32_t *>(b + o_v1);
-    uint2 *rng = reinterpret_cast<uint2 *>(b + o_rng);
-    float4 *sv = reinterpret_cast<float4 *>(b + o_sv);
-
-    StageTimer timer(ST_LBS_KNN, stream);
-    hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(256), 0, stream, verts, V, meta);
-    hipLaunchKernelGGL(grid_cells_kernel, dim3((V + 255) / 256), dim3(256), 0, stream, verts, V, meta, k0, v0);
-    SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, sort_bytes, k0, k1, v0, v1, (size_t)V, 0u, 18u, stream));
-    SOAR_HIP_OK(hipMemsetAsync(rng, 0, sizeof(uint2) * (size_t)GRID_CELLS, stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3((V + 255) / 256), dim3(256), 0, stream, verts, V, k1, v1, rng, sv);
-    if (fast) {
-        uint32_t *qk0 = reinterpret_cast<uint32_t *>(b + o_qk0), *qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
-        uint32_t *qv0 = reinterpret_cast<uint32_t *>(b + o_qv0), *qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
-        hipLaunchKernelGGL(query_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, meta, qk0, qv0);
-        SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, sort_bytes, qk0, qk1, qv0, qv1, (size_t)P, 0u, 18u, stream));
-        float *rows = reinterpret_cast<float *>(b + o_rows);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3((V * KNN_JMAX + 255) / 256), dim3(256), 0, stream, vert_weights, V, J, sv, rows);
-        const dim3 grid((P + WAVE - 1) / WAVE, KNN_SLOTS);
-        const float *rows4 = rows;
-        const char *log_path = getenv("SOAR_KNN_LOG");            // diagnostic: per-wave timeline of one launch
-        if (log_path && !knn_idx_out) {
-            unsigned long long *log_dev = nullptr;
-            const size_t nbytes = sizeof(unsigned long long) * 8 * (size_t)grid.x * KNN_SLOTS * KNN_WAVES;
-            SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
-            SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
-            hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1,
-                               rows4, J, weights_out, knn_idx_out, log_dev);
-            SOAR_HIP_OK(hipStreamSynchronize(stream));
-            unsigned long long *host = (unsigned long long *)malloc(nbytes);
-            SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
-            FILE *f = fopen(log_path, "wb");
-            if (f) { fwrite(host, 1, nbytes, f); fclose(f); }
-            free(host);
-            (void)hipFree(log_dev);
-            return 0;
-        }
-        if (knn_idx_out)
-            hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1, rows4,
-                               J, weights_out, knn_idx_out);
-        else
-            hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, meta, rng, sv, qk1, qv1, rows4,
-                               J, weights_out, knn_idx_out);
-    } else {
-        hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P,
-                           V, meta, rng, sv, vert_weights, J, K, weights_out, knn_idx_out);
+    uint32_t *qk0 = reinterpret_cast<uint32_t *>(b + o_qk0), *qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
+    uint32_t *qv0 = reinterpret_cast<uint32_t *>(b + o_qv0), *qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
+    hipLaunchKernelGGL(query_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, g.meta, qk0, qv0);
+    SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, qsort_bytes, qk0, qk1, qv0, qv1, (size_t)P, 0u, 18u, stream));
+    const dim3 grid((P + WAVE - 1) / WAVE, KNN_SLOTS);
+    const char *log_path = getenv("SOAR_KNN_LOG");            // diagnostic: per-wave timeline of one launch
+    if (log_path && !knn_idx_out) {
+        unsigned long long *log_dev = nullptr;
+        const size_t nbytes = sizeof(unsigned long long) * 8 * (size_t)grid.x * KNN_SLOTS * KNN_WAVES;
+        SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
+        SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
+        hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, log_dev);
+        SOAR_HIP_OK(hipStreamSynchronize(stream));
+        unsigned long long *host = (unsigned long long *)malloc(nbytes);
+        SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
+        FILE *f = fopen(log_path, "wb");
+        if (f) { fwrite(host, 1, nbytes, f); fclose(f); }
+        free(host);
+        (void)hipFree(log_dev);
+        return 0;
     }
+    if (knn_idx_out)
+        hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out);
+    else
+        hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out);
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
     return 0;
+}
+
+int check_knn_sizes(int32_t P, int32_t V, int32_t J, int32_t K)
+{
+    if (P < 0 || V <= 0 || J <= 0 || K <= 0) { set_error("soar_lbs_knn: bad sizes P=%d V=%d J=%d K=%d", P, V, J, K); return 1; }
+    if (K > KNN_MAXK || K > V) { set_error("soar_lbs_knn: K=%d unsupported (max %d, V=%d)", K, KNN_MAXK, V); return 1; }
+    return 0;
+}
+
+KnnWorkspace g_grid_ws;      // internal grid of the one-call form
+
+}  // namespace
+
+extern "C" int soar_lbs_knn_grid_bytes(int32_t V, size_t *bytes)
+{
+    if (V <= 0 || !bytes) { set_error("soar_lbs_knn_grid_bytes: bad arguments"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(nullptr, V, &g, nullptr)) return 1;
+    *bytes = g.total;
+    return 0;
+}
+
+extern "C" int soar_lbs_knn_build_grid(const float *verts, int32_t V, const float *vert_weights, int32_t J, void *grid_buffer,
+                                       void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (V <= 0 || J <= 0 || !verts || !vert_weights || !grid_buffer) { set_error("soar_lbs_knn_build_grid: bad arguments"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(grid_buffer, V, &g, stream)) return 1;
+    return knn_build(verts, V, vert_weights, J, g, stream);
+}
+
+extern "C" int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz,
+                                  int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_knn_sizes(P, V, J, K)) return 1;
+    if (P == 0) return 0;
+    if (!grid_buffer || !xyz || !vert_weights || !weights_out) { set_error("soar_lbs_knn_query: NULL pointer"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
+    StageTimer timer(ST_LBS_KNN, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, stream);
+}
+
+extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights,
+                                    int32_t J, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_knn_sizes(P, V, J, K)) return 1;
+    if (P == 0) return 0;
+    if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(nullptr, V, &g, stream)) return 1;
+    int dev = 0;
+    SOAR_HIP_OK(hipGetDevice(&dev));
+    if (g_grid_ws.bytes < g.total || g_grid_ws.device != dev) {
+        if (g_grid_ws.base) {
+            SOAR_HIP_OK(hipDeviceSynchronize());
+            (void)hipFree(g_grid_ws.base);
+            g_grid_ws.base = nullptr;
+            g_grid_ws.bytes = 0;
+        }
+        SOAR_HIP_OK(hipMalloc(&g_grid_ws.base, g.total));
+        g_grid_ws.bytes = g.total;
+        g_grid_ws.device = dev;
+    }
+    if (carve_knn_grid(g_grid_ws.base, V, &g, stream)) return 1;
+    StageTimer timer(ST_LBS_KNN, stream);
+    if (knn_build(verts, V, vert_weights, J, g, stream)) return 1;
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, stream);
 }

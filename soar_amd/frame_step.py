@@ -71,10 +71,11 @@ class AvatarSequence:
         self.cano2live = d(torch.matmul(A_live, torch.linalg.inv(A_cano)))          # [F,55,4,4]  (smpl.py:609)
         self.num_frames = F_
         self.blend_weights: Optional[torch.Tensor] = None
+        self.knn_grid = lbs.KnnGrid(self.cano_vertices, self.lbs_weights)       # canonical vertices are static
 
     # ---- once per optimizer step ----
     def refresh_blend_weights(self):
-        self.blend_weights = lbs.knn_blend_weights(self.xyz.detach(), self.cano_vertices, self.lbs_weights)
+        self.blend_weights = self.knn_grid.query(self.xyz.detach())
         return self.blend_weights
 
     def leaves(self) -> Dict[str, torch.Tensor]:

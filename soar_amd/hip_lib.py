@@ -47,6 +47,9 @@ SIGNATURES = {
     "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_rast_export_state": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64] + [_vp] * 17 + [_vp]),
     "soar_lbs_knn_weights": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "soar_lbs_knn_grid_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_lbs_knn_build_grid": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
+    "soar_lbs_knn_query": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),

@@ -33,6 +33,39 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class KnnGrid:
+    """The part of ``knn_blend_weights`` that depends on the vertex set only (uniform grid of the vertices, their
+    skinning rows in grid order): SOAR's canonical SMPL-X vertices are constants of a training run
+    (TS/utils/smpl.py:508-511), so the grid is built once and queried every optimizer step."""
+
+    def __init__(self, verts: torch.Tensor, vert_weights: torch.Tensor):
+        _need_hip(verts, "verts")
+        L = hip_lib.lib()
+        self.verts = _f32(verts)
+        self.V = int(self.verts.shape[0])
+        self.weights = _f32(vert_weights.to(verts.device)).reshape(self.V, -1)
+        self.J = int(self.weights.shape[1])
+        import ctypes as C
+        n = C.c_size_t(0)
+        check(L.soar_lbs_knn_grid_bytes(self.V, C.byref(n)), "soar_lbs_knn_grid_bytes")
+        self.buffer = torch.empty(int(n.value), dtype=torch.uint8, device=verts.device)
+        with torch.cuda.device(verts.device):
+            check(L.soar_lbs_knn_build_grid(ptr(self.verts), self.V, ptr(self.weights), self.J, ptr(self.buffer),
+                                            _stream(verts.device)), "soar_lbs_knn_build_grid")
+
+    def query(self, xyz: torch.Tensor, K: int = 30, return_idx: bool = False):
+        _need_hip(xyz, "xyz")
+        L = hip_lib.lib()
+        x = _f32(xyz)
+        P = int(x.shape[0])
+        out = torch.empty((P, self.J), dtype=torch.float32, device=x.device)
+        idx = torch.empty((P, K), dtype=torch.int32, device=x.device) if return_idx else None
+        with torch.cuda.device(x.device):
+            check(L.soar_lbs_knn_query(ptr(self.buffer), self.V, ptr(self.weights), self.J, ptr(x), P, K, ptr(out), ptr(idx),
+                                       _stream(x.device)), "soar_lbs_knn_query")
+        return (out, idx) if return_idx else out
+
+
 def knn_blend_weights(xyz: torch.Tensor, verts: torch.Tensor, vert_weights: torch.Tensor, K: int = KNN_K,
                       return_idx: bool = False):
     """xyz [P,3], verts [V,3], vert_weights [V,J] -> weights [P,J] (detached), optionally the K-NN indices [P,K]."""

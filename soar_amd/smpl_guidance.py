@@ -46,6 +46,7 @@ class SMPLGuidance:
         Tm = torch.einsum("vj,jxy->vxy", self.ori_lbs[0], A_cano[0])
         self.cano_vertices = (torch.einsum("vxy,vy->vx", Tm[:, :3, :3], v_shaped) + Tm[:, :3, 3]).contiguous()
         self._w_cache = None
+        self._knn_grid = lbs.KnnGrid(self.cano_vertices, self.ori_lbs[0])         # canonical vertices are static
 
     # ---- parameter plumbing -------------------------------------------------------------------------------------
     def _betas(self, parms, idx):
@@ -99,6 +100,8 @@ class SMPLGuidance:
     def query_weights_smpl(self, x, smpl_verts=None, smpl_weights=None, K=30):
         verts = self.cano_vertices if smpl_verts is None else smpl_verts
         weights = self.ori_lbs if smpl_weights is None else smpl_weights
+        if smpl_verts is None and smpl_weights is None:
+            return self._knn_grid.query(x.detach())
         return lbs.knn_blend_weights(x.detach(), verts, weights.squeeze(0), K=30)       # K is ignored upstream too
 
     def __call__(self, points, smpl_parms_in=None, idx=None, zero_out=False, delta=None, **kwargs):

@@ -113,3 +113,16 @@ def test_full_size_properties_C1():
     p, q = lbs.lbs_warp(s.xyz.to(DEV), s.rot.to(DEV), w, G.to(DEV)[None].repeat(55, 1, 1))
     assert torch.allclose(p.cpu(), s.xyz @ Rg.T + G[:3, 3], atol=2e-6)
     assert torch.allclose(lo.quaternion_to_matrix(q.cpu()), Rg @ lo.quaternion_to_matrix(s.rot), atol=1e-5)
+
+
+def test_knn_grid_built_once_matches_one_call_form():
+    """lbs.KnnGrid (vertex grid built once, queried per step) == knn_blend_weights (grid rebuilt per call), for several
+    query sets against the same grid."""
+    from soar_amd import lbs
+    bm = syn.make_body_model(0)
+    grid = lbs.KnnGrid(bm.v_template.to(DEV), bm.lbs_weights.to(DEV))
+    for seed, P in ((0, 3000), (5, 777), (9, 64)):
+        x = syn.make_surfels(P, seed).xyz.to(DEV)
+        w_ref, i_ref = lbs.knn_blend_weights(x, bm.v_template.to(DEV), bm.lbs_weights.to(DEV), return_idx=True)
+        w, i = grid.query(x, return_idx=True)
+        assert torch.equal(w, w_ref) and torch.equal(i, i_ref)
