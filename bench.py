@@ -106,10 +106,12 @@ def step_body(seq, targets, flat, frames, bg, capacity=None, joint_mats=None):
     """zero grads -> KNN blend weights -> LBS warp + rasterize (main + fused occlusion) of every frame -> loss -> backward"""
     flat.zero()
     seq.refresh_blend_weights()
-    outs = seq.render_frames(frames, bg, with_occ=True, capacity=capacity, joint_mats=joint_mats)
-    loss = synthetic_loss(outs[0], targets)
+    # L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth) per frame (SURVEY 8d),
+    # evaluated behind each frame's blend on the frame's stream (soar_amd/losses.py kernel)
+    outs = seq.render_frames(frames, bg, with_occ=True, capacity=capacity, joint_mats=joint_mats, loss_targets=targets)
+    loss = outs[0].loss
     for out in outs[1:]:
-        loss = loss + synthetic_loss(out, targets)
+        loss = loss + out.loss
     loss.backward()
 
 

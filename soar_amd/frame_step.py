@@ -33,6 +33,7 @@ class FrameOutputs:
     occ: torch.Tensor        # [3,H,W]
     radii: torch.Tensor      # [P]
     viewspace_points: torch.Tensor
+    loss: Optional[torch.Tensor] = None   # scalar image loss of the frame (render_frames(loss_targets=...))
 
 
 class AvatarSequence:
@@ -111,11 +112,14 @@ class AvatarSequence:
 
     # ---- several frames of one optimizer step at once ----
     def render_frames(self, frames: List[int], bg: torch.Tensor, with_occ: bool = True, capacity: Optional[int] = None,
-                      joint_mats: Optional[torch.Tensor] = None) -> List[FrameOutputs]:
+                      joint_mats: Optional[torch.Tensor] = None, loss_targets=None,
+                      loss_weights=(1.0, 1.0, 0.1, 0.01)) -> List[FrameOutputs]:
         """Same results as ``[render_frame(f, bg) for f in frames]`` with ONE host synchronisation for the whole batch:
         all LBS warps and geometry stages are enqueued first (``rasterize_views``).  ``capacity``: sync-free form (see
         ``rasterize_views``).  ``joint_mats`` [len(frames),55,4,4]: use these transforms instead of indexing the sequence
-        (a static input buffer when the step is replayed from a HIP graph)."""
+        (a static input buffer when the step is replayed from a HIP graph).  ``loss_targets`` (dict or one dict per
+        frame with "color", "mask", "normal"): also evaluate the per-frame image loss behind each frame's blend, on the
+        frame's stream (``FrameOutputs.loss``)."""
         if self.blend_weights is None:
             self.refresh_blend_weights()
         ones = torch.ones_like(self.opacity)
@@ -132,5 +136,7 @@ class AvatarSequence:
                                rotations=rot_p))
             if with_occ:
                 inputs[-1]["occ_values"] = self.occ          # occlusion pass fused into the main blend
-        views = rasterize_views(settings, inputs, capacity=capacity)
-        return [FrameOutputs(m[0], m[1], m[2], m[3], m[5] if with_occ else None, m[4], t) for m, t in zip(views, taps)]
+        fl = None if loss_targets is None else {"targets": loss_targets, "weights": loss_weights}
+        views = rasterize_views(settings, inputs, capacity=capacity, frame_loss=fl)
+        return [FrameOutputs(m[0], m[1], m[2], m[3], m[5] if with_occ else None, m[4], t, m[-1] if fl is not None else None)
+                for m, t in zip(views, taps)]

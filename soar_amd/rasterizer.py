@@ -433,10 +433,11 @@ class _RasterizeViews(torch.autograd.Function):
 
     # tensors per view: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, occ_values
     N_IN = 9
-    N_OUT = 6     # color, normal, depth, opac, radii, occ (empty unless occ_values was given)
+    N_OUT = 7     # color, normal, depth, opac, radii, occ (empty unless occ_values was given), loss (empty unless asked)
+    N_SAVED = 10
 
     @staticmethod
-    def forward(ctx, settings_list, capacity, *flat):
+    def forward(ctx, settings_list, capacity, frame_loss, *flat):
         n = _RasterizeViews.N_IN
         views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
         states = []
@@ -450,8 +451,35 @@ class _RasterizeViews(torch.autograd.Function):
         calls = [] if use_sides else None
         if capacity is not None and any(rs.sort_descending for rs in settings_list):
             raise ValueError("the sync-free capacity mode needs sort_descending = False on every view")
-        ctx.num_rendered = [_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls, capacity=capacity)
-                            for st, v in zip(states, views)]
+        L = hip_lib.lib()
+        ctx.num_rendered = []
+        for i, (st, v) in enumerate(zip(states, views)):
+            if frame_loss is not None and st["P"] > 0:
+                # buffers of the fused image loss: allocated before the view forks to its stream
+                dev, H, W = st["device"], st["H"], st["W"]
+                tg = frame_loss["targets"][i] if isinstance(frame_loss["targets"], (list, tuple)) else frame_loss["targets"]
+                f = dict(dtype=torch.float32, device=dev)
+                st["loss"] = torch.empty((), **f)
+                st["loss_sums"] = torch.empty((4,), **f)
+                st["loss_grads"] = [torch.empty((3, H, W), **f), torch.empty((3, H, W), **f), torch.empty((1, H, W), **f),
+                                    torch.empty((1, H, W), **f)]
+                st["loss_targets"] = [_dev_f32(tg["color"], dev, "target color"), _dev_f32(tg["mask"], dev, "target mask"),
+                                      _dev_f32(tg["normal"], dev, "target normal")]
+            ctx.num_rendered.append(_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls,
+                                                             capacity=capacity))
+            if "loss" in st:
+                def loss_launch(st=st):
+                    o, g, t = st["out"], st["loss_grads"], st["loss_targets"]
+                    wc, wm, wn, wd = (float(x) for x in frame_loss["weights"])
+                    stream = st["side"].cuda_stream if st["side"] is not None else _stream(st["device"])
+                    with torch.cuda.device(st["device"]):
+                        check(L.soar_frame_loss(st["W"], st["H"], ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(t[0]), ptr(t[1]),
+                                                ptr(t[2]), wc, wm, wn, wd, ptr(st["loss"]), ptr(st["loss_sums"]), ptr(g[0]),
+                                                ptr(g[1]), ptr(g[2]), ptr(g[3]), stream), "soar_frame_loss")
+                if calls is not None:
+                    calls.append(loss_launch)
+                else:
+                    loss_launch()
         global _last_batch
         _last_batch = [(st["geom"], st["P"], st["M"], st["device"]) for st in states] if capacity is not None else []
         if use_sides:
@@ -462,30 +490,53 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.opac_shapes = [v[4].shape for v in views]
         saved, outs, nondiff = [], [], []
         for st, v in zip(states, views):
+            empty = torch.empty((0,), dtype=torch.float32, device=st["device"])
             saved += [v[3], v[0], v[5], v[6], v[7], st["radii"], v[2], st["geom"], st["binning"], st["img"]]
             occ = st.get("occ")
             if occ is None:
-                occ = torch.empty((0,), dtype=torch.float32, device=st["device"])
-            outs += st["out"] + [st["radii"], occ]
+                occ = empty
+            outs += st["out"] + [st["radii"], occ, st.get("loss", empty)]
             nondiff += [st["radii"], occ]
         ctx.save_for_backward(*saved)
+        # gradient planes written by the fused loss kernel: scratch of this node (scaled in place by backward), not graph tensors
+        ctx.loss_grads = [st.get("loss_grads") for st in states]
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)          # views whose outputs are unused (e.g. occlusion passes) are skipped
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
-        grads = [None, None]
+        grads = [None, None, None]
         used = set()
         calls = [] if ctx.use_sides else None
+        NS, NO = _RasterizeViews.N_SAVED, _RasterizeViews.N_OUT
+        saved_all = ctx.saved_tensors
         for i, rs in enumerate(ctx.settings_list):
-            colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = ctx.saved_tensors[i * 10:(i + 1) * 10]
-            g_color, g_normal, g_depth, g_opac, _, _ = gouts[i * 6:(i + 1) * 6]
-            if g_color is None and g_normal is None and g_depth is None and g_opac is None:
+            colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = saved_all[i * NS:(i + 1) * NS]
+            g_color, g_normal, g_depth, g_opac, _, _, g_loss = gouts[i * NO:(i + 1) * NO]
+            if g_color is None and g_normal is None and g_depth is None and g_opac is None and g_loss is None:
                 grads += [None] * 9
                 continue
             H, W = int(rs.image_height), int(rs.image_width)
             dev = means3D.device
+            if g_loss is not None and ctx.loss_grads[i] is not None:
+                # gradient of the fused image loss: the planes the loss kernel wrote, scaled by the upstream scalar on
+                # the view's own stream (in place: one backward per forward)
+                lg = ctx.loss_grads[i]
+                side = _view_stream(dev, i) if ctx.use_sides else None
+                if side is not None:
+                    _fork(dev, side)
+                    with torch.cuda.stream(side):
+                        torch._foreach_mul_(lg, g_loss)
+                        for t, extra in zip(lg, (g_color, g_normal, g_depth, g_opac)):
+                            if extra is not None:
+                                t.add_(extra)
+                else:
+                    torch._foreach_mul_(lg, g_loss)
+                    for t, extra in zip(lg, (g_color, g_normal, g_depth, g_opac)):
+                        if extra is not None:
+                            t.add_(extra)
+                g_color, g_normal, g_depth, g_opac = lg
             g_color = g_color if g_color is not None else torch.zeros((3, H, W), device=dev)
             g_normal = g_normal if g_normal is not None else torch.zeros((3, H, W), device=dev)
             g_depth = g_depth if g_depth is not None else torch.zeros((1, H, W), device=dev)
@@ -527,7 +578,7 @@ def check_binning():
     return out
 
 
-def rasterize_views(settings_list, inputs, capacity=None):
+def rasterize_views(settings_list, inputs, capacity=None, frame_loss=None):
     """Batched form of ``GaussianRasterizer(rs)(**kw)`` for several views at once.
 
     settings_list: list of GaussianRasterizationSettings; inputs: list of dicts with the keyword arguments of
@@ -543,7 +594,12 @@ def rasterize_views(settings_list, inputs, capacity=None):
     ``capacity``: sync-free form.  The reference blocks the host in every forward call to read ``num_rendered`` and size
     the binning buffer (rasterizer_impl.cu:250); with ``capacity`` = an upper bound of the (tile, Gaussian) instances of a
     view the buffers are sized by it, nothing is read back and whole optimizer steps can be enqueued (or captured in a
-    HIP graph).  The device checks the bound; call ``check_binning()`` afterwards (e.g. once per step)."""
+    HIP graph).  The device checks the bound; call ``check_binning()`` afterwards (e.g. once per step).
+
+    ``frame_loss`` = ``{"targets": dict or list of dicts with "color" / "mask" / "normal", "weights": (wc, wm, wn, wd)}``:
+    the per-frame image loss of ``soar_amd.losses`` is evaluated right behind each view's blend on the view's own stream
+    (the views' losses and their gradients overlap with the other views' work); every tuple gets the scalar loss as its
+    last element, and backward feeds the rasterizer with the gradient planes the loss kernel wrote."""
     empty = torch.Tensor([])
     flat = []
     for kw in inputs:
@@ -556,11 +612,15 @@ def rasterize_views(settings_list, inputs, capacity=None):
         o = lambda t: empty if t is None else t
         flat += [kw["means3D"], kw["means2D"], o(shs), o(cols), kw["opacities"], o(scales), o(rot), o(cov),
                  o(kw.get("occ_values"))]
-    outs = _RasterizeViews.apply(list(settings_list), capacity, *flat)
+    if frame_loss is not None:
+        frame_loss = {"targets": frame_loss["targets"], "weights": tuple(frame_loss.get("weights", (1.0, 1.0, 0.1, 0.01)))}
+    outs = _RasterizeViews.apply(list(settings_list), capacity, frame_loss, *flat)
     res = []
+    NO = _RasterizeViews.N_OUT
     for i, kw in enumerate(inputs):
-        v = tuple(outs[i * 6:(i + 1) * 6])
-        res.append(v if kw.get("occ_values") is not None else v[:5])
+        v = tuple(outs[i * NO:(i + 1) * NO])
+        r = v[:6] if kw.get("occ_values") is not None else v[:5]
+        res.append(r + (v[6],) if frame_loss is not None else r)
     return res
 
 

@@ -282,3 +282,32 @@ def test_step_replayed_from_hip_graph_matches_eager():
         got = flat.flat
         assert float(want.abs().sum()) > 0
         assert _rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-4
+
+
+def test_fused_frame_loss_in_rasterize_views():
+    """render_frames(loss_targets=...) (loss kernel behind each frame's blend, on the frame's stream) == rendering and
+    calling losses.frame_loss per frame: same loss values, same leaf gradients; extra image gradients still add in."""
+    from soar_amd.frame_step import AvatarSequence
+    from soar_amd.losses import frame_loss
+    body, poses = syn.make_body_model(0), syn.make_pose_sequence(8, 0)
+    cam = syn.make_camera(W, H, distance=3.0, elevation=0.1, azimuth=0.3)
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    tg = {k: v.to(DEV) for k, v in syn.make_loss_targets(H, W, 0).items()}
+
+    def step(fused):
+        seq = AvatarSequence(syn.make_surfels(P, 1), body, poses, cam, DEV)
+        if fused:
+            outs = seq.render_frames([1, 4, 6], bg, loss_targets=tg)
+            losses = [o.loss for o in outs]
+        else:
+            outs = seq.render_frames([1, 4, 6], bg)
+            losses = [frame_loss(o.render, o.normal, o.depth, o.mask, tg) for o in outs]
+        total = 2.0 * losses[0] + losses[1] + 0.5 * losses[2] + 0.01 * outs[1].depth.mean()
+        total.backward()
+        return [float(l.detach()) for l in losses], {k: v.grad.clone() for k, v in seq.leaves().items()}
+
+    l_ref, g_ref = step(False)
+    l_got, g_got = step(True)
+    np.testing.assert_allclose(l_got, l_ref, rtol=1e-6)
+    for k in g_ref:
+        assert _rel(g_got[k].cpu().numpy(), g_ref[k].cpu().numpy()) < 1e-4, k
