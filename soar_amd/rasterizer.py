@@ -111,7 +111,18 @@ NUM_STREAMS = max(1, int(os.environ.get("SOAR_STREAMS", "4")))
 _side_streams = {}
 
 
+def _all_views_on_sides() -> bool:
+    """While a HIP graph is being captured every view gets a side stream: the graph executor schedules the branches of
+    the captured graph itself and (measured) does better when the caller's stream carries no view."""
+    return torch.cuda.is_current_stream_capturing()
+
+
 def _view_stream(device: torch.device, i: int):
+    """Stream of view i of a batch: views 0, NUM_STREAMS, ... stay on the caller's stream (None), the others go to
+    NUM_STREAMS - 1 side streams -- NUM_STREAMS streams in all (the GPU exposes 4 hardware queues by default; a fifth
+    stream would share one)."""
+    if i % NUM_STREAMS == 0 and not _all_views_on_sides():
+        return None
     key = (device.index, i % NUM_STREAMS)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
@@ -440,20 +451,24 @@ class _RasterizeViews(torch.autograd.Function):
     def forward(ctx, settings_list, capacity, frame_loss, *flat):
         n = _RasterizeViews.N_IN
         views = [flat[i * n:(i + 1) * n] for i in range(len(settings_list))]
-        states = []
+        states = [None] * len(settings_list)
         use_sides = NUM_STREAMS > 1 and len(settings_list) > 1 and views[0][0].is_cuda
-        for i, (rs, (means3D, means2D, sh, colors, opac, scales, rot, cov, _occ)) in enumerate(zip(settings_list, views)):
-            states.append(_NativeOps._geometry_stage(
+        # views on side streams first: what stays on the caller's stream is enqueued after every fork point
+        order = sorted(range(len(settings_list)), key=lambda i: (_view_stream(views[i][0].device, i) is None) if use_sides else 0)
+        for i in order:
+            rs, (means3D, means2D, sh, colors, opac, scales, rot, cov, _occ) = settings_list[i], views[i]
+            states[i] = _NativeOps._geometry_stage(
                 rs.bg, means3D, colors, opac, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
                 rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
                 rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config,
-                side=_view_stream(means3D.device, i) if use_sides else None))
+                side=_view_stream(means3D.device, i) if use_sides else None)
         calls = [] if use_sides else None
         if capacity is not None and any(rs.sort_descending for rs in settings_list):
             raise ValueError("the sync-free capacity mode needs sort_descending = False on every view")
         L = hip_lib.lib()
-        ctx.num_rendered = []
-        for i, (st, v) in enumerate(zip(states, views)):
+        ctx.num_rendered = [0] * len(states)
+        for i in order:
+            st, v = states[i], views[i]
             if frame_loss is not None and st["P"] > 0:
                 # buffers of the fused image loss: allocated before the view forks to its stream
                 dev, H, W = st["device"], st["H"], st["W"]
@@ -465,8 +480,8 @@ class _RasterizeViews(torch.autograd.Function):
                                     torch.empty((1, H, W), **f)]
                 st["loss_targets"] = [_dev_f32(tg["color"], dev, "target color"), _dev_f32(tg["mask"], dev, "target mask"),
                                       _dev_f32(tg["normal"], dev, "target normal")]
-            ctx.num_rendered.append(_NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls,
-                                                             capacity=capacity))
+            ctx.num_rendered[i] = _NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls,
+                                                           capacity=capacity)
             if "loss" in st:
                 def loss_launch(st=st):
                     o, g, t = st["out"], st["loss_grads"], st["loss_targets"]
@@ -511,11 +526,15 @@ class _RasterizeViews(torch.autograd.Function):
         calls = [] if ctx.use_sides else None
         NS, NO = _RasterizeViews.N_SAVED, _RasterizeViews.N_OUT
         saved_all = ctx.saved_tensors
-        for i, rs in enumerate(ctx.settings_list):
+        n_views = len(ctx.settings_list)
+        per_view = [None] * n_views
+        order = sorted(range(n_views), key=lambda i: (_view_stream(saved_all[1].device, i) is None) if ctx.use_sides else 0)
+        for i in order:
+            rs = ctx.settings_list[i]
             colors, means3D, scales, rot, cov, radii, sh, geom, binning, img = saved_all[i * NS:(i + 1) * NS]
             g_color, g_normal, g_depth, g_opac, _, _, g_loss = gouts[i * NO:(i + 1) * NO]
             if g_color is None and g_normal is None and g_depth is None and g_opac is None and g_loss is None:
-                grads += [None] * 9
+                per_view[i] = [None] * 9
                 continue
             H, W = int(rs.image_height), int(rs.image_width)
             dev = means3D.device
@@ -547,15 +566,18 @@ class _RasterizeViews(torch.autograd.Function):
                     rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
                     rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config,
                     side=_view_stream(dev, i) if ctx.use_sides else None, defer=calls)
-            if ctx.use_sides:
+            if ctx.use_sides and _view_stream(dev, i) is not None:
                 used.add(_view_stream(dev, i))
             like = lambda g, ref: g if ref.numel() > 0 else None
-            grads += [g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors), g_opacities.reshape(ctx.opac_shapes[i]),
-                      like(g_scales, scales), like(g_rot, rot), like(g_cov3D, cov), None]
+            per_view[i] = [g_means3D, g_means2D, like(g_sh, sh), like(g_colors, colors),
+                           g_opacities.reshape(ctx.opac_shapes[i]), like(g_scales, scales), like(g_rot, rot),
+                           like(g_cov3D, cov), None]
+        if calls:
+            _run_deferred(saved_all[1].device, calls)
         if used:
-            dev = next(iter(used)).device
-            _run_deferred(dev, calls)
-            _join(dev, used)
+            _join(next(iter(used)).device, used)
+        for g in per_view:
+            grads += g
         return tuple(grads)
 
 
