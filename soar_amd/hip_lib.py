@@ -74,6 +74,9 @@ def lib() -> C.CDLL:
     """Load libsoar_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own HIP runtime: it must be the one this process uses, so torch is loaded first
+        # (loading libsoar_hip.so first would pull a second libamdhip64 from /opt/rocm into the process)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise SoarHipError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m soar_amd.build` "
