@@ -207,13 +207,17 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
-    ap.add_argument("--mode", default="graph", choices=["graph", "async", "sync"],
-                    help="graph: each step replayed from a HIP graph (falls back to async if capture fails); async: "
-                         "sync-free rasterizer, eager launches; sync: the reference's blocking num_rendered read-back")
+    ap.add_argument("--mode", default=None, choices=["graph", "async", "sync"],
+                    help="graph: each step replayed from a HIP graph (falls back to async if capture fails; default on one "
+                         "GPU); async: sync-free rasterizer, eager launches (default with several ranks: graph capture next "
+                         "to a live RCCL communicator could not be tested on the 1-GPU development box); sync: the "
+                         "reference's blocking num_rendered read-back")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.mode is None:
+        args.mode = "graph" if world == 1 else "async"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
