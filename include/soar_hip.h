@@ -134,6 +134,21 @@ int soar_rast_backward(const SoarRastParams *prm,
                        float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos,
                        void *workspace, size_t workspace_bytes,
                        void *stream);
+/* Same, with the four image gradients multiplied by the device scalar *grad_scale_dev while they are loaded (the
+ * upstream gradient of a scalar image loss whose gradient planes soar_frame_loss wrote): no scaling pass. */
+int soar_rast_backward_scaled(const SoarRastParams *prm,
+                              const float *means3D, const int32_t *radii, const float *shs,
+                              const float *colors_precomp, const float *scales, const float *rotations,
+                              const float *cov3D_precomp,
+                              const void *geom_buffer, const void *binning_buffer, const void *image_buffer,
+                              int64_t num_rendered,
+                              const float *dL_dout_color, const float *dL_dout_normal,
+                              const float *dL_dout_depth, const float *dL_dout_opac, const float *grad_scale_dev,
+                              float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D,
+                              float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                              float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos,
+                              void *workspace, size_t workspace_bytes,
+                              void *stream);
 /* bytes of `workspace` needed by soar_rast_backward (per-Gaussian accumulation rows) */
 int soar_rast_backward_workspace_bytes(int32_t P, size_t *bytes);
 

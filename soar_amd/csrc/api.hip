@@ -369,6 +369,23 @@ int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const in
                        float *dL_dsh, float *dL_dscales, float *dL_drotations, float *dL_dviewmat, float *dL_dprojmat,
                        float *dL_dcampos, void *workspace, size_t workspace_bytes, void *stream_)
 {
+    return soar_rast_backward_scaled(prm, means3D, radii, shs, colors_precomp, scales, rotations, cov3D_precomp, geom_buffer,
+                                     binning_buffer, image_buffer, num_rendered, dL_dout_color, dL_dout_normal, dL_dout_depth,
+                                     dL_dout_opac, nullptr, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                                     dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos, workspace, workspace_bytes,
+                                     stream_);
+}
+
+int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
+                              const float *colors_precomp, const float *scales, const float *rotations,
+                              const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
+                              const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
+                              const float *dL_dout_normal, const float *dL_dout_depth, const float *dL_dout_opac,
+                              const float *grad_scale_dev, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                              float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, void *workspace,
+                              size_t workspace_bytes, void *stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
     if (!dL_dviewmat || !dL_dprojmat || !dL_dcampos) { set_error("camera gradient pointers must not be NULL"); return 1; }
@@ -402,7 +419,8 @@ int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const in
     float *acc = static_cast<float *>(workspace);
     SOAR_HIP_OK(hipMemsetAsync(acc, 0, sizeof(float) * ACC_STRIDE * (size_t)prm->P, stream));
     if (num_rendered > 0) {
-        if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, acc, stream))
+        if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
+                                   stream))
             return 1;
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,

@@ -47,6 +47,7 @@ struct BwdArgs {
     const float *final_D;
     const uint32_t *n_contrib;
     const float *dL_dcolor, *dL_dnormal, *dL_ddepth, *dL_dopac;
+    const float *grad_scale;         // optional device scalar the four image gradients are multiplied by
     float *acc;
 };
 
@@ -92,10 +93,11 @@ __device__ __forceinline__ void load_pixel(const BwdArgs &a, int px, int py, boo
     float dO = 0.f;
     c.dC0 = c.dC1 = c.dC2 = c.dN0 = c.dN1 = c.dN2 = c.dD = 0.f;
     if (inside) {
-        c.dC0 = a.dL_dcolor[pix]; c.dC1 = a.dL_dcolor[hw + pix]; c.dC2 = a.dL_dcolor[2 * hw + pix];
-        c.dN0 = a.dL_dnormal[pix]; c.dN1 = a.dL_dnormal[hw + pix]; c.dN2 = a.dL_dnormal[2 * hw + pix];
-        c.dD = a.dL_ddepth[pix];
-        dO = a.dL_dopac[pix];
+        const float gs = a.grad_scale ? *a.grad_scale : 1.f;
+        c.dC0 = gs * a.dL_dcolor[pix]; c.dC1 = gs * a.dL_dcolor[hw + pix]; c.dC2 = gs * a.dL_dcolor[2 * hw + pix];
+        c.dN0 = gs * a.dL_dnormal[pix]; c.dN1 = gs * a.dL_dnormal[hw + pix]; c.dN2 = gs * a.dL_dnormal[2 * hw + pix];
+        c.dD = gs * a.dL_ddepth[pix];
+        dO = gs * a.dL_dopac[pix];
     }
     const float bg_dot = a.bg[0] * c.dC0 + a.bg[1] * c.dC1 + a.bg[2] * c.dC2;     // :798-800
     c.ddelx_dx = 0.5f * a.W; c.ddely_dy = 0.5f * a.H;                             // :622-623
@@ -649,9 +651,10 @@ int bwd_variant()     // 0 = slots (default), 1 = dpp, 2 = lanes
 
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
-                           float *acc, hipStream_t stream)
+                           const float *grad_scale, float *acc, hipStream_t stream)
 {
     BwdArgs a;
+    a.grad_scale = grad_scale;
     a.W = prm.W; a.H = prm.H;
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
     a.ntiles = a.gx * a.gy;

@@ -17,6 +17,7 @@ call goes to the HIP library and raises if it is missing or if a tensor is not o
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import NamedTuple, Optional, Tuple
@@ -313,7 +314,7 @@ class _NativeOps:
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                      viewmatrix, projmatrix, prcppoint, patchbbox, tan_fovx, tan_fovy, dL_dout_color,
                                      dL_dout_normal, dL_dout_depth, dL_dout_opac, sh, degree, campos, geomBuffer, R,
-                                     binningBuffer, imageBuffer, debug, config, side=None, defer=None):
+                                     binningBuffer, imageBuffer, debug, config, side=None, defer=None, grad_scale=None):
         """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
         dL_dscales[P,3], dL_drotations[P,4], dL_dviewmat[4,4], dL_dprojmat[4,4], dL_dcampos[3])
         (rasterize_points.cu:107-187)"""
@@ -360,13 +361,16 @@ class _NativeOps:
                 cols = scl = rot = cov = radii_i = None
                 work_ptr, work_n = None, 0
             stream = _fork(device, side) if side is not None else _stream(device)
-            alive = [ctx, work if P > 0 else None, means, dC, dN, dD, dO, cols, scl, rot, cov, radii_i, sh_t]
+            gs = None
+            if grad_scale is not None:
+                gs = grad_scale.detach().to(device=device, dtype=torch.float32).reshape(1).contiguous()
+            alive = [ctx, work if P > 0 else None, means, dC, dN, dD, dO, cols, scl, rot, cov, radii_i, sh_t, gs]
 
             def launch():
-                check(L.soar_rast_backward(
+                check(L.soar_rast_backward_scaled(
                     C.byref(ctx.params), ptr(means), ptr(radii_i), ptr(sh_t), ptr(cols), ptr(scl), ptr(rot), ptr(cov),
                     ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), int(R),
-                    ptr(dC), ptr(dN), ptr(dD), ptr(dO),
+                    ptr(dC), ptr(dN), ptr(dD), ptr(dO), ptr(gs),
                     ptr(g_means2D), ptr(g_colors), ptr(g_opacity), ptr(g_means3D), ptr(g_cov3D), ptr(g_sh), ptr(g_scales),
                     ptr(g_rot), g_view.data_ptr(), g_proj.data_ptr(), g_campos.data_ptr(), work_ptr, work_n, stream),
                     "rasterize_gaussians_backward")
@@ -470,7 +474,7 @@ class _RasterizeViews(torch.autograd.Function):
         for i in order:
             st, v = states[i], views[i]
             if frame_loss is not None and st["P"] > 0:
-                # buffers of the fused image loss: allocated before the view forks to its stream
+                # buffers of the image loss: allocated before the view forks to its stream
                 dev, H, W = st["device"], st["H"], st["W"]
                 tg = frame_loss["targets"][i] if isinstance(frame_loss["targets"], (list, tuple)) else frame_loss["targets"]
                 f = dict(dtype=torch.float32, device=dev)
@@ -480,9 +484,15 @@ class _RasterizeViews(torch.autograd.Function):
                                     torch.empty((1, H, W), **f)]
                 st["loss_targets"] = [_dev_f32(tg["color"], dev, "target color"), _dev_f32(tg["mask"], dev, "target mask"),
                                       _dev_f32(tg["normal"], dev, "target normal")]
+                for t, ch, name in zip(st["loss_targets"], (3, 1, 3), ("color", "mask", "normal")):
+                    if t.numel() != ch * H * W:
+                        raise ValueError(f"loss target {name} must have {ch}x{H}x{W} elements, got {tuple(t.shape)}")
             ctx.num_rendered[i] = _NativeOps._render_stage(st, v[8] if v[8].numel() > 0 else None, defer=calls,
                                                            capacity=capacity)
             if "loss" in st:
+                # the loss kernel runs right behind the view's blend, on the view's stream.  (Evaluating the loss inside
+                # the blend's epilogue was measured slower: the 4x4-pixel lane mapping of the blend turns the 15 extra
+                # planes into 16-byte accesses, the separate kernel streams them at 4.3 TB/s.)
                 def loss_launch(st=st):
                     o, g, t = st["out"], st["loss_grads"], st["loss_targets"]
                     wc, wm, wn, wd = (float(x) for x in frame_loss["weights"])
@@ -538,23 +548,23 @@ class _RasterizeViews(torch.autograd.Function):
                 continue
             H, W = int(rs.image_height), int(rs.image_width)
             dev = means3D.device
+            scale = None
             if g_loss is not None and ctx.loss_grads[i] is not None:
-                # gradient of the fused image loss: the planes the loss kernel wrote, scaled by the upstream scalar on
-                # the view's own stream (in place: one backward per forward)
+                # gradient of the fused image loss = the planes the forward epilogue wrote x the upstream scalar
                 lg = ctx.loss_grads[i]
-                side = _view_stream(dev, i) if ctx.use_sides else None
-                if side is not None:
-                    _fork(dev, side)
-                    with torch.cuda.stream(side):
+                extras = (g_color, g_normal, g_depth, g_opac)
+                if all(e is None for e in extras):
+                    scale = g_loss                                  # multiplied in while the backward blend loads the planes
+                else:
+                    # image gradients from elsewhere as well: scale in place and add (one backward per forward)
+                    side = _view_stream(dev, i) if ctx.use_sides else None
+                    if side is not None:
+                        _fork(dev, side)
+                    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                         torch._foreach_mul_(lg, g_loss)
-                        for t, extra in zip(lg, (g_color, g_normal, g_depth, g_opac)):
+                        for t, extra in zip(lg, extras):
                             if extra is not None:
                                 t.add_(extra)
-                else:
-                    torch._foreach_mul_(lg, g_loss)
-                    for t, extra in zip(lg, (g_color, g_normal, g_depth, g_opac)):
-                        if extra is not None:
-                            t.add_(extra)
                 g_color, g_normal, g_depth, g_opac = lg
             g_color = g_color if g_color is not None else torch.zeros((3, H, W), device=dev)
             g_normal = g_normal if g_normal is not None else torch.zeros((3, H, W), device=dev)
@@ -565,7 +575,7 @@ class _RasterizeViews(torch.autograd.Function):
                     rs.bg, means3D, radii, colors, scales, rot, rs.scale_modifier, cov, rs.viewmatrix, rs.projmatrix,
                     rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
                     rs.sh_degree, rs.campos, geom, ctx.num_rendered[i], binning, img, rs.debug, rs.config,
-                    side=_view_stream(dev, i) if ctx.use_sides else None, defer=calls)
+                    side=_view_stream(dev, i) if ctx.use_sides else None, defer=calls, grad_scale=scale)
             if ctx.use_sides and _view_stream(dev, i) is not None:
                 used.add(_view_stream(dev, i))
             like = lambda g, ref: g if ref.numel() > 0 else None
