@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     const bool inside = px < a.W && py < a.H;
 
     const uint2 range = a.ranges[tile];
+    if (range.x == range.y) return;              // nothing was blended in this tile (most of the image)
     set_wave_priority_by_length(range.y - range.x);
     PixelConsts c;
     PixelState s;

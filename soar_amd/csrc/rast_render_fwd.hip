@@ -97,6 +97,33 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     const uint2 range = a.ranges[tile];
     set_wave_priority_by_length(range.y - range.x);
 
+    // tiles no Gaussian touches (most of the image): the 8x8 quad gets its background values with one aligned float4
+    // store per thread instead of walking the blend loop's prologue / epilogue in four wavefronts
+    {
+        const int qx0 = tx * TILE + (quad & 1) * 8, qy0 = ty * TILE + (quad >> 1) * 8;
+        if (!LOG && range.x == range.y && qx0 + 8 <= a.W && qy0 + 8 <= a.H && (a.W & 3) == 0) {
+            const int plane = tid >> 4, r = tid & 15;
+            const size_t hw = (size_t)a.H * a.W;
+            const size_t at = (size_t)a.W * (qy0 + (r >> 1)) + qx0 + (r & 1) * 4;
+            const float Tc = (float)(1 - 0.000001);            // the epilogue's clamp of T = 1 (forward.cu:618-633)
+            float v = 0.f;
+            float *dst = nullptr;
+            switch (plane) {
+            case 0: dst = a.final_T; v = Tc; break;
+            case 1: dst = reinterpret_cast<float *>(a.n_contrib); v = 0.f; break;        // bits of 0u
+            case 2: case 3: case 4: dst = a.out_color + (plane - 2) * hw; v = 0.f + Tc * a.bg[plane - 2]; break;
+            case 5: case 6: case 7: dst = a.out_normal + (plane - 5) * hw; v = 0.f; break;
+            case 8: dst = a.out_depth; v = a.normalize_depth ? 0.f / (1.f - Tc) : 0.f + Tc * 10.f; break;
+            case 9: dst = a.out_opac; v = 1.f - Tc; break;
+            case 10: if (a.normalize_depth) { dst = a.final_D; v = 0.f; } break;
+            case 11: case 12: case 13: if (OCC) { dst = a.out_occ + (plane - 11) * hw; v = 0.f + Tc * a.bg[plane - 11]; } break;
+            default: break;
+            }
+            if (dst) *reinterpret_cast<float4 *>(dst + at) = make_float4(v, v, v, v);
+            return;
+        }
+    }
+
     float T = 1.0f;                                  // replicated in the four lanes of a pixel
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
     uint32_t last_contributor = 0;                   // per-slot, folded with max at the end
