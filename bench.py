@@ -20,6 +20,12 @@ import os
 import sys
 import time
 
+# Replaying several different HIP graphs in turn (step plan: prologue / one graph per frame / epilogue) faults inside the
+# ROCm 7 runtime's AQL-packet capture of graphs ("write access to a read-only page" on the second round of replays; each
+# graph alone, a single graph per step, and the same launches issued eagerly on the same streams are all fine).  The
+# documented switch back to the regular graph launch path must be set before the HIP runtime initialises:
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -207,8 +213,10 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
-    ap.add_argument("--mode", default=None, choices=["graph", "async", "sync"],
-                    help="graph: each step replayed from a HIP graph (falls back to async if capture fails; default on one "
+    ap.add_argument("--mode", default=None, choices=["plan", "graph", "async", "sync"],
+                    help="plan: explicit launch plan of the step (soar_amd/step_plan.py: per-frame forward+backward chains as HIP "
+                         "graphs on their own streams, no autograd in the loop; default on one GPU, falls back to graph); "
+                         "graph: each step replayed from a HIP graph (falls back to async if capture fails; default on one "
                          "GPU); async: sync-free rasterizer, eager launches (default with several ranks: graph capture next "
                          "to a live RCCL communicator could not be tested on the 1-GPU development box); sync: the "
                          "reference's blocking num_rendered read-back")
@@ -217,7 +225,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.mode is None:
-        args.mode = "graph" if world == 1 else "async"
+        args.mode = "plan" if world == 1 else "async"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -263,6 +271,19 @@ def main():
     stats_warm = dict(rasterizer.stats)
     capacity = None if args.mode == "sync" else 2 * r_seen
     mode, stepper = args.mode, None
+    plan = None
+    if mode == "plan":
+        try:
+            from soar_amd.step_plan import FrameStepPlan
+            plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat)
+
+            def stepper(frames):
+                plan.run(frames)
+                return flat.all_reduce()
+        except Exception as e:
+            print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode graph", file=sys.stderr)
+            torch.cuda.synchronize()
+            mode, plan, stepper = "graph", None, None
     if mode == "graph":
         try:
             stepper = GraphStep(seq, targets, flat, bg, len(frames_of(0)), capacity)
@@ -285,8 +306,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if capacity is not None:
-        rasterizer.check_binning()                               # raises if a binning buffer of the last step was too small
+    if plan is not None:
+        plan.check()                                             # raises if a binning buffer of the last step was too small
+    elif capacity is not None:
+        rasterizer.check_binning()
     stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
     # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
     #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views

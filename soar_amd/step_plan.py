@@ -1,0 +1,214 @@
+"""One optimizer step of the per-frame path as an explicit launch plan (no autograd in the loop).
+
+``AvatarSequence.render_frames`` + ``loss.backward()`` is the general form: any loss, any graph.  For the fixed training
+step of the avatar stage -- KNN blend weights, then for every frame of the batch LBS warp -> rasterize (main + fused
+occlusion pass) -> per-frame image loss -> rasterizer backward -> warp backward, then sum the frames' gradients -- every
+operation is a call of the C ABI whose backward is another call of the C ABI, so the step can be laid out once:
+
+* all buffers are allocated when the plan is built (288 GB of HBM: nothing is recycled between frames);
+* each frame's forward+backward chain is a straight line of ~20 launches on the frame's own HIP stream, independent of
+  the other frames (they only share read-only inputs), captured as ONE HIP graph per frame;
+* a prologue (zero gradients, KNN blend weights) and an epilogue (sum of the per-frame gradients into the flat
+  gradient buffer) run on the caller's stream.
+
+Per step the host replays 2 + n_frames graphs instead of enqueueing ~105 launches through autograd, and the frames'
+chains overlap by ordinary stream semantics (a single captured graph with four branches was measured to be released
+one branch at a time by the graph executor).  The kernels and their results are those of the autograd path
+(``tests/test_plugin_gpu.py::test_step_plan_matches_autograd``).
+
+Runtime note (ROCm 7.2): replaying several different graphs in turn faults inside the runtime's AQL-packet capture of
+graphs; run the process with ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` (set before the first HIP call -- ``bench.py`` and
+``tests/conftest.py`` do) or build the plan with ``use_graphs=False`` (same streams, eager launches).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import hip_lib
+from .hip_lib import check, ptr
+from .rasterizer import _Ctx
+
+
+class FrameStepPlan:
+    def __init__(self, seq, n_frames: int, targets: Dict[str, torch.Tensor], bg: torch.Tensor, capacity: int, flat,
+                 loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True):
+        """seq: AvatarSequence; targets: {"color","mask","normal"} image targets shared by the frames; capacity: bound
+        of the (tile, Gaussian) instances of one frame (checked on the device, see ``check()``); flat: FlatGradBuffer of
+        ``seq.leaves()`` that receives the summed gradients."""
+        L = hip_lib.lib()
+        self.L, self.seq, self.flat, self.n = L, seq, flat, int(n_frames)
+        dev = seq.device
+        self.device = dev
+        P, H, W = int(seq.xyz.shape[0]), int(seq.camera.height), int(seq.camera.width)
+        self.P, self.H, self.W, self.capacity = P, H, W, int(capacity)
+        self.weights = tuple(float(w) for w in loss_weights)
+        f = dict(dtype=torch.float32, device=dev)
+        self.bg = bg.to(**f).contiguous()
+        self.targets = [targets[k].to(**f).contiguous() for k in ("color", "mask", "normal")]
+        self.mats = torch.empty((self.n, 55, 4, 4), **f)                 # static input: joint transforms of the step's frames
+        self.blend_weights = torch.empty((P, seq.lbs_weights.shape[1]), **f)
+        self.ones = torch.ones((P, 1), **f)
+        self.ctx = _Ctx(P, 0, H, W, seq.camera.tanfovx, seq.camera.tanfovy, 1.0, 0, False, False, False, False, self.bg,
+                        seq.view, seq.proj, seq.prcp, seq.patch, seq.campos, seq.config, dev)
+        nbytes = C.c_size_t(0)
+        check(L.soar_rast_geometry_bytes(P, 0, C.byref(nbytes)), "geometry_bytes"); geom_b = nbytes.value
+        check(L.soar_rast_image_bytes(W, H, C.byref(nbytes)), "image_bytes"); img_b = nbytes.value
+        check(L.soar_rast_binning_bytes(self.capacity, C.byref(nbytes)), "binning_bytes"); bin_b = nbytes.value
+        check(L.soar_rast_backward_workspace_bytes(P, C.byref(nbytes)), "workspace_bytes"); work_b = nbytes.value
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.views: List[dict] = []
+        for _ in range(self.n):
+            v = dict(
+                xyz_p=torch.empty((P, 3), **f), rot_p=torch.empty((P, 4), **f), radii=torch.empty((P,), dtype=torch.int32, device=dev),
+                color=torch.empty((3, H, W), **f), normal=torch.empty((3, H, W), **f), depth=torch.empty((1, H, W), **f),
+                opac=torch.empty((1, H, W), **f), occ=torch.empty((3, H, W), **f),
+                geom=torch.empty(geom_b, **u8), img=torch.empty(img_b, **u8), binning=torch.empty(bin_b, **u8),
+                work=torch.empty(work_b, **u8), loss=torch.empty((), **f), sums=torch.empty((4,), **f),
+                gC=torch.empty((3, H, W), **f), gN=torch.empty((3, H, W), **f), gD=torch.empty((1, H, W), **f),
+                gO=torch.empty((1, H, W), **f),
+                g_means2D=torch.empty((P, 3), **f), g_colors=torch.empty((P, 3), **f), g_opacity=torch.empty((P, 1), **f),
+                g_means3D=torch.empty((P, 3), **f), g_cov3D=torch.empty((P, 6), **f), g_scales=torch.empty((P, 3), **f),
+                g_rot_p=torch.empty((P, 4), **f), g_view=torch.empty((4, 4), **f), g_proj=torch.empty((4, 4), **f),
+                g_campos=torch.empty((3,), **f))
+            self.views.append(v)
+        # per-frame gradients of the leaves, frame-major so that one reduction per leaf sums them
+        self.g_xyz = torch.empty((self.n, P, 3), **f)
+        self.g_rot = torch.empty((self.n, P, 4), **f)
+        self.g_scales = torch.empty((self.n, P, 3), **f)
+        self.g_colors = torch.empty((self.n, P, 3), **f)
+        self.losses = torch.empty((self.n,), **f)
+        # frame 0 stays on the caller's stream, the others get their own (4 hardware queues in all for 4 frames)
+        self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)]
+        self.graphs = None
+        if use_graphs:
+            if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+                raise RuntimeError("FrameStepPlan(use_graphs=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment "
+                                   "before the HIP runtime starts (see the module docstring); use use_graphs=False otherwise")
+            self._capture()
+
+    # ---- the three pieces -------------------------------------------------------------------------------------------
+    def _prologue(self, stream: int) -> None:
+        L, s = self.L, self.seq
+        self.flat.flat.zero_()
+        check(L.soar_lbs_knn_query(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
+                                   ptr(s.xyz.detach()), self.P, 30, ptr(self.blend_weights), None, stream), "knn_query")
+
+    def _frame(self, i: int, stream: int) -> None:
+        """forward and backward of frame i: a straight line of launches on one stream"""
+        L, s, v, P, W, H = self.L, self.seq, self.views[i], self.P, self.W, self.H
+        prm = C.byref(self.ctx.params)
+        J = int(self.blend_weights.shape[1])
+        mats = self.mats[i]
+        xyz, rot = s.xyz.detach(), s.rot.detach()
+        check(L.soar_lbs_warp_forward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, None, P, J, ptr(v["xyz_p"]),
+                                      ptr(v["rot_p"]), None, stream), "warp_forward")
+        check(L.soar_rast_forward_geometry(prm, ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
+                                           ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream), "geometry")
+        check(L.soar_rast_forward_render_occ(prm, ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
+                                             ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
+                                             ptr(v["occ"]), stream), "render")
+        wc, wm, wn, wd = self.weights
+        tc, tm, tn = self.targets
+        check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
+                                wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
+                                ptr(v["gO"]), stream), "frame_loss")
+        check(L.soar_rast_backward(prm, ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()), ptr(s.scales.detach()),
+                                   ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
+                                   ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
+                                   ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]), ptr(v["g_cov3D"]), None,
+                                   ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
+                                   ptr(v["work"]), v["work"].numel(), stream), "backward")
+        check(L.soar_lbs_warp_backward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, P, J, ptr(v["g_means3D"]),
+                                       ptr(v["g_rot_p"]), ptr(self.g_xyz[i]), ptr(self.g_rot[i]), stream), "warp_backward")
+
+    def _epilogue(self) -> None:
+        fv = self.flat.views
+        torch.sum(self.g_xyz, dim=0, out=fv["xyz"])
+        torch.sum(self.g_rot, dim=0, out=fv["rot"])
+        torch.sum(self.g_scales, dim=0, out=fv["scales"])
+        torch.sum(self.g_colors, dim=0, out=fv["colors"])
+
+    # ---- graphs -------------------------------------------------------------------------------------------------------
+    def _capture(self) -> None:
+        dev = self.device
+        self.mats.copy_(self.seq.cano2live[: self.n] if self.seq.num_frames >= self.n else self.seq.cano2live[[0] * self.n])
+        self._run_eager()                       # warm-up: lazy workspaces, code objects
+        torch.cuda.synchronize(dev)
+        cap = torch.cuda.Stream(device=dev)
+        graphs = {}
+        with torch.cuda.device(dev):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                self._prologue(cap.cuda_stream)
+            graphs["prologue"] = g
+            for i in range(self.n):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    self._frame(i, cap.cuda_stream)
+                graphs[i] = g
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                self._epilogue()
+            graphs["epilogue"] = g
+        torch.cuda.synchronize(dev)
+        self.graphs = graphs
+
+    def _run_eager(self) -> None:
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):
+            self._prologue(main.cuda_stream)
+            self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
+            self._epilogue()
+
+    def _fan_out(self, main, fn) -> None:
+        """frames 1.. on their own streams (forked from `main`), frame 0 on `main`, then join"""
+        ev = torch.cuda.Event()
+        ev.record(main)
+        done = []
+        for i in range(1, self.n):
+            s = self.streams[i]
+            s.wait_event(ev)
+            with torch.cuda.stream(s):
+                fn(i, s)
+            e = torch.cuda.Event()
+            e.record(s)
+            done.append(e)
+        fn(0, main)
+        for e in done:
+            main.wait_event(e)
+
+    # ---- one step -----------------------------------------------------------------------------------------------------
+    def run(self, frames: Sequence[int]):
+        """Gradients of sum_i loss(frame_i) w.r.t. the leaves into the flat buffer; returns the [n] per-frame losses."""
+        if len(frames) != self.n:
+            raise ValueError(f"the plan was built for {self.n} frames per step, got {len(frames)}")
+        dev = self.device
+        idx = torch.as_tensor([f % self.seq.num_frames for f in frames], device=dev)
+        torch.index_select(self.seq.cano2live, 0, idx, out=self.mats)
+        if self.graphs is None:
+            self._run_eager()
+            return self.losses
+        main = torch.cuda.current_stream(dev)
+        self.graphs["prologue"].replay()
+        self._fan_out(main, lambda i, s: self.graphs[i].replay())
+        self.graphs["epilogue"].replay()
+        return self.losses
+
+    def check(self):
+        """Synchronise and verify that no frame exceeded the binning capacity (see rasterize_views(capacity=...))."""
+        out = []
+        for v in self.views:
+            n, o = C.c_int64(0), C.c_int64(0)
+            with torch.cuda.device(self.device):
+                check(self.L.soar_rast_binning_status(ptr(v["geom"]), self.P, 0, C.byref(n), C.byref(o),
+                                                      torch.cuda.current_stream(self.device).cuda_stream), "binning_status")
+            out.append((int(n.value), int(o.value)))
+        bad = [o for _, o in out if o]
+        if bad:
+            raise RuntimeError(f"binning capacity exceeded: {max(bad)} (tile, Gaussian) instances needed; raise `capacity`")
+        return out

@@ -1,4 +1,9 @@
 import os
+
+# see bench.py: the step-plan tests replay several HIP graphs in turn; must be set before the HIP runtime initialises
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import os
 import sys
 
 import pytest
