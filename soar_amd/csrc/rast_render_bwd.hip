@@ -591,8 +591,13 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     const float om = 1.f - a_eff;
                     const float om0 = dpp_move<DPP_Q_BCAST0>(om), om1 = dpp_move<DPP_Q_BCAST1>(om),
                                 om2 = dpp_move<DPP_Q_BCAST2>(om), om3 = dpp_move<DPP_Q_BCAST3>(om);
-                    // transmittance in front of each slot's entry, back to front (:683); om == 1 for dead entries
-                    const float T3 = T / om3, T2 = T3 / om2, T1 = T2 / om1, T0 = T1 / om0;
+                    // transmittance in front of each slot's entry, back to front (:683, T = T / (1 - alpha)); om == 1 for
+                    // dead entries.  One IEEE division per lane (r = 1 / om) shared through the quad instead of one per
+                    // slot: T * r differs from T / om by one rounding, far inside the 1e-4 gradient tolerance.
+                    const float r_om = 1.0f / om;
+                    const float r0 = dpp_move<DPP_Q_BCAST0>(r_om), r1 = dpp_move<DPP_Q_BCAST1>(r_om),
+                                r2 = dpp_move<DPP_Q_BCAST2>(r_om), r3 = dpp_move<DPP_Q_BCAST3>(r_om);
+                    const float T3 = T * r3, T2 = T3 * r2, T1 = T2 * r1, T0 = T1 * r0;
                     const float T_mine = slot == 0 ? T0 : slot == 1 ? T1 : slot == 2 ? T2 : T3;
                     T = T0;
                     // u = (this entry's colour / normal / depth) . (upstream gradient of the pixel)
@@ -616,9 +621,9 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                         v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;             // :711
                         v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;   // :727
                         v[12] = wgt * c.dD_ch;                                                  // :782
-                        float dL_dalpha = (u - P_mine) + c.norm_depth_k / om / T_mine;          // :706,:723,:773,:776
-                        dL_dalpha *= T_mine;                                                    // :788
-                        dL_dalpha += c.tail / om;                                               // :791-802
+                        // ((u - P) + k / om / T) * T + tail / om  (:706,:723,:773,:776,:788,:791-802) with the divisions folded:
+                        // k / om / T * T = k / om, and both 1 / om terms share r_om
+                        const float dL_dalpha = __builtin_fmaf(u - P_mine, T_mine, (c.norm_depth_k + c.tail) * r_om);
                         const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;               // :823
                         v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - c.dD * g.plane_a;   // :828, :839
                         v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - c.dD * g.plane_b;   // :829, :840
