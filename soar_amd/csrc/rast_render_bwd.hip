@@ -613,25 +613,25 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     const float P_mine = slot == 0 ? P0 : slot == 1 ? P1 : slot == 2 ? P2 : P3;
                     P = __builtin_fmaf(om0, P0, t0);
 
+                    // per-pair gradient terms; a dead pair (live == false) contributes exact zeros through wgt = 0 and
+                    // dL_dalpha = 0 (no branch, no zero-initialised array)
                     float v[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) v[k] = 0.f;
-                    if (live) {
-                        const float wgt = alpha * T_mine;                                       // dchannel_dcolor
-                        v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;             // :711
-                        v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;   // :727
-                        v[12] = wgt * c.dD_ch;                                                  // :782
-                        // ((u - P) + k / om / T) * T + tail / om  (:706,:723,:773,:776,:788,:791-802) with the divisions folded:
-                        // k / om / T * T = k / om, and both 1 / om terms share r_om
-                        const float dL_dalpha = __builtin_fmaf(u - P_mine, T_mine, (c.norm_depth_k + c.tail) * r_om);
-                        const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;               // :823
-                        v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - c.dD * g.plane_a;   // :828, :839
-                        v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - c.dD * g.plane_b;   // :829, :840
-                        v[2] = dL_ddist * (dx * dx);                                            // :831-835
-                        v[3] = dL_ddist * (dx * dy);
-                        v[4] = dL_ddist * (dy * dy);
-                        v[5] = G * dL_dalpha;                                                   // :854
-                    }
+                    const float wgt = live ? alpha * T_mine : 0.f;                              // dchannel_dcolor
+                    v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;                 // :711
+                    v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;   // :727
+                    v[12] = wgt * c.dD_ch;                                                      // :782
+                    // ((u - P) + k / om / T) * T + tail / om  (:706,:723,:773,:776,:788,:791-802) with the divisions folded:
+                    // k / om / T * T = k / om, and both 1 / om terms share r_om
+                    const float dL_dalpha = live ? __builtin_fmaf(u - P_mine, T_mine, (c.norm_depth_k + c.tail) * r_om) : 0.f;
+                    const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;                   // :823
+                    const float dD_live = live ? c.dD : 0.f;
+                    v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - dD_live * g.plane_a;   // :828, :839
+                    v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - dD_live * g.plane_b;   // :829, :840
+                    v[2] = dL_ddist * (dx * dx);                                                // :831-835
+                    v[3] = dL_ddist * (dx * dy);
+                    v[4] = dL_ddist * (dy * dy);
+                    v[5] = G * dL_dalpha;                                                       // :854
+                    v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
                     const float total = pixel_reduce16(v, lane);
                     // entries of this step with at least one live pixel: bits slot, slot+4, ... of the ballot
                     const bool entry_live = ((live_mask >> slot) & 0x1111111111111111ull) != 0ull;
