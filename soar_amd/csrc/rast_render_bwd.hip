@@ -534,6 +534,8 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     if (deepest == 0u) return;
 
     const int qslot = pixel_reduce16_slot(lane);
+    const float dN0x10 = c.dN0 * 10.f, dN1x10 = c.dN1 * 10.f, dN2x10 = c.dN2 * 10.f;          // per-pixel constants of the pair terms
+    const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     uint32_t rid = 0;
@@ -594,7 +596,9 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     // transmittance in front of each slot's entry, back to front (:683, T = T / (1 - alpha)); om == 1 for
                     // dead entries.  One IEEE division per lane (r = 1 / om) shared through the quad instead of one per
                     // slot: T * r differs from T / om by one rounding, far inside the 1e-4 gradient tolerance.
-                    const float r_om = 1.0f / om;
+                    // r = 1 / om: hardware reciprocal + one Newton step (< 1 ulp; om is in [0.01, 1])
+                    float r_om = __builtin_amdgcn_rcpf(om);
+                    r_om = __builtin_fmaf(__builtin_fmaf(-om, r_om, 1.0f), r_om, r_om);
                     const float r0 = dpp_move<DPP_Q_BCAST0>(r_om), r1 = dpp_move<DPP_Q_BCAST1>(r_om),
                                 r2 = dpp_move<DPP_Q_BCAST2>(r_om), r3 = dpp_move<DPP_Q_BCAST3>(r_om);
                     const float T3 = T * r3, T2 = T3 * r2, T1 = T2 * r1, T0 = T1 * r0;
@@ -618,15 +622,15 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     float v[16];
                     const float wgt = live ? alpha * T_mine : 0.f;                              // dchannel_dcolor
                     v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;                 // :711
-                    v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;   // :727
+                    v[9] = wgt * dN0x10; v[10] = wgt * dN1x10; v[11] = wgt * dN2x10;          // :727 (x10 normal gain)
                     v[12] = wgt * c.dD_ch;                                                      // :782
                     // ((u - P) + k / om / T) * T + tail / om  (:706,:723,:773,:776,:788,:791-802) with the divisions folded:
                     // k / om / T * T = k / om, and both 1 / om terms share r_om
                     const float dL_dalpha = live ? __builtin_fmaf(u - P_mine, T_mine, (c.norm_depth_k + c.tail) * r_om) : 0.f;
                     const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;                   // :823
                     const float dD_live = live ? c.dD : 0.f;
-                    v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - dD_live * g.plane_a;   // :828, :839
-                    v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - dD_live * g.plane_b;   // :829, :840
+                    v[0] = dL_ddist * (g.A * dx + g.B * dy) * two_ddelx - dD_live * g.plane_a;     // :828, :839
+                    v[1] = dL_ddist * (g.C * dy + g.B * dx) * two_ddely - dD_live * g.plane_b;     // :829, :840
                     v[2] = dL_ddist * (dx * dx);                                                // :831-835
                     v[3] = dL_ddist * (dx * dy);
                     v[4] = dL_ddist * (dy * dy);
