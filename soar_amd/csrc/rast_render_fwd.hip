@@ -197,21 +197,33 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     const float om = 1.f - a_eff;
                     const float om0 = quad_move<DPP_QUAD_BCAST0>(om), om1 = quad_move<DPP_QUAD_BCAST1>(om),
                                 om2 = quad_move<DPP_QUAD_BCAST2>(om), om3 = quad_move<DPP_QUAD_BCAST3>(om);
-                    const float t0 = mul_keep(T, om0);
-                    const bool s0 = t0 < 0.0001f;
-                    const float T1 = s0 ? T : t0;
-                    const float t1 = mul_keep(T1, om1);
-                    const bool s1 = s0 || (t1 < 0.0001f);
-                    const float T2 = s1 ? T1 : t1;
-                    const float t2 = mul_keep(T2, om2);
-                    const bool s2 = s1 || (t2 < 0.0001f);
-                    const float T3 = s2 ? T2 : t2;
-                    const float t3 = mul_keep(T3, om3);
-                    const bool s3 = s2 || (t3 < 0.0001f);
-                    // transmittance in front of MY entry, and whether the pixel had stopped at or before it
-                    const float T_mine = slot == 0 ? T : slot == 1 ? T1 : slot == 2 ? T2 : T3;
-                    const bool stopped = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
-                    const float w = stopped ? 0.f : a_eff * T_mine;
+                    // unclamped running products first: transmittances only shrink, so some slot stops the pixel in
+                    // this step iff the last product is below the threshold -- and in most steps no pixel of the
+                    // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed
+                    const float t0 = mul_keep(T, om0), p1 = mul_keep(t0, om1), p2 = mul_keep(p1, om2), p3 = mul_keep(p2, om3);
+                    float w;
+                    if (__ballot(p3 < 0.0001f) == 0ull) {
+                        const float T_mine = slot == 0 ? T : slot == 1 ? t0 : slot == 2 ? p1 : p2;
+                        w = a_eff * T_mine;
+                        T = p3;
+                    } else {
+                        const bool s0 = t0 < 0.0001f;
+                        const float T1 = s0 ? T : t0;
+                        const float t1 = mul_keep(T1, om1);
+                        const bool s1 = s0 || (t1 < 0.0001f);
+                        const float T2 = s1 ? T1 : t1;
+                        const float t2 = mul_keep(T2, om2);
+                        const bool s2 = s1 || (t2 < 0.0001f);
+                        const float T3 = s2 ? T2 : t2;
+                        const float t3 = mul_keep(T3, om3);
+                        const bool s3 = s2 || (t3 < 0.0001f);
+                        // transmittance in front of MY entry, and whether the pixel had stopped at or before it
+                        const float T_mine = slot == 0 ? T : slot == 1 ? T1 : slot == 2 ? T2 : T3;
+                        const bool stopped = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
+                        w = stopped ? 0.f : a_eff * T_mine;
+                        T = s3 ? T3 : t3;
+                        done = done || s3;
+                    }
                     const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
                     const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
                     D = __builtin_fmaf(depth, w, D);
@@ -222,8 +234,6 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     N1 = __builtin_fmaf(q3.y, w, N1);
                     N2 = __builtin_fmaf(q3.z, w, N2);
                     last_contributor = blend ? contrib0 + (uint32_t)(j - sub) + 1u : last_contributor;
-                    T = s3 ? T3 : t3;
-                    done = done || s3;
                     if (OCC) {
                         // the same chain over the camera-facing entries only, with its own transmittance and stop
                         const float2 e4 = sq4[j];
@@ -231,23 +241,30 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                         const float mo = 1.f - a_o;
                         const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
                                     mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
-                        const float u0 = mul_keep(T_o, mo0);
-                        const bool z0 = u0 < 0.0001f;
-                        const float U1 = z0 ? T_o : u0;
-                        const float u1 = mul_keep(U1, mo1);
-                        const bool z1 = z0 || (u1 < 0.0001f);
-                        const float U2 = z1 ? U1 : u1;
-                        const float u2 = mul_keep(U2, mo2);
-                        const bool z2 = z1 || (u2 < 0.0001f);
-                        const float U3 = z2 ? U2 : u2;
-                        const float u3 = mul_keep(U3, mo3);
-                        const bool z3 = z2 || (u3 < 0.0001f);
-                        const float U_mine = slot == 0 ? T_o : slot == 1 ? U1 : slot == 2 ? U2 : U3;
-                        const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
-                        const float w_o = stopped_o ? 0.f : a_o * U_mine;
+                        const float u0 = mul_keep(T_o, mo0), v1 = mul_keep(u0, mo1), v2 = mul_keep(v1, mo2), v3 = mul_keep(v2, mo3);
+                        float w_o;
+                        if (__ballot(v3 < 0.0001f) == 0ull) {
+                            const float U_mine = slot == 0 ? T_o : slot == 1 ? u0 : slot == 2 ? v1 : v2;
+                            w_o = a_o * U_mine;
+                            T_o = v3;
+                        } else {
+                            const bool z0 = u0 < 0.0001f;
+                            const float U1 = z0 ? T_o : u0;
+                            const float u1 = mul_keep(U1, mo1);
+                            const bool z1 = z0 || (u1 < 0.0001f);
+                            const float U2 = z1 ? U1 : u1;
+                            const float u2 = mul_keep(U2, mo2);
+                            const bool z2 = z1 || (u2 < 0.0001f);
+                            const float U3 = z2 ? U2 : u2;
+                            const float u3 = mul_keep(U3, mo3);
+                            const bool z3 = z2 || (u3 < 0.0001f);
+                            const float U_mine = slot == 0 ? T_o : slot == 1 ? U1 : slot == 2 ? U2 : U3;
+                            const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
+                            w_o = stopped_o ? 0.f : a_o * U_mine;
+                            T_o = z3 ? U3 : u3;
+                            done_o = done_o || z3;
+                        }
                         Co = __builtin_fmaf(e4.x, w_o, Co);
-                        T_o = z3 ? U3 : u3;
-                        done_o = done_o || z3;
                     }
                     if (__ballot(!(done && done_o)) == 0ull) { wave_done = true; break; }
                 }
