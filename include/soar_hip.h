@@ -188,6 +188,12 @@ int soar_lbs_knn_build_grid(const float *verts, int32_t V, const float *vert_wei
                             void *stream);
 int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J,
                        const float *xyz, int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream);
+/* Same with a caller-owned query order [P] (uint32): resort != 0 sorts the queries by grid cell and stores the order;
+ * resort == 0 reuses the stored order (only the cell keys are recomputed from the current positions).  Canonical positions
+ * move little between optimizer steps, so a training loop re-sorts every few steps; results never depend on the order. */
+int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J,
+                               const float *xyz, int32_t P, int32_t K, uint32_t *order, int32_t resort,
+                               float *weights_out, int32_t *knn_idx_out, void *stream);
 
 /* soar_lbs_warp_forward: blend + apply, i.e. SMPL_Guidance.__call__ line TS/utils/smpl.py:613
  *   (pt_mats = einsum("bnj,bjxy->bnxy", w, cano2live)) fused with DiffGaussian.forward's warp

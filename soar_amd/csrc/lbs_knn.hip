@@ -240,6 +240,22 @@ query_cells_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restr
     vals[p] = (uint32_t)p;
 }
 
+// cell keys of the queries taken in a given order (an earlier sort's permutation: positions move little between
+// optimizer steps, so the order still groups most queries by cell; correctness never depends on it)
+__global__ void __launch_bounds__(256)
+query_cells_ordered_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restrict__ meta,
+                           const uint32_t *__restrict__ order, uint32_t *__restrict__ keys)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P) return;
+    const GridMeta m = *meta;
+    const uint32_t p = order[q];
+    const int cx = cell_coord(xyz[3 * p], m.minx, m.inv_h, m.nx);
+    const int cy = cell_coord(xyz[3 * p + 1], m.miny, m.inv_h, m.ny);
+    const int cz = cell_coord(xyz[3 * p + 2], m.minz, m.inv_h, m.nz);
+    keys[q] = (uint32_t)((cz * GRID_MAX + cy) * GRID_MAX + cx);
+}
+
 __device__ __forceinline__ float dist2_exact(float x, float y, float z, float4 v)
 {
 #pragma clang fp contract(off)            // both passes must see the same bits
@@ -595,8 +611,10 @@ int knn_build(const float *verts, int32_t V, const float *vert_weights, int32_t 
     return 0;
 }
 
+// order / resort: optional caller-owned query order [P].  resort != 0 (or order == NULL): the queries are sorted by cell
+// and the order is stored; resort == 0: the stored order is reused and only the cell keys are recomputed.
 int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P, int32_t K,
-              float *weights_out, int32_t *knn_idx_out, hipStream_t stream)
+              float *weights_out, int32_t *knn_idx_out, uint32_t *order, int resort, hipStream_t stream)
 {
     const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
     if (!fast) {
@@ -629,8 +647,15 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
     char *b = static_cast<char *>(g_ws.base);
     uint32_t *qk0 = reinterpret_cast<uint32_t *>(b + o_qk0), *qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
     uint32_t *qv0 = reinterpret_cast<uint32_t *>(b + o_qv0), *qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
-    hipLaunchKernelGGL(query_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, g.meta, qk0, qv0);
-    SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, qsort_bytes, qk0, qk1, qv0, qv1, (size_t)P, 0u, 18u, stream));
+    if (order && !resort) {
+        hipLaunchKernelGGL(query_cells_ordered_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, g.meta, order, qk1);
+        qv1 = order;
+    } else {
+        hipLaunchKernelGGL(query_cells_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, g.meta, qk0, qv0);
+        SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, qsort_bytes, qk0, qk1, qv0, order ? order : qv1, (size_t)P, 0u, 18u,
+                                              stream));
+        if (order) qv1 = order;
+    }
     const dim3 grid((P + WAVE - 1) / WAVE, KNN_SLOTS);
     const char *log_path = getenv("SOAR_KNN_LOG");            // diagnostic: per-wave timeline of one launch
     if (log_path && !knn_idx_out) {
@@ -699,7 +724,21 @@ extern "C" int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const floa
     KnnGrid g;
     if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
     StageTimer timer(ST_LBS_KNN, stream);
-    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1, stream);
+}
+
+extern "C" int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz,
+                                          int32_t P, int32_t K, uint32_t *order, int32_t resort, float *weights_out,
+                                          int32_t *knn_idx_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_knn_sizes(P, V, J, K)) return 1;
+    if (P == 0) return 0;
+    if (!grid_buffer || !xyz || !vert_weights || !weights_out || !order) { set_error("soar_lbs_knn_query_ordered: NULL pointer"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
+    StageTimer timer(ST_LBS_KNN, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, order, resort, stream);
 }
 
 extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights,
@@ -727,5 +766,5 @@ extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *ve
     if (carve_knn_grid(g_grid_ws.base, V, &g, stream)) return 1;
     StageTimer timer(ST_LBS_KNN, stream);
     if (knn_build(verts, V, vert_weights, J, g, stream)) return 1;
-    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1, stream);
 }

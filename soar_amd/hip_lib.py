@@ -52,6 +52,8 @@ SIGNATURES = {
     "soar_lbs_knn_grid_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_lbs_knn_build_grid": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "soar_lbs_knn_query": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "soar_lbs_knn_query_ordered": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp,
+                                             _vp]),
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),

@@ -53,16 +53,28 @@ class KnnGrid:
             check(L.soar_lbs_knn_build_grid(ptr(self.verts), self.V, ptr(self.weights), self.J, ptr(self.buffer),
                                             _stream(verts.device)), "soar_lbs_knn_build_grid")
 
-    def query(self, xyz: torch.Tensor, K: int = 30, return_idx: bool = False):
+    RESORT_EVERY = 8     # queries between two sorts of the query order (positions move little between optimizer steps)
+
+    def query(self, xyz: torch.Tensor, K: int = 30, return_idx: bool = False, out: Optional[torch.Tensor] = None):
+        """Blend weights of `xyz`.  The order in which the queries are grouped by grid cell is kept between calls and
+        refreshed every RESORT_EVERY calls (or when the number of queries changes); it only affects speed."""
         _need_hip(xyz, "xyz")
         L = hip_lib.lib()
         x = _f32(xyz)
         P = int(x.shape[0])
-        out = torch.empty((P, self.J), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((P, self.J), dtype=torch.float32, device=x.device)
         idx = torch.empty((P, K), dtype=torch.int32, device=x.device) if return_idx else None
+        order = getattr(self, "_order", None)
+        resort = order is None or order.numel() != P or self._since_sort >= self.RESORT_EVERY
+        if resort:
+            if order is None or order.numel() != P:
+                order = self._order = torch.empty((P,), dtype=torch.int32, device=x.device)
+            self._since_sort = 0
+        self._since_sort += 1
         with torch.cuda.device(x.device):
-            check(L.soar_lbs_knn_query(ptr(self.buffer), self.V, ptr(self.weights), self.J, ptr(x), P, K, ptr(out), ptr(idx),
-                                       _stream(x.device)), "soar_lbs_knn_query")
+            check(L.soar_lbs_knn_query_ordered(ptr(self.buffer), self.V, ptr(self.weights), self.J, ptr(x), P, K, ptr(order),
+                                               int(resort), ptr(out), ptr(idx), _stream(x.device)), "soar_lbs_knn_query_ordered")
         return (out, idx) if return_idx else out
 
 

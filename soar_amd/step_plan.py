@@ -81,6 +81,8 @@ class FrameStepPlan:
         self.g_scales = torch.empty((self.n, P, 3), **f)
         self.g_colors = torch.empty((self.n, P, 3), **f)
         self.losses = torch.empty((self.n,), **f)
+        self.knn_order = torch.empty((P,), dtype=torch.int32, device=dev)     # query order of the KNN, refreshed every few steps
+        self.steps = 0
         # frame 0 stays on the caller's stream, the others get their own (4 hardware queues in all for 4 frames)
         self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)]
         self.graphs = None
@@ -91,11 +93,14 @@ class FrameStepPlan:
             self._capture()
 
     # ---- the three pieces -------------------------------------------------------------------------------------------
-    def _prologue(self, stream: int) -> None:
+    RESORT_EVERY = 8      # steps between two sorts of the KNN query order (lbs.KnnGrid.RESORT_EVERY)
+
+    def _prologue(self, stream: int, resort: bool = True) -> None:
         L, s = self.L, self.seq
         self.flat.flat.zero_()
-        check(L.soar_lbs_knn_query(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
-                                   ptr(s.xyz.detach()), self.P, 30, ptr(self.blend_weights), None, stream), "knn_query")
+        check(L.soar_lbs_knn_query_ordered(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
+                                           ptr(s.xyz.detach()), self.P, 30, ptr(self.knn_order), int(resort),
+                                           ptr(self.blend_weights), None, stream), "knn_query")
 
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
@@ -141,10 +146,11 @@ class FrameStepPlan:
         cap = torch.cuda.Stream(device=dev)
         graphs = {}
         with torch.cuda.device(dev):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
-                self._prologue(cap.cuda_stream)
-            graphs["prologue"] = g
+            for name, resort in (("prologue_resort", True), ("prologue", False)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    self._prologue(cap.cuda_stream, resort)
+                graphs[name] = g
             for i in range(self.n):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=cap):
@@ -161,9 +167,10 @@ class FrameStepPlan:
         dev = self.device
         main = torch.cuda.current_stream(dev)
         with torch.cuda.device(dev):
-            self._prologue(main.cuda_stream)
+            self._prologue(main.cuda_stream, self.steps % self.RESORT_EVERY == 0)
             self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
             self._epilogue()
+        self.steps += 1
 
     def _fan_out(self, main, fn) -> None:
         """frames 1.. on their own streams (forked from `main`), frame 0 on `main`, then join"""
@@ -194,9 +201,10 @@ class FrameStepPlan:
             self._run_eager()
             return self.losses
         main = torch.cuda.current_stream(dev)
-        self.graphs["prologue"].replay()
+        self.graphs["prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"].replay()
         self._fan_out(main, lambda i, s: self.graphs[i].replay())
         self.graphs["epilogue"].replay()
+        self.steps += 1
         return self.losses
 
     def check(self):

@@ -126,3 +126,22 @@ def test_knn_grid_built_once_matches_one_call_form():
         w_ref, i_ref = lbs.knn_blend_weights(x, bm.v_template.to(DEV), bm.lbs_weights.to(DEV), return_idx=True)
         w, i = grid.query(x, return_idx=True)
         assert torch.equal(w, w_ref) and torch.equal(i, i_ref)
+
+
+def test_knn_query_order_reuse_is_exact():
+    """KnnGrid.query keeps the cell-grouping order of the queries between calls: with moved points and a stale order the
+    weights and neighbour sets are those of a freshly sorted query."""
+    from soar_amd import lbs
+    bm = syn.make_body_model(0)
+    v, w = bm.v_template.to(DEV), bm.lbs_weights.to(DEV)
+    grid = lbs.KnnGrid(v, w)
+    x0 = syn.make_surfels(3000, 2).xyz.to(DEV)
+    grid.query(x0)                                              # sorts and stores the order
+    g = torch.Generator().manual_seed(3)
+    for step in range(1, 12):                                   # crosses a re-sort (RESORT_EVERY = 8)
+        x = x0 + 0.02 * step * torch.randn(x0.shape, generator=g).to(DEV)
+        w_got, i_got = grid.query(x, return_idx=True)
+        w_ref, i_ref = lbs.knn_blend_weights(x, v, w, return_idx=True)
+        same = (torch.sort(i_got, 1).values == torch.sort(i_ref, 1).values).all(1)
+        assert float(same.float().mean()) > 0.999
+        torch.testing.assert_close(w_got[same], w_ref[same], rtol=1e-5, atol=1e-7)
