@@ -261,9 +261,11 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     SOAR_HIP_OK(hipMemsetAsync(g.bucket_cnt, 0, 8192 * sizeof(uint32_t), stream));
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
-    if (launch_scan(*prm, g, stream)) return 1;
     if (!prm->sort_descending && launch_depth_buckets(*prm, g, stream)) return 1;
-    if (!num_rendered_host) return 0;             // asynchronous form: read R later with soar_rast_num_rendered()
+    // asynchronous form: R (and the prefix sum of tiles_touched it comes from) is produced by soar_rast_num_rendered() if
+    // the caller asks for it; the sync-free form never needs it
+    if (!num_rendered_host) return 0;
+    if (launch_scan(*prm, g, stream)) return 1;
     // the one host synchronisation of the forward pass (rasterizer_impl.cu:250-252)
     uint32_t r = 0;
     SOAR_HIP_OK(hipMemcpyAsync(&r, g.point_offsets + (prm->P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -281,6 +283,9 @@ int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_
     if (check_aligned(geom_buffer, "geom_buffer")) return 1;
     GeomBuf g;
     carve_geom(const_cast<void *>(geom_buffer), P, M, &g);
+    SoarRastParams scan_prm = {};
+    scan_prm.P = P;
+    if (launch_scan(scan_prm, g, stream)) return 1;            // inclusive sum of tiles_touched (rasterizer_impl.cu:242-245)
     uint32_t r = 0;
     SOAR_HIP_OK(hipMemcpyAsync(&r, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SOAR_HIP_OK(hipStreamSynchronize(stream));
@@ -353,8 +358,9 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
     // of back views keeps the 64-bit key sort (rast_binning.hip)
     if (num_rendered > 0 && !prm->sort_descending) {
         if (launch_tile_binning(*prm, g, b, img, num_rendered, stream)) return 1;
-    } else if (launch_binning(*prm, g, b, img, num_rendered, stream)) {
-        return 1;
+    } else {
+        if (launch_scan(*prm, g, stream)) return 1;                // key emission needs the prefix sum of tiles_touched
+        if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
     }
     if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
@@ -490,6 +496,9 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
     if (dst) SOAR_HIP_OK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, stream))
     COPY(cov3D, g.cov3D, P * 6 * sizeof(float));
     COPY(tiles_touched, g.tiles_touched, P * sizeof(uint32_t));
+    if (point_offsets || keys_unsorted || vals_unsorted || keys_sorted) {
+        if (launch_scan(*prm, g, stream)) return 1;                // the sync-free forward never computes the prefix sum
+    }
     COPY(point_offsets, g.point_offsets, P * sizeof(uint32_t));
     if (image_buffer) {
         carve_image(const_cast<void *>(image_buffer), prm->W, prm->H, &img);
