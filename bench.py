@@ -213,19 +213,20 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
-    ap.add_argument("--mode", default=None, choices=["plan", "graph", "async", "sync"],
+    ap.add_argument("--mode", default=None, choices=["plan", "plan-eager", "graph", "async", "sync"],
                     help="plan: explicit launch plan of the step (soar_amd/step_plan.py: per-frame forward+backward chains as HIP "
                          "graphs on their own streams, no autograd in the loop; default on one GPU, falls back to graph); "
-                         "graph: each step replayed from a HIP graph (falls back to async if capture fails; default on one "
-                         "GPU); async: sync-free rasterizer, eager launches (default with several ranks: graph capture next "
-                         "to a live RCCL communicator could not be tested on the 1-GPU development box); sync: the "
-                         "reference's blocking num_rendered read-back")
+                         "plan-eager: the same launch plan without graphs (default with several ranks: graph capture next to a "
+                         "live RCCL communicator could not be tested on the 1-GPU development box); "
+                         "graph: the autograd step replayed from one HIP graph (falls back to async if capture fails); "
+                         "async: sync-free rasterizer through autograd, eager launches; sync: the reference's blocking "
+                         "num_rendered read-back")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.mode is None:
-        args.mode = "plan" if world == 1 else "async"
+        args.mode = "plan" if world == 1 else "plan-eager"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -270,20 +271,22 @@ def main():
     torch.cuda.synchronize()
     stats_warm = dict(rasterizer.stats)
     capacity = None if args.mode == "sync" else 2 * r_seen
+
     mode, stepper = args.mode, None
     plan = None
-    if mode == "plan":
+    if mode in ("plan", "plan-eager"):
         try:
             from soar_amd.step_plan import FrameStepPlan
-            plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat)
+            plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat, use_graphs=(mode == "plan"))
 
             def stepper(frames):
                 plan.run(frames)
                 return flat.all_reduce()
         except Exception as e:
-            print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode graph", file=sys.stderr)
+            fallback = "graph" if (mode == "plan" and world == 1) else "async"
+            print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode {fallback}", file=sys.stderr)
             torch.cuda.synchronize()
-            mode, plan, stepper = "graph", None, None
+            mode, plan, stepper = fallback, None, None
     if mode == "graph":
         try:
             stepper = GraphStep(seq, targets, flat, bg, len(frames_of(0)), capacity)
