@@ -231,6 +231,19 @@ int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *norma
                     float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
                     float *dL_dopac, void *stream);
 
+/* ---- renderer post-ops: depth2normal and normal2curv
+ *      (TS/renderer/diff_gaussian_rasterizer.py:359-448) as fused 5-point-stencil kernels with analytic backward.
+ *   depth [1,H,W], normal [3,H,W], curv [1,H,W]; mask [1,H,W] one byte per pixel (torch.bool);
+ *   prcp_* = principal point (cx/W, cy/H); focal_k00 = focal(FoVy, H) is applied to x and focal_k11 = focal(FoVx, W) to y,
+ *   as the reference's K does (:386-389).  The backward calls zero-fill and fully define their outputs. */
+int soar_depth2normal(int32_t W, int32_t H, const float *depth, const uint8_t *mask, float prcp_x, float prcp_y,
+                      float focal_k00, float focal_k11, float *normal_out, void *stream);
+int soar_depth2normal_backward(int32_t W, int32_t H, const float *depth, const uint8_t *mask, float prcp_x, float prcp_y,
+                               float focal_k00, float focal_k11, const float *dL_dnormal, float *dL_ddepth, void *stream);
+int soar_normal2curv(int32_t W, int32_t H, const float *normal, const uint8_t *mask, float *curv_out, void *stream);
+int soar_normal2curv_backward(int32_t W, int32_t H, const float *normal, const uint8_t *mask, const float *dL_dcurv,
+                              float *dL_dnormal, void *stream);
+
 /* ---- per-stage timing (no reference counterpart; used by bench.py for the roofline figure) ----
  * When enabled, every kernel stage is bracketed by two hipEvents recorded on the launch stream.
  * soar_prof_read synchronises the pending events and returns the accumulated device time and launch count of

@@ -34,9 +34,11 @@ EXTRA_FLAGS = {
     # the per-Gaussian backward has cancellation-prone expressions (quaternion gradient): keep the reference's
     # operation order un-contracted so that rounding follows an IEEE evaluation of the reference source
     "rast_geom_bwd.hip": ["-ffp-contract=off"],
+    # differences of identical products must be exactly zero (replicate-padded borders), as in the reference's torch ops
+    "postops.hip": ["-ffp-contract=off"],
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
-           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip"]
+           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip"]
 HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
 
 

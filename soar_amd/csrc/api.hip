@@ -49,7 +49,7 @@ double g_stage_ms[ST_COUNT];
 long long g_stage_n[ST_COUNT];
 const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "emit_keys", "sort", "tile_ranges", "render_forward",
                                        "render_backward", "geometry_backward", "lbs_knn_weights", "lbs_warp_forward",
-                                       "lbs_warp_backward", "dist2_knn3", "frame_loss"};
+                                       "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops"};
 void prof_drain()
 {
     for (int i = 0; i < g_slot_used; i++) {

@@ -1,0 +1,199 @@
+// postops.hip -- the renderer plugin's image-space post-ops as fused 5-point-stencil kernels, forward and backward.
+//
+// Replaces depth2normal and normal2curv (TS/renderer/diff_gaussian_rasterizer.py:359-448): in eager torch each is a
+// dozen full-image kernels (pad, four masked neighbour differences, four cross products, normalise, mask) plus the
+// autograd graph behind them.  Here one thread per pixel reads its five stencil points once.
+//
+// Shared definition (replicate padding: a neighbour outside the image is the border pixel itself):
+//   c = v[p] m[p],  u = (v[up] - c) m[up],  l = (v[left] - c) m[left],  b = (v[down] - c) m[down],  r = (v[right] - c) m[right]
+// depth2normal: v = back-projected point d (ax, ay, 1), ax = (x - cx W) / K00, ay = (y - cy H) / K11 with the reference's
+//   K00 = focal(FoVy, H), K11 = focal(FoVx, W);  N = u x l + r x u + b x r + l x b;  n = N / max(|N|, 1e-12) m[p].
+// normal2curv: v = normal;  curv = sum_ch |(u + l + b + r)_ch| m[p].
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct D2NArgs {
+    int W, H;
+    float cxW, cyH, inv_k00, inv_k11;
+    const float *depth;
+    const uint8_t *mask;
+    float *normal;                 // forward out [3,H,W]
+    const float *dL_dnormal;       // backward in
+    float *dL_ddepth;              // backward out (zero-filled by the caller of the kernel)
+};
+
+struct Stencil {
+    int ip, iu, il, ib, ir;        // pixel indices (replicate padding)
+    float mp, mu, ml, mb, mr;
+};
+__device__ __forceinline__ Stencil stencil_of(int x, int y, int W, int H, const uint8_t *mask)
+{
+    Stencil s;
+    const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    s.ip = y * W + x; s.iu = yu * W + x; s.ib = yb * W + x; s.il = y * W + xl; s.ir = y * W + xr;
+    s.mp = mask[s.ip] ? 1.f : 0.f; s.mu = mask[s.iu] ? 1.f : 0.f; s.ml = mask[s.il] ? 1.f : 0.f;
+    s.mb = mask[s.ib] ? 1.f : 0.f; s.mr = mask[s.ir] ? 1.f : 0.f;
+    return s;
+}
+__device__ __forceinline__ V3 ray_of(const D2NArgs &a, int idx)
+{
+    const int x = idx % a.W, y = idx / a.W;
+    return {((float)x - a.cxW) * a.inv_k00, ((float)y - a.cyH) * a.inv_k11, 1.f};
+}
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) depth2normal_kernel(D2NArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const Stencil s = stencil_of(x, y, a.W, a.H, a.mask);
+    const V3 ap = ray_of(a, s.ip), au = ray_of(a, s.iu), al = ray_of(a, s.il), ab = ray_of(a, s.ib), ar = ray_of(a, s.ir);
+    // back-projected points in the reference's order of operations: ((x - cx W) d) / K  (the differences below cancel
+    // most of the digits, so the rounding of the points decides the last digits of the normal)
+    auto point = [&](int idx) -> V3 {
+        const float d = a.depth[idx];
+        const int px = idx % a.W, py = idx / a.W;
+        return {(((float)px - a.cxW) * d) * a.inv_k00, (((float)py - a.cyH) * d) * a.inv_k11, d};
+    };
+    const V3 c = point(s.ip) * s.mp;
+    const V3 u = (point(s.iu) - c) * s.mu, l = (point(s.il) - c) * s.ml;
+    const V3 b = (point(s.ib) - c) * s.mb, r = (point(s.ir) - c) * s.mr;
+    const V3 N = cross(u, l) + cross(r, u) + cross(b, r) + cross(l, b);
+    const float len = sqrtf(dot(N, N)), inv = 1.f / fmaxf(len, 1e-12f);
+    const V3 n = N * inv;
+    const size_t hw = (size_t)a.W * a.H;
+    if (!BACKWARD) {
+        a.normal[s.ip] = n.x * s.mp; a.normal[hw + s.ip] = n.y * s.mp; a.normal[2 * hw + s.ip] = n.z * s.mp;
+        return;
+    }
+    // out = n m[p];  dL/dN = (g - n (n.g)) / |N|.  Where N vanishes (|N| <= eps: masked-out or replicate-padded neighbours
+    // leave fewer than two independent differences) the normalisation is the linear map N / eps: formally dL/dN = g / eps
+    // = 1e12 g, but every term it feeds is multiplied by a vanishing difference or cancels against its mirror image
+    // (up == centre at the border), so the exact gradient contribution of such a pixel is zero.  It is dropped here; in
+    // float32 the 1e12-scaled pairs only cancel up to the order of summation (torch's own autograd absorbs the
+    // neighbours' finite terms into them).
+    V3 g = {a.dL_dnormal[s.ip] * s.mp, a.dL_dnormal[hw + s.ip] * s.mp, a.dL_dnormal[2 * hw + s.ip] * s.mp};
+    if (!(len > 1e-12f)) return;
+    const V3 gN = (g - n * dot(n, g)) * inv;
+    // N = u x l + r x u + b x r + l x b  ->  dL/du = (l - r) x gN, dL/dl = (b - u) x gN, dL/db = (r - l) x gN, dL/dr = (u - b) x gN
+    const V3 du = cross(l - r, gN) * s.mu, dl = cross(b - u, gN) * s.ml, db = cross(r - l, gN) * s.mb, dr = cross(u - b, gN) * s.mr;
+    const V3 dc = (du + dl + db + dr) * -1.f;               // every difference subtracts c (before its own mask, applied above)
+    atomicAdd(&a.dL_ddepth[s.ip], dot(ap, dc) * s.mp);
+    atomicAdd(&a.dL_ddepth[s.iu], dot(au, du));
+    atomicAdd(&a.dL_ddepth[s.il], dot(al, dl));
+    atomicAdd(&a.dL_ddepth[s.ib], dot(ab, db));
+    atomicAdd(&a.dL_ddepth[s.ir], dot(ar, dr));
+}
+
+struct N2CArgs {
+    int W, H;
+    const float *normal;
+    const uint8_t *mask;
+    float *curv;                   // forward out [1,H,W]
+    const float *dL_dcurv;         // backward in
+    float *dL_dnormal;             // backward out [3,H,W] (zero-filled by the caller of the kernel)
+};
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) normal2curv_kernel(N2CArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const Stencil s = stencil_of(x, y, a.W, a.H, a.mask);
+    const size_t hw = (size_t)a.W * a.H;
+    auto at = [&](int i) -> V3 { return {a.normal[i], a.normal[hw + i], a.normal[2 * hw + i]}; };
+    const V3 c = at(s.ip) * s.mp;
+    const V3 sum = ((at(s.iu) - c) * s.mu + (at(s.il) - c) * s.ml + (at(s.ib) - c) * s.mb + (at(s.ir) - c) * s.mr) * s.mp;
+    if (!BACKWARD) {
+        a.curv[s.ip] = fabsf(sum.x) + fabsf(sum.y) + fabsf(sum.z);
+        return;
+    }
+    const float g = a.dL_dcurv[s.ip] * s.mp;
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    const V3 ds = {g * sgn(sum.x), g * sgn(sum.y), g * sgn(sum.z)};
+    const float wc = -(s.mu + s.ml + s.mb + s.mr) * s.mp;
+    const int idx[5] = {s.ip, s.iu, s.il, s.ib, s.ir};
+    const float w[5] = {wc, s.mu, s.ml, s.mb, s.mr};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (w[k] == 0.f) continue;
+        atomicAdd(&a.dL_dnormal[idx[k]], ds.x * w[k]);
+        atomicAdd(&a.dL_dnormal[hw + idx[k]], ds.y * w[k]);
+        atomicAdd(&a.dL_dnormal[2 * hw + idx[k]], ds.z * w[k]);
+    }
+}
+
+dim3 pix_grid(int W, int H) { return dim3((W + 31) / 32, (H + 7) / 8); }
+
+}  // namespace
+
+}  // namespace soar
+
+using namespace soar;
+
+extern "C" int soar_depth2normal(int32_t W, int32_t H, const float *depth, const uint8_t *mask, float prcp_x, float prcp_y,
+                                 float focal_k00, float focal_k11, float *normal_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !depth || !mask || !normal_out) { set_error("soar_depth2normal: bad arguments"); return 1; }
+    D2NArgs a = {};
+    a.W = W; a.H = H; a.cxW = prcp_x * W; a.cyH = prcp_y * H; a.inv_k00 = 1.f / focal_k00; a.inv_k11 = 1.f / focal_k11;
+    a.depth = depth; a.mask = mask; a.normal = normal_out;
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(depth2normal_kernel<false>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("depth2normal", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_depth2normal_backward(int32_t W, int32_t H, const float *depth, const uint8_t *mask, float prcp_x, float prcp_y,
+                                          float focal_k00, float focal_k11, const float *dL_dnormal, float *dL_ddepth, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !depth || !mask || !dL_dnormal || !dL_ddepth) { set_error("soar_depth2normal_backward: bad arguments"); return 1; }
+    D2NArgs a = {};
+    a.W = W; a.H = H; a.cxW = prcp_x * W; a.cyH = prcp_y * H; a.inv_k00 = 1.f / focal_k00; a.inv_k11 = 1.f / focal_k11;
+    a.depth = depth; a.mask = mask; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth;
+    SOAR_HIP_OK(hipMemsetAsync(dL_ddepth, 0, sizeof(float) * (size_t)W * H, stream));
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(depth2normal_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("depth2normal_backward", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_normal2curv(int32_t W, int32_t H, const float *normal, const uint8_t *mask, float *curv_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !normal || !mask || !curv_out) { set_error("soar_normal2curv: bad arguments"); return 1; }
+    N2CArgs a = {};
+    a.W = W; a.H = H; a.normal = normal; a.mask = mask; a.curv = curv_out;
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(normal2curv_kernel<false>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("normal2curv", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_normal2curv_backward(int32_t W, int32_t H, const float *normal, const uint8_t *mask, const float *dL_dcurv,
+                                         float *dL_dnormal, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !normal || !mask || !dL_dcurv || !dL_dnormal) { set_error("soar_normal2curv_backward: bad arguments"); return 1; }
+    N2CArgs a = {};
+    a.W = W; a.H = H; a.normal = normal; a.mask = mask; a.dL_dcurv = dL_dcurv; a.dL_dnormal = dL_dnormal;
+    SOAR_HIP_OK(hipMemsetAsync(dL_dnormal, 0, sizeof(float) * 3 * (size_t)W * H, stream));
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(normal2curv_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("normal2curv_backward", stream, 0);
+    return 0;
+}

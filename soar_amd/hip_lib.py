@@ -57,6 +57,11 @@ SIGNATURES = {
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    "soar_depth2normal": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
+    "soar_depth2normal_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp,
+                                             _vp]),
+    "soar_normal2curv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "soar_normal2curv_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_frame_loss": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_selftest_wave_reduce": (C.c_int, [_vp, _vp]),

@@ -1,55 +1,96 @@
 """Image-space post-ops of the renderer plugin: ``depth2normal`` and ``normal2curv``
-(TS/renderer/diff_gaussian_rasterizer.py:359-448).  SURVEY.md section 8(f) row 1 marks these "next": for now they
-run as differentiable torch ops on the HIP device (checked against golden vectors of the reference functions)."""
+(TS/renderer/diff_gaussian_rasterizer.py:359-448) as fused 5-point-stencil HIP kernels with analytic backward
+(soar_amd/csrc/postops.hip).  The reference runs ~25 full-image torch kernels per view for
+these two; here each direction of each op is one launch.  HIP devices only -- no eager fallback (the torch restatement
+that pins the semantics lives in oracle/postops_oracle.py and is used by the tests)."""
 from __future__ import annotations
 
 import math
 
 import torch
-import torch.nn.functional as F
+
+from .. import hip_lib
+from ..hip_lib import check, ptr
 
 
 def fov2focal(fov, pixels):
     return pixels / (2 * math.tan(fov / 2))
 
 
-def _cross_stencil(img_hwc: torch.Tensor, mask_hwc: torch.Tensor):
-    """Centre value and the four masked neighbour differences on a replicate-padded grid."""
-    p = F.pad(img_hwc[None], [0, 0, 1, 1, 1, 1], mode="replicate")
-    m = F.pad(mask_hwc[None].to(torch.float32), [0, 0, 1, 1, 1, 1], mode="replicate").to(torch.bool)
-    c = p[:, 1:-1, 1:-1, :] * m[:, 1:-1, 1:-1, :]
-    u = (p[:, :-2, 1:-1, :] - c) * m[:, :-2, 1:-1, :]
-    l = (p[:, 1:-1, :-2, :] - c) * m[:, 1:-1, :-2, :]
-    b = (p[:, 2:, 1:-1, :] - c) * m[:, 2:, 1:-1, :]
-    r = (p[:, 1:-1, 2:, :] - c) * m[:, 1:-1, 2:, :]
-    return c, u, l, b, r, m[0, 1:-1, 1:-1, :]
+def _need_hip(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on '{t.device}': the post-ops run on HIP devices only (torch device type 'cuda' on "
+                           "ROCm); there is no CPU fallback")
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _Depth2Normal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, mask, prcp_x, prcp_y, k00, k11):
+        _need_hip(depth, "depth")
+        L = hip_lib.lib()
+        H, W = int(depth.shape[-2]), int(depth.shape[-1])
+        d = depth.detach().to(torch.float32).contiguous()
+        m = mask.to(device=depth.device, dtype=torch.uint8).contiguous()
+        out = torch.empty((3, H, W), dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            check(L.soar_depth2normal(W, H, ptr(d), ptr(m), prcp_x, prcp_y, k00, k11, ptr(out), _stream(depth.device)),
+                  "soar_depth2normal")
+        ctx.save_for_backward(d, m)
+        ctx.consts = (W, H, prcp_x, prcp_y, k00, k11, depth.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, m = ctx.saved_tensors
+        W, H, prcp_x, prcp_y, k00, k11, shape = ctx.consts
+        L = hip_lib.lib()
+        g = g.to(torch.float32).contiguous()
+        gd = torch.empty((1, H, W), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            check(L.soar_depth2normal_backward(W, H, ptr(d), ptr(m), prcp_x, prcp_y, k00, k11, ptr(g), ptr(gd), _stream(d.device)),
+                  "soar_depth2normal_backward")
+        return gd.reshape(shape), None, None, None, None, None
+
+
+class _Normal2Curv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, normal, mask):
+        _need_hip(normal, "normal")
+        L = hip_lib.lib()
+        H, W = int(normal.shape[-2]), int(normal.shape[-1])
+        n = normal.detach().to(torch.float32).contiguous()
+        m = mask.to(device=normal.device, dtype=torch.uint8).contiguous()
+        out = torch.empty((1, H, W), dtype=torch.float32, device=normal.device)
+        with torch.cuda.device(normal.device):
+            check(L.soar_normal2curv(W, H, ptr(n), ptr(m), ptr(out), _stream(normal.device)), "soar_normal2curv")
+        ctx.save_for_backward(n, m)
+        ctx.consts = (W, H, normal.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, m = ctx.saved_tensors
+        W, H, shape = ctx.consts
+        L = hip_lib.lib()
+        g = g.to(torch.float32).contiguous()
+        gn = torch.empty((3, H, W), dtype=torch.float32, device=n.device)
+        with torch.cuda.device(n.device):
+            check(L.soar_normal2curv_backward(W, H, ptr(n), ptr(m), ptr(g), ptr(gn), _stream(n.device)), "soar_normal2curv_backward")
+        return gn.reshape(shape), None
 
 
 def depth2normal(depth: torch.Tensor, mask: torch.Tensor, camera) -> torch.Tensor:
-    """depth [1,H,W], mask [1,H,W] bool -> normals [3,H,W] from back-projected depth (4-neighbour cross products)."""
-    camD = depth.permute(1, 2, 0)
-    msk = mask.permute(1, 2, 0)
-    H, W = camD.shape[:2]
-    dev = camD.device
-    hh, ww = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev),
-                            indexing="ij")
-    px = ww[..., None] - float(camera.prcppoint[0]) * camera.image_width
-    py = hh[..., None] - float(camera.prcppoint[1]) * camera.image_height
-    p = torch.cat([px, py], -1) * camD
-    # the reference builds K = diag(focal(FoVy,H), focal(FoVx,W)) and applies its inverse to (x, y) in that order
-    K00 = fov2focal(float(camera.FoVy), camera.image_height)
-    K11 = fov2focal(float(camera.FoVx), camera.image_width)
-    p = p * torch.tensor([1.0 / K00, 1.0 / K11], device=dev)
-    cam_pos = torch.cat([p, camD], -1)
-    _, u, l, b, r, m = _cross_stencil(cam_pos, msk)
-    n = (torch.linalg.cross(u, l, dim=-1) + torch.linalg.cross(r, u, dim=-1) + torch.linalg.cross(b, r, dim=-1)
-         + torch.linalg.cross(l, b, dim=-1))[0]
-    n = F.normalize(n, dim=-1)
-    return (n * m).permute(2, 0, 1)
+    """depth [1,H,W], mask [1,H,W] bool -> normals [3,H,W] from back-projected depth (4-neighbour cross products).
+    The reference builds K = diag(focal(FoVy,H), focal(FoVx,W)) and applies its inverse to (x, y) in that order."""
+    k00 = fov2focal(float(camera.FoVy), camera.image_height)
+    k11 = fov2focal(float(camera.FoVx), camera.image_width)
+    return _Depth2Normal.apply(depth, mask, float(camera.prcppoint[0]), float(camera.prcppoint[1]), float(k00), float(k11))
 
 
 def normal2curv(normal: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """normal [3,H,W], mask [1,H,W] bool -> curvature proxy [1,H,W] (L1 norm of the masked 4-neighbour Laplacian)."""
-    _, u, l, b, r, _ = _cross_stencil(normal.permute(1, 2, 0), mask.permute(1, 2, 0))
-    curv = (u + l + b + r)[0].permute(2, 0, 1) * mask
-    return curv.norm(1, 0, True)
+    return _Normal2Curv.apply(normal, mask)

@@ -344,3 +344,56 @@ def test_step_plan_matches_autograd(use_graphs):
         assert float(want.abs().sum()) > 0
         np.testing.assert_allclose(losses.cpu().numpy(), want_losses.cpu().numpy(), rtol=1e-6)
         assert _rel(flat.flat.cpu().numpy(), want.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (61, 97), (540, 960)])
+def test_postop_kernels_match_oracle(hw):
+    """soar_depth2normal / soar_normal2curv (fused 5-point stencils, analytic backward) == oracle/postops_oracle.py
+    (the torch restatement pinned on the reference's golden vectors): values and gradients, borders and masks included."""
+    import os
+    from oracle import postops_oracle as po
+    from soar_amd.renderer import postops
+    Hh, Ww = hw
+    g = torch.Generator().manual_seed(11)
+    yy, xx = torch.meshgrid(torch.arange(Hh, dtype=torch.float32), torch.arange(Ww, dtype=torch.float32), indexing="ij")
+    # a smooth surface with some roughness (pure per-pixel noise makes the cross-product sums cancel to rounding level)
+    depth = (2.0 + 0.3 * torch.sin(xx / 7.0) * torch.cos(yy / 5.0) + 0.02 * torch.rand(Hh, Ww, generator=g))[None]
+    mask = torch.rand(1, Hh, Ww, generator=g) > 0.3
+    normal = torch.nn.functional.normalize(torch.randn(3, Hh, Ww, generator=g), dim=0)
+    cam = types.SimpleNamespace(prcppoint=torch.tensor([0.47, 0.55]), image_width=Ww, image_height=Hh, FoVx=1.1, FoVy=0.8)
+    up_n, up_c = torch.randn(3, Hh, Ww, generator=g), torch.randn(1, Hh, Ww, generator=g)
+
+    # gradient reference in float64: where a pixel's summed cross products vanish (masked / replicate-padded neighbours) the
+    # normalisation contributes +-1e12-scaled pairs that cancel exactly in exact arithmetic; float32 autograd absorbs the
+    # neighbours' finite terms into them (it returns 0 there), float64 keeps them
+    d_ref = depth.double().requires_grad_(True)
+    n_out_ref = po.depth2normal(d_ref, mask, cam)
+    (n_out_ref * up_n.double()).sum().backward()
+    d_ref = types.SimpleNamespace(grad=d_ref.grad.float())
+    n_out_ref = po.depth2normal(depth, mask, cam)                 # values: against the float32 restatement
+    d_hip = depth.to(DEV).requires_grad_(True)
+    n_out = postops.depth2normal(d_hip, mask.to(DEV), cam)
+    (n_out * up_n.to(DEV)).sum().backward()
+    np.testing.assert_allclose(n_out.detach().cpu().numpy(), n_out_ref.detach().numpy(), rtol=0, atol=2e-5)
+    assert _rel(d_hip.grad.cpu().numpy(), d_ref.grad.numpy()) < 2e-4
+    assert float(np.linalg.norm(d_hip.grad.cpu().numpy() - d_ref.grad.numpy()) / np.linalg.norm(d_ref.grad.numpy())) < 1e-4
+
+    n_ref = normal.clone().requires_grad_(True)
+    c_out_ref = po.normal2curv(n_ref, mask)
+    (c_out_ref * up_c).sum().backward()
+    n_hip = normal.to(DEV).requires_grad_(True)
+    c_out = postops.normal2curv(n_hip, mask.to(DEV))
+    (c_out * up_c.to(DEV)).sum().backward()
+    np.testing.assert_allclose(c_out.detach().cpu().numpy(), c_out_ref.detach().numpy(), rtol=0, atol=5e-6)
+    assert _rel(n_hip.grad.cpu().numpy(), n_ref.grad.numpy()) < 1e-5
+
+    if hw == (24, 40):      # the reference's own outputs on these very inputs
+        G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_functions.npz"))
+        out = postops.depth2normal(torch.from_numpy(G["d2n_depth"]).to(DEV), torch.from_numpy(G["d2n_mask"]).to(DEV),
+                                   types.SimpleNamespace(prcppoint=torch.from_numpy(G["d2n_prcp"]), image_width=Ww, image_height=Hh,
+                                                         FoVx=float(G["d2n_fov"][0]), FoVy=float(G["d2n_fov"][1])))
+        np.testing.assert_allclose(out.cpu().numpy(), G["d2n_out"], rtol=0, atol=5e-6)
+        out = postops.normal2curv(torch.from_numpy(G["n2c_normal"]).to(DEV), torch.from_numpy(G["d2n_mask"]).to(DEV))
+        np.testing.assert_allclose(out.cpu().numpy(), G["n2c_out"], rtol=0, atol=5e-6)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        postops.normal2curv(normal, mask)

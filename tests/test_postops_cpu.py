@@ -1,4 +1,4 @@
-"""CPU tests of the renderer plugin's host-side pieces against golden vectors of the reference's own functions
+"""CPU tests of the post-op oracle (oracle/postops_oracle.py) and of the renderer plugin's host-side pieces against golden vectors of the reference's own functions
 (tests/golden/reference_functions.npz, produced by tests/golden/make_lbs_golden.py from
 TS/renderer/diff_gaussian_rasterizer.py:321-448 and TS/renderer/gaussian_batch_renderer.py:404-471)."""
 import os
@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from soar_amd.renderer import cameras, postops
+from oracle import postops_oracle as postops
+from soar_amd.renderer import cameras
 from soar_amd.renderer.diff_gaussian import axis_permutation, transform_point_cloud
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_functions.npz"))
