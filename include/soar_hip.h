@@ -231,6 +231,14 @@ int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *norma
                     float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
                     float *dL_dopac, void *stream);
 
+/* ---- SSIM (TS/utils/loss_utils.py:36-76: 11x11 Gaussian window, sigma 1.5, zero padding):
+ *      mean SSIM of img1, img2 [C,H,W] and, when dssim_dimg1 != NULL, its gradient w.r.t. img1 -- one kernel per
+ *      direction instead of five grouped convolutions and ~15 element-wise kernels each way.
+ *   scratch: soar_ssim_scratch_floats(C, H, W) floats. */
+int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count);
+int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
+              float *dssim_dimg1, void *stream);
+
 /* ---- renderer post-ops: depth2normal and normal2curv
  *      (TS/renderer/diff_gaussian_rasterizer.py:359-448) as fused 5-point-stencil kernels with analytic backward.
  *   depth [1,H,W], normal [3,H,W], curv [1,H,W]; mask [1,H,W] one byte per pixel (torch.bool);

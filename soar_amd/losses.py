@@ -58,3 +58,43 @@ def frame_loss(color: torch.Tensor, normal: torch.Tensor, depth: torch.Tensor, o
                targets: Dict[str, torch.Tensor], weights: Sequence[float] = DEFAULT_WEIGHTS) -> torch.Tensor:
     """targets: {"color": [3,H,W], "mask": [1,H,W], "normal": [3,H,W]}; returns the scalar loss (autograd-enabled)."""
     return _FrameLoss.apply(color, normal, depth, opac, targets["color"], targets["mask"], targets["normal"], tuple(weights))
+
+
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        if not img1.is_cuda:
+            raise RuntimeError("ssim runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
+        import ctypes as C
+        L = hip_lib.lib()
+        dev = img1.device
+        a = img1.detach().to(torch.float32).contiguous()
+        b = img2.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if a.shape != b.shape or a.dim() not in (3, 4):
+            raise ValueError(f"ssim needs two images of the same [C,H,W] / [B,C,H,W] shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+        Ht, Wd = int(a.shape[-2]), int(a.shape[-1])
+        Cn = int(a.numel() // (Ht * Wd))                  # batch and channels fold: the window acts per plane
+        n = C.c_size_t(0)
+        check(L.soar_ssim_scratch_floats(Cn, Ht, Wd, C.byref(n)), "soar_ssim_scratch_floats")
+        scratch = torch.empty((int(n.value),), dtype=torch.float32, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        grad = torch.empty_like(a) if img1.requires_grad else None
+        with torch.cuda.device(dev):
+            check(L.soar_ssim(Cn, Ht, Wd, ptr(a), ptr(b), ptr(out), ptr(scratch), ptr(grad), torch.cuda.current_stream(dev).cuda_stream),
+                  "soar_ssim")
+        ctx.grad = grad
+        ctx.shape = img1.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return None, None
+        return (ctx.grad * g).view(ctx.shape), None
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
+    """Mean SSIM of two images [C,H,W] or [B,C,H,W] (11x11 Gaussian window, sigma 1.5, zero padding: the reference's
+    ``ssim``, TS/utils/loss_utils.py:36-76); differentiable w.r.t. ``img1`` (the rendered image).  One HIP kernel per
+    direction."""
+    return _Ssim.apply(img1, img2)

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 REF = "/root/reference/soar/threestudio-soar"
+HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(OUT, "..", ".."))
 
@@ -124,5 +125,27 @@ def main():
     print("wrote", [f for f in os.listdir(OUT) if f.endswith(".npz")])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--losses" not in sys.argv:
     main()
+
+
+def make_loss_golden():
+    """SSIM / L1 of the reference's own loss_utils.py (TS/utils/loss_utils.py:9-76; it only imports torch) on seeded images."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_loss_utils", os.path.join(REF, "utils", "loss_utils.py"))
+    lu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lu)
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for name, (H, W) in (("a", (24, 40)), ("b", (37, 53))):
+        img1 = torch.rand(1, 3, H, W, generator=g)
+        img2 = (img1 + 0.2 * torch.randn(1, 3, H, W, generator=g)).clamp(0, 1)
+        out[f"ssim_{name}_img1"], out[f"ssim_{name}_img2"] = img1.numpy(), img2.numpy()
+        out[f"ssim_{name}_out"] = np.array(float(lu.ssim(img1, img2)), np.float32)
+        out[f"l1_{name}_out"] = np.array(float(lu.l1_loss_w(img1, img2)), np.float32)
+    np.savez_compressed(os.path.join(HERE, "reference_losses.npz"), **out)
+    print("wrote reference_losses.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__" and "--losses" in sys.argv:
+    make_loss_golden()

@@ -397,3 +397,29 @@ def test_postop_kernels_match_oracle(hw):
         np.testing.assert_allclose(out.cpu().numpy(), G["n2c_out"], rtol=0, atol=5e-6)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         postops.normal2curv(normal, mask)
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 40), (1, 3, 37, 53), (3, 270, 480)])
+def test_ssim_kernel_matches_oracle_and_reference_goldens(shape):
+    """soar_ssim (fused separable 11x11 window, value + gradient) == oracle/loss_oracle.py ssim (pinned on the reference's
+    loss_utils.py) and, on the golden images, the reference's own outputs."""
+    import os
+    from oracle import loss_oracle as lo
+    from soar_amd.losses import ssim
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(*shape, generator=g)
+    b = (a + 0.2 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    a_ref = a.clone().requires_grad_(True)
+    v_ref = lo.ssim(a_ref, b)
+    (3.0 * (1 - v_ref)).backward()
+    a_hip = a.to(DEV).requires_grad_(True)
+    v = ssim(a_hip, b.to(DEV))
+    (3.0 * (1 - v)).backward()
+    assert abs(float(v) - float(v_ref)) < 2e-6
+    assert _rel(a_hip.grad.cpu().numpy(), a_ref.grad.numpy()) < 1e-4
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_losses.npz"))
+    for name in ("a", "b"):
+        out = ssim(torch.from_numpy(G[f"ssim_{name}_img1"]).to(DEV), torch.from_numpy(G[f"ssim_{name}_img2"]).to(DEV))
+        assert abs(float(out) - float(G[f"ssim_{name}_out"])) < 2e-6
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ssim(a, b)

@@ -67,3 +67,13 @@ def test_camera_random_patch():
     assert cam.random_patch().tolist() == [0, 0, 24, 40]
     h0, w0, h1, w1 = cam.random_patch(8, 16).tolist()
     assert h1 - h0 == 8 and w1 - w0 == 16 and 0 <= h0 and h1 <= 24 and 0 <= w0 and w1 <= 40
+
+
+def test_loss_oracle_matches_reference_loss_utils():
+    """oracle/loss_oracle.py ssim / l1_loss_w == the reference's loss_utils.py on the seeded golden images."""
+    from oracle import loss_oracle as lo
+    L = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_losses.npz"))
+    for name in ("a", "b"):
+        a, b = torch.from_numpy(L[f"ssim_{name}_img1"]), torch.from_numpy(L[f"ssim_{name}_img2"])
+        assert abs(float(lo.ssim(a, b)) - float(L[f"ssim_{name}_out"])) < 1e-6
+        assert abs(float(lo.l1_loss_w(a, b)) - float(L[f"l1_{name}_out"])) < 1e-7
