@@ -239,6 +239,22 @@ int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count);
 int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
               float *dssim_dimg1, void *stream);
 
+/* ---- masked image losses of the avatar stage, value in one pass, gradient in one pass:
+ *   masked L1  = l1_loss_w(img[mask], gt[mask])  (TS/system/gaussian_surfel_mvdream.py:311-314, TS/utils/loss_utils.py:9-10)
+ *   cosine loss = cos_loss(output, gt, mask, thrsh, weight)  (TS/system/gaussian_surfel_mvdream.py:622-630; cos_thrsh = cos(thrsh))
+ *   img / gt / output [C,H,W]; mask [H,W] one byte per pixel or NULL; stats2 [2] = {loss, selected count} (device);
+ *   scratch: soar_image_loss_scratch_floats() floats; upstream_dev: device scalar dL/dloss or NULL (= 1). */
+int soar_image_loss_scratch_floats(size_t *count);
+int soar_masked_l1(int32_t C, int32_t H, int32_t W, const float *img, const float *gt, const uint8_t *mask, float *stats2,
+                   float *scratch, void *stream);
+int soar_masked_l1_backward(int32_t C, int32_t H, int32_t W, const float *img, const float *gt, const uint8_t *mask,
+                            const float *stats2, const float *upstream_dev, float *dL_dimg, void *stream);
+int soar_cos_loss(int32_t C, int32_t H, int32_t W, const float *output, const float *gt, const uint8_t *mask, float cos_thrsh,
+                  float weight, float *stats2, float *scratch, void *stream);
+int soar_cos_loss_backward(int32_t C, int32_t H, int32_t W, const float *output, const float *gt, const uint8_t *mask,
+                           float cos_thrsh, float weight, const float *stats2, const float *upstream_dev, float *dL_doutput,
+                           void *stream);
+
 /* ---- renderer post-ops: depth2normal and normal2curv
  *      (TS/renderer/diff_gaussian_rasterizer.py:359-448) as fused 5-point-stencil kernels with analytic backward.
  *   depth [1,H,W], normal [3,H,W], curv [1,H,W]; mask [1,H,W] one byte per pixel (torch.bool);

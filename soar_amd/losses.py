@@ -11,7 +11,7 @@ kernel wrote, backward scales them by the incoming scalar gradient.  HIP only --
 """
 from __future__ import annotations
 
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -98,3 +98,92 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
     ``ssim``, TS/utils/loss_utils.py:36-76); differentiable w.r.t. ``img1`` (the rendered image).  One HIP kernel per
     direction."""
     return _Ssim.apply(img1, img2)
+
+
+def _loss_common(img, gt, mask, name):
+    if not img.is_cuda:
+        raise RuntimeError(f"{name} runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
+    dev = img.device
+    a = img.detach().to(torch.float32).contiguous()
+    b = gt.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if a.shape != b.shape or a.dim() != 3:
+        raise ValueError(f"{name} needs two [C,H,W] images of the same shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+    m = None
+    if mask is not None:
+        m = mask.detach().to(device=dev).reshape(-1)
+        if m.numel() != a.shape[1] * a.shape[2]:
+            raise ValueError(f"{name}: mask must have H*W = {a.shape[1] * a.shape[2]} elements, got {m.numel()}")
+        m = (m != 0).to(torch.uint8).contiguous()
+    import ctypes as C
+    n = C.c_size_t(0)
+    check(hip_lib.lib().soar_image_loss_scratch_floats(C.byref(n)), "soar_image_loss_scratch_floats")
+    scratch = torch.empty((int(n.value),), dtype=torch.float32, device=dev)
+    stats = torch.empty((2,), dtype=torch.float32, device=dev)
+    return a, b, m, scratch, stats
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, mask):
+        a, b, m, scratch, stats = _loss_common(img, gt, mask, "masked_l1")
+        Cn, H, W = a.shape
+        with torch.cuda.device(a.device):
+            check(hip_lib.lib().soar_masked_l1(Cn, H, W, ptr(a), ptr(b), ptr(m), ptr(stats), ptr(scratch),
+                                               torch.cuda.current_stream(a.device).cuda_stream), "soar_masked_l1")
+        ctx.saved = (a, b, m, stats)
+        return stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m, stats = ctx.saved
+        Cn, H, W = a.shape
+        grad = torch.empty_like(a)
+        gs = g.detach().to(device=a.device, dtype=torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(a.device):
+            check(hip_lib.lib().soar_masked_l1_backward(Cn, H, W, ptr(a), ptr(b), ptr(m), ptr(stats), ptr(gs), ptr(grad),
+                                                        torch.cuda.current_stream(a.device).cuda_stream), "soar_masked_l1_backward")
+        return grad, None, None
+
+
+class _CosLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, gt, mask, thrsh, weight):
+        import math
+        a, b, m, scratch, stats = _loss_common(output, gt, mask, "cos_loss")
+        Cn, H, W = a.shape
+        ct, wt = float(math.cos(thrsh)), float(weight)
+        with torch.cuda.device(a.device):
+            check(hip_lib.lib().soar_cos_loss(Cn, H, W, ptr(a), ptr(b), ptr(m), ct, wt, ptr(stats), ptr(scratch),
+                                              torch.cuda.current_stream(a.device).cuda_stream), "soar_cos_loss")
+        ctx.saved = (a, b, m, stats, ct, wt)
+        return stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m, stats, ct, wt = ctx.saved
+        Cn, H, W = a.shape
+        grad = torch.empty_like(a)
+        gs = g.detach().to(device=a.device, dtype=torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(a.device):
+            check(hip_lib.lib().soar_cos_loss_backward(Cn, H, W, ptr(a), ptr(b), ptr(m), ct, wt, ptr(stats), ptr(gs), ptr(grad),
+                                                       torch.cuda.current_stream(a.device).cuda_stream), "soar_cos_loss_backward")
+        return grad, None, None, None, None
+
+
+def masked_l1(img: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``l1_loss_w(img[mask], gt[mask])`` for channel-first images: img, gt [C,H,W], mask [H,W] / [1,H,W] (bool) or None.
+    (The reference indexes [H,W,3] images with the [H,W] mask, TS/system/gaussian_surfel_mvdream.py:311-314.)"""
+    return _MaskedL1.apply(img, gt, mask)
+
+
+def cos_loss(output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None, thrsh: float = 0.0,
+             weight: float = 1.0) -> torch.Tensor:
+    """``cos_loss`` of the reference (TS/system/gaussian_surfel_mvdream.py:622-630) for channel-first [3,H,W] normal images
+    in [0,1]: mean of 1 - cos over the masked pixels whose cosine is below cos(thrsh)."""
+    return _CosLoss.apply(output, gt, mask, thrsh, weight)
+
+
+def recon_loss(comp_rgb: torch.Tensor, gt_rgb: torch.Tensor, gt_blended: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """The reference's photometric term: 0.8 l1_loss_w(comp_rgb[mask], gt_rgb[mask]) + 0.2 (1 - ssim(comp_rgb, gt_blended))
+    (TS/system/gaussian_surfel_mvdream.py:311-320), channel-first images."""
+    return 0.8 * masked_l1(comp_rgb, gt_rgb, mask) + 0.2 * (1.0 - ssim(comp_rgb, gt_blended))

@@ -143,6 +143,25 @@ def make_loss_golden():
         out[f"ssim_{name}_img1"], out[f"ssim_{name}_img2"] = img1.numpy(), img2.numpy()
         out[f"ssim_{name}_out"] = np.array(float(lu.ssim(img1, img2)), np.float32)
         out[f"l1_{name}_out"] = np.array(float(lu.l1_loss_w(img1, img2)), np.float32)
+    # cos_loss is a module-level function of the avatar system file (TS/system/gaussian_surfel_mvdream.py:622-630), which
+    # imports threestudio; the function is compiled from the reference's file at generation time (only outputs are stored)
+    import ast
+    sys_path = os.path.join(REF, "system", "gaussian_surfel_mvdream.py")
+    tree = ast.parse(open(sys_path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cos_loss"]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), sys_path, "exec"), ns)
+    for name, (H, W), thr, wt in (("a", (24, 40), 0.0, 1.0), ("b", (37, 53), 0.6, 0.5)):
+        o = torch.rand(H, W, 3, generator=g)
+        t = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1) * 0.5 + 0.5
+        o = (0.5 * o + 0.5 * t).clamp(0, 1)
+        m = torch.rand(H, W, generator=g) > 0.4
+        out[f"cos_{name}_output"], out[f"cos_{name}_gt"], out[f"cos_{name}_mask"] = o.numpy(), t.numpy(), m.numpy()
+        out[f"cos_{name}_thrsh_weight"] = np.array([thr, wt], np.float32)
+        out[f"cos_{name}_out"] = np.array(float(ns["cos_loss"](o, t, m, thrsh=thr, weight=wt)), np.float32)
+        out[f"cos_{name}_out_nomask"] = np.array(float(ns["cos_loss"](o, t, None, thrsh=thr, weight=wt)), np.float32)
+        # masked L1 exactly as the avatar stage calls it: l1_loss_w(comp_rgb[mask], gt_rgb[mask]) on [H,W,3] images
+        out[f"ml1_{name}_out"] = np.array(float(lu.l1_loss_w(o[m], t[m])), np.float32)
     np.savez_compressed(os.path.join(HERE, "reference_losses.npz"), **out)
     print("wrote reference_losses.npz", {k: v.shape for k, v in out.items()})
 

@@ -423,3 +423,59 @@ def test_ssim_kernel_matches_oracle_and_reference_goldens(shape):
         assert abs(float(out) - float(G[f"ssim_{name}_out"])) < 2e-6
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ssim(a, b)
+
+
+@pytest.mark.parametrize("shape", [(24, 40), (37, 53), (540, 960)])
+def test_masked_l1_and_cos_loss_kernels(shape):
+    """soar_masked_l1 / soar_cos_loss (value + gradient) == oracle/loss_oracle.py (pinned on the reference's functions) and,
+    on the golden inputs, the reference's own outputs (TS/system/gaussian_surfel_mvdream.py:311-314, 622-630)."""
+    import os
+    from oracle import loss_oracle as lo
+    from soar_amd.losses import cos_loss, masked_l1, recon_loss
+    H, W = shape
+    g = torch.Generator().manual_seed(H)
+    o = torch.rand(H, W, 3, generator=g)
+    t = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1) * 0.5 + 0.5
+    o = (0.5 * o + 0.5 * t).clamp(0, 1)
+    m = torch.rand(H, W, generator=g) > 0.4
+    for mask in (m, None):
+        for thr, wt in ((0.0, 1.0), (0.6, 0.5)):
+            o_ref = o.clone().requires_grad_(True)
+            v_ref = lo.cos_loss(o_ref, t, mask, thrsh=thr, weight=wt)
+            (2.0 * v_ref).backward()
+            o_hip = o.permute(2, 0, 1).contiguous().to(DEV).requires_grad_(True)
+            v = cos_loss(o_hip, t.permute(2, 0, 1).to(DEV), None if mask is None else mask.to(DEV), thrsh=thr, weight=wt)
+            (2.0 * v).backward()
+            assert abs(float(v) - float(v_ref)) < 1e-5 * max(1.0, abs(float(v_ref)))
+            assert _rel(o_hip.grad.permute(1, 2, 0).cpu().numpy(), o_ref.grad.numpy()) < 1e-4
+        o_ref = o.clone().requires_grad_(True)
+        v_ref = lo.l1_loss_w(o_ref[mask], t[mask]) if mask is not None else lo.l1_loss_w(o_ref, t)
+        (3.0 * v_ref).backward()
+        o_hip = o.permute(2, 0, 1).contiguous().to(DEV).requires_grad_(True)
+        v = masked_l1(o_hip, t.permute(2, 0, 1).to(DEV), None if mask is None else mask.to(DEV))
+        (3.0 * v).backward()
+        assert abs(float(v) - float(v_ref)) < 1e-5 * max(1.0, abs(float(v_ref)))
+        assert _rel(o_hip.grad.permute(1, 2, 0).cpu().numpy(), o_ref.grad.numpy()) < 1e-4
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_losses.npz"))
+    for name in ("a", "b"):
+        go, gt, gm = (torch.from_numpy(G[f"cos_{name}_{k}"]) for k in ("output", "gt", "mask"))
+        thr, wt = (float(x) for x in G[f"cos_{name}_thrsh_weight"])
+        oc, tc = go.permute(2, 0, 1).contiguous().to(DEV), gt.permute(2, 0, 1).contiguous().to(DEV)
+        assert abs(float(cos_loss(oc, tc, gm.to(DEV), thr, wt)) - float(G[f"cos_{name}_out"])) < 2e-6
+        assert abs(float(cos_loss(oc, tc, None, thr, wt)) - float(G[f"cos_{name}_out_nomask"])) < 2e-6
+        assert abs(float(masked_l1(oc, tc, gm.to(DEV))) - float(G[f"ml1_{name}_out"])) < 2e-6
+    # the combined photometric term of the avatar stage
+    a = o.permute(2, 0, 1).contiguous()
+    b = t.permute(2, 0, 1).contiguous()
+    a_ref = a.clone().requires_grad_(True)
+    ref = 0.8 * lo.l1_loss_w(a_ref.permute(1, 2, 0)[m], b.permute(1, 2, 0)[m]) + 0.2 * (1 - lo.ssim(a_ref, b))
+    ref.backward()
+    a_hip = a.to(DEV).requires_grad_(True)
+    out = recon_loss(a_hip, b.to(DEV), b.to(DEV), m.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-5
+    assert _rel(a_hip.grad.cpu().numpy(), a_ref.grad.numpy()) < 1e-4
+    # an empty selection is NaN, like the reference's mean over an empty tensor
+    assert torch.isnan(masked_l1(a.to(DEV), b.to(DEV), torch.zeros(H, W, dtype=torch.bool, device=DEV)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        masked_l1(a, b, m)

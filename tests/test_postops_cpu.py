@@ -77,3 +77,8 @@ def test_loss_oracle_matches_reference_loss_utils():
         a, b = torch.from_numpy(L[f"ssim_{name}_img1"]), torch.from_numpy(L[f"ssim_{name}_img2"])
         assert abs(float(lo.ssim(a, b)) - float(L[f"ssim_{name}_out"])) < 1e-6
         assert abs(float(lo.l1_loss_w(a, b)) - float(L[f"l1_{name}_out"])) < 1e-7
+        o, t, m = (torch.from_numpy(L[f"cos_{name}_{k}"]) for k in ("output", "gt", "mask"))
+        thr, wt = (float(v) for v in L[f"cos_{name}_thrsh_weight"])
+        assert abs(float(lo.cos_loss(o, t, m, thrsh=thr, weight=wt)) - float(L[f"cos_{name}_out"])) < 1e-6
+        assert abs(float(lo.cos_loss(o, t, None, thrsh=thr, weight=wt)) - float(L[f"cos_{name}_out_nomask"])) < 1e-6
+        assert abs(float(lo.l1_loss_w(o[m], t[m])) - float(L[f"ml1_{name}_out"])) < 1e-7
