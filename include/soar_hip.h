@@ -69,7 +69,8 @@ int soar_rast_binning_bytes(int64_t num_rendered, size_t *bytes);
  *
  * stage 1: preprocess (forward.cu:205-385) + inclusive scan (:242-245) + blocking read-back of num_rendered.
  *   means3D [P,3]; opacities [P]; exactly one of shs [P,M,3] / colors_precomp [P,3];
- *   exactly one of (scales [P,3], rotations [P,4]) / cov3D_precomp [P,6].
+ *   (scales [P,3], rotations [P,4]) or cov3D_precomp [P,6] (the Python layer enforces exactly one; like the reference's _C
+ *   module this level also takes rotations WITH cov3D_precomp: covariance from cov3D_precomp, surfel normal from rotations).
  *   radii_out [P] int32 (API output).  *num_rendered_host receives R (NULL: asynchronous form, see below). */
 int soar_rast_forward_geometry(const SoarRastParams *prm,
                                const float *means3D, const float *shs, const float *colors_precomp,

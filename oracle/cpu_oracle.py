@@ -5,7 +5,7 @@ reference rasterizer, see rasterizer_oracle.c).  Only ``tests/``, ``__graft_entr
 and ``bench.py``'s ``cpu_baseline`` leg may import this module; nothing under ``soar_amd/``
 does.
 
-PARITY STATUS: parity unpinned (see rasterizer_oracle.h).
+PARITY STATUS: pinned on the reference's own kernels built for gfx950 (see rasterizer_oracle.h, oracle/ref_build/).
 """
 from __future__ import annotations
 

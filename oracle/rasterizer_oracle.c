@@ -1,7 +1,7 @@
 /*
  * oracle/rasterizer_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See rasterizer_oracle.h.
  *
- * PARITY STATUS: parity unpinned (no reference golden vectors exist; CUDA sources are unbuildable here).
+ * PARITY STATUS: pinned on the reference's own kernels built for gfx950 (oracle/_ref, tests/test_reference_build_gpu.py).
  *
  * Scalar CPU restatement of hangg7/soar's Gaussian-surfel rasterizer.  Citations are
  * file:line relative to /root/reference/submodules/diff-gaussian-rasterization/ ("DGR/").

@@ -246,9 +246,11 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
         set_error("Please provide excatly one of either SHs or precomputed colors!");   // __init__.py:316-321
         return 1;
     }
-    if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
-        ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
-        set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");   // :323-328
+    // The Python layer enforces "exactly one of" (__init__.py:323-328).  At this level, like the reference's _C module, a
+    // precomputed covariance may come WITH rotations: the reference's preprocess reads rotations[idx] for the surfel normal
+    // whatever the covariance source is (forward.cu:273), so that is the only way its cov3D_precomp path can run at all.
+    if ((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) {
+        set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
         return 1;
     }
     if (shs && prm->M <= 0) { set_error("SH path needs M > 0"); return 1; }

@@ -1,8 +1,8 @@
 """GPU parity tests of the HIP rasterizer (through the C ABI) against the CPU oracle.
 
 Bars: tile/key indexing bit-exact (radii, tiles_touched, point_offsets, sort keys, point_list,
-ranges); images and gradients within 1e-4 relative.  The oracle is a restatement of the reference (parity unpinned, see
-oracle/rasterizer_oracle.h).
+ranges); images and gradients within 1e-4 relative.  The oracle is a restatement of the reference, pinned on the reference's own kernels
+(tests/test_reference_build_gpu.py, oracle/rasterizer_oracle.h).
 """
 import ctypes as C
 
