@@ -240,6 +240,17 @@ int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count);
 int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
               float *dssim_dimg1, void *stream);
 
+/* ---- SMPL-X joint transforms of B frames in one launch.
+ * Replaces, for the per-frame path, SMPLX.forward -> lbs() -> batch_rodrigues / batch_rigid_transform
+ * (TS/utils/smplx/lbs.py:147-246,293-396, body_models.py:1383) and the A_live @ inv(A_cano) product of SMPL_Guidance
+ * (TS/utils/smpl.py:601-609).  J <= 64 joints; betas [betas_batch,NB] with betas_batch 1 or B (shape and expression
+ * coefficients concatenated); J_template [J,3] = J_regressor v_template; J_dirs [J,3,NB] = J_regressor shapedirs;
+ * parents [J] (root < 0); full_pose [B,J*3] axis-angle; transl [B,3] or NULL; right_mats [J,4,4] or NULL
+ * (out_j = A_j right_mats_j, e.g. inv(A_cano)); out [B,J,4,4].  The parameters are not optimised in the reference: no backward. */
+int soar_smplx_joint_mats(int32_t B, int32_t J, int32_t NB, const float *betas, int32_t betas_batch, const float *J_template,
+                          const float *J_dirs, const int32_t *parents, const float *full_pose, const float *transl,
+                          const float *right_mats, float *out, void *stream);
+
 /* ---- masked image losses of the avatar stage, value in one pass, gradient in one pass:
  *   masked L1  = l1_loss_w(img[mask], gt[mask])  (TS/system/gaussian_surfel_mvdream.py:311-314, TS/utils/loss_utils.py:9-10)
  *   cosine loss = cos_loss(output, gt, mask, thrsh, weight)  (TS/system/gaussian_surfel_mvdream.py:622-630; cos_thrsh = cos(thrsh))

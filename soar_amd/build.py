@@ -38,7 +38,7 @@ EXTRA_FLAGS = {
     "postops.hip": ["-ffp-contract=off"],
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
-           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip"]
+           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip"]
 HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
 
 

@@ -68,8 +68,10 @@ class AvatarSequence:
         cano_pose[:, 5] = leg_angle_deg / 180 * torch.pi           # TS/utils/smpl.py:497-500
         cano_pose[:, 8] = -leg_angle_deg / 180 * torch.pi
         A_cano = jt(betas[:1], cano_pose, torch.tensor([[0.0, 0.30, 0.0]]))
-        A_live = jt(betas, poses["full_pose"], poses["transl"])
-        self.cano2live = d(torch.matmul(A_live, torch.linalg.inv(A_cano)))          # [F,55,4,4]  (smpl.py:609)
+        # all F frames in one launch of the joint-chain kernel, A_live @ inv(A_cano) folded in  (smpl.py:609)
+        self.joint_transformer = jt
+        self.inv_cano = d(torch.linalg.inv(A_cano)[0])
+        self.cano2live = jt.hip(d(betas), d(poses["full_pose"]), d(poses["transl"]), right=self.inv_cano)    # [F,55,4,4]
         self.num_frames = F_
         self.blend_weights: Optional[torch.Tensor] = None
         self.knn_grid = lbs.KnnGrid(self.cano_vertices, self.lbs_weights)       # canonical vertices are static

@@ -64,6 +64,7 @@ SIGNATURES = {
     "soar_normal2curv_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_ssim_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_ssim": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "soar_smplx_joint_mats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_image_loss_scratch_floats": (C.c_int, [C.POINTER(C.c_size_t)]),
     "soar_masked_l1": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_masked_l1_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

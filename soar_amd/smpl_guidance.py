@@ -86,7 +86,8 @@ class SMPLGuidance:
     def joint_mats(self, smpl_parms_in=None, idx=None, zero_out=False) -> torch.Tensor:
         """cano2live_jnt_mats = A_live @ inv(A_cano)  [55,4,4]   (:601-609)"""
         betas, pose, transl = self._select(smpl_parms_in, idx, zero_out)
-        return torch.matmul(self._jt(betas, pose, transl), self.inv_mats)[0]
+        # one launch: Rodrigues, the 55-joint chain, transl and the product with inv(A_cano)  (csrc/smplx_joints.hip)
+        return self._jt.hip(betas, pose, transl, right=self.inv_mats[0])[0]
 
     def blend_weights(self, points: torch.Tensor, refresh: bool = False) -> torch.Tensor:
         """query_weights_smpl cached on (storage, version) of `points`: the weights depend on the canonical positions

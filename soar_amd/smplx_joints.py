@@ -84,6 +84,32 @@ class JointTransformer:
             setattr(self, k, getattr(self, k).to(device))
         return self
 
+    def hip(self, betas: torch.Tensor, full_pose: torch.Tensor, transl: Optional[torch.Tensor] = None,
+            right: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same transforms for B frames in ONE kernel launch (C: soar_smplx_joint_mats): betas [1|B,NB], full_pose
+        [B,J*3], transl [B,3] -> A [B,J,4,4], or A @ right ([J,4,4], e.g. inv(A_cano)) when `right` is given.  HIP only."""
+        from . import hip_lib
+        from .hip_lib import check, ptr
+        if not full_pose.is_cuda:
+            raise RuntimeError("JointTransformer.hip runs on HIP devices only (torch device type 'cuda' on ROCm)")
+        dev = full_pose.device
+        f = lambda x: None if x is None else x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if not hasattr(self, "_hip_consts") or self._hip_consts[0].device != dev:
+            self._hip_consts = (f(self.J_template), f(self.J_dirs), self.parents.to(device=dev, dtype=torch.int32).contiguous())
+        Jt, Jd, par = self._hip_consts
+        J, NB = Jt.shape[0], Jd.shape[2]
+        pose, be, tr, rm = f(full_pose).reshape(-1, J * 3), f(betas).reshape(-1, NB), f(transl), f(right)
+        B = pose.shape[0]
+        if be.shape[0] not in (1, B) or (tr is not None and tr.shape != (B, 3)) or (rm is not None and rm.shape != (J, 4, 4)):
+            raise ValueError(f"bad shapes: betas {tuple(be.shape)}, transl {None if tr is None else tuple(tr.shape)}, "
+                             f"right {None if rm is None else tuple(rm.shape)} for B={B}, J={J}")
+        out = torch.empty(B, J, 4, 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(hip_lib.lib().soar_smplx_joint_mats(B, J, NB, ptr(be), be.shape[0], ptr(Jt), ptr(Jd), ptr(par), ptr(pose), ptr(tr),
+                                                      ptr(rm), ptr(out), torch.cuda.current_stream(dev).cuda_stream),
+                  "soar_smplx_joint_mats")
+        return out
+
     def joints(self, betas: torch.Tensor) -> torch.Tensor:
         """betas [B,NB] (shape + expression coefficients concatenated, body_models.py:1330) -> rest joints [B,J,3]."""
         return self.J_template[None] + torch.einsum("bl,jkl->bjk", betas, self.J_dirs)

@@ -145,3 +145,33 @@ def test_knn_query_order_reuse_is_exact():
         same = (torch.sort(i_got, 1).values == torch.sort(i_ref, 1).values).all(1)
         assert float(same.float().mean()) > 0.999
         torch.testing.assert_close(w_got[same], w_ref[same], rtol=1e-5, atol=1e-7)
+
+
+def test_smplx_joint_chain_kernel_matches_reference_lbs_goldens():
+    """soar_smplx_joint_mats (Rodrigues + 55-joint chain + transl + right product, all frames in one launch) == the
+    reference's lbs() transforms A (tests/golden/smplx_joint_transforms.npz, generated by the reference's own smplx code)
+    and the host JointTransformer, which the CPU suite pins on the same goldens."""
+    import os
+    from soar_amd import smplx_joints as sj
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "smplx_joint_transforms.npz")))
+    t = lambda k: torch.from_numpy(g[k])
+    jt = sj.JointTransformer(t("v_template"), t("shapedirs"), t("J_regressor"), torch.from_numpy(g["parents"]))
+    dev = torch.device("cuda:0")
+    A = jt.hip(t("betas").to(dev), t("pose").to(dev), t("transl").to(dev))
+    np.testing.assert_allclose(A.cpu().numpy(), g["A_with_transl"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(jt.hip(t("betas").to(dev), t("pose").to(dev)).cpu().numpy(), g["A"], rtol=0, atol=5e-6)
+    # shared betas row, right-hand product, a 300-frame batch with large rotations and a zero pose (the 1e-8 quirk)
+    gen = torch.Generator().manual_seed(3)
+    pose = torch.randn(300, 165, generator=gen) * 1.5
+    pose[7] = 0.0
+    transl = torch.randn(300, 3, generator=gen)
+    betas = t("betas")[:1]
+    right = torch.linalg.inv(jt(betas, torch.zeros(1, 165), torch.tensor([[0.0, 0.3, 0.0]])))[0]
+    want = torch.matmul(jt(betas, pose, transl), right)
+    got = jt.hip(betas.to(dev), pose.to(dev), transl.to(dev), right=right.to(dev)).cpu()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert jt.hip(betas.to(dev), pose[:0].to(dev)).shape == (0, 55, 4, 4)
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        jt.hip(betas, pose, transl)
+    with pytest.raises(ValueError):
+        jt.hip(t("betas")[:3].to(dev), pose.to(dev))
