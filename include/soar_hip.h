@@ -240,6 +240,39 @@ int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count);
 int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
               float *dssim_dimg1, void *stream);
 
+/* ---- densification / pruning state machine (TS/geometry/surfel_base.py:850-1136,1198-1230).
+ * soar_densify_stats: update_states' per-view body + add_densification_stats (:1102-1128,1208-1216) in one pass.
+ *   radii [P] int32 (filter = radii > 0), grad2d [P,grad_stride] (viewspace gradient, first two columns read),
+ *   scaling_grad [P,3], rotation [P,4], opacity [P] (raw), accum [5,P] = {xyz, scale, rot, opac gradient accumulators, denom},
+ *   max_radii2D [P]; all updated in place.
+ * soar_densify_plan: adaptive_prune (:1067-1087, when do_prune) + the clone / split masks of adaptive_densify
+ *   (:982-1000,1032-1046,1089-1100, when do_densify) over the points that survive the prune, and the destination row of
+ *   every point.  Thresholds are passed as the reference compares them: prune_scale_max = 0.5 extent, prune_area_min =
+ *   1e-8 extent^2, dense_scale = percent_dense * extent.  plan: soar_densify_plan_bytes(P) bytes, 256-byte aligned, opaque.
+ *   counts_host [3] = {kept, clones, split parents} (blocking read-back) or NULL.  New size = kept + clones + N * split.
+ * soar_densify_flags: copies the per-point flag byte (1 pruned, 2 clone, 4 split) to flags_out [P].
+ * soar_densify_apply: moves every listed tensor (rows of `width` floats) into its new buffer in one launch, layout
+ *   [kept and not split | clones | split children rep 0 | rep 1 ...] exactly as the reference's cat / prune sequence leaves it.
+ *   mode 0: copy rows; 1: Adam moments (new rows zero); 2: xyz (children = R(q) (noise * exp(scaling)) + xyz, :1001-1004);
+ *   3: scaling (children = log(exp(s) / (0.8 N)), last column -1e10 when surface, :1005-1009).
+ *   scaling / rotation: the OLD [P,3] / [P,4] tensors; noise [N * split, 3] standard normals (row = child index; may be NULL
+ *   only when the plan holds no split parents). */
+typedef struct SoarDensifyRow {
+    const float *src;
+    float *dst;
+    int32_t width;
+    int32_t mode;
+} SoarDensifyRow;
+int soar_densify_stats(int32_t P, const int32_t *radii, const float *grad2d, int32_t grad_stride, const float *scaling_grad,
+                       const float *rotation, const float *opacity, float *accum, float *max_radii2D, void *stream);
+int soar_densify_plan_bytes(int32_t P, size_t *bytes);
+int soar_densify_plan(int32_t P, const float *accum, const float *scaling, const float *opacity, int32_t do_prune,
+                      int32_t do_densify, float min_opacity, float prune_scale_max, float prune_area_min, float max_grad,
+                      float dense_scale, void *plan, int64_t *counts_host, void *stream);
+int soar_densify_flags(int32_t P, const void *plan, uint8_t *flags_out, void *stream);
+int soar_densify_apply(int32_t P, int32_t N, const void *plan, int32_t n_rows, const SoarDensifyRow *rows, const float *scaling,
+                       const float *rotation, const float *noise, int32_t surface, void *stream);
+
 /* ---- SMPL-X joint transforms of B frames in one launch.
  * Replaces, for the per-frame path, SMPLX.forward -> lbs() -> batch_rodrigues / batch_rigid_transform
  * (TS/utils/smplx/lbs.py:147-246,293-396, body_models.py:1383) and the A_live @ inv(A_cano) product of SMPL_Guidance

@@ -36,9 +36,11 @@ EXTRA_FLAGS = {
     "rast_geom_bwd.hip": ["-ffp-contract=off"],
     # differences of identical products must be exactly zero (replicate-padded borders), as in the reference's torch ops
     "postops.hip": ["-ffp-contract=off"],
+    # thresholds decide the integer layout of the densified model
+    "densify.hip": ["-ffp-contract=off"],
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
-           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip"]
+           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip", "densify.hip"]
 HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
 
 

@@ -75,3 +75,13 @@ def all_reduce_densification_stats(grad_accum: torch.Tensor, denom: torch.Tensor
         grad_accum.copy_(packed[:n].view_as(grad_accum))
         denom.copy_(packed[n:].view_as(denom))
     return grad_accum, denom
+
+
+def all_reduce_densifier_stats(accum: torch.Tensor, max_radii2D: torch.Tensor, group=None):
+    """The statistics block of ``soar_amd.densify.SurfelDensifier``: accum [5,P] (the four gradient accumulators and the
+    visibility count, TS/geometry/surfel_base.py:1102-1128) is summed and max_radii2D [P] maxed over the ranks, so that every
+    rank plans the same prune / clone / split decisions.  In place; a no-op outside a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+    return accum, max_radii2D

@@ -28,6 +28,11 @@ class SoarRastParams(C.Structure):
     ]
 
 
+class SoarDensifyRow(C.Structure):
+    """Mirror of ``struct SoarDensifyRow`` (include/soar_hip.h)."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("width", C.c_int32), ("mode", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/soar_hip.h declares
 SIGNATURES = {
     "soar_last_error": (C.c_char_p, []),
@@ -64,6 +69,12 @@ SIGNATURES = {
     "soar_normal2curv_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_ssim_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_ssim": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "soar_densify_stats": (C.c_int, [C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "soar_densify_plan_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_densify_plan": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, _vp, C.POINTER(C.c_int64), _vp]),
+    "soar_densify_flags": (C.c_int, [C.c_int32, _vp, _vp, _vp]),
+    "soar_densify_apply": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.POINTER(SoarDensifyRow), _vp, _vp, _vp, C.c_int32, _vp]),
     "soar_smplx_joint_mats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_image_loss_scratch_floats": (C.c_int, [C.POINTER(C.c_size_t)]),
     "soar_masked_l1": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

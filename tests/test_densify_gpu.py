@@ -1,0 +1,111 @@
+"""The HIP densification / pruning state machine (csrc/densify.hip, soar_amd/densify.py) against the reference's own methods
+(tests/golden/reference_densify.npz) and the pinned restatement (oracle/densify_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import densify_oracle as do
+from test_densify_cpu import G, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def make(name):
+    from soar_amd.densify import SurfelDensifier
+    st, views, cfg, noise = load_case(name)
+    params = {k: nn.Parameter(st["params"][k].clone().to(DEV)) for k in do.PARAMS}
+    opt = torch.optim.Adam([{"params": [params[k]], "lr": 1e-3, "name": k} for k in do.PARAMS], lr=0.0, eps=1e-15)
+    for k in do.PARAMS:
+        opt.state[params[k]] = {"step": torch.tensor(1.0), "exp_avg": st["m"][k].clone().to(DEV), "exp_avg_sq": st["v"][k].clone().to(DEV)}
+    return SurfelDensifier(params, opt, percent_dense=cfg["percent_dense"], surface=cfg["surface"]), st, views, cfg, noise
+
+
+def check_against_golden(name, d):
+    for k in do.PARAMS:
+        got, want = d.params[k].detach().cpu().numpy(), G[f"{name}_out_{k}"]
+        assert got.shape == want.shape, k
+        if k in ("xyz", "scaling"):          # children go through expf / logf: device libm vs torch CPU, one ulp
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7, err_msg=k)
+        else:
+            np.testing.assert_array_equal(got, want, err_msg=k)
+        st = d.optimizer.state[d.params[k]]
+        assert d.optimizer.param_groups[do.PARAMS.index(k)]["params"][0] is d.params[k]
+        np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), G[f"{name}_out_m_{k}"])
+        np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), G[f"{name}_out_v_{k}"])
+    assert float(d.accum.abs().sum()) == 0 and d.accum.shape[1] == d.num_points and float(d.max_radii2D.sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_densify_state_machine_matches_reference(name):
+    d, st, views, cfg, noise = make(name)
+    # statistics: three views through the fused kernel
+    for radii, grad2d, sgrad in views:
+        d.add_densification_stats(radii.to(DEV), grad2d.to(DEV), sgrad.to(DEV))
+    acc = {k: G[f"{name}_acc_{k}"] for k in do.ACCUMS + ("max_radii2D",)}
+    for row, k in enumerate(do.ACCUMS):
+        np.testing.assert_allclose(d.accum[row].cpu().numpy(), acc[k][:, 0], rtol=2e-6, atol=1e-12, err_msg=k)
+    np.testing.assert_array_equal(d.accum[4].cpu().numpy(), acc["denom"][:, 0])
+    np.testing.assert_array_equal(d.max_radii2D.cpu().numpy(), acc["max_radii2D"])
+    # decisions are thresholds on the accumulators: feed the reference's own values so that layouts can be compared row by row
+    d.accum.copy_(torch.from_numpy(np.stack([acc[k][:, 0] for k in do.ACCUMS])).to(DEV))
+    # flags against the pinned restatement
+    for radii, grad2d, sgrad in views:
+        do.add_densification_stats(st, radii, grad2d, sgrad)
+    flags = d.flags(cfg["do_prune"], True, cfg["min_opac"], cfg["extent"], cfg["max_grad"]).cpu()
+    pruned = do.adaptive_prune(st, cfg["min_opac"], cfg["extent"]) if cfg["do_prune"] else torch.zeros(len(flags), dtype=torch.bool)
+    masks = do.adaptive_densify(st, cfg["max_grad"], cfg["extent"], cfg["percent_dense"], cfg["surface"], noise)
+    assert torch.equal((flags & 1) > 0, pruned)
+    assert torch.equal(((flags & 2) > 0)[~pruned], masks["clone"]) and torch.equal(((flags & 4) > 0)[~pruned], masks["split"])
+    # the two-call form of the reference
+    saved = d.accum.clone()
+    if cfg["do_prune"]:
+        r = d.adaptive_prune(cfg["min_opac"], cfg["extent"])
+        assert r["pruned"] == int(pruned.sum())
+        np.testing.assert_array_equal(d.params["xyz"].detach().cpu().numpy(), G[f"{name}_after_prune_xyz"])
+        d.accum.copy_(saved[:, ~pruned.to(DEV)])          # adaptive_prune keeps the accumulators of the survivors (:883-889)
+    r = d.adaptive_densify(cfg["max_grad"], cfg["extent"], noise=noise)
+    assert r["cloned"] == int(masks["clone"].sum()) and r["split"] == int(masks["split"].sum())
+    check_against_golden(name, d)
+    # ... and both phases fused in one plan reach the same state
+    d2, _, _, _, _ = make(name)
+    d2.accum.copy_(saved)
+    if cfg["do_prune"]:
+        d2.prune_and_densify(cfg["min_opac"], cfg["max_grad"], cfg["extent"], noise=noise)
+    else:
+        d2.adaptive_densify(cfg["max_grad"], cfg["extent"], noise=noise)
+    check_against_golden(name, d2)
+    # a step of the optimizer on the new parameters works
+    for k in do.PARAMS:
+        d2.params[k].grad = torch.ones_like(d2.params[k])
+    d2.optimizer.step()
+
+
+def test_densify_edge_cases_and_determinism():
+    from soar_amd.densify import SurfelDensifier
+    d, st, views, cfg, noise = make("a")
+    # nothing visible yet: denom == 0 everywhere -> prune removes every point, densify alone selects nothing
+    r = d.adaptive_densify(cfg["max_grad"], cfg["extent"])
+    assert r == dict(kept=600, cloned=0, split=0, pruned=0, num_points=600)
+    r = d.adaptive_prune(cfg["min_opac"], cfg["extent"])
+    assert r["num_points"] == 0 and d.params["xyz"].shape == (0, 3) and d.accum.shape == (5, 0)
+    assert d.adaptive_prune(0.1, 1.0)["kept"] == 0
+    # same generator seed -> identical models (what frame-DP ranks rely on); a million points in one plan
+    P = 1_000_000
+    g = torch.Generator(device=DEV).manual_seed(1)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    base = dict(xyz=mk(P, 3), f_dc=mk(P, 1, 3), f_rest=mk(P, 3, 3), color=mk(P, 3), opacity=mk(P, 1),
+                scaling=torch.log(torch.rand(P, 3, device=DEV, generator=g) * 0.016 + 1e-3), rotation=mk(P, 4))
+    outs = []
+    for _ in range(2):
+        d = SurfelDensifier({k: v.clone() for k, v in base.items()}, None)
+        d.add_densification_stats(torch.randint(0, 9, (P,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)),
+                                  mk(P, 3) * 0 + 3e-4, torch.zeros(P, 3, device=DEV))
+        r = d.prune_and_densify(0.1, 2e-4, 1.3, generator=torch.Generator(device=DEV).manual_seed(7))
+        assert r["num_points"] == r["kept"] + r["cloned"] + 2 * r["split"] and r["cloned"] > 1000 and r["split"] > 1000
+        outs.append({k: v.clone() for k, v in d.params.items()})
+    for k in do.PARAMS:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SurfelDensifier({k: v.cpu()[:4] for k, v in base.items()})

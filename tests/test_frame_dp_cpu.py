@@ -68,7 +68,10 @@ def _worker(rank, world, port, P, out_dir):
         work.wait()
         acc, den = torch.full((P, 1), float(rank + 1)), torch.full((P, 1), 1.0)
         frame_dp.all_reduce_densification_stats(acc, den)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=buf.flat.numpy(), acc=acc.numpy(), den=den.numpy())
+        acc5, rad = torch.full((5, P), float(rank + 1)), torch.arange(P, dtype=torch.float32) * (1 if rank else -1)
+        frame_dp.all_reduce_densifier_stats(acc5, rad)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=buf.flat.numpy(), acc=acc.numpy(), den=den.numpy(),
+                 acc5=acc5.numpy(), rad=rad.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -90,3 +93,6 @@ def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
     assert np.abs(buf.flat.numpy()[P * 13:]).sum() == 0                          # leaves not registered stay zero
     np.testing.assert_array_equal(r0["acc"], np.full((P, 1), 3.0, np.float32))
     np.testing.assert_array_equal(r1["den"], np.full((P, 1), 2.0, np.float32))
+    for r in (r0, r1):                                                          # densifier statistics: sum and max
+        np.testing.assert_array_equal(r["acc5"], np.full((5, P), 3.0, np.float32))
+        np.testing.assert_array_equal(r["rad"], np.arange(P, dtype=np.float32))
