@@ -226,7 +226,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.mode is None:
-        args.mode = "plan" if world == 1 else "plan-eager"
+        args.mode = "plan" if world == 1 and os.environ.get("SOAR_BENCH_FORCE_DIST", "0") != "1" else "plan-eager"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -234,15 +234,24 @@ def main():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # SOAR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, all-reduces, default mode) with
+    # a single rank too -- the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("SOAR_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if world == 1:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from soar_amd import build, hip_lib, rasterizer
+    from soar_amd import frame_dp
     from soar_amd.frame_dp import FlatGradBuffer, global_batch, shard_frames
+    frame_dp.FORCE_COLLECTIVES = use_dist and world == 1
     if rank == 0:
         build.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     L = hip_lib.lib()
 
@@ -299,14 +308,14 @@ def main():
     for s in range(2):                                           # untimed steps in the timed mode
         stepper(frames_of(s))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
         stepper(frames_of(args.warmup + s))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if plan is not None:
@@ -329,7 +338,7 @@ def main():
         rasterizer.NUM_STREAMS = streams_timed
         for k, v in stats_timed.items():
             rasterizer.stats[k] = v
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -391,7 +400,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -7,7 +7,7 @@
  *
  * PARITY STATUS: *pinned on the reference itself*.  The reference ships no tests, golden
  * vectors or fixtures for this path, so the pin is an executed reference:
- * oracle/ref_build/build_ref.sh compiles the reference's own cuda_rasterizer/*.cu (from where
+ * oracle/ref_build/build_ref.sh compiles the reference's own cuda_rasterizer .cu units (from where
  * they lie under /root/reference, with its vendored glm) for gfx950 through ROCm's hipify-perl
  * into oracle/_ref/libref_rasterizer.so, and tests/test_reference_build_gpu.py runs those
  * kernels, this restatement and the HIP product on the same seeded scenes: num_rendered, radii,

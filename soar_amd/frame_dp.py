@@ -33,6 +33,10 @@ def global_batch(step: int, frames_per_rank: int, world_size: int, num_frames: i
     return [(step * n + k) % num_frames for k in range(n)]
 
 
+# set by bench.py under SOAR_BENCH_FORCE_DIST=1: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)
+FORCE_COLLECTIVES = False
+
+
 class FlatGradBuffer:
     """One contiguous fp32 buffer of 15*P floats; each leaf's ``.grad`` is a contiguous [P,w] VIEW into it (leaf after
     leaf), so autograd accumulates the frames of a step in place and the all-reduce is a single collective on a single
@@ -60,7 +64,7 @@ class FlatGradBuffer:
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks (no-op for a single process).  Returns the work handle when async."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         return None
 
