@@ -108,3 +108,11 @@ def adaptive_densify(st: dict, max_grad: float, extent: float, percent_dense: fl
     keep = torch.cat([~split, torch.ones(N * int(split.sum()), dtype=torch.bool)])
     _keep(st, keep)
     return dict(clone=clone, split=split[: clone.shape[0]])
+
+
+def reset_opacity(st: dict, ratio: float) -> None:
+    """:754-764 + replace_tensor_to_optimizer (:846-860): opacity <- inverse_sigmoid(sigmoid(opacity) * ratio), moments zeroed."""
+    x = torch.sigmoid(st["params"]["opacity"]) * ratio
+    st["params"]["opacity"] = torch.log(x / (1 - x))
+    st["m"]["opacity"] = torch.zeros_like(st["m"]["opacity"])
+    st["v"]["opacity"] = torch.zeros_like(st["v"]["opacity"])

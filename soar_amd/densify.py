@@ -100,16 +100,19 @@ class SurfelDensifier:
 
     def update_states(self, iteration: int, radii, viewspace_grads, cfg, extent: float, generator=None, scaling_grads=None,
                       group=None):
-        """``update_states`` (:1198-1230) without the opacity reset: per-view statistics, then every
-        ``cfg.densification_interval`` iterations prune (after ``cfg.prune_from_iter``) and densify."""
+        """``update_states`` (:1198-1230): per-view statistics, then every ``cfg.densification_interval`` iterations prune
+        (after ``cfg.prune_from_iter``) and densify, then the periodic opacity reset."""
         if iteration <= cfg.densify_from_iter:
             return None
         for i in range(len(radii)):
             self.add_densification_stats(radii[i], viewspace_grads[i], None if scaling_grads is None else scaling_grads[i])
-        if iteration % cfg.densification_interval != 0:
-            return None
-        self.sync_stats(group)
-        return self._run(iteration > cfg.prune_from_iter, True, 0.1, extent, cfg.densify_grad_threshold, generator)
+        result = None
+        if iteration % cfg.densification_interval == 0:
+            self.sync_stats(group)
+            result = self._run(iteration > cfg.prune_from_iter, True, 0.1, extent, cfg.densify_grad_threshold, generator)
+        if (iteration - 1) % cfg.opacity_reset_interval == 0 and cfg.opacity_lr > 0:
+            self.reset_opacity(0.12)
+        return result
 
     def _run(self, do_prune, do_densify, min_opacity, extent, max_grad, generator, N: int = 2, noise=None):
         L = hip_lib.lib()
@@ -163,6 +166,19 @@ class SurfelDensifier:
         self._reset_stats()
         return dict(kept=kept, cloned=cloned, split=split, pruned=P - kept - split, num_points=P_new)
 
+    def reset_opacity(self, ratio: float):
+        """``reset_opacity`` (:754-764): opacity <- inverse_sigmoid(sigmoid(opacity) * ratio); the Adam moments of that tensor
+        are zeroed (``replace_tensor_to_optimizer``, :846-860).  Elementwise over [P,1]: plain device ops."""
+        old = self.params["opacity"]
+        x = torch.sigmoid(old.detach()) * ratio
+        new = torch.log(x / (1 - x))
+        st = self._adam_state(old)
+        states = {}
+        if st is not None:
+            states["opacity"] = {"exp_avg": torch.zeros_like(new), "exp_avg_sq": torch.zeros_like(new)}
+        keep = {k: (new if k == "opacity" else None) for k in PARAMS}
+        self._install(keep, states)
+
     def flags(self, do_prune, do_densify, min_opacity, extent, max_grad) -> torch.Tensor:
         """The per-point decision byte (1 pruned, 2 clone, 4 split) without applying it (diagnostics / tests)."""
         L = hip_lib.lib()
@@ -196,6 +212,8 @@ class SurfelDensifier:
 
     def _install(self, news, states):
         for k in PARAMS:
+            if news[k] is None:
+                continue
             old = self.params[k]
             new = nn.Parameter(news[k].requires_grad_(True)) if isinstance(old, nn.Parameter) or old.requires_grad else news[k]
             g = self._group(k)

@@ -20,7 +20,8 @@ from torch import nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("SOAR_REFERENCE", "/root/reference") + "/soar/threestudio-soar"
 METHODS = ("add_densification_stats", "adaptive_prune", "adaptive_densify", "densify_and_clone", "densify_and_split",
-           "densification_postfix", "cat_tensors_to_optimizer", "prune_points", "_prune_optimizer")
+           "densification_postfix", "cat_tensors_to_optimizer", "prune_points", "_prune_optimizer", "reset_opacity",
+           "replace_tensor_to_optimizer")
 
 
 def _functions(path, names):
@@ -142,6 +143,12 @@ def run_case(name, P, seed, surface, do_prune, out):
         out[f"{name}_out_m_{k}"], out[f"{name}_out_v_{k}"] = s["exp_avg"].numpy().copy(), s["exp_avg_sq"].numpy().copy()
     for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
         out[f"{name}_out_{k}"] = getattr(stub, k).numpy().copy()
+    # reset_opacity (:754-764) on the densified model: new raw opacities, zeroed Adam moments for that tensor
+    with torch.no_grad():
+        stub.reset_opacity(0.12, 0)
+    out[f"{name}_reset_opacity"] = stub._opacity.detach().numpy().copy()
+    s = stub.optimizer.state[stub._opacity]
+    assert float(s["exp_avg"].abs().sum()) == 0 and float(s["exp_avg_sq"].abs().sum()) == 0
     # the standard normals torch.normal(mean=0, std=stds) consumed: same generator state, same shape -> randn * stds
     std, samples = captured["std"], captured["samples"]
     torch.manual_seed(seed + 2)

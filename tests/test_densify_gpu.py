@@ -76,6 +76,11 @@ def test_densify_state_machine_matches_reference(name):
     else:
         d2.adaptive_densify(cfg["max_grad"], cfg["extent"], noise=noise)
     check_against_golden(name, d2)
+    # reset_opacity on the densified model, then update_states drives the same machinery from a config
+    d.reset_opacity(0.12)
+    np.testing.assert_allclose(d.params["opacity"].detach().cpu().numpy(), G[f"{name}_reset_opacity"], rtol=2e-6, atol=1e-6)
+    st_op = d.optimizer.state[d.params["opacity"]]
+    assert float(st_op["exp_avg"].abs().sum()) == 0 and st_op["exp_avg"].shape == d.params["opacity"].shape
     # a step of the optimizer on the new parameters works
     for k in do.PARAMS:
         d2.params[k].grad = torch.ones_like(d2.params[k])
@@ -107,5 +112,17 @@ def test_densify_edge_cases_and_determinism():
         outs.append({k: v.clone() for k, v in d.params.items()})
     for k in do.PARAMS:
         assert torch.equal(outs[0][k], outs[1][k]), k
+    # update_states: statistics every iteration, prune + densify on the interval, opacity reset on its own interval
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(densify_from_iter=0, densification_interval=2, prune_from_iter=0, densify_grad_threshold=2e-4,
+                          opacity_reset_interval=3, opacity_lr=0.05)
+    Q = 5000
+    d = SurfelDensifier({k: v[:Q].clone() for k, v in base.items()}, None)
+    radii = [torch.randint(0, 9, (Q,), device=DEV)]
+    assert d.update_states(1, radii, [mk(Q, 3) * 0 + 3e-4], cfg, 1.3, scaling_grads=[torch.zeros(Q, 3, device=DEV)]) is None
+    assert float(d.accum[4].sum()) > 0 and float(torch.sigmoid(d.params["opacity"]).max()) <= 0.1201     # iteration 1: reset
+    r = d.update_states(2, radii, [mk(Q, 3) * 0 + 3e-4], cfg, 1.3, generator=torch.Generator(device=DEV).manual_seed(3),
+                        scaling_grads=[torch.zeros(Q, 3, device=DEV)])
+    assert r is not None and r["num_points"] == d.num_points and float(d.accum.sum()) == 0
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         SurfelDensifier({k: v.cpu()[:4] for k, v in base.items()})
