@@ -14,9 +14,12 @@ for o in order:
     print(f"tile {t} wave {w}: start {start.ravel()[o]:8.1f} end {end.ravel()[o]:8.1f} dur {dur.ravel()[o]:8.1f} us  list {a[t, w, 2]}  iters {a[t, w, 3]}")
 for cut in (25, 50, 100, 150, 200, 250, 300):
     print(f"waves still running at {cut} us:", int(((start < cut) & (end > cut)).sum()))
+useful = (a[..., 3] >> np.uint64(24)).astype(np.float64)
+a[..., 3] &= np.uint64((1 << 24) - 1)
 it = a[..., 3].astype(np.float64)
 ln = a[..., 2].astype(np.float64)
 print("sum iters %.3e  (per SIMD: %.0f)   sum list entries over waves %.3e (phase-A sub-chunk tests per SIMD: %.0f)" %
       (it.sum(), it.sum() / 1024, ln.sum(), ln.sum() / 64 / 1024))
 busy = (a[..., 2] > 0)
 print("waves with a non-empty list:", int(busy.sum()), " iters/wave among them mean %.1f max %d" % (it[busy].mean(), it.max()))
+print("useful (pixel, entry) pairs: %.3e of %.3e evaluated lanes = %.1f %%" % (useful.sum(), it.sum() * 64, 100 * useful.sum() / max(it.sum() * 64, 1)))

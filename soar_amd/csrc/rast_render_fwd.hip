@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
     __shared__ int wave_alive[2][4];
-    unsigned long long t_start = 0, n_iter = 0;
+    unsigned long long t_start = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
                     // skip rules (:512, :545) zero the effective alpha of this lane's entry
                     float a_live = (power > 0.0f) ? 0.f : alpha;
                     a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
+                    if (LOG) n_useful += (unsigned long long)__builtin_popcountll(__ballot(a_live > 0.f && !done));
                     const float a_eff = done ? 0.f : a_live;
                     // running transmittance through the four slots, reference order (:548-553, :602).
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
     }
     if (LOG && lane == 0) {
         unsigned long long *w = a.wave_log + ((size_t)seq * 4 + wave) * 4;
-        w[0] = t_start; w[1] = wall_clock64(); w[2] = range.y - range.x; w[3] = n_iter;
+        w[0] = t_start; w[1] = wall_clock64(); w[2] = range.y - range.x; w[3] = n_iter | (n_useful << 24);
     }
 }
 
