@@ -323,8 +323,9 @@ int soar_prof_stage_count(void);
 const char *soar_prof_stage_name(int stage);
 int soar_prof_read(int stage, double *total_ms, int64_t *launches);
 
-/* ---- device self-test of the wave-level 16-value transpose-reduce used by the backward blend.
- * out128_dev [128] floats: [0..63] the total each lane ends up with, [64..127] the value slot q(lane) it belongs to. */
+/* ---- device self-test of the 16-value transpose-reduce of the backward blend (sum over the 16 pixel-lanes of each slot,
+ * lane = 4 * pixel + slot).  out128_dev [128] floats: [0..63] the total each lane ends up with, [64..127] the value index
+ * q(lane) that total belongs to. */
 int soar_selftest_wave_reduce(float *out128_dev, void *stream);
 
 const char *soar_last_error(void);

@@ -2,34 +2,19 @@
 //
 // Replaces renderCUDA<3> backward (DGR/cuda_rasterizer/backward.cu:529-858).
 //
-// The reference issues 13 global atomicAdd per contributing (pixel, Gaussian) pair, all 256 pixels of a tile
-// hitting the same addresses, and every thread walks the whole tile list from its end.  Here each wavefront owns an
-// 8x8 pixel quad (same mapping as the forward kernel), walks the tile list backwards starting at the deepest
-// contributor of ITS 64 pixels, in 64-entry chunks that are software-pipelined (records of chunk k+1 are in flight
-// while chunk k is processed).  Per chunk:
+// The reference issues 13 global atomicAdd per contributing (pixel, Gaussian) pair, all 256 pixels of a tile hitting the
+// same addresses, and every thread walks the whole tile list from its end.  Here the forward kernel's decomposition is
+// reused (workgroup = 8x8 pixel quad of a tile, wavefront = 4x4 pixel block, lane = (pixel, slot)): the list is walked back
+// to front from the deepest contributor of the wavefront's pixels in staged chunks, four surviving entries per step; the 13
+// gradient terms of a step are summed over the 16 pixels with a transpose-reduce (v_permlane32/16_swap + DPP) and leave as
+// ONE global_atomic_add_f32 wave-instruction into the 64-byte accumulation rows acc[gaussian][16], which
+// geometry_backward_kernel (rast_geom_bwd.hip) consumes.  Details at the kernel below.
 //
-//   phase A  lanes = list entries.  Each lane parks its 60-byte record in the wave's LDS slab (structure of arrays)
-//            and votes on the conservative quad test (splat_may_touch_quad); a ballot gives the entries that matter.
-//   phase B1 lanes = pixels, uniform walk over the surviving entries: recompute alpha with the forward's exact
-//            arithmetic and record, PER LANE, a 64-bit mask of the entries that are live for that pixel
-//            (position < n_contrib, power <= 0, alpha >= 1/255 -- backward.cu:653-680).
-//   phase B2 lanes = pixels, each lane pops ITS OWN live entries back to front (different lanes work on different
-//            Gaussians in the same instruction), runs the gradient recurrences and adds its 13 terms into the
-//            per-chunk accumulator rows in LDS with ds_add_f32 (rows of different entries live in different banks).
-//            The loop length is the LARGEST per-pixel live count of the quad, not the number of entries that are
-//            live for at least one of its pixels, and no cross-lane reduction is needed.
-//   flush    the touched rows leave as global_atomic_add_f32 wave-instructions, 4 entries x 16 lanes each, into the
-//            64-byte accumulation row acc[gaussian][16] (one memory-side atomic request per (quad, Gaussian)).
-//
-// The per-Gaussian rows are consumed by geometry_backward_kernel (rast_geom_bwd.hip).
-// MEASURED (MI355X, C3): the per-lane variant is 2x SLOWER than the uniform walk + DPP wave reduction below
-// (2190 us vs 1045 us per launch): neighbouring pixels pop the same entry in the same step, so the ds_add_f32 of a
-// step hit the same LDS address and serialise.  The DPP kernel is therefore the default; SOAR_BWD_VARIANT=lanes selects
-// the per-lane kernel for A/B timing.
+// Two earlier layouts were measured and retired (profiles/README.md, negative results): per-lane entry pointers with
+// ds_add_f32 accumulation rows (2190 us: neighbouring pixels pop the same entry in the same step and the LDS atomics
+// serialise) and one wavefront per 8x8 quad walking the entries uniformly (1045 us).
 #include "soar_common.h"
 
-#include <cstdlib>
-#include <cstring>
 
 namespace soar {
 
@@ -50,13 +35,6 @@ struct BwdArgs {
     const float *grad_scale;         // optional device scalar the four image gradients are multiplied by
     float *acc;
 };
-
-__device__ __forceinline__ int xcd_tile(int bid, int n)
-{
-    const int q = n >> 3, r = n & 7;
-    const int xcd = bid & 7, within = bid >> 3;
-    return xcd * q + min(xcd, r) + within;
-}
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -112,192 +90,6 @@ __device__ __forceinline__ void load_pixel(const BwdArgs &a, int px, int py, boo
     s.ac0 = s.ac1 = s.ac2 = s.an0 = s.an1 = s.an2 = s.ad = 0.f;
 }
 
-// gradient terms of one live (pixel, Gaussian) pair; advances the pixel's recurrences (backward.cu:683-855)
-// v: [0,1] dL_dmean2D.xy  [2,3,4] dL_dconic (x,y,w)  [5] dL_dopacity  [6..8] dL_dcolor  [9..11] dL_dnormal  [12] dL_ddepth
-__device__ __forceinline__ void pair_backward(const PixelConsts &c, PixelState &s, const Splat &g, float dx, float dy,
-                                              float G, float alpha, float v[13])
-{
-    const float one_m_alpha = 1.f - alpha;
-    s.T = s.T / one_m_alpha;                                                  // :683
-    const float wgt = alpha * s.T;                                            // dchannel_dcolor
-    const float keep = 1.f - s.last_alpha;
-    // colour (:698-713)
-    s.ac0 = s.last_alpha * s.lc0 + keep * s.ac0; s.lc0 = g.r;
-    s.ac1 = s.last_alpha * s.lc1 + keep * s.ac1; s.lc1 = g.g;
-    s.ac2 = s.last_alpha * s.lc2 + keep * s.ac2; s.lc2 = g.b;
-    float dL_dalpha = (g.r - s.ac0) * c.dC0 + (g.g - s.ac1) * c.dC1 + (g.b - s.ac2) * c.dC2;
-    v[6] = wgt * c.dC0; v[7] = wgt * c.dC1; v[8] = wgt * c.dC2;
-    // normal, gain 10 on the per-Gaussian gradient (:715-731)
-    s.an0 = s.last_alpha * s.ln0 + keep * s.an0; s.ln0 = g.nx;
-    s.an1 = s.last_alpha * s.ln1 + keep * s.an1; s.ln1 = g.ny;
-    s.an2 = s.last_alpha * s.ln2 + keep * s.an2; s.ln2 = g.nz;
-    dL_dalpha += (g.nx - s.an0) * c.dN0 + (g.ny - s.an1) * c.dN1 + (g.nz - s.an2) * c.dN2;
-    v[9] = wgt * c.dN0 * 10.f; v[10] = wgt * c.dN1 * 10.f; v[11] = wgt * c.dN2 * 10.f;
-    // depth on the surfel plane (:758-784)
-    const float d_cur = g.depth - (dx * g.plane_a + dy * g.plane_b);
-    s.ad = s.last_alpha * s.ld + keep * s.ad; s.ld = d_cur;
-    dL_dalpha += c.norm_depth_k / one_m_alpha / s.T + (d_cur - s.ad) * c.dD_ch;
-    v[12] = wgt * c.dD_ch;
-
-    dL_dalpha *= s.T;                                                         // :788
-    dL_dalpha += c.tail / one_m_alpha;                                        // :791-802
-    s.last_alpha = alpha;
-
-    const float dL_ddist = dL_dalpha * g.opacity * -0.5f * G;                 // :823
-    v[0] = dL_ddist * 2.f * (g.A * dx + g.B * dy) * c.ddelx_dx - c.dD * g.plane_a;   // :828, :839
-    v[1] = dL_ddist * 2.f * (g.C * dy + g.B * dx) * c.ddely_dy - c.dD * g.plane_b;   // :829, :840
-    v[2] = dL_ddist * (dx * dx);                                              // :831-835
-    v[3] = dL_ddist * (dx * dy);
-    v[4] = dL_ddist * (dy * dy);
-    v[5] = G * dL_dalpha;                                                     // :854
-}
-
-// ================================================================================================
-// variant "lanes": per-lane live masks + LDS accumulation (default)
-// ================================================================================================
-constexpr int NF = 15;                 // floats per splat in the slab
-constexpr int ACC_LDS_STRIDE = 17;     // padded row: rows of different entries start in different banks
-
-struct WaveSlab {
-    float f[NF][WAVE];                 // structure of arrays: field-major, entry-minor
-    float acc[WAVE * ACC_LDS_STRIDE];
-    uint32_t id[WAVE];
-};
-
-__global__ void __launch_bounds__(256) render_backward_lanes_kernel(BwdArgs a)
-{
-    __shared__ WaveSlab slabs[4];
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);
-    const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < a.W && py < a.H;
-
-    const uint2 range = a.ranges[tile];
-    set_wave_priority_by_length(range.y - range.x);
-    PixelConsts c;
-    PixelState s;
-    load_pixel(a, px, py, inside, c, s);
-    const uint32_t deepest = wave_max_u32(c.last);                           // wave-uniform
-    if (deepest == 0u) return;
-
-    const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
-    WaveSlab &sl = slabs[wave];
-
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    uint32_t rid = 0;
-    const int cfirst = (int)((deepest - 1u) & ~63u);
-    if (cfirst + lane < (int)deepest) {
-        rid = a.point_list[range.x + cfirst + lane];
-        const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
-        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-    }
-    for (int cbase = cfirst; cbase >= 0; cbase -= WAVE) {
-        const int n = min(WAVE, (int)deepest - cbase);
-        // ---- phase A: lanes = entries
-        bool relevant = false;
-        if (lane < n) {
-            sl.f[0][lane] = r0.x; sl.f[1][lane] = r0.y; sl.f[2][lane] = r0.z; sl.f[3][lane] = r0.w;
-            sl.f[4][lane] = r1.x; sl.f[5][lane] = r1.y; sl.f[6][lane] = r1.z; sl.f[7][lane] = r1.w;
-            sl.f[8][lane] = r2.x; sl.f[9][lane] = r2.y; sl.f[10][lane] = r2.z; sl.f[11][lane] = r2.w;
-            sl.f[12][lane] = r3.x; sl.f[13][lane] = r3.y; sl.f[14][lane] = r3.z;
-            sl.id[lane] = rid;
-            relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
-        }
-        if (cbase >= WAVE) {
-            rid = a.point_list[range.x + cbase - WAVE + lane];
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
-            r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-        }
-        unsigned long long todo = __ballot(relevant);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (todo == 0ull) continue;
-
-        // ---- phase B1: which entries are live for which pixel
-        uint32_t mlo = 0u, mhi = 0u;
-        unsigned long long touched = 0ull;
-        while (todo != 0ull) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const float dx = sl.f[0][j] - c.fx, dy = sl.f[1][j] - c.fy;
-            const float power = falloff_power(sl.f[2][j], sl.f[3][j], sl.f[4][j], dx, dy);
-            const float alpha = fminf(0.99f, sl.f[5][j] * exp_nonpositive(power));
-            const bool live = ((uint32_t)(cbase + j) < c.last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const uint32_t bit = 1u << (j & 31);
-            if (j < 32) mlo |= live ? bit : 0u;
-            else mhi |= live ? bit : 0u;
-            if (__ballot(live) != 0ull) touched |= 1ull << j;
-        }
-        if (touched == 0ull) continue;
-
-        // ---- zero the accumulator rows of the touched entries (lanes = entries again)
-        if ((touched >> lane) & 1ull) {
-#pragma unroll
-            for (int k = 0; k < 13; k++) sl.acc[lane * ACC_LDS_STRIDE + k] = 0.f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- phase B2: every lane pops its own live entries, back to front
-        while (__ballot((mlo | mhi) != 0u) != 0ull) {
-            if ((mlo | mhi) != 0u) {
-                int j;
-                if (mhi != 0u) {
-                    const int b = 31 - __builtin_clz(mhi);
-                    mhi &= ~(1u << b);
-                    j = 32 + b;
-                } else {
-                    const int b = 31 - __builtin_clz(mlo);
-                    mlo &= ~(1u << b);
-                    j = b;
-                }
-                Splat g;
-                g.x = sl.f[0][j]; g.y = sl.f[1][j]; g.A = sl.f[2][j]; g.B = sl.f[3][j]; g.C = sl.f[4][j];
-                g.opacity = sl.f[5][j]; g.depth = sl.f[6][j]; g.plane_a = sl.f[7][j]; g.plane_b = sl.f[8][j];
-                g.r = sl.f[9][j]; g.g = sl.f[10][j]; g.b = sl.f[11][j];
-                g.nx = sl.f[12][j]; g.ny = sl.f[13][j]; g.nz = sl.f[14][j];
-                const float dx = g.x - c.fx, dy = g.y - c.fy;
-                const float power = falloff_power(g.A, g.B, g.C, dx, dy);
-                const float G = exp_nonpositive(power);
-                const float alpha = fminf(0.99f, g.opacity * G);
-                float v[13];
-                pair_backward(c, s, g, dx, dy, G, alpha, v);
-                float *row = sl.acc + j * ACC_LDS_STRIDE;
-#pragma unroll
-                for (int k = 0; k < 13; k++) atomicAdd(row + k, v[k]);       // ds_add_f32
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- flush: 4 touched entries per wave-instruction, 16 lanes (13 used) per entry
-        const int grp = lane >> 4, q = lane & 15;
-        while (touched != 0ull) {
-            int e[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                e[t] = touched ? __builtin_ctzll(touched) : -1;
-                touched = touched ? (touched & (touched - 1ull)) : 0ull;
-            }
-            const int mine = grp == 0 ? e[0] : grp == 1 ? e[1] : grp == 2 ? e[2] : e[3];
-            if (mine >= 0 && q < 13) {
-                const float val = sl.acc[mine * ACC_LDS_STRIDE + q];
-                atomicAdd(a.acc + (size_t)sl.id[mine] * ACC_STRIDE + q, val);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                                     // slab is overwritten by the next chunk
-    }
-}
-
-// ================================================================================================
-// variant "dpp" (default): uniform walk over the entries, transpose-reduce of the 13 terms per live entry
-// ================================================================================================
 // ---- 16 values x 64 lanes -> 16 totals in one pass ("transpose-reduce") --------------------------------------------
 // Summing 13 per-lane terms over the wave one after the other costs 13 x 6 dependent DPP adds.  Instead every
 // halving step also halves the number of live registers: v_permlane32_swap / v_permlane16_swap exchange register
@@ -306,7 +98,7 @@ __global__ void __launch_bounds__(256) render_backward_lanes_kernel(BwdArgs a)
 // the totals), and the totals end up in 16 different lane groups, ready for a single atomic wave-instruction:
 // lane l holds the total of value q(l) = 8*bit5(l) + 4*bit4(l) + 2*bit3(l) + bit0(l).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_XOR3 = 0x1B;
+constexpr int DPP_QUAD_XOR3 = 0x1B;
 constexpr int DPP_ROW_ROR8 = 0x128, DPP_ROW_HALF_MIRROR = 0x141;
 
 template <int CTRL>
@@ -324,140 +116,8 @@ __device__ __forceinline__ float swap16_add(float a, float b)
     const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-__device__ __forceinline__ int reduce16_slot(int lane)
-{
-    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + (lane & 1);
-}
-__device__ __forceinline__ float wave_reduce16(float v[16], int lane)
-{
-#pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = swap32_add(v[k], v[k + 8]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = swap16_add(v[k], v[k + 4]);
-    const bool b3 = (lane & 8) != 0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const float keep = b3 ? v[k + 2] : v[k];
-        const float send = b3 ? v[k] : v[k + 2];
-        v[k] = keep + dpp_move<DPP_ROW_ROR8>(send);
-    }
-    const bool b0 = (lane & 1) != 0;
-    const float keep = b0 ? v[1] : v[0];
-    const float send = b0 ? v[0] : v[1];
-    float t = keep + dpp_move<DPP_QUAD_XOR1>(send);
-    t += dpp_move<DPP_QUAD_XOR2>(t);
-    t += dpp_move<DPP_QUAD_XOR3>(dpp_move<DPP_ROW_HALF_MIRROR>(t));      // lane ^ 4
-    return t;
-}
-
-__global__ void selftest_wave_reduce_kernel(float *out)
-{
-    const int lane = threadIdx.x & 63;
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = (float)((lane + 1) * (q + 1)) + 0.25f * (float)((lane * 7 + q * 3) % 5);
-    const float tot = wave_reduce16(v, lane);
-    out[lane] = tot;
-    out[64 + lane] = (float)reduce16_slot(lane);
-}
-
-__global__ void __launch_bounds__(256) render_backward_dpp_kernel(BwdArgs a)
-{
-    __shared__ GaussRec slab[4][WAVE];
-    __shared__ uint32_t slab_id[4][WAVE];
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);
-    const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < a.W && py < a.H;
-
-    const uint2 range = a.ranges[tile];
-    set_wave_priority_by_length(range.y - range.x);
-    PixelConsts c;
-    PixelState s;
-    load_pixel(a, px, py, inside, c, s);
-    const uint32_t deepest = wave_max_u32(c.last);
-    if (deepest == 0u) return;
-
-    const float quad_x0 = (float)(tx * TILE + (wave & 1) * 8), quad_y0 = (float)(ty * TILE + (wave >> 1) * 8);
-    GaussRec *my = slab[wave];
-    uint32_t *my_id = slab_id[wave];
-    const float4 *myq = reinterpret_cast<const float4 *>(my);
-    const int slot = reduce16_slot(lane);
-
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    uint32_t rid = 0;
-    const int cfirst = (int)((deepest - 1u) & ~63u);
-    if (cfirst + lane < (int)deepest) {
-        rid = a.point_list[range.x + cfirst + lane];
-        const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
-        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-    }
-    for (int cbase = cfirst; cbase >= 0; cbase -= WAVE) {
-        const int n = min(WAVE, (int)deepest - cbase);
-        bool relevant = false;
-        if (lane < n) {
-            float4 *dst = reinterpret_cast<float4 *>(my + lane);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-            my_id[lane] = rid;
-            relevant = splat_may_touch_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, quad_x0, quad_y0);
-        }
-        if (cbase >= WAVE) {
-            rid = a.point_list[range.x + cbase - WAVE + lane];
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
-            r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-        }
-        unsigned long long todo = __ballot(relevant);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // software pipeline over the surviving entries (back to front): the next record's four LDS reads are in
-        // flight while the current entry is processed
-        float4 n0, n1, n2, n3;
-        int jn = -1;
-        if (todo != 0ull) {
-            jn = 63 - __builtin_clzll(todo);
-            todo &= ~(1ull << jn);
-            n0 = myq[4 * jn + 0]; n1 = myq[4 * jn + 1]; n2 = myq[4 * jn + 2]; n3 = myq[4 * jn + 3];
-        }
-        while (jn >= 0) {
-            const int j = jn;
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            jn = -1;
-            if (todo != 0ull) {
-                jn = 63 - __builtin_clzll(todo);
-                todo &= ~(1ull << jn);
-                n0 = myq[4 * jn + 0]; n1 = myq[4 * jn + 1]; n2 = myq[4 * jn + 2]; n3 = myq[4 * jn + 3];
-            }
-            const float dx = q0.x - c.fx, dy = q0.y - c.fy;
-            const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
-            const float G = exp_nonpositive(power);
-            const float alpha = fminf(0.99f, q1.y * G);
-            const bool live = ((uint32_t)(cbase + j) < c.last) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(live) == 0ull) continue;
-            float v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = 0.f;
-            if (live) {
-                Splat g;
-                g.x = q0.x; g.y = q0.y; g.A = q0.z; g.B = q0.w; g.C = q1.x; g.opacity = q1.y; g.depth = q1.z;
-                g.plane_a = q1.w; g.plane_b = q2.x; g.r = q2.y; g.g = q2.z; g.b = q2.w; g.nx = q3.x; g.ny = q3.y; g.nz = q3.z;
-                pair_backward(c, s, g, dx, dy, G, alpha, v);
-            }
-            // 64 lanes x 13 terms -> 13 totals in 13 lane groups, then ONE atomic wave-instruction into the row
-            const float total = wave_reduce16(v, lane);
-            const uint32_t gid = my_id[j];
-            if ((lane & 6) == 0 && slot < 13) atomicAdd(a.acc + (size_t)gid * ACC_STRIDE + slot, total);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ================================================================================================
-// variant "slots" (default): lane = (pixel, slot) -- four list entries per pixel and step
+// the kernel: lane = (pixel, slot) -- four list entries per pixel and step
 // ================================================================================================
 // Same decomposition as the forward kernel: workgroup = 8x8 quad of a tile, wavefront = 4x4 pixel block, the four
 // lanes of a pixel take the four deepest remaining surviving entries.  Per step:
@@ -494,6 +154,17 @@ __device__ __forceinline__ float pixel_reduce16(float v[16], int lane)
 __device__ __forceinline__ int pixel_reduce16_slot(int lane)
 {
     return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
+// device self-test of pixel_reduce16 (soar_selftest_wave_reduce): every lane contributes 16 known values
+__global__ void selftest_wave_reduce_kernel(float *out)
+{
+    const int lane = threadIdx.x & 63;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = (float)((lane + 1) * (q + 1)) + 0.25f * (float)((lane * 7 + q * 3) % 5);
+    out[lane] = pixel_reduce16(v, lane);
+    out[64 + lane] = (float)pixel_reduce16_slot(lane);
 }
 
 __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
@@ -647,16 +318,6 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     }
 }
 
-int bwd_variant()     // 0 = slots (default), 1 = dpp, 2 = lanes
-{
-    static int cached = -1;
-    if (cached < 0) {
-        const char *v = getenv("SOAR_BWD_VARIANT");
-        cached = (v && !strcmp(v, "lanes")) ? 2 : (v && !strcmp(v, "dpp")) ? 1 : 0;
-    }
-    return cached;
-}
-
 }  // namespace
 
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
@@ -674,13 +335,7 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc;
     StageTimer timer(ST_RENDER_BWD, stream);
-    const int variant = bwd_variant();
-    if (variant == 0)
-        hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * ((a.ntiles + 7) / 8 * 8)), dim3(256), 0, stream, a);
-    else if (variant == 1)
-        hipLaunchKernelGGL(render_backward_dpp_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(render_backward_lanes_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * ((a.ntiles + 7) / 8 * 8)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_backward", stream, prm.debug);
     return 0;
 }
