@@ -52,6 +52,9 @@ SCENES = [
     lambda: _cov_scene(),
     lambda: S.depth_plane_scene(),
     lambda: S.big_splats_scene(),
+    lambda: S.blob_scene(P=700, W=96, H=64, seed=31, config=(1, 1, 1, 1), lrn_cam=True),
+    lambda: S.person_scene(P=2500, W=160, H=120, seed=32, config=(1, 1, 1, 0), prcp=(0.45, 0.56), opacity=None),
+    lambda: S.person_scene(P=2500, W=160, H=120, seed=33, config=(1, 0, 1, 0), patch=(10, 24, 100, 140), opacity=None),
 ]
 
 
@@ -79,7 +82,7 @@ def _state_agreement(a, b, vis):
 
 
 IDS = ["person_cfg1110", "person_cfg0000", "person_front", "person_descending", "blob", "blob_sh3", "blob_cov3d", "depth_plane",
-       "big_splats"]
+       "big_splats", "blob_lrn_cam", "person_principal_point", "person_patch"]
 
 
 @pytest.mark.parametrize("mk", SCENES, ids=IDS)
