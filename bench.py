@@ -40,6 +40,7 @@ WORKLOADS = {
     "C5": (300_000, 3840, 2160, 400),
     "tiny": (5_000, 256, 192, 8),
 }
+TARGET_SETS = 8               # distinct per-frame target sets kept on the device (C3: 8 x 58 MB)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -97,7 +98,9 @@ def build_sequence(workload, device, seed=0):
     poses = syn.make_pose_sequence(max(F, 4), seed)
     cam = syn.make_camera(W, H)
     seq = AvatarSequence(surfels, body, poses, cam, device)
-    targets = {k: v.to(device) for k, v in syn.make_loss_targets(H, W, seed).items()}
+    # per-frame targets resident on the device (the video of the avatar stage): TARGET_SETS distinct frames' worth, frame f
+    # uses set f mod TARGET_SETS -- more data than the 256 MB Infinity Cache holds, so a step reads its targets from HBM
+    targets = syn.make_loss_target_pool(H, W, TARGET_SETS, seed, device)
     return seq, targets, (surfels, body, poses, cam)
 
 
@@ -114,7 +117,9 @@ def step_body(seq, targets, flat, frames, bg, capacity=None, joint_mats=None):
     seq.refresh_blend_weights()
     # L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth) per frame,
     # evaluated behind each frame's blend on the frame's stream (soar_amd/losses.py kernel)
-    outs = seq.render_frames(frames, bg, with_occ=True, capacity=capacity, joint_mats=joint_mats, loss_targets=targets)
+    from soar_amd.synthetic import pool_targets
+    per_frame = [pool_targets(targets, f) for f in frames] if torch.is_tensor(targets) else targets
+    outs = seq.render_frames(frames, bg, with_occ=True, capacity=capacity, joint_mats=joint_mats, loss_targets=per_frame)
     loss = outs[0].loss
     for out in outs[1:]:
         loss = loss + out.loss
@@ -298,7 +303,9 @@ def main():
             mode, plan, stepper = fallback, None, None
     if mode == "graph":
         try:
-            stepper = GraphStep(seq, targets, flat, bg, len(frames_of(0)), capacity)
+            # the whole-step graph bakes its target pointers in: every frame uses target set 0 in this mode
+            from soar_amd.synthetic import pool_targets
+            stepper = GraphStep(seq, pool_targets(targets, 0), flat, bg, len(frames_of(0)), capacity)
         except Exception as e:                                   # capture not supported here: eager sync-free launches
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); falling back to --mode async", file=sys.stderr)
             torch.cuda.synchronize()

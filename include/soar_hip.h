@@ -232,6 +232,14 @@ int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *norma
                     float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
                     float *dL_dopac, void *stream);
 
+/* Same loss with the frame data resident in HBM: target_pool [n_sets][7][H*W] (colour 3, mask 1, normal 3 planes per
+ * frame), the set is chosen on the DEVICE as *set_index_dev mod n_sets -- the launch stays valid when it is replayed from a
+ * HIP graph for another frame (the host only rewrites the 4-byte index). */
+int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
+                           const float *opac, const float *target_pool, int32_t n_sets, const int32_t *set_index_dev,
+                           float w_color, float w_mask, float w_normal, float w_depth, float *loss_out, float *sums4,
+                           float *dL_dcolor, float *dL_dnormal, float *dL_ddepth, float *dL_dopac, void *stream);
+
 /* ---- SSIM (TS/utils/loss_utils.py:36-76: 11x11 Gaussian window, sigma 1.5, zero padding):
  *      mean SSIM of img1, img2 [C,H,W] and, when dssim_dimg1 != NULL, its gradient w.r.t. img1 -- one kernel per
  *      direction instead of five grouped convolutions and ~15 element-wise kernels each way.

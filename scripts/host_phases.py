@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import bench
 from soar_amd.frame_dp import FlatGradBuffer
-seq, targets, parts = bench.build_sequence("C3", torch.device("cuda:0"))
+seq, targets, parts = bench.build_sequence("C3", torch.device("cuda:0"))  # targets: resident pool [sets,7,H,W]
 flat = FlatGradBuffer(seq.leaves())
 bg = torch.tensor([0.2, 0.5, 0.7], device="cuda:0")
 for s in range(5):

@@ -18,6 +18,8 @@ struct LossArgs {
     float wc, wm, wn, wd;
     float *dcolor, *dnormal, *ddepth, *dopac;
     float *sums;                 // [4] un-normalised sums of the four terms
+    const int *set_index;        // optional: the targets are set (*set_index mod n_sets) of a resident pool [n_sets][7][n]
+    int n_sets;
 };
 
 __device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -32,6 +34,10 @@ __device__ __forceinline__ float wave_sum(float v)
 __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
 {
     const int n4 = a.n >> 2;
+    if (a.set_index) {           // frame data resident in HBM: pick this frame's planes (colour 3, mask 1, normal 3)
+        const float *set = a.t_color + (size_t)((unsigned)*a.set_index % (unsigned)a.n_sets) * 7u * (size_t)a.n;
+        a.t_color = set; a.t_mask = set + 3 * (size_t)a.n; a.t_normal = set + 4 * (size_t)a.n;
+    }
     float s_c = 0.f, s_m = 0.f, s_n = 0.f, s_d = 0.f;
     const float gc = a.wc / (3.f * a.n), gm = a.wm / a.n, gn = a.wn / (3.f * a.n), gd = a.wd / a.n;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
@@ -83,13 +89,41 @@ __global__ void frame_loss_finish_kernel(const float *sums, int n, float wc, flo
 
 using namespace soar;
 
+static int frame_loss_launch(int32_t W, int32_t H, const float *color, const float *normal, const float *depth, const float *opac,
+                             const float *target_color, const float *target_mask, const float *target_normal,
+                             const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
+                             float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                             float *dL_dopac, hipStream_t stream);
+
 extern "C" int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                                const float *opac, const float *target_color, const float *target_mask,
                                const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
                                float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
                                float *dL_dopac, void *stream_)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return frame_loss_launch(W, H, color, normal, depth, opac, target_color, target_mask, target_normal, nullptr, 1, w_color,
+                             w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac,
+                             static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
+                                      const float *opac, const float *target_pool, int32_t n_sets,
+                                      const int32_t *set_index_dev, float w_color, float w_mask, float w_normal, float w_depth,
+                                      float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                                      float *dL_dopac, void *stream_)
+{
+    if (n_sets <= 0 || !set_index_dev) { set_error("soar_frame_loss_pooled: need n_sets > 0 and a device index"); return 1; }
+    return frame_loss_launch(W, H, color, normal, depth, opac, target_pool, target_pool, target_pool, set_index_dev, n_sets,
+                             w_color, w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac,
+                             static_cast<hipStream_t>(stream_));
+}
+
+static int frame_loss_launch(int32_t W, int32_t H, const float *color, const float *normal, const float *depth, const float *opac,
+                             const float *target_color, const float *target_mask, const float *target_normal,
+                             const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
+                             float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                             float *dL_dopac, hipStream_t stream)
+{
     if (W <= 0 || H <= 0) { set_error("soar_frame_loss: bad image size %dx%d", W, H); return 1; }
     if (!color || !normal || !depth || !opac || !target_color || !target_mask || !target_normal || !loss_out || !sums4 ||
         !dL_dcolor || !dL_dnormal || !dL_ddepth || !dL_dopac) {
@@ -103,6 +137,7 @@ extern "C" int soar_frame_loss(int32_t W, int32_t H, const float *color, const f
     a.wc = w_color; a.wm = w_mask; a.wn = w_normal; a.wd = w_depth;
     a.dcolor = dL_dcolor; a.dnormal = dL_dnormal; a.ddepth = dL_ddepth; a.dopac = dL_dopac;
     a.sums = sums4;
+    a.set_index = set_index_dev; a.n_sets = n_sets;
     if (a.n & 3) {        // planes of a [3,n] tensor are 16-byte aligned only when n % 4 == 0
         set_error("soar_frame_loss: W*H must be a multiple of 4 (got %d)", a.n);
         return 1;

@@ -36,7 +36,8 @@ from .rasterizer import _Ctx
 class FrameStepPlan:
     def __init__(self, seq, n_frames: int, targets: Dict[str, torch.Tensor], bg: torch.Tensor, capacity: int, flat,
                  loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True):
-        """seq: AvatarSequence; targets: {"color","mask","normal"} image targets shared by the frames; capacity: bound
+        """seq: AvatarSequence; targets: {"color","mask","normal"} image targets shared by the frames, or a resident pool
+        [n_sets,7,H,W] of per-frame targets (``synthetic.make_loss_target_pool``; frame f uses set f mod n_sets); capacity: bound
         of the (tile, Gaussian) instances of one frame (checked on the device, see ``check()``); flat: FlatGradBuffer of
         ``seq.leaves()`` that receives the summed gradients."""
         L = hip_lib.lib()
@@ -48,7 +49,15 @@ class FrameStepPlan:
         self.weights = tuple(float(w) for w in loss_weights)
         f = dict(dtype=torch.float32, device=dev)
         self.bg = bg.to(**f).contiguous()
-        self.targets = [targets[k].to(**f).contiguous() for k in ("color", "mask", "normal")]
+        self.pool = None
+        if torch.is_tensor(targets):
+            if targets.dim() != 4 or targets.shape[1:] != (7, H, W) or not targets.is_cuda or not targets.is_contiguous():
+                raise ValueError(f"target pool must be a contiguous device tensor [n_sets,7,{H},{W}], got {tuple(targets.shape)}")
+            self.pool = targets
+            self.targets = None
+        else:
+            self.targets = [targets[k].to(**f).contiguous() for k in ("color", "mask", "normal")]
+        self.frame_sel = torch.zeros((self.n,), dtype=torch.int32, device=dev)   # static input: target set of each slot's frame
         self.mats = torch.empty((self.n, 55, 4, 4), **f)                 # static input: joint transforms of the step's frames
         self.blend_weights = torch.empty((P, seq.lbs_weights.shape[1]), **f)
         self.ones = torch.ones((P, 1), **f)
@@ -117,10 +126,16 @@ class FrameStepPlan:
                                              ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
                                              ptr(v["occ"]), stream), "render")
         wc, wm, wn, wd = self.weights
-        tc, tm, tn = self.targets
-        check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
-                                wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
-                                ptr(v["gO"]), stream), "frame_loss")
+        if self.pool is not None:
+            check(L.soar_frame_loss_pooled(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
+                                           int(self.pool.shape[0]), ptr(self.frame_sel[i]), wc, wm, wn, wd, ptr(self.losses[i]),
+                                           ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), stream),
+                  "frame_loss_pooled")
+        else:
+            tc, tm, tn = self.targets
+            check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
+                                    wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
+                                    ptr(v["gO"]), stream), "frame_loss")
         check(L.soar_rast_backward(prm, ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()), ptr(s.scales.detach()),
                                    ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
                                    ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
@@ -197,6 +212,8 @@ class FrameStepPlan:
         dev = self.device
         idx = torch.as_tensor([f % self.seq.num_frames for f in frames], device=dev)
         torch.index_select(self.seq.cano2live, 0, idx, out=self.mats)
+        if self.pool is not None:
+            self.frame_sel.copy_(idx % int(self.pool.shape[0]))
         if self.graphs is None:
             self._run_eager()
             return self.losses

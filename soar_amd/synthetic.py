@@ -294,6 +294,23 @@ def make_loss_targets(H: int, W: int, seed: int = 0) -> Dict[str, torch.Tensor]:
             "normal": torch.nn.functional.normalize(_randn(gen, 3, H, W), dim=0)}
 
 
+def make_loss_target_pool(H: int, W: int, n_sets: int, seed: int = 0, device="cpu") -> torch.Tensor:
+    """Per-frame targets of a video resident on the device: [n_sets, 7, H, W] = colour 3, mask 1, normal 3 planes per frame
+    (set k is what ``make_loss_targets``-style data looks like for frame k).  Generated on `device`."""
+    gen = torch.Generator(device=device).manual_seed(3000 + seed)
+    pool = torch.empty(n_sets, 7, H, W, dtype=torch.float32, device=device)
+    pool[:, 0:3] = torch.rand(n_sets, 3, H, W, generator=gen, device=device)
+    pool[:, 3:4] = (torch.rand(n_sets, 1, H, W, generator=gen, device=device) > 0.5).float()
+    pool[:, 4:7] = torch.nn.functional.normalize(torch.randn(n_sets, 3, H, W, generator=gen, device=device), dim=1)
+    return pool
+
+
+def pool_targets(pool: torch.Tensor, k: int) -> Dict[str, torch.Tensor]:
+    """Set k of a target pool as the {"color","mask","normal"} dict the loss functions take (views, no copy)."""
+    s = pool[k % pool.shape[0]]
+    return {"color": s[0:3], "mask": s[3:4], "normal": s[4:7]}
+
+
 def loss_and_pixel_grads(color, normal, depth, opac, targets):
     """Closed-form upstream gradients of the synthetic loss (no autograd needed): returns (loss, dC, dN, dD, dO)."""
     dC = torch.sign(color - targets["color"]) / color.numel()

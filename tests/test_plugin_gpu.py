@@ -264,7 +264,9 @@ def test_step_replayed_from_hip_graph_matches_eager():
     import bench
     from soar_amd import rasterizer
     from soar_amd.frame_dp import FlatGradBuffer
-    seq, targets, _ = bench.build_sequence("tiny", DEV)
+    from soar_amd.synthetic import pool_targets
+    seq, pool, _ = bench.build_sequence("tiny", DEV)
+    targets = pool_targets(pool, 0)             # the whole-step graph bakes its target pointers in: one set for all frames
     flat = FlatGradBuffer(seq.leaves())
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     bench.run_step(seq, targets, flat, [0, 1, 2, 3], bg)
@@ -313,15 +315,19 @@ def test_fused_frame_loss_in_rasterize_views():
         assert _rel(g_got[k].cpu().numpy(), g_ref[k].cpu().numpy()) < 1e-4, k
 
 
-@pytest.mark.parametrize("use_graphs", [False, True], ids=["eager", "graphs"])
-def test_step_plan_matches_autograd(use_graphs):
+@pytest.mark.parametrize("use_graphs,pooled", [(False, True), (True, True), (True, False)],
+                         ids=["eager-per-frame-targets", "graphs-per-frame-targets", "graphs-shared-targets"])
+def test_step_plan_matches_autograd(use_graphs, pooled):
     """FrameStepPlan (explicit launch plan: per-frame forward+backward chains on their own streams / HIP graphs, no
-    autograd) gives the losses and leaf gradients of the autograd path (render_frames + fused loss + backward)."""
+    autograd) gives the losses and leaf gradients of the autograd path (render_frames + fused loss + backward) -- with the
+    per-frame targets of a resident pool picked on the device (soar_frame_loss_pooled) and with one shared target set."""
     import bench
     from soar_amd import rasterizer
     from soar_amd.frame_dp import FlatGradBuffer
     from soar_amd.step_plan import FrameStepPlan
-    seq, targets, _ = bench.build_sequence("tiny", DEV)
+    from soar_amd.synthetic import pool_targets
+    seq, pool, _ = bench.build_sequence("tiny", DEV)
+    targets = pool if pooled else pool_targets(pool, 3)
     flat = FlatGradBuffer(seq.leaves())
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     bench.run_step(seq, targets, flat, [0, 1, 2, 3], bg)
@@ -335,9 +341,11 @@ def test_step_plan_matches_autograd(use_graphs):
     for frames in ([5, 2, 7, 1], [3, 3, 0, 6]):
         flat.zero()
         seq.refresh_blend_weights()
-        outs = seq.render_frames(frames, bg, loss_targets=targets)
+        outs = seq.render_frames(frames, bg, loss_targets=[pool_targets(pool, f) for f in frames] if pooled else targets)
         sum(o.loss for o in outs).backward()
         want, want_losses = flat.flat.clone(), torch.stack([o.loss.detach() for o in outs])
+        if pooled:
+            assert len({round(float(l), 5) for l in want_losses}) == len(set(frames))  # different frames, different targets
         losses = plan.run(frames)
         torch.cuda.synchronize()
         plan.check()
