@@ -336,6 +336,10 @@ int soar_prof_read(int stage, double *total_ms, int64_t *launches);
  * q(lane) that total belongs to. */
 int soar_selftest_wave_reduce(float *out128_dev, void *stream);
 
+/* ---- device self-test of the blend kernels' exp: out_dev[i] = the kernels' exp(x[i]), expf_dev[i] = the device math
+ * library's expf(x[i]) (what the reference's `exp(power)` becomes when built for this GPU); equal bit for bit on [-87, 0]. */
+int soar_selftest_exp(const float *x_dev, int32_t n, float *out_dev, float *expf_dev, void *stream);
+
 const char *soar_last_error(void);
 int soar_abi_version(void);
 

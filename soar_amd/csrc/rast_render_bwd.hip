@@ -342,6 +342,26 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
 
 }  // namespace soar
 
+namespace soar {
+namespace {
+// out[i] = exp_nonpositive(x[i]), ref[i] = expf(x[i]) (the device math library)
+__global__ void selftest_exp_kernel(const float *x, int n, float *out, float *ref)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { out[i] = exp_nonpositive(x[i]); ref[i] = expf(x[i]); }
+}
+}  // namespace
+}  // namespace soar
+
+extern "C" int soar_selftest_exp(const float *x_dev, int32_t n, float *out_dev, float *expf_dev, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n <= 0 || !x_dev || !out_dev || !expf_dev) { soar::set_error("soar_selftest_exp: bad arguments"); return 1; }
+    hipLaunchKernelGGL(soar::selftest_exp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x_dev, n, out_dev, expf_dev);
+    SOAR_LAUNCH_OK("selftest_exp", stream, 1);
+    return 0;
+}
+
 extern "C" int soar_selftest_wave_reduce(float *out128_dev, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

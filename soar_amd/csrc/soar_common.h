@@ -116,18 +116,23 @@ int carve_binning(void *base, int64_t R, BinBuf *out);
 constexpr int ACC_STRIDE = 16;
 
 #if defined(__HIPCC__)
-// exp(x) for x <= 0 to ~1 ulp: v_exp_f32 on the rounded product x*log2(e), corrected for the product's rounding
-// error.  (The hardware exp2 alone leaves up to 4e-7 relative error at |x| ~ 6, which the blend amplifies by
-// 1/(1-alpha) <= 100; the reference's expf is a <= 2 ulp routine.)
+// exp(x) for x <= 0.  (The hardware exp2 alone leaves up to 4e-7 relative error at |x| ~ 6, which the blend amplifies by
+// 1/(1-alpha) <= 100.)
 __device__ __forceinline__ float exp_nonpositive(float x)
 {
-    const float L2E_HI = 1.44269502162933349609375f;   // 0x3fb8aa3b
-    const float L2E_LO = 1.925963033500011e-08f;        // 0x32a5705f
+    // The algorithm of the device math library's expf (ROCm ocml, the function the reference's `exp(power)` resolves to when
+    // its kernels are built for this GPU), without the overflow / underflow clamps that x <= 0 and the 1/255 alpha cut make
+    // unreachable: exp(x) = 2^n * exp2((t - n) + lo), t = x log2(e) in double-float (t, lo), n = rint(t).  Same bits as
+    // expf on [-87, 0] (tests/test_rasterizer_gpu.py), so alpha, the transmittance chain and every skip / stop decision
+    // are those of the reference kernels on the same hardware.
+#pragma clang fp contract(off)      // t must be the ROUNDED product in (t - n): (t, lo) is a double-float pair
+    const float L2E_HI = __uint_as_float(0x3fb8aa3bu), L2E_LO = __uint_as_float(0x32a5705fu);
     const float t = x * L2E_HI;
     float lo = __builtin_fmaf(x, L2E_HI, -t);
     lo = __builtin_fmaf(x, L2E_LO, lo);
-    const float e = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(e, lo * 0.693147180559945309f, e);
+    const float n = __builtin_rintf(t);
+    const float f = (t - n) + lo;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store

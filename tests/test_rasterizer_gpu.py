@@ -243,6 +243,20 @@ def test_wave_transpose_reduce_selftest():
     np.testing.assert_allclose(out[:64], expect[lane & 3, q_of], rtol=1e-6)
 
 
+def test_blend_exp_is_the_device_expf_bit_for_bit():
+    """The blends' exp (soar_common.h exp_nonpositive) == expf of the device math library on the range the blend uses: the
+    alphas, transmittance products and skip / stop decisions are then those of the reference's kernels built for this GPU."""
+    from soar_amd import hip_lib
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([-torch.rand(4_000_000, generator=g) * 12.0, -torch.rand(1_000_000, generator=g) * 87.0,
+                   -torch.rand(200_000, generator=g) * 1e-3, torch.tensor([0.0, -0.0, -5.541263580322266, -1e-30])]).to(_dev())
+    out, ref = torch.empty_like(x), torch.empty_like(x)
+    hip_lib.check(hip_lib.lib().soar_selftest_exp(x.data_ptr(), x.numel(), out.data_ptr(), ref.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "selftest_exp")
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert torch.equal(ref, torch.exp(x))          # and torch's own device exp agrees with both
+
+
 def test_empty_inputs():
     """P == 0: zero images, empty radii, no launches (rasterize_points.cu:61-78)."""
     scene = S.person_scene(P=16)

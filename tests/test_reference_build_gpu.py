@@ -121,11 +121,12 @@ def test_oracle_and_hip_match_the_reference_kernels(mk):
     for k in ("radii", "tiles_touched", "point_offsets", "point_list", "keys_sorted", "keys_unsorted", "vals_unsorted"):
         np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(hip["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
-    same = hip["n_contrib"].reshape(scene.H, scene.W) == ref["n_contrib"].reshape(scene.H, scene.W)
-    assert same.mean() >= 1 - 1e-3
+    # the blends' exp is the device expf bit for bit and the transmittance products run in the reference's order: every
+    # skip / stop decision, the per-pixel contributor count and the final transmittance are identical, not just close
+    np.testing.assert_array_equal(hip["n_contrib"], ref["n_contrib"])
+    np.testing.assert_array_equal(hip["final_T"], ref["final_T"])
     for name in ("color", "normal", "depth", "opac"):
-        m = np.broadcast_to(same[None], ref[name].shape)
-        assert rel_err(hip[name][m], ref[name][m]) <= REL, name
+        assert rel_err(hip[name], ref[name]) <= 1e-5, name
     check_backward(scene, hip, ref_o)
 
 
@@ -158,10 +159,8 @@ def test_full_size_frame_matches_the_reference_kernels():
     for k in ("radii", "tiles_touched", "point_offsets", "keys_unsorted", "vals_unsorted", "keys_sorted", "point_list"):
         np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(hip["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
-    same = hip["n_contrib"] == ref["n_contrib"]
-    assert same.mean() >= 1 - 1e-3
-    same = same.reshape(scene.H, scene.W)
+    np.testing.assert_array_equal(hip["n_contrib"], ref["n_contrib"])
+    np.testing.assert_array_equal(hip["final_T"], ref["final_T"])
     for name in ("color", "normal", "depth", "opac"):
-        m = np.broadcast_to(same[None], ref[name].shape)
-        assert rel_err(hip[name][m], ref[name][m]) <= REL, name
+        assert rel_err(hip[name], ref[name]) <= 1e-5, name
     check_backward(scene, hip, _AsOracle(ref, scene))
