@@ -5,6 +5,7 @@ TS/renderer/gaussian_batch_renderer.py:401-471 (checked against golden vectors p
 tests/golden/reference_functions.npz)."""
 from __future__ import annotations
 
+import functools
 import math
 import random
 from typing import NamedTuple
@@ -12,6 +13,17 @@ from typing import NamedTuple
 import torch
 
 from ..synthetic import camera_from_c2w, projection_matrix
+
+
+@functools.lru_cache(maxsize=8192)
+def _device_constant(values: tuple, device_str: str) -> torch.Tensor:
+    return torch.tensor(values, dtype=torch.float32, device=device_str)
+
+
+def device_constant(values, device) -> torch.Tensor:
+    """A small read-only fp32 tensor on `device`, created once per distinct value: building it from Python numbers is a
+    pageable host-to-device copy, which drains the stream it is ordered on -- per frame that stalls the whole pipeline."""
+    return _device_constant(tuple(float(v) for v in values), str(device))
 
 
 class Camera(NamedTuple):
@@ -29,8 +41,7 @@ class Camera(NamedTuple):
         h_size, w_size = min(h_size, h), min(w_size, w)
         h0 = random.randint(0, h - h_size)
         w0 = random.randint(0, w - w_size)
-        return torch.tensor([h0, w0, h0 + h_size, w0 + w_size], dtype=torch.float32,
-                            device=self.world_view_transform.device)
+        return device_constant((h0, w0, h0 + h_size, w0 + w_size), self.world_view_transform.device)
 
 
 def get_projection_matrix_gaussian(znear, zfar, fovX, fovY, device="cuda", cxcy=None, img_wh=None, z_sign=1.0):

@@ -25,6 +25,7 @@ from .. import lbs
 from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
 from . import registry
 from .batch import GaussianBatchRenderer
+from .cameras import device_constant
 from .postops import depth2normal, normal2curv
 
 _DIR2VEC = {"+x": (1, 0, 0), "+y": (0, 1, 0), "+z": (0, 0, 1), "-x": (-1, 0, 0), "-y": (0, -1, 0), "-z": (0, 0, -1)}
@@ -164,11 +165,11 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         mask = rendered_opac > 1e-5
         normal_mask = mask.repeat(3, 1, 1)
         rendered_normal = torch.where(normal_mask, rendered_normal, rendered_normal.detach())
-        rendered_normal = rendered_normal * torch.tensor([1.0, -1.0, -1.0], device=rendered_normal.device)[:, None, None]
+        rendered_normal = rendered_normal * device_constant((1.0, -1.0, -1.0), rendered_normal.device)[:, None, None]
         curv = normal2curv(rendered_normal, rendered_opac.detach() > 1e-5)
         rendered_normal = (rendered_normal + 1) / 2
         depth_normal = depth2normal(rendered_depth, rendered_opac.detach() > 1e-5, viewpoint_camera)
-        depth_normal = depth_normal * torch.tensor([1.0, -1.0, -1.0], device=depth_normal.device)[:, None, None]
+        depth_normal = depth_normal * device_constant((1.0, -1.0, -1.0), depth_normal.device)[:, None, None]
         depth_normal = (depth_normal + 1) / 2
 
         return {

@@ -108,6 +108,7 @@ class SMPLGuidance:
     def __call__(self, points, smpl_parms_in=None, idx=None, zero_out=False, delta=None, **kwargs):
         mats = self.joint_mats(smpl_parms_in, idx, zero_out)
         w = self.blend_weights(points)
-        pt_mats = lbs.point_transforms(points.detach(), torch.zeros(points.shape[0], 4, device=points.device).index_fill_(
-            1, torch.tensor([0], device=points.device), 1.0), w, mats)
+        ident = torch.zeros(points.shape[0], 4, device=points.device)
+        ident[:, 0] = 1.0                                                   # identity quaternions (r, x, y, z)
+        pt_mats = lbs.point_transforms(points.detach(), ident, w, mats)
         return self.root, pt_mats[None], self.scale
