@@ -17,7 +17,12 @@ DEV = torch.device("cuda:0")
 P, W, H, F = 100_000, 1920, 1080, 16
 body, poses = syn.make_body_model(0), syn.make_pose_sequence(F, 0)
 guide = SMPLGuidance(body, TP._smpl_parms(poses), device=DEV)
-pc = TP.SurfelModel(syn.make_surfels(P, 0), guide)
+surf = syn.make_surfels(P, 0)
+# the avatar's surfels live on the canonical body of the guidance (da-pose, translated): start them there, as SOAR does
+g0 = torch.Generator().manual_seed(5)
+cv = guide.cano_vertices.cpu()
+surf.xyz = (cv[torch.randint(0, cv.shape[0], (P,), generator=g0)] + 0.01 * torch.randn(P, 3, generator=g0)).contiguous()
+pc = TP.SurfelModel(surf, guide)
 renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=pc)
 spec = syn.make_camera(W, H)
 cam = cameras.Camera(FoVx=spec.fovx, FoVy=spec.fovy, camera_center=spec.camera_center.to(DEV), image_width=W, image_height=H,
