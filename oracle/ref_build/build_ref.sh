@@ -23,7 +23,7 @@ for f in "$REF"/cuda_rasterizer/*.cu "$REF"/cuda_rasterizer/*.h; do
         -e '/cooperative_groups\/reduce.h/d' -e 's/<< </<<</g' -e 's/>> >/>>>/g' > "$TMP/$(basename "$f")"
 done
 # REF_VARIANT=fast: the compiler's defaults (-O3, FMA contraction on) -> libref_rasterizer_fast.so, used only by
-# scripts/ref_compare.py to time the reference's kernels without the parity build's floating-point restriction.
+# tests/tools/ref_compare.py to time the reference's kernels without the parity build's floating-point restriction.
 NAME=libref_rasterizer.so; FP="-O2 -ffp-contract=off"
 if [ "${REF_VARIANT:-}" = fast ]; then NAME=libref_rasterizer_fast.so; FP="-O3"; fi
 FLAGS="--offload-arch=gfx950 $FP -fPIC -std=c++17 -w -D__trap=__builtin_trap -I$REF/third_party/glm -I$TMP"

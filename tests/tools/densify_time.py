@@ -2,7 +2,7 @@
 on the device (the restatement in oracle/densify_oracle.py moved to cuda -- the shape of the reference's implementation)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import densify_oracle as do
 from soar_amd.densify import SurfelDensifier
 

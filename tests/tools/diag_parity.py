@@ -1,7 +1,7 @@
 """Diagnostic: print the norm-wise parity errors of every scene of tests/test_rasterizer_gpu.py (GPU box)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import scenes as S
 import importlib.util
 spec = importlib.util.spec_from_file_location("tg", os.path.join(os.path.dirname(__file__), "..", "tests", "test_rasterizer_gpu.py"))

@@ -1,13 +1,13 @@
 """Randomised parity sweep: the product against the REFERENCE's own kernels (oracle/_ref) on N random scenes (scene family,
 size, image size, config switches, order, opacity, principal point drawn from a seeded generator).  Integer state must be
-bit-exact, images and gradients within the bars of tests/test_rasterizer_gpu.py.  usage: python scripts/fuzz_vs_reference.py [N] [seed0]"""
+bit-exact, images and gradients within the bars of tests/test_rasterizer_gpu.py.  usage: python tests/tools/fuzz_vs_reference.py [N] [seed0]"""
 import os
 import sys
 import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenes as S  # noqa: E402
@@ -78,7 +78,7 @@ def main():
                 # (2) fp32 conditioning: distance of each implementation from the oracle, which accumulates in double
                 fw, bw = S.run_oracle(scene, grads=grads, n_threads=8)
                 r2 = ref.run(scene, grads=grads, state=False)
-                cond = True
+                worst_p, worst_r = 0.0, 0.0
                 for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
                     o = getattr(bw, k)
                     if o is None or o.size == 0:
@@ -87,11 +87,11 @@ def main():
                     e2 = rel_err(r2[k], r[k])
                     if ep > 1e-4:
                         detail += f" {k}: product {ep:.1e} / reference {er:.1e} from the double-accumulated oracle, reference run-to-run {e2:.1e};"
-                    if ep > 1e-4 and ep > 4 * max(er, e2):
-                        cond = False
+                    worst_p, worst_r = max(worst_p, ep), max(worst_r, er, e2)
                 if flips:
                     kind = f"threshold flip ({flips} pixel(s) whose transmittance differs)"
-                elif cond:
+                elif worst_p <= 4 * worst_r:
+                    # the scene's worst tensor deviates no more (x4) for the product than for the reference itself
                     kind = "fp32 conditioning (the reference is as far from the double-accumulated oracle)"
             if kind == "MISMATCH":
                 bad += 1

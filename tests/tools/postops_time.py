@@ -1,6 +1,6 @@
 """Time the post-op kernels at 1080p (HIP events) next to the torch restatement on the same device."""
 import os, sys, types
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from oracle import postops_oracle as po
 from soar_amd.renderer import postops

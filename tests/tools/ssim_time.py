@@ -1,6 +1,6 @@
 """Time soar_ssim at 1080p (value + gradient) next to the torch restatement on the same device."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from oracle import loss_oracle as lo
 from soar_amd.losses import ssim
