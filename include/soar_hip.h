@@ -224,7 +224,7 @@ int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
 /* ---- per-frame image loss, value + pixel gradients in one pass (the dense
  *      four-output loss of section 8(d):  L = wc mean|color - tc| + wm mean|opac - tm| + wn mean(normal . tn) + wd mean(depth);
  *      same per-pixel structure as the reference's frame losses, TS/system/gaussian_surfel_mvdream.py:311-330,622-630).
- *   color/normal/target_color/target_normal [3,H,W], depth/opac/target_mask [1,H,W]; W*H must be a multiple of 4.
+ *   color/normal/target_color/target_normal [3,H,W], depth/opac/target_mask [1,H,W] (16-byte accesses when W*H is a multiple of 4 and the planes are aligned).
  *   loss_out [1], sums4 [4] (scratch: the four un-normalised sums), dL_d* = gradient of L w.r.t. the four images. */
 int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                     const float *opac, const float *target_color, const float *target_mask,

@@ -31,39 +31,51 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// V = 4: float4 accesses (planes of a [3,n] tensor are 16-byte aligned only when n % 4 == 0); V = 1: any image size
+template <int V> struct Vec;
+template <> struct Vec<4> { typedef float4 type; };
+template <> struct Vec<1> { typedef float type; };
+__device__ __forceinline__ float4 ld(const float4 *p, int i) { return p[i]; }
+__device__ __forceinline__ float4 ld(const float *p, int i) { return make_float4(p[i], 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void st(float4 *p, int i, float4 v) { p[i] = v; }
+__device__ __forceinline__ void st(float *p, int i, float4 v) { p[i] = v.x; }
+
+template <int V>
 __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
 {
-    const int n4 = a.n >> 2;
+    typedef typename Vec<V>::type T;
+    const int nv = a.n / V;
     if (a.set_index) {           // frame data resident in HBM: pick this frame's planes (colour 3, mask 1, normal 3)
         const float *set = a.t_color + (size_t)((unsigned)*a.set_index % (unsigned)a.n_sets) * 7u * (size_t)a.n;
         a.t_color = set; a.t_mask = set + 3 * (size_t)a.n; a.t_normal = set + 4 * (size_t)a.n;
     }
     float s_c = 0.f, s_m = 0.f, s_n = 0.f, s_d = 0.f;
     const float gc = a.wc / (3.f * a.n), gm = a.wm / a.n, gn = a.wn / (3.f * a.n), gd = a.wd / a.n;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const float4 pad = V == 4 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(1.f, 0.f, 0.f, 0.f);   // lanes that exist
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
         float4 nsum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float4 c = reinterpret_cast<const float4 *>(a.color + (size_t)ch * a.n)[i];
-            const float4 t = reinterpret_cast<const float4 *>(a.t_color + (size_t)ch * a.n)[i];
+            const float4 c = ld(reinterpret_cast<const T *>(a.color + (size_t)ch * a.n), i);
+            const float4 t = ld(reinterpret_cast<const T *>(a.t_color + (size_t)ch * a.n), i);
             const float4 d = make_float4(c.x - t.x, c.y - t.y, c.z - t.z, c.w - t.w);
             s_c += (fabsf(d.x) + fabsf(d.y)) + (fabsf(d.z) + fabsf(d.w));
-            reinterpret_cast<float4 *>(a.dcolor + (size_t)ch * a.n)[i] =
-                make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w));
-            const float4 nr = reinterpret_cast<const float4 *>(a.normal + (size_t)ch * a.n)[i];
-            const float4 nt = reinterpret_cast<const float4 *>(a.t_normal + (size_t)ch * a.n)[i];
+            st(reinterpret_cast<T *>(a.dcolor + (size_t)ch * a.n), i,
+               make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w)));
+            const float4 nr = ld(reinterpret_cast<const T *>(a.normal + (size_t)ch * a.n), i);
+            const float4 nt = ld(reinterpret_cast<const T *>(a.t_normal + (size_t)ch * a.n), i);
             nsum.x += nr.x * nt.x; nsum.y += nr.y * nt.y; nsum.z += nr.z * nt.z; nsum.w += nr.w * nt.w;
-            reinterpret_cast<float4 *>(a.dnormal + (size_t)ch * a.n)[i] = make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w);
+            st(reinterpret_cast<T *>(a.dnormal + (size_t)ch * a.n), i, make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w));
         }
         s_n += (nsum.x + nsum.y) + (nsum.z + nsum.w);
-        const float4 o = reinterpret_cast<const float4 *>(a.opac)[i];
-        const float4 m = reinterpret_cast<const float4 *>(a.t_mask)[i];
+        const float4 o = ld(reinterpret_cast<const T *>(a.opac), i);
+        const float4 m = ld(reinterpret_cast<const T *>(a.t_mask), i);
         const float4 e = make_float4(o.x - m.x, o.y - m.y, o.z - m.z, o.w - m.w);
         s_m += (fabsf(e.x) + fabsf(e.y)) + (fabsf(e.z) + fabsf(e.w));
-        reinterpret_cast<float4 *>(a.dopac)[i] = make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w));
-        const float4 dp = reinterpret_cast<const float4 *>(a.depth)[i];
+        st(reinterpret_cast<T *>(a.dopac), i, make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w)));
+        const float4 dp = ld(reinterpret_cast<const T *>(a.depth), i);
         s_d += (dp.x + dp.y) + (dp.z + dp.w);
-        reinterpret_cast<float4 *>(a.ddepth)[i] = make_float4(gd, gd, gd, gd);
+        st(reinterpret_cast<T *>(a.ddepth), i, make_float4(gd * pad.x, gd * pad.y, gd * pad.z, gd * pad.w));
     }
     __shared__ float part[4][4];
     s_c = wave_sum(s_c); s_m = wave_sum(s_m); s_n = wave_sum(s_n); s_d = wave_sum(s_d);
@@ -138,14 +150,14 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
     a.dcolor = dL_dcolor; a.dnormal = dL_dnormal; a.ddepth = dL_ddepth; a.dopac = dL_dopac;
     a.sums = sums4;
     a.set_index = set_index_dev; a.n_sets = n_sets;
-    if (a.n & 3) {        // planes of a [3,n] tensor are 16-byte aligned only when n % 4 == 0
-        set_error("soar_frame_loss: W*H must be a multiple of 4 (got %d)", a.n);
-        return 1;
-    }
     SOAR_HIP_OK(hipMemsetAsync(sums4, 0, 4 * sizeof(float), stream));
     StageTimer timer(ST_FRAME_LOSS, stream);
-    const int blocks = min(2048, max(1, (a.n / 4 + 255) / 256));
-    hipLaunchKernelGGL(frame_loss_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    const bool vec4 = (a.n & 3) == 0 && (((uintptr_t)color | (uintptr_t)normal | (uintptr_t)depth | (uintptr_t)opac | (uintptr_t)target_color |
+                                          (uintptr_t)target_mask | (uintptr_t)target_normal | (uintptr_t)dL_dcolor | (uintptr_t)dL_dnormal |
+                                          (uintptr_t)dL_ddepth | (uintptr_t)dL_dopac) & 15) == 0;
+    const int blocks = min(2048, max(1, (a.n / (vec4 ? 4 : 1) + 255) / 256));
+    if (vec4) hipLaunchKernelGGL(frame_loss_kernel<4>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(frame_loss_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(64), 0, stream, sums4, a.n, w_color, w_mask, w_normal, w_depth,
                        loss_out);
     SOAR_LAUNCH_OK("frame_loss", stream, 0);
