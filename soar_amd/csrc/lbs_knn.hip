@@ -465,6 +465,8 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
         const bool single = N <= KNN_CAND;                            // candidates still staged from pass 1
         float norm_lane = 0.f;                                        // lane = query: sum of 1/d over all chunks
         int cnt_lane = 0;
+        int need_left = need;                                         // lane = query: candidates AT tau still to take (the
+                                                                      // count runs on through the chunks of a large box)
         uint32_t *lpos = list_pos[wave];
         float *lw = list_w[wave];
         for (int base = 0; base < N; base += KNN_CAND) {
@@ -480,7 +482,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 const int l = (int)__builtin_ctzll(todo);
                 const float ux = __shfl(x, l), uy = __shfl(y, l), uz = __shfl(z, l), utau = __shfl(tau, l);
                 const int pl = __builtin_amdgcn_readlane(p, l);
-                int uneed = __builtin_amdgcn_readlane(need, l);
+                int uneed = __builtin_amdgcn_readlane(need_left, l);
                 const int taken0 = __builtin_amdgcn_readlane(cnt_lane, l);
                 int cnt = 0;
                 __builtin_amdgcn_wave_barrier();
@@ -520,7 +522,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 }
                 if (WITH_IDX && lane < cnt && taken0 + lane < K)
                     knn_idx_out[(size_t)pl * K + taken0 + lane] = (int)__float_as_uint(sorted_verts[lpos[lane]].w);
-                if (lane == l) { norm_lane += norm; cnt_lane += cnt; }
+                if (lane == l) { norm_lane += norm; cnt_lane += cnt; need_left = uneed; }
                 if (lane < J) {
                     float *out = weights_out + (size_t)pl * J + lane;
                     if (single) *out = accj / norm;

@@ -175,3 +175,28 @@ def test_smplx_joint_chain_kernel_matches_reference_lbs_goldens():
         jt.hip(betas, pose, transl)
     with pytest.raises(ValueError):
         jt.hip(t("betas")[:3].to(dev), pose.to(dev))
+
+
+def test_knn_ties_across_candidate_chunks():
+    """Exact distance ties at the K-th place in a box with more candidates than one staged chunk (dense, duplicated vertices):
+    exactly K neighbours are taken -- the tie counter runs on through the chunks -- their distances are the brute-force ones
+    and the blend is the blend of the reported neighbour list."""
+    from soar_amd import lbs
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    base = torch.randn(2500, 3, generator=g) * 0.004                      # thousands of vertices in one grid cell ...
+    far = torch.randn(300, 3, generator=g) * torch.tensor([0.3, 0.9, 0.2])
+    verts = torch.cat([base, base.clone(), far])                          # ... every one of them twice
+    w = torch.rand(verts.shape[0], 55, generator=g)
+    w = w / w.sum(1, keepdim=True)
+    xyz = base[torch.randint(0, 2500, (3000,), generator=g)] + 0.001 * torch.randn(3000, 3, generator=g)
+    out, idx = lbs.KnnGrid(verts.to(dev), w.to(dev)).query(xyz.to(dev), return_idx=True)
+    d = torch.cdist(xyz.to(dev).double(), verts.to(dev).double())
+    dk = torch.topk(d, 30, dim=1, largest=False).values
+    got = torch.gather(d, 1, idx.long())
+    assert float((torch.sort(got, 1).values - dk).abs().max()) < 1e-7
+    assert all(len(set(r)) == 30 for r in idx[:200].tolist())              # 30 distinct neighbours
+    wi = 1.0 / got.clamp(0.0001, 1.0)
+    wi = wi / wi.sum(-1, keepdim=True)
+    own = (wi[..., None] * w.to(dev).double()[idx.long()]).sum(-2)
+    assert float((out.double() - own).abs().max()) < 2e-6
