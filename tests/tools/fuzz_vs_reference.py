@@ -22,10 +22,16 @@ def random_scene(rng):
     kind = rng.integers(0, 4)
     seed = int(rng.integers(0, 10_000))
     if kind == 0:
-        return S.person_scene(P=int(rng.integers(200, 6000)), W=W, H=H, seed=seed, config=cfg, opacity=None,
-                              render_front=bool(rng.integers(0, 2)), sort_descending=bool(rng.integers(0, 2)),
-                              sane_scale_z=cfg[0] == 0, distance=float(rng.uniform(1.5, 4.0)),
-                              prcp=(float(rng.uniform(0.4, 0.6)), float(rng.uniform(0.4, 0.6))))
+        patch = None
+        if rng.integers(0, 3) == 0:                       # a random patch bounding box (h0, w0, h1, w1)
+            h0, w0 = int(rng.integers(0, H // 2)), int(rng.integers(0, W // 2))
+            patch = (h0, w0, int(rng.integers(h0 + 8, H + 1)), int(rng.integers(w0 + 8, W + 1)))
+        sc = S.person_scene(P=int(rng.integers(200, 6000)), W=W, H=H, seed=seed, config=cfg, opacity=None,
+                            render_front=bool(rng.integers(0, 2)), sort_descending=bool(rng.integers(0, 2)),
+                            sane_scale_z=cfg[0] == 0, distance=float(rng.uniform(0.6, 4.0)),
+                            prcp=(float(rng.uniform(0.4, 0.6)), float(rng.uniform(0.4, 0.6))), patch=patch)
+        sc.scale_modifier = float(rng.choice([1.0, 1.0, 0.7, 1.6]))
+        return sc
     if kind == 1:
         return S.blob_scene(P=int(rng.integers(50, 1500)), W=W, H=H, seed=seed, config=cfg, use_sh=bool(rng.integers(0, 2)),
                             sh_degree=int(rng.integers(0, 4)))
