@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t quad_move_u(uint32_t v)
 // back-face cull, forward.cu:262-266), so a second transmittance chain that ignores the back-facing entries reproduces
 // that pass without a second preprocess / sort / blend.
 template <bool LOG, bool OCC>
-__global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) render_forward_kernel(FwdArgs a)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
@@ -163,12 +163,30 @@ __global__ void __launch_bounds__(256) render_forward_kernel(FwdArgs a)
         lds_barrier();           // LDS only: the gathers of the next chunk stay in flight while this one is blended
 
         if (!wave_done) {
+            // The entries only matter for the pixels that are still blending: the test rectangle of phase A is the bounding
+            // box of those pixels inside the 4x4 block (a block on the silhouette keeps walking the list for its uncovered
+            // pixels long after the covered ones have saturated; entries that touch only finished pixels are dropped).
+            float rx0 = (float)bx0, ry0 = (float)by0, rex = 3.f, rey = 3.f;
+            {
+                const unsigned long long am = __ballot(!(done && done_o));                // 4 lanes per pixel, pixel = lane >> 2
+                uint32_t cols = 0, rows = 0;                                               // active columns / rows of the block
+#pragma unroll
+                for (int pp = 0; pp < 16; pp++) {
+                    const uint32_t on = (uint32_t)((am >> (4 * pp)) & 1ull);
+                    cols |= on << (pp & 3);
+                    rows |= on << (pp >> 2);
+                }
+                if (cols) {
+                    const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), r0 = __builtin_ctz(rows), r1 = 31 - __builtin_clz(rows);
+                    rx0 = (float)(bx0 + c0); ry0 = (float)(by0 + r0); rex = (float)(c1 - c0); rey = (float)(r1 - r0);
+                }
+            }
             for (int sub = 0; sub < n; sub += WAVE) {
-                // phase A -- lanes = entries of this 64-entry sub-chunk: conservative test against the 4x4 block
+                // phase A -- lanes = entries of this 64-entry sub-chunk: conservative test against that rectangle
                 bool relevant = false;
                 if (sub + lane < n) {
                     const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
-                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[sub + lane].w, (float)bx0, (float)by0, 3.f);
+                    relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[sub + lane].w, rx0, ry0, rex, rey);
                 }
                 unsigned long long todo = __ballot(relevant);
                 const uint32_t contrib0 = base - range.x + (uint32_t)sub;       // list entries before this sub-chunk

@@ -166,11 +166,11 @@ __device__ __forceinline__ float falloff_power(float A, float B, float Cc, float
 // (forward.cu:545, backward.cu:680) with a safety margin, so dropping a splat never changes a result: splats that
 // fail are exactly those every lane would have skipped.  Returns true when in doubt (non-PD conic, NaN).
 __device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A, float B, float Cc, float thr,
-                                                     float x0, float y0, float extent)
+                                                     float x0, float y0, float extent_x, float extent_y)
 {
-    // pixel centres of the block span [x0, x0+extent] x [y0, y0+extent]
-    const float dx_hi = gx - x0, dx_lo = dx_hi - extent;
-    const float dy_hi = gy - y0, dy_lo = dy_hi - extent;
+    // pixel centres of the block span [x0, x0+extent_x] x [y0, y0+extent_y]
+    const float dx_hi = gx - x0, dx_lo = dx_hi - extent_x;
+    const float dy_hi = gy - y0, dy_lo = dy_hi - extent_y;
     const bool pd = (A > 0.f) && (Cc > 0.f) && (A * Cc - B * B > 0.f);
     const float nx = dx_lo > 0.f ? dx_lo : (dx_hi < 0.f ? dx_hi : 0.f);
     const float ny = dy_lo > 0.f ? dy_lo : (dy_hi < 0.f ? dy_hi : 0.f);
@@ -189,6 +189,11 @@ __device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A
     // (thr is precomputed per splat by the preprocess kernel; -3e38 when 255*opacity < 0.999, NaN stays "visible")
     const bool certainly_invisible = (qmin * 0.9999f - 1.0e-3f > thr);
     return !(pd && certainly_invisible);
+}
+__device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A, float B, float Cc, float thr,
+                                                     float x0, float y0, float extent)
+{
+    return splat_may_touch_rect(gx, gy, A, B, Cc, thr, x0, y0, extent, extent);
 }
 __device__ __forceinline__ float splat_cull_threshold(float opacity)
 {

@@ -193,8 +193,11 @@ def test_render_frames_equals_per_frame_path():
     a, ga, ta = step(False)
     b, gb, tb = step(True)
     for x, y in zip(a, b):
-        for k in ("render", "normal", "depth", "mask", "radii"):
-            assert torch.equal(getattr(x, k), getattr(y, k)), k
+        assert torch.equal(x.radii, y.radii) and torch.equal(x.mask, y.mask)        # transmittance: same products, same order
+        for k in ("render", "normal", "depth"):
+            # the fused kernel keeps a pixel in its cull rectangle until BOTH passes have saturated, so its survivors are
+            # grouped into steps differently: the per-slot partial sums fold in another order (last-bit differences)
+            assert (getattr(x, k) - getattr(y, k)).abs().max() < 2e-6, k
         assert (x.occ - y.occ).abs().max() < 1e-5
     for k in ga:
         assert _rel(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 1e-4, k
