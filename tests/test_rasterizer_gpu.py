@@ -374,3 +374,35 @@ def test_full_size_properties():
     diff = np.abs(c["color"] - a["color"]).max(0)
     assert float((diff > 1e-5).mean()) < 5e-3
     np.testing.assert_array_equal(c["radii"], a["radii"][perm])
+
+
+def test_module_accepts_noncontiguous_and_double_inputs():
+    """The reference calls .contiguous().data<float>() on every argument (rasterize_points.cu): strided views and float64
+    tensors must give the results of their contiguous float32 copies, and gradients must come back in the inputs' layout."""
+    from soar_amd.rasterizer import GaussianRasterizer
+    scene = S.person_scene(P=1500, W=96, H=64, seed=12, opacity=None)
+    dev = _dev()
+    st = S.torch_settings(scene, dev)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+    base = dict(means3D=t(scene.means3D), opacities=t(scene.opacities), colors_precomp=t(scene.colors), scales=t(scene.scales),
+                rotations=t(scene.rotations))
+
+    def run(kw):
+        kw = {k: v.clone().requires_grad_(True) if v.is_floating_point() else v for k, v in kw.items()}
+        out = GaussianRasterizer(st)(means2D=torch.zeros_like(kw["means3D"]), **kw)
+        (out[0].sum() + out[1].sum() + out[2].sum() + out[3].sum()).backward()
+        return [o.detach() for o in out], {k: v.grad for k, v in kw.items()}
+
+    want, gw = run(base)
+    # column-major storage (a transposed view) and double precision
+    strided = {k: v.t().contiguous().t() for k, v in base.items()}
+    assert not strided["means3D"].is_contiguous()
+    got, gg = run(strided)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    for k in gw:
+        assert gg[k].shape == base[k].shape and rel_err(gg[k].cpu().numpy(), gw[k].cpu().numpy()) < 1e-4, k
+    got64, g64 = run({k: v.double() for k, v in base.items()})
+    for a, b in zip(want, got64):
+        assert torch.equal(a, b.to(a.dtype))
+    assert g64["means3D"].dtype == torch.float64 and rel_err(g64["means3D"].cpu().numpy(), gw["means3D"].cpu().numpy()) < 1e-4
