@@ -36,7 +36,7 @@ for it in range(N):
     dk, ik = torch.topk(d, K, dim=1, largest=False)
     got_d = torch.gather(d, 1, idx.long()[:, :K])
     # same neighbour DISTANCES (indices may differ at exact ties), sorted
-    err = (torch.sort(got_d, 1).values - dk).abs().max().item()
+    err = ((torch.sort(got_d, 1).values - dk).abs() / dk.clamp(min=1.0)).max().item()        # relative beyond distance 1 (float32 keys)
     # blended weights from the brute-force neighbours (inverse-distance weights as the kernel's oracle states them)
     # blend of the brute-force neighbours, as oracle/lbs_oracle.py query_weights states it (TS/utils/smpl.py:618-637)
     dist = dk.clamp(0.0001, 1.0)

@@ -58,7 +58,10 @@ for it in range(N):
     xg, rg = xyz.to(DEV).requires_grad_(True), rot.to(DEV).requires_grad_(True)
     p, q = lbs.lbs_warp(xg, rg, w.to(DEV), A.to(DEV), None if off is None else off.to(DEV), None if T is None else T.to(DEV))
     ((p * gp.to(DEV)).sum() + (q * gq.to(DEV)).sum()).backward()
-    e = (rel(p, p_ref), rel(q, q_ref), rel(xg.grad, xc.grad), rel(rg.grad, rc.grad))
+    # q and -q are the same rotation; when the real part is ~0 the sign convention (non-negative real part) is decided by rounding
+    qd, qr = q.detach().cpu().double(), q_ref.detach().double()
+    q_err = float(torch.minimum((qd - qr).abs().max(1).values, (qd + qr).abs().max(1).values).max() / qr.abs().max())
+    e = (rel(p, p_ref), q_err, rel(xg.grad, xc.grad), rel(rg.grad, rc.grad))
     check("warp", it, e[0] < 1e-5 and e[1] < 2e-4 and e[2] < 1e-4 and e[3] < 2e-4, f"P {P} errs {e}")
 
     # ---- distCUDA2 -----------------------------------------------------------------------------------------------
