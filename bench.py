@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- fwd+bwd frames/s of SOAR's per-frame avatar path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 under torch.distributed.run (WORLD_SIZE set): this process is one rank.
+        N > 1 without a launcher: this process only starts N ranks of itself (one per GPU, RCCL over 127.0.0.1),
+        relays rank 0's JSON line and exits non-zero if a rank fails or fewer than N GPUs are visible.
 
 One STEP = one pass of the hot path over one batch of `--frames-per-step` (default 4) synthetic video frames per GPU:
 KNN blend weights once, then per frame  LBS warp -> main rasterize fwd -> occlusion rasterize fwd (no grad) ->
@@ -44,39 +47,54 @@ TARGET_SETS = 8               # distinct per-frame target sets kept on the devic
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-# stage timer name -> kernel name in the rocprofv3 summaries / HBM counter file under profiles/
-STAGE_KERNEL = {"preprocess": "preprocess_kernel", "emit_keys": "emit_keys_kernel", "tile_ranges": "tile_ranges_kernel",
-                "render_forward": "render_forward_kernel", "render_backward": "render_backward_slots_kernel",
-                "geometry_backward": "geometry_backward_kernel", "lbs_knn_weights": "knn_grid_kernel",
-                "lbs_warp_forward": "warp_forward_kernel", "lbs_warp_backward": "warp_backward_kernel"}
+# stage timer name (soar_prof_stage_name) -> kernels it brackets.  The first kernel of each list is the one whose HBM counters
+# (profiles/*_hbm_traffic.json) are reported as `roofline.traffic` when that stage dominates.
+STAGE_KERNELS = {
+    "preprocess": ["preprocess_kernel"],
+    "scan": ["rocprim inclusive_scan (synchronous form / key export only)"],
+    "depth_order": ["bucket_sort_kernel", "bucket_count_kernel", "bucket_scatter_kernel"],
+    "tile_ranges": ["bin_count_kernel", "tile_scan_kernel"],
+    "tile_lists": ["bin_tiles_kernel", "tile_order_kernel"],
+    "render_forward": ["render_forward_kernel"],
+    "render_backward": ["render_backward_slots_kernel"],
+    "geometry_backward": ["geometry_backward_kernel"],
+    "lbs_knn_weights": ["knn_cell_kernel"],
+    "lbs_warp_forward": ["warp_forward_kernel"],
+    "lbs_warp_backward": ["warp_backward_kernel"],
+    "frame_loss": ["frame_loss_kernel"],
+}
 
 
 def measured_traffic(stage):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/*_hbm_traffic.json; collected with
-    scripts/profile_round.sh, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, gfx950 correction applied there)."""
+    """(HBM bytes per launch, source file) of the stage's main kernel from the newest COMMITTED PMC summary
+    (profiles/*_hbm_traffic.json; collected with scripts/profile_round.sh, FETCH_SIZE / WRITE_SIZE in separate rocprofv3
+    passes, gfx950 correction applied there).  Not measured in this run: the JSON line says where it comes from."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files or stage not in STAGE_KERNEL:
-        return None
+    if not files or stage not in STAGE_KERNELS:
+        return None, None
     try:
-        return json.load(open(files[-1]))["kernels"][STAGE_KERNEL[stage]]["traffic_bytes"]
+        return json.load(open(files[-1]))["kernels"][STAGE_KERNELS[stage][0]]["traffic_bytes"], os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def algorithmic_bytes(P, R, W, H, R_occ=None):
-    """compulsory bytes per launch of every stage (passes = 6).  R_occ: the forward blend also
-    does the occlusion pass (render_front instances) in the same launch -> both passes' bytes."""
+    """compulsory bytes per launch of every stage.  The reference's `sort` (24 * passes * R) and
+    `emit_keys` rows have no counterpart any more: tile binning orders the P Gaussians by depth (depth_order: keys + pairs +
+    sorted ids / rectangles, 44 * P) and writes each tile list once (tile_lists: rectangles + ids read, 12 * P, point_list
+    written, 4 * R); tile_ranges reads the rectangles and writes counts + ranges.  R_occ: the forward blend also does the
+    occlusion pass (render_front instances) in the same launch -> both passes' bytes."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     pix = W * H
-    passes = 6
     fused_occ = 0 if R_occ is None else 8 * T + 96 * R_occ + 44 * pix
     return {
-        "preprocess": 160 * P, "scan": 8 * P, "emit_keys": 20 * P + 12 * R, "sort": 24 * passes * R,
-        "tile_ranges": 8 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix + fused_occ,
+        "preprocess": 160 * P, "scan": 8 * P, "depth_order": 44 * P, "tile_ranges": 8 * P + 12 * T,
+        "tile_lists": 12 * P + 4 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix + fused_occ,
         "render_backward": 44 * pix + 96 * R + 60 * P, "geometry_backward": (92 + 148) * P,
         "lbs_warp_forward": 276 * P, "lbs_warp_backward": 304 * P,
         "lbs_knn_weights": 232 * P + 232 * 10475,
+        "frame_loss": 92 * pix,
     }
 
 
@@ -209,6 +227,54 @@ def cpu_baseline(workload, parts, n_frames=8, seed=0):
                       f"(oracle/rasterizer_oracle.c, OpenMP {threads} threads); {dt:.1f} s wall"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: start N ranks of this script (fresh processes, one per GPU,
+    rendezvous on 127.0.0.1) from a parent that has not initialised the GPU, print rank 0's JSON line, return the exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()              # counts devices without initialising the HIP runtime
+    if have < n:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) visible: not running (a line with n_gpus != --gpus would be wrong)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # a rank that dies leaves the others blocked in a collective: watch all of them, stop the job on the first failure
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                      # exactly the children started above
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else ""
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
+        return 1
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
+        print(f"[bench] rank 0 did not produce one {n}-GPU line: {out0!r}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,20 +294,32 @@ def main():
                          "num_rendered read-back")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process only starts the ranks (it never touches the GPU itself) and relays rank 0's line
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.mode is None:
-        args.mode = "plan" if world == 1 and os.environ.get("SOAR_BENCH_FORCE_DIST", "0") != "1" else "plan-eager"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
+    # SOAR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, all-reduces, default mode) with
+    # a single rank too -- the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("SOAR_BENCH_FORCE_DIST", "0") == "1"
+    if args.mode is None:
+        args.mode = "plan"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                         "bench.py has no CPU path")
+    # RCCL / the runtime print banners on stdout: keep fd 1 clean for the ONE JSON line (everything else goes to stderr)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # SOAR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, all-reduces, default mode) with
-    # a single rank too -- the only way to exercise it on a one-GPU box
-    use_dist = world > 1 or os.environ.get("SOAR_BENCH_FORCE_DIST", "0") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -296,8 +374,10 @@ def main():
             plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat, use_graphs=(mode == "plan"))
 
             def stepper(frames):
+                # plan.run waits for the xyz bucket of the previous step's all-reduce before the KNN prologue and for the
+                # other bucket before the frames; this step's buckets are issued behind its epilogue (frame_dp.FlatGradBuffer)
                 plan.run(frames)
-                return flat.all_reduce()
+                return flat.all_reduce_buckets()
         except Exception as e:
             fallback = "graph" if (mode == "plan" and world == 1) else "async"
             print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode {fallback}", file=sys.stderr)
@@ -316,6 +396,7 @@ def main():
         stepper = lambda frames: run_step(seq, targets, flat, frames, bg, capacity)
     for s in range(2):                                           # untimed steps in the timed mode
         stepper(frames_of(s))
+    flat.wait_all()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -323,6 +404,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         stepper(frames_of(args.warmup + s))
+    flat.wait_all()                                              # the last step's gradient buckets
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -378,12 +460,16 @@ def main():
             if bytes_per_launch:
                 avg_s = ms / n / 1e3
                 achieved = bytes_per_launch / avg_s / 1e9
-                traffic = measured_traffic(dom) if args.workload == "C3" else None
+                traffic, traffic_src = measured_traffic(dom) if args.workload == "C3" else (None, None)
                 roof = {"bound": "hbm", "kernel": dom,
                         "measured": f"HIP events around every stage on its launch stream, {args.steps} more steps of the same "
                                     f"workload right after the timed region with the views of a step serialised on one stream "
                                     f"(the timed region overlaps them on {rasterizer.NUM_STREAMS} streams)", "stage_total_ms": {k: round(v[0], 3) for k, v in stages.items()}, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": (f"not measured in this run: FETCH_SIZE + WRITE_SIZE per launch of "
+                                           f"{STAGE_KERNELS[dom][0]} from the committed rocprofv3 --pmc summary {traffic_src}")
+                        if traffic is not None else None,
+                        "kernels_in_stage": STAGE_KERNELS.get(dom),
                         "avg_launch_us": round(1e3 * ms / n, 2), "launches": n,
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "whole_frame": {"algorithmic_bytes_per_frame": int(frame_bytes(P, R_main, R_occ, W, H)),
@@ -399,6 +485,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
                                f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
                                f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}", "mode": mode,
+                   "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")
+                   if use_dist else "none",
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,
@@ -412,9 +500,11 @@ def main():
                                           "sample": f"failed: {ex!r}"}
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())       # the one line on the real stdout, after every banner
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SOAR_HIP_ABI_VERSION 1
+#define SOAR_HIP_ABI_VERSION 2
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
@@ -176,25 +176,35 @@ int soar_rast_export_state(const SoarRastParams *prm, const void *geom_buffer, c
  * soar_lbs_knn_weights: SMPL_Guidance.query_weights_smpl (TS/utils/smpl.py:618-637).
  *   xyz [P,3] canonical points, verts [V,3] canonical SMPL-X vertices, vert_weights [V,J] skinning weights;
  *   K nearest vertices (the reference hard-codes 30), d = clamp(sqrt(d2), 1e-4, 1), ws = (1/d)/sum(1/d),
- *   weights_out [P,J] = sum_k ws_k * vert_weights[idx_k].  knn_idx_out [P,K] int32 optional (may be NULL). */
+ *   weights_out [P,J] = sum_k ws_k * vert_weights[idx_k].  knn_idx_out [P,K] int32 optional (may be NULL).
+ *   workspace: soar_lbs_knn_weights_bytes(P, V) bytes of 256-byte aligned device memory owned by the CALLER (vertex grid +
+ *   query sort scratch), like every other scratch buffer of this ABI: the library keeps no device state of its own, so
+ *   concurrent callers on different streams / threads and captured HIP graphs never share or outlive a hidden buffer. */
+int soar_lbs_knn_weights_bytes(int32_t P, int32_t V, size_t *bytes);
 int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V,
                          const float *vert_weights, int32_t J, int32_t K,
-                         float *weights_out, int32_t *knn_idx_out, void *stream);
+                         float *weights_out, int32_t *knn_idx_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same in two steps for a STATIC vertex set (SOAR's canonical SMPL-X vertices and lbs_weights never change during
  * training, TS/utils/smpl.py:508-511): build the vertex grid once, query it every optimizer step.
- *   grid_buffer: soar_lbs_knn_grid_bytes(V) bytes of 256-byte aligned device memory, owned by the caller. */
+ *   grid_buffer: soar_lbs_knn_grid_bytes(V) bytes of 256-byte aligned device memory, owned by the caller.
+ *   query_workspace: soar_lbs_knn_query_bytes(P) bytes, owned by the caller (one per concurrent query / per step plan;
+ *   a plan that captures the query in a HIP graph keeps it alive as long as the graph). */
 int soar_lbs_knn_grid_bytes(int32_t V, size_t *bytes);
+int soar_lbs_knn_query_bytes(int32_t P, size_t *bytes);
 int soar_lbs_knn_build_grid(const float *verts, int32_t V, const float *vert_weights, int32_t J, void *grid_buffer,
                             void *stream);
 int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J,
-                       const float *xyz, int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream);
+                       const float *xyz, int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out,
+                       void *query_workspace, size_t query_workspace_bytes, void *stream);
 /* Same with a caller-owned query order [P] (uint32): resort != 0 sorts the queries by grid cell and stores the order;
  * resort == 0 reuses the stored order (only the cell keys are recomputed from the current positions).  Canonical positions
  * move little between optimizer steps, so a training loop re-sorts every few steps; results never depend on the order. */
 int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J,
                                const float *xyz, int32_t P, int32_t K, uint32_t *order, int32_t resort,
-                               float *weights_out, int32_t *knn_idx_out, void *stream);
+                               float *weights_out, int32_t *knn_idx_out,
+                               void *query_workspace, size_t query_workspace_bytes, void *stream);
 
 /* soar_lbs_warp_forward: blend + apply, i.e. SMPL_Guidance.__call__ line TS/utils/smpl.py:613
  *   (pt_mats = einsum("bnj,bjxy->bnxy", w, cano2live)) fused with DiffGaussian.forward's warp

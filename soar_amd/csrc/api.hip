@@ -47,7 +47,10 @@ int g_slot_used = 0;
 bool g_slots_init = false;
 double g_stage_ms[ST_COUNT];
 long long g_stage_n[ST_COUNT];
-const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "emit_keys", "sort", "tile_ranges", "render_forward",
+// ST_EMIT_KEYS / ST_SORT keep their enum names from the reference's stages; what they bracket today: "tile_lists" = the
+// per-tile list construction (bin_tiles; emit_keys in the descending / export path), "depth_order" = the depth order of the P
+// Gaussians (bucket_count / _scatter / _sort; the rocPRIM key sort in the descending path)
+const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "tile_lists", "depth_order", "tile_ranges", "render_forward",
                                        "render_backward", "geometry_backward", "lbs_knn_weights", "lbs_warp_forward",
                                        "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops"};
 void prof_drain()

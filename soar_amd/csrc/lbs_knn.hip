@@ -547,14 +547,6 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
     }
 }
 
-// persistent device workspace of the vertex grid (grown on demand, one per process)
-struct KnnWorkspace {
-    void *base = nullptr;
-    size_t bytes = 0;
-    int device = -1;
-};
-KnnWorkspace g_ws;
-
 }  // namespace
 
 }  // namespace soar
@@ -578,8 +570,8 @@ struct KnnGrid {
 int carve_knn_grid(void *base, int32_t V, KnnGrid *g, hipStream_t stream)
 {
     size_t sort_bytes = 0;
-    SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                          (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)V, 0u, 18u, stream));
+    (void)rocprim::radix_sort_pairs((void *)nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)V, 0u, 18u, stream);     // size query only
     char *b = static_cast<char *>(base);
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return b + o; };
@@ -615,8 +607,34 @@ int knn_build(const float *verts, int32_t V, const float *vert_weights, int32_t 
 
 // order / resort: optional caller-owned query order [P].  resort != 0 (or order == NULL): the queries are sorted by cell
 // and the order is stored; resort == 0: the stored order is reused and only the cell keys are recomputed.
+struct QueryWs {
+    size_t sort_bytes, total;
+    uint32_t *qk0, *qk1, *qv0, *qv1;
+};
+// layout of the caller-owned query workspace: [rocPRIM sort temp | qk0 | qk1 | qv0 | qv1], each 256-byte aligned
+int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
+{
+    size_t qsort_bytes = 0;
+    // size query only (the return code is ignored like in scan_temp_bytes / sort_temp_bytes: it must also work on a box
+    // without a GPU, where the sizing entry points are part of the CPU test suite)
+    (void)rocprim::radix_sort_pairs((void *)nullptr, qsort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)(P > 0 ? P : 1), 0u, 18u, stream);
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return o; };
+    const size_t o_tmp = carve(qsort_bytes), o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P),
+                 o_qv0 = carve(4 * (size_t)P), o_qv1 = carve(4 * (size_t)P);
+    (void)o_tmp;
+    char *b = static_cast<char *>(base);
+    out->sort_bytes = qsort_bytes;
+    out->total = off;
+    out->qk0 = reinterpret_cast<uint32_t *>(b + o_qk0); out->qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
+    out->qv0 = reinterpret_cast<uint32_t *>(b + o_qv0); out->qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
+    return 0;
+}
+
 int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P, int32_t K,
-              float *weights_out, int32_t *knn_idx_out, uint32_t *order, int resort, hipStream_t stream)
+              float *weights_out, int32_t *knn_idx_out, uint32_t *order, int resort, void *query_ws, size_t query_ws_bytes,
+              hipStream_t stream)
 {
     const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
     if (!fast) {
@@ -625,30 +643,17 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
         SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
         return 0;
     }
-    // query-side workspace (keys / ids of the cell sort): persistent, grown on demand
-    size_t qsort_bytes = 0;
-    SOAR_HIP_OK(rocprim::radix_sort_pairs((void *)nullptr, qsort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                          (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, 0u, 18u, stream));
-    size_t off = 0;
-    auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return o; };
-    const size_t o_tmp = carve(qsort_bytes), o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P),
-                 o_qv0 = carve(4 * (size_t)P), o_qv1 = carve(4 * (size_t)P);
-    int dev = 0;
-    SOAR_HIP_OK(hipGetDevice(&dev));
-    if (g_ws.bytes < off || g_ws.device != dev) {
-        if (g_ws.base) {
-            SOAR_HIP_OK(hipDeviceSynchronize());
-            (void)hipFree(g_ws.base);
-            g_ws.base = nullptr;
-            g_ws.bytes = 0;
-        }
-        SOAR_HIP_OK(hipMalloc(&g_ws.base, off));
-        g_ws.bytes = off;
-        g_ws.device = dev;
+    // query-side workspace (keys / ids of the cell sort): caller-owned, carved here
+    QueryWs ws;
+    if (carve_query_ws(query_ws, P, &ws, stream)) return 1;
+    if (ws.total > query_ws_bytes) {
+        set_error("soar_lbs_knn_query: query workspace too small (%zu bytes, need %zu for P=%d)", query_ws_bytes, ws.total, P);
+        return 1;
     }
-    char *b = static_cast<char *>(g_ws.base);
-    uint32_t *qk0 = reinterpret_cast<uint32_t *>(b + o_qk0), *qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
-    uint32_t *qv0 = reinterpret_cast<uint32_t *>(b + o_qv0), *qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
+    size_t qsort_bytes = ws.sort_bytes;
+    char *b = static_cast<char *>(query_ws);
+    const size_t o_tmp = 0;
+    uint32_t *qk0 = ws.qk0, *qk1 = ws.qk1, *qv0 = ws.qv0, *qv1 = ws.qv1;
     if (order && !resort) {
         hipLaunchKernelGGL(query_cells_ordered_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, xyz, P, g.meta, order, qk1);
         qv1 = order;
@@ -693,8 +698,6 @@ int check_knn_sizes(int32_t P, int32_t V, int32_t J, int32_t K)
     return 0;
 }
 
-KnnWorkspace g_grid_ws;      // internal grid of the one-call form
-
 }  // namespace
 
 extern "C" int soar_lbs_knn_grid_bytes(int32_t V, size_t *bytes)
@@ -716,57 +719,86 @@ extern "C" int soar_lbs_knn_build_grid(const float *verts, int32_t V, const floa
     return knn_build(verts, V, vert_weights, J, g, stream);
 }
 
+extern "C" int soar_lbs_knn_query_bytes(int32_t P, size_t *bytes)
+{
+    if (P < 0 || !bytes) { set_error("soar_lbs_knn_query_bytes: bad arguments"); return 1; }
+    QueryWs ws;
+    if (carve_query_ws(nullptr, P, &ws, nullptr)) return 1;
+    *bytes = ws.total;
+    return 0;
+}
+
+static int check_ws(const char *who, const void *ws, size_t have)
+{
+    if (!ws) { set_error("%s: NULL workspace (caller-owned, see the *_bytes query)", who); return 1; }
+    if (reinterpret_cast<uintptr_t>(ws) % ALIGN) { set_error("%s: workspace is not %zu-byte aligned", who, ALIGN); return 1; }
+    (void)have;
+    return 0;
+}
+
 extern "C" int soar_lbs_knn_query(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz,
-                                  int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
+                                  int32_t P, int32_t K, float *weights_out, int32_t *knn_idx_out, void *query_workspace,
+                                  size_t query_workspace_bytes, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_knn_sizes(P, V, J, K)) return 1;
     if (P == 0) return 0;
     if (!grid_buffer || !xyz || !vert_weights || !weights_out) { set_error("soar_lbs_knn_query: NULL pointer"); return 1; }
+    if (check_ws("soar_lbs_knn_query", query_workspace, query_workspace_bytes)) return 1;
     KnnGrid g;
     if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
     StageTimer timer(ST_LBS_KNN, stream);
-    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1, query_workspace, query_workspace_bytes,
+                     stream);
 }
 
 extern "C" int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz,
                                           int32_t P, int32_t K, uint32_t *order, int32_t resort, float *weights_out,
-                                          int32_t *knn_idx_out, void *stream_)
+                                          int32_t *knn_idx_out, void *query_workspace, size_t query_workspace_bytes, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_knn_sizes(P, V, J, K)) return 1;
     if (P == 0) return 0;
     if (!grid_buffer || !xyz || !vert_weights || !weights_out || !order) { set_error("soar_lbs_knn_query_ordered: NULL pointer"); return 1; }
+    if (check_ws("soar_lbs_knn_query_ordered", query_workspace, query_workspace_bytes)) return 1;
     KnnGrid g;
     if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
     StageTimer timer(ST_LBS_KNN, stream);
-    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, order, resort, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, order, resort, query_workspace,
+                     query_workspace_bytes, stream);
+}
+
+extern "C" int soar_lbs_knn_weights_bytes(int32_t P, int32_t V, size_t *bytes)
+{
+    if (P < 0 || V <= 0 || !bytes) { set_error("soar_lbs_knn_weights_bytes: bad arguments"); return 1; }
+    KnnGrid g;
+    if (carve_knn_grid(nullptr, V, &g, nullptr)) return 1;
+    QueryWs ws;
+    if (carve_query_ws(nullptr, P, &ws, nullptr)) return 1;
+    *bytes = align_up(g.total) + ws.total;
+    return 0;
 }
 
 extern "C" int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_t V, const float *vert_weights,
-                                    int32_t J, int32_t K, float *weights_out, int32_t *knn_idx_out, void *stream_)
+                                    int32_t J, int32_t K, float *weights_out, int32_t *knn_idx_out, void *workspace,
+                                    size_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_knn_sizes(P, V, J, K)) return 1;
     if (P == 0) return 0;
     if (!xyz || !verts || !vert_weights || !weights_out) { set_error("soar_lbs_knn_weights: NULL pointer"); return 1; }
+    if (check_ws("soar_lbs_knn_weights", workspace, workspace_bytes)) return 1;
     KnnGrid g;
-    if (carve_knn_grid(nullptr, V, &g, stream)) return 1;
-    int dev = 0;
-    SOAR_HIP_OK(hipGetDevice(&dev));
-    if (g_grid_ws.bytes < g.total || g_grid_ws.device != dev) {
-        if (g_grid_ws.base) {
-            SOAR_HIP_OK(hipDeviceSynchronize());
-            (void)hipFree(g_grid_ws.base);
-            g_grid_ws.base = nullptr;
-            g_grid_ws.bytes = 0;
-        }
-        SOAR_HIP_OK(hipMalloc(&g_grid_ws.base, g.total));
-        g_grid_ws.bytes = g.total;
-        g_grid_ws.device = dev;
+    if (carve_knn_grid(workspace, V, &g, stream)) return 1;
+    QueryWs ws;
+    if (carve_query_ws(nullptr, P, &ws, stream)) return 1;
+    const size_t grid_part = align_up(g.total);
+    if (workspace_bytes < grid_part + ws.total) {
+        set_error("soar_lbs_knn_weights: workspace too small (%zu bytes, need %zu)", workspace_bytes, grid_part + ws.total);
+        return 1;
     }
-    if (carve_knn_grid(g_grid_ws.base, V, &g, stream)) return 1;
     StageTimer timer(ST_LBS_KNN, stream);
     if (knn_build(verts, V, vert_weights, J, g, stream)) return 1;
-    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, nullptr, 1,
+                     static_cast<char *>(workspace) + grid_part, workspace_bytes - grid_part, stream);
 }

@@ -6,8 +6,13 @@ row order, same optimizer surgery (Adam moments of kept rows carried over, zero 
 (``csrc/densify.hip``) instead of ~150 boolean-index / cat / repeat launches.  ``prune_and_densify`` does both phases in
 one plan.  HIP only: there is no CPU path.
 
-Frame data-parallel jobs call ``sync_stats()`` before planning (accumulators summed, radii maxed over ranks) and pass a
-generator seeded identically on every rank; the state machine is deterministic, so all ranks hold the same model afterwards.
+Frame data-parallel jobs call ``sync_stats()`` before planning (accumulators summed, radii maxed over ranks): every rank
+then plans the same decisions, and the split noise -- the only random input -- is drawn on rank 0 and broadcast
+(``_split_noise``), so all ranks hold the same model afterwards whatever their local RNG state.
+
+Densification replaces the parameter tensors (new P): objects that baked the old ones in (``frame_dp.FlatGradBuffer`` views,
+``step_plan.FrameStepPlan`` buffers / captured graphs) are told through ``register_dependent`` / ``invalidate`` and refuse
+to run until they are rebuilt.
 """
 from __future__ import annotations
 
@@ -41,7 +46,27 @@ class SurfelDensifier:
         self.percent_dense = percent_dense
         self.surface = surface
         self.device = params["xyz"].device
+        self.generation = 0              # bumped whenever parameter tensors are replaced
+        self._dependents = []
         self._reset_stats()
+
+    def register_dependent(self, obj) -> None:
+        """obj.invalidate(reason) is called when the parameter tensors are replaced (FlatGradBuffer, FrameStepPlan)."""
+        self._dependents.append(obj)
+
+    def _split_noise(self, n_rows: int, generator, group=None) -> torch.Tensor:
+        """[n_rows,3] standard normals for the split children (:1001-1004).  In a multi-rank job rank 0 draws and broadcasts:
+        n_rows is the same everywhere after ``sync_stats`` but the ranks' RNG states need not be."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if multi and dist.get_rank(group) != 0:
+            noise = torch.empty(n_rows, 3, dtype=torch.float32, device=self.device)
+        else:
+            noise = torch.randn(n_rows, 3, dtype=torch.float32, device=self.device, generator=generator)
+        if multi:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(noise, src=src, group=group)
+        return noise
 
     # ---- statistics ---------------------------------------------------------------------------------------------------
     @property
@@ -109,12 +134,13 @@ class SurfelDensifier:
         result = None
         if iteration % cfg.densification_interval == 0:
             self.sync_stats(group)
-            result = self._run(iteration > cfg.prune_from_iter, True, 0.1, extent, cfg.densify_grad_threshold, generator)
+            result = self._run(iteration > cfg.prune_from_iter, True, 0.1, extent, cfg.densify_grad_threshold, generator,
+                               group=group)
         if (iteration - 1) % cfg.opacity_reset_interval == 0 and cfg.opacity_lr > 0:
             self.reset_opacity(0.12)
         return result
 
-    def _run(self, do_prune, do_densify, min_opacity, extent, max_grad, generator, N: int = 2, noise=None):
+    def _run(self, do_prune, do_densify, min_opacity, extent, max_grad, generator, N: int = 2, noise=None, group=None):
         L = hip_lib.lib()
         P = self.num_points
         if P == 0:
@@ -134,7 +160,7 @@ class SurfelDensifier:
         kept, cloned, split = int(counts[0]), int(counts[1]), int(counts[2])
         P_new = kept + cloned + N * split
         if split and noise is None:
-            noise = torch.randn(N * split, 3, dtype=torch.float32, device=self.device, generator=generator)
+            noise = self._split_noise(N * split, generator, group)
         elif split:
             noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
             if noise.dim() != 2 or noise.shape[1] != 3 or noise.shape[0] < N * split:
@@ -225,3 +251,7 @@ class SurfelDensifier:
                         st["exp_avg"], st["exp_avg_sq"] = states[k]["exp_avg"], states[k]["exp_avg_sq"]
                     self.optimizer.state[new] = st
             self.params[k] = new
+        self.generation += 1
+        for d in self._dependents:
+            d.invalidate(f"the densifier replaced the parameter tensors (generation {self.generation}, "
+                         f"{self.num_points} points)")

@@ -40,13 +40,26 @@ FORCE_COLLECTIVES = False
 class FlatGradBuffer:
     """One contiguous fp32 buffer of 15*P floats; each leaf's ``.grad`` is a contiguous [P,w] VIEW into it (leaf after
     leaf), so autograd accumulates the frames of a step in place and the all-reduce is a single collective on a single
-    tensor."""
+    tensor.
+
+    The views only stay the gradients while nobody replaces ``leaf.grad``: ``optimizer.zero_grad()`` defaults to
+    ``set_to_none=True`` and would drop them (autograd then allocates fresh ``.grad`` tensors and the flat buffer goes
+    stale).  Use ``zero()`` (or ``zero_grad(set_to_none=False)``); every reduction first checks the aliases
+    (``check_views``) and raises instead of reducing a stale buffer.
+
+    Two reduction forms: ``all_reduce()`` -- one collective on the whole buffer -- and ``all_reduce_buckets()`` -- two
+    asynchronous collectives, the xyz slice first and then the rest, so that what depends on the positions only (the next
+    step's KNN blend weights, behind the optimizer's update of xyz) can start while the larger bucket is still in flight;
+    ``wait_bucket(0)`` / ``wait_all()`` make the CURRENT STREAM wait for them (no host block)."""
 
     def __init__(self, leaves: Dict[str, torch.Tensor]):
         P = next(iter(leaves.values())).shape[0]
         dev = next(iter(leaves.values())).device
         self.flat = torch.zeros((P * FLOATS_PER_GAUSSIAN,), dtype=torch.float32, device=dev)
         self.views: Dict[str, torch.Tensor] = {}
+        self.leaves: Dict[str, torch.Tensor] = {}
+        self.pending: List = []                   # work handles of all_reduce_buckets(), bucket 0 = xyz
+        self.stale = None                         # set by invalidate(): the leaves were replaced (densification)
         start = 0
         for name, width in LEAVES:
             if name in leaves:
@@ -57,16 +70,63 @@ class FlatGradBuffer:
                 self.views[name] = v
                 if t.requires_grad:
                     t.grad = v
+                    self.leaves[name] = t
             start += P * width
+        self.split = P * LEAVES[0][1]             # end of the xyz slice = boundary between the two buckets
+
+    def attach(self):
+        """(Re-)install the views as the leaves' ``.grad`` (after something set them to None)."""
+        for name, t in self.leaves.items():
+            t.grad = self.views[name]
+
+    def invalidate(self, reason: str):
+        """The leaves this buffer aliases were replaced (``SurfelDensifier.register_dependent``): build a new buffer."""
+        self.stale = reason
+
+    def check_views(self):
+        if self.stale is not None:
+            raise RuntimeError(f"FlatGradBuffer is stale: {self.stale}; build a new one from the new leaves")
+        for name, t in self.leaves.items():
+            if t.grad is None or t.grad.data_ptr() != self.views[name].data_ptr():
+                raise RuntimeError(
+                    f"leaf '{name}': .grad is no longer the view into the flat gradient buffer (optimizer.zero_grad() with "
+                    "set_to_none=True drops it) -- the reduction would sum a stale buffer; use FlatGradBuffer.zero() / "
+                    "zero_grad(set_to_none=False), or call attach()")
 
     def zero(self):
+        self.wait_all()
         self.flat.zero_()
+        self.attach()
+
+    def _collectives_on(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
     def all_reduce(self, async_op: bool = False):
         """Sum over ranks (no-op for a single process).  Returns the work handle when async."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
+        self.check_views()
+        if self._collectives_on():
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         return None
+
+    def all_reduce_buckets(self):
+        """Issue the two asynchronous bucket reductions (xyz, then the rest) behind everything enqueued on the current
+        stream.  No-op for a single process."""
+        self.check_views()
+        self.wait_all()
+        if self._collectives_on():
+            self.pending = [dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM, async_op=True),
+                            dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
+        return self.pending
+
+    def wait_bucket(self, k: int):
+        if k < len(self.pending) and self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+
+    def wait_all(self):
+        for k in range(len(self.pending)):
+            self.wait_bucket(k)
+        self.pending = []
 
 
 def all_reduce_densification_stats(grad_accum: torch.Tensor, denom: torch.Tensor):

@@ -11,6 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libsoar_hip.so")
 
+ABI_VERSION = 2          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 
@@ -53,12 +54,14 @@ SIGNATURES = {
                                   + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_rast_export_state": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64] + [_vp] * 17 + [_vp]),
-    "soar_lbs_knn_weights": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "soar_lbs_knn_weights_bytes": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_lbs_knn_weights": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "soar_lbs_knn_grid_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_lbs_knn_query_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_lbs_knn_build_grid": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
-    "soar_lbs_knn_query": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "soar_lbs_knn_query": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "soar_lbs_knn_query_ordered": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp,
-                                             _vp]),
+                                             _vp, C.c_size_t, _vp]),
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
@@ -117,7 +120,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)          # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.soar_abi_version() != 1:
+        if handle.soar_abi_version() != ABI_VERSION:
             raise SoarHipError("libsoar_hip.so ABI version mismatch; rebuild with `python -m soar_amd.build --force`")
         _lib = handle
     return _lib

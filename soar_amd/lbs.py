@@ -55,6 +55,14 @@ class KnnGrid:
 
     RESORT_EVERY = 8     # queries between two sorts of the query order (positions move little between optimizer steps)
 
+    def query_workspace(self, P: int) -> torch.Tensor:
+        """A caller-owned scratch buffer for queries of P points (``soar_lbs_knn_query_bytes``).  The grid object keeps one
+        per (P, stream) for its own ``query`` calls; a step plan that captures the query in a HIP graph allocates its own."""
+        import ctypes as C
+        n = C.c_size_t(0)
+        check(hip_lib.lib().soar_lbs_knn_query_bytes(int(P), C.byref(n)), "soar_lbs_knn_query_bytes")
+        return torch.empty(int(n.value), dtype=torch.uint8, device=self.verts.device)
+
     def query(self, xyz: torch.Tensor, K: int = 30, return_idx: bool = False, out: Optional[torch.Tensor] = None):
         """Blend weights of `xyz`.  The order in which the queries are grouped by grid cell is kept between calls and
         refreshed every RESORT_EVERY calls (or when the number of queries changes); it only affects speed."""
@@ -72,9 +80,17 @@ class KnnGrid:
                 order = self._order = torch.empty((P,), dtype=torch.int32, device=x.device)
             self._since_sort = 0
         self._since_sort += 1
+        # scratch of this call: one buffer per (P, stream) -- two streams never share one; stream-ordered reuse on the same
+        # stream is safe
+        stream = _stream(x.device)
+        cache = self.__dict__.setdefault("_query_ws", {})
+        ws = cache.get((P, stream))
+        if ws is None:
+            ws = cache[(P, stream)] = self.query_workspace(P)
         with torch.cuda.device(x.device):
             check(L.soar_lbs_knn_query_ordered(ptr(self.buffer), self.V, ptr(self.weights), self.J, ptr(x), P, K, ptr(order),
-                                               int(resort), ptr(out), ptr(idx), _stream(x.device)), "soar_lbs_knn_query_ordered")
+                                               int(resort), ptr(out), ptr(idx), ptr(ws), ws.numel(), stream),
+                  "soar_lbs_knn_query_ordered")
         return (out, idx) if return_idx else out
 
 
@@ -88,9 +104,13 @@ def knn_blend_weights(xyz: torch.Tensor, verts: torch.Tensor, vert_weights: torc
     w = w.reshape(V, J)
     out = torch.empty((P, J), dtype=torch.float32, device=x.device)
     idx = torch.empty((P, K), dtype=torch.int32, device=x.device) if return_idx else None
+    import ctypes as C
+    n = C.c_size_t(0)
+    check(L.soar_lbs_knn_weights_bytes(P, V, C.byref(n)), "soar_lbs_knn_weights_bytes")
+    ws = torch.empty(int(n.value), dtype=torch.uint8, device=x.device)        # caller-owned scratch (grid + query sort)
     with torch.cuda.device(x.device):
-        check(L.soar_lbs_knn_weights(ptr(x), P, ptr(v), V, ptr(w), J, K, ptr(out), ptr(idx), _stream(x.device)),
-              "soar_lbs_knn_weights")
+        check(L.soar_lbs_knn_weights(ptr(x), P, ptr(v), V, ptr(w), J, K, ptr(out), ptr(idx), ptr(ws), ws.numel(),
+                                     _stream(x.device)), "soar_lbs_knn_weights")
     return (out, idx) if return_idx else out
 
 

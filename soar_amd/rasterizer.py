@@ -28,7 +28,8 @@ import torch.nn as nn
 from . import hip_lib
 from .hip_lib import SoarRastParams, check, ptr
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_views", "_C"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_views", "cpu_deep_copy_tuple",
+           "_C"]
 
 # running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
 stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
@@ -407,15 +408,40 @@ _C = _NativeOps()
 # ---------------------------------------------------------------------------------------------------
 # autograd op and module
 # ---------------------------------------------------------------------------------------------------
+def cpu_deep_copy_tuple(input_tuple):
+    """Host copies of the tensor arguments, taken BEFORE the call so that a failing kernel cannot corrupt them
+    (DGR/diff_gaussian_rasterization/__init__.py:19-24)."""
+    return tuple(item.detach().cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _debug_call(fn, args, dump_path, what):
+    """``raster_settings.debug``: copy the argument tuple to the host, call, and on ANY failure write the copy to `dump_path`
+    with ``torch.save`` and re-raise -- the reference's snapshot protocol (__init__.py:105-126 forward -> snapshot_fw.dump,
+    :210-233 backward -> snapshot_bw.dump).  With debug set the C ABI synchronises and checks after every stage
+    (``SoarRastParams.debug``), so a faulting kernel surfaces here as an exception of this call."""
+    cpu_args = cpu_deep_copy_tuple(args)
+    try:
+        return fn(*args)
+    except Exception as ex:
+        torch.save(cpu_args, dump_path)
+        print(f"\nAn error occured in {what}. Please forward {dump_path} for debugging.")
+        raise ex
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
                 projmatrix, campos, raster_settings):
         rs = raster_settings
-        (num_rendered, color, normal, depth, opac, radii, geom, binning, img) = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, viewmatrix,
-            projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, campos, rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config)
+        # positional argument tuple of _C.rasterize_gaussians, in the reference's order (__init__.py:74-101)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, viewmatrix,
+                projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, campos, rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config)
+        if rs.debug:
+            res = _debug_call(_C.rasterize_gaussians, args, "snapshot_fw.dump", "forward")
+        else:
+            res = _C.rasterize_gaussians(*args)
+        (num_rendered, color, normal, depth, opac, radii, geom, binning, img) = res
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.opac_shape = opacities.shape
@@ -427,11 +453,15 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, g_color, g_normal, g_depth, g_opac, _g_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_view, g_proj,
-         g_campos) = _C.rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
-            rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
-            rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, rs.config)
+        # positional argument tuple of _C.rasterize_gaussians_backward (__init__.py:178-207)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_normal, g_depth, g_opac, sh,
+                rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, rs.config)
+        if rs.debug:
+            res = _debug_call(_C.rasterize_gaussians_backward, args, "snapshot_bw.dump", "backward")
+        else:
+            res = _C.rasterize_gaussians_backward(*args)
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_view, g_proj, g_campos) = res
         # gradients in input order: means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, view, proj,
         # campos, settings (__init__.py:249-262).  Empty placeholder inputs receive correspondingly empty gradients.
         def like(g, ref):

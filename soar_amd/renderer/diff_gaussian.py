@@ -143,7 +143,11 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         cam_leaf = any(getattr(t, "requires_grad", False) for t in (viewpoint_camera.world_view_transform,
                                                                     viewpoint_camera.full_proj_transform,
                                                                     viewpoint_camera.camera_center))
-        if render_front and full_patch and not cam_leaf:
+        # The reference hands `pc.get_occ.repeat(1, 3)` UNDETACHED to the occlusion pass (:280-291): `rendered_occ` carries
+        # gradient to the occlusion parameter (loss_occ, TS/system/gaussian_surfel_mvdream.py:412-417).  The fused blend
+        # produces the occlusion image without a backward, so it is only taken when no such gradient can be asked for.
+        occ_needs_grad = torch.is_grad_enabled() and bool(getattr(pc.get_occ, "requires_grad", False))
+        if render_front and full_patch and not cam_leaf and not occ_needs_grad:
             # main pass sorted front-to-back and both passes on the same (full) patch: the occlusion pass (:193-211,
             # :281-291) is a subsequence of the main one and is blended in the same kernel launch
             (rendered_image, rendered_normal, rendered_depth, rendered_opac, radii, rendered_occ) = rasterize_views(

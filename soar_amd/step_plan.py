@@ -5,7 +5,8 @@ step of the avatar stage -- KNN blend weights, then for every frame of the batch
 occlusion pass) -> per-frame image loss -> rasterizer backward -> warp backward, then sum the frames' gradients -- every
 operation is a call of the C ABI whose backward is another call of the C ABI, so the step can be laid out once:
 
-* all buffers are allocated when the plan is built (288 GB of HBM: nothing is recycled between frames);
+* all buffers are allocated when the plan is built (a C3 step holds ~0.8 GB of them; with 288 GB of HBM per GPU nothing
+  is recycled between frames);
 * each frame's forward+backward chain is a straight line of ~20 launches on the frame's own HIP stream, independent of
   the other frames (they only share read-only inputs), captured as ONE HIP graph per frame;
 * a prologue (zero gradients, KNN blend weights) and an epilogue (sum of the per-frame gradients into the flat
@@ -91,7 +92,10 @@ class FrameStepPlan:
         self.g_colors = torch.empty((self.n, P, 3), **f)
         self.losses = torch.empty((self.n,), **f)
         self.knn_order = torch.empty((P,), dtype=torch.int32, device=dev)     # query order of the KNN, refreshed every few steps
+        self.knn_ws = seq.knn_grid.query_workspace(P)        # query scratch owned by THIS plan (its graphs hold the pointer)
         self.steps = 0
+        self.stale = None
+        self._baked = self._leaf_signature()
         # frame 0 stays on the caller's stream, the others get their own (4 hardware queues in all for 4 frames)
         self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)]
         self.graphs = None
@@ -101,15 +105,33 @@ class FrameStepPlan:
                                    "before the HIP runtime starts (see the module docstring); use use_graphs=False otherwise")
             self._capture()
 
+    def _leaf_signature(self):
+        s = self.seq
+        return tuple((t.data_ptr(), tuple(t.shape)) for t in (s.xyz, s.rot, s.scales, s.colors, s.occ))
+
+    def invalidate(self, reason: str):
+        """The model tensors whose pointers / sizes this plan (and its captured graphs) baked in were replaced
+        (``SurfelDensifier.register_dependent``): the plan refuses to run; build a new one."""
+        self.stale = reason
+
+    def _check_fresh(self):
+        if self.stale is None and self._leaf_signature() != self._baked:
+            self.stale = "the sequence's parameter tensors changed (pointer or shape) since the plan was built"
+        if self.stale is not None:
+            raise RuntimeError(f"FrameStepPlan is stale: {self.stale}; build a new plan (buffers and HIP graphs hold the old "
+                               "pointers)")
+
     # ---- the three pieces -------------------------------------------------------------------------------------------
     RESORT_EVERY = 8      # steps between two sorts of the KNN query order (lbs.KnnGrid.RESORT_EVERY)
 
     def _prologue(self, stream: int, resort: bool = True) -> None:
         L, s = self.L, self.seq
-        self.flat.flat.zero_()
+        # (the flat gradient buffer is not zeroed here: the epilogue overwrites every registered slice, and the previous
+        # step's second all-reduce bucket may still be reading it)
         check(L.soar_lbs_knn_query_ordered(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
                                            ptr(s.xyz.detach()), self.P, 30, ptr(self.knn_order), int(resort),
-                                           ptr(self.blend_weights), None, stream), "knn_query")
+                                           ptr(self.blend_weights), None, ptr(self.knn_ws), self.knn_ws.numel(), stream),
+              "knn_query")
 
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
@@ -182,7 +204,9 @@ class FrameStepPlan:
         dev = self.device
         main = torch.cuda.current_stream(dev)
         with torch.cuda.device(dev):
+            self.flat.wait_bucket(0)
             self._prologue(main.cuda_stream, self.steps % self.RESORT_EVERY == 0)
+            self.flat.wait_all()
             self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
             self._epilogue()
         self.steps += 1
@@ -209,6 +233,7 @@ class FrameStepPlan:
         """Gradients of sum_i loss(frame_i) w.r.t. the leaves into the flat buffer; returns the [n] per-frame losses."""
         if len(frames) != self.n:
             raise ValueError(f"the plan was built for {self.n} frames per step, got {len(frames)}")
+        self._check_fresh()
         dev = self.device
         idx = torch.as_tensor([f % self.seq.num_frames for f in frames], device=dev)
         torch.index_select(self.seq.cano2live, 0, idx, out=self.mats)
@@ -218,7 +243,12 @@ class FrameStepPlan:
             self._run_eager()
             return self.losses
         main = torch.cuda.current_stream(dev)
+        # frame-DP: the previous step's gradient buckets may still be in flight (FlatGradBuffer.all_reduce_buckets).  The KNN
+        # prologue depends on the positions only -> it waits for the xyz bucket (where an optimizer's update of xyz sits);
+        # the frames read every parameter -> they wait for the rest.  Stream-side waits, no host block; no-ops on one rank.
+        self.flat.wait_bucket(0)
         self.graphs["prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"].replay()
+        self.flat.wait_all()
         self._fan_out(main, lambda i, s: self.graphs[i].replay())
         self.graphs["epilogue"].replay()
         self.steps += 1

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in soar_hip.h but not exported"
     assert sorted(hip_lib.SIGNATURES) == declared, "ctypes binding and header disagree"
-    assert lib.soar_abi_version() == 1
+    assert lib.soar_abi_version() == hip_lib.ABI_VERSION == 2
 
 
 def test_sizing_functions(lib):
@@ -55,8 +55,17 @@ def test_bad_arguments_fail_loudly_without_touching_the_gpu(lib):
     R = C.c_int64(0)
     rc = lib.soar_rast_forward_geometry(C.byref(prm), None, None, None, None, None, None, None, None, None, C.byref(R), None)
     assert rc != 0 and "NULL" in hip_lib.last_error()
-    assert lib.soar_lbs_knn_weights(None, 10, None, 100, None, 55, 64, None, None, None) != 0
+    assert lib.soar_lbs_knn_weights(None, 10, None, 100, None, 55, 64, None, None, None, 0, None) != 0
     assert "K=64" in hip_lib.last_error()
+    # the KNN scratch is caller-owned: a query without a workspace is refused before anything is launched
+    n = C.c_size_t(0)
+    assert lib.soar_lbs_knn_query_bytes(100000, C.byref(n)) == 0 and n.value >= 4 * 4 * 100000 and n.value % 256 == 0
+    g = C.c_size_t(0)
+    assert lib.soar_lbs_knn_grid_bytes(10475, C.byref(g)) == 0
+    w = C.c_size_t(0)
+    assert lib.soar_lbs_knn_weights_bytes(100000, 10475, C.byref(w)) == 0 and w.value >= g.value + n.value
+    assert lib.soar_lbs_knn_query(0x1000, 100, 0x1000, 55, 0x1000, 10, 30, 0x1000, None, None, 0, None) != 0
+    assert "workspace" in hip_lib.last_error()
     assert lib.soar_lbs_warp_forward(None, None, None, None, None, None, 5, 100, None, None, None, None) != 0
 
 
@@ -77,3 +86,43 @@ def test_python_api_rejects_cpu_tensors_instead_of_falling_back():
         "patch_bbox", "prcppoint", "sh_degree", "campos", "prefiltered", "render_front", "sort_descending", "debug", "config")
     import diff_gaussian_rasterization as dgr
     assert dgr.GaussianRasterizer is GaussianRasterizer
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself; with fewer than N devices it must exit non-zero and
+    print no line (never an n_gpus that differs from --gpus)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 2), "--steps", "1",
+                        "--warmup", "1", "--workload", "tiny"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "visible" in r.stderr
+    # a launcher's WORLD_SIZE that disagrees with --gpus is refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=4" in r.stderr
+
+
+def test_debug_snapshot_protocol_forward(tmp_path, monkeypatch):
+    """raster_settings.debug: a failing forward writes the host copy of the argument tuple to snapshot_fw.dump and re-raises
+    (DGR/diff_gaussian_rasterization/__init__.py:105-126).  The failure used here is the one available without a GPU: CPU tensors."""
+    from soar_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    st = GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4),
+                                       torch.tensor([0., 0., 8., 8.]), torch.tensor([.5, .5]), 0, torch.zeros(3), False,
+                                       False, False, True, torch.tensor([1., 1., 1., 0.]))
+    means = torch.arange(12.0).reshape(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRasterizer(st)(means, torch.zeros(4, 3), torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
+                               scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    dump = torch.load(tmp_path / "snapshot_fw.dump")
+    assert isinstance(dump, tuple) and len(dump) == 24                 # the 24 positional arguments of _C.rasterize_gaussians
+    assert torch.equal(dump[1], means) and dump[14] == 8 and dump[22] is True
+    # without debug nothing is written
+    (tmp_path / "snapshot_fw.dump").unlink()
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(st._replace(debug=False))(means, torch.zeros(4, 3), torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
+                                                     scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    assert not (tmp_path / "snapshot_fw.dump").exists()

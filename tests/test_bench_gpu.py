@@ -33,3 +33,31 @@ def test_bench_line_schema(mode):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_bench_forced_dist_path_runs_rccl():
+    """SOAR_BENCH_FORCE_DIST=1: the multi-rank code path (RCCL process group, barriers, bucketed asynchronous all-reduce, the
+    same default mode as a real multi-rank job) with a single rank -- the only way to exercise it on a one-GPU box.  stdout
+    must still be exactly the one JSON line (RCCL prints banners)."""
+    env = dict(os.environ, SOAR_BENCH_FORCE_DIST="1", MASTER_PORT="29537")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["mode"] == "plan" and d["config"]["collectives"].startswith("rccl")
+    assert d["value"] > 0
+
+
+def test_bench_gpus_flag_must_match_the_job():
+    """--gpus 2 on a one-GPU box: no line at all (never n_gpus: 1 for --gpus 2)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""

@@ -64,14 +64,25 @@ def _worker(rank, world, port, P, out_dir):
         batch = frame_dp.global_batch(3, 2, world, num_frames=50)
         for f in frame_dp.shard_frames(batch, rank, world):
             _frame_loss(leaves, f).backward()
-        work = buf.all_reduce(async_op=True)
-        work.wait()
+        if rank == 0:
+            works = buf.all_reduce_buckets()           # two asynchronous buckets: xyz first, then the rest
+            assert len(works) == 2
+        else:
+            works = buf.all_reduce_buckets()
+        buf.wait_bucket(0)
+        buf.wait_all()
+        assert buf.pending == []
+        # split noise of the densifier: ranks with different RNG states must end up with rank 0's draw
+        from soar_amd.densify import SurfelDensifier
+        dens = SurfelDensifier.__new__(SurfelDensifier)
+        dens.device = torch.device("cpu")
+        noise = dens._split_noise(6, torch.Generator().manual_seed(100 + rank))
         acc, den = torch.full((P, 1), float(rank + 1)), torch.full((P, 1), 1.0)
         frame_dp.all_reduce_densification_stats(acc, den)
         acc5, rad = torch.full((5, P), float(rank + 1)), torch.arange(P, dtype=torch.float32) * (1 if rank else -1)
         frame_dp.all_reduce_densifier_stats(acc5, rad)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=buf.flat.numpy(), acc=acc.numpy(), den=den.numpy(),
-                 acc5=acc5.numpy(), rad=rad.numpy())
+                 acc5=acc5.numpy(), rad=rad.numpy(), noise=noise.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -93,6 +104,27 @@ def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
     assert np.abs(buf.flat.numpy()[P * 13:]).sum() == 0                          # leaves not registered stay zero
     np.testing.assert_array_equal(r0["acc"], np.full((P, 1), 3.0, np.float32))
     np.testing.assert_array_equal(r1["den"], np.full((P, 1), 2.0, np.float32))
+    np.testing.assert_array_equal(r0["noise"], r1["noise"])                     # broadcast from rank 0
+    np.testing.assert_array_equal(r0["noise"], torch.randn(6, 3, generator=torch.Generator().manual_seed(100)).numpy())
     for r in (r0, r1):                                                          # densifier statistics: sum and max
         np.testing.assert_array_equal(r["acc5"], np.full((5, P), 3.0, np.float32))
         np.testing.assert_array_equal(r["rad"], np.arange(P, dtype=np.float32))
+
+
+def test_flat_buffer_refuses_stale_views():
+    P = 5
+    leaves = {n: torch.randn(P, w, requires_grad=True) for n, w in frame_dp.LEAVES[:4]}
+    buf = frame_dp.FlatGradBuffer(leaves)
+    opt = torch.optim.Adam(list(leaves.values()), lr=1e-3)
+    opt.zero_grad()                                    # set_to_none=True: drops the aliases
+    with pytest.raises(RuntimeError, match="no longer the view"):
+        buf.all_reduce()
+    buf.zero()                                         # re-attaches
+    buf.all_reduce()
+    sum(t.sum() for t in leaves.values()).backward()
+    assert float(buf.flat[: P * 13].sum()) == P * 13
+    opt.zero_grad(set_to_none=False)                   # keeps the aliases
+    buf.all_reduce_buckets()
+    buf.invalidate("densified")
+    with pytest.raises(RuntimeError, match="stale"):
+        buf.all_reduce()

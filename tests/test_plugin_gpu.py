@@ -67,7 +67,7 @@ def world():
     return types.SimpleNamespace(body=body, poses=poses, guide=guide, surf=surf, pc=pc, renderer=renderer, cam=cam, spec=spec)
 
 
-def _oracle_frame(w, frame, render_front, colors, T=None, zero_out=False, descending=False):
+def _oracle_frame(w, frame, render_front, colors, T=None, zero_out=False, descending=False, grads=None):
     """CPU oracle chain for one video frame: joint transforms -> KNN weights -> warp -> rasterizer oracle."""
     from oracle import lbs_oracle as lo
     b, p = w.body, w.poses
@@ -91,6 +91,8 @@ def _oracle_frame(w, frame, render_front, colors, T=None, zero_out=False, descen
     scene = S.Scene("plugin", H, W, pts.numpy(), np.ones((P, 1), np.float32), scales, q.numpy(), colors, None, None, w.spec,
                     np.array([0.2, 0.5, 0.7], np.float32), np.array([0, 0, H, W], np.float32),
                     np.array([1, 1, 1, 0], np.float32), render_front=render_front, sort_descending=descending)
+    if grads is not None:
+        return S.run_oracle(scene, grads)
     return S.run_oracle(scene)[0]
 
 
@@ -123,6 +125,40 @@ def test_plugin_video_frame_matches_oracle_chain(world):
     for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color, out["viewspace_points"]):
         assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
         t.grad = None
+
+
+def test_plugin_occlusion_image_carries_gradient_to_the_occ_parameter(world):
+    """The reference passes `pc.get_occ.repeat(1,3)` undetached (:280-291) and trains `_occ` with
+    loss_occ = (1 - comp_occ[mask]).mean() (gaussian_surfel_mvdream.py:412-417): d loss / d _occ must be the occlusion pass's
+    dL_dcolors summed over the three channels."""
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    occ0 = w.pc._occ
+    w.pc._occ = occ0.clone().requires_grad_(True)
+    try:
+        out = w.renderer(w.cam, bg, gt=True, gt_index=3)
+        assert out["occ"].requires_grad
+        mask = (out["mask"].detach() > 1e-5).repeat(3, 1, 1)
+        loss_occ = (1 - out["occ"][mask]).mean()
+        loss_occ.backward()
+        g = w.pc._occ.grad
+        assert g is not None and g.abs().sum() > 0
+        # oracle: occlusion pass (render_front) with colours = occ repeated, upstream gradient of the same loss
+        gC = (-(mask.float()) / mask.sum()).cpu().numpy().astype(np.float32)
+        z3, z1 = np.zeros((3, H, W), np.float32), np.zeros((1, H, W), np.float32)
+        fw, bw = _oracle_frame(w, 3, True, np.repeat(occ0.cpu().numpy(), 3, 1), grads=(gC, z3, z1, z1))
+        assert np.abs(out["occ"].detach().cpu().numpy() - fw.out_color).mean() < 1e-5
+        ref = bw.dL_dcolors.sum(1, keepdims=True)
+        assert np.abs(g.cpu().numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30) + 1e-9
+        # with gradients disabled (evaluation) the fused single-walk path is taken and gives the same image
+        with torch.no_grad():
+            out2 = w.renderer(w.cam, bg, gt=True, gt_index=3)
+        assert not out2["occ"].requires_grad
+        assert np.abs(out2["occ"].cpu().numpy() - out["occ"].detach().cpu().numpy()).max() < 1e-5
+    finally:
+        w.pc._occ = occ0
+        for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
+            t.grad = None
 
 
 def test_plugin_sds_view_uses_axis_permutation_and_zeroed_root(world):
@@ -358,6 +394,43 @@ def test_step_plan_matches_autograd(use_graphs, pooled):
         assert float(want.abs().sum()) > 0
         np.testing.assert_allclose(losses.cpu().numpy(), want_losses.cpu().numpy(), rtol=1e-6)
         assert _rel(flat.flat.cpu().numpy(), want.cpu().numpy()) < 1e-4
+
+
+def test_step_plan_matches_autograd_at_c3_size():
+    """BASELINE config C3 at full size (100k Gaussians, 1080x1920, batch = 4 frames): one FrameStepPlan step (HIP graphs, four
+    streams, sync-free binning) against the autograd path on the same four frames -- the bench's timed step is this object."""
+    import bench
+    from soar_amd import rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+    from soar_amd.synthetic import pool_targets
+    seq, pool, _ = bench.build_sequence("C3", DEV)
+    assert seq.xyz.shape[0] == 100_000 and (seq.camera.height, seq.camera.width) == (1080, 1920)
+    flat = FlatGradBuffer(seq.leaves())
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    frames = [40, 41, 42, 43]
+    flat.zero()
+    seq.refresh_blend_weights()
+    outs = seq.render_frames(frames, bg, loss_targets=[pool_targets(pool, f) for f in frames])
+    sum(o.loss for o in outs).backward()
+    torch.cuda.synchronize()
+    assert rasterizer.last_num_rendered > 500_000
+    want, want_losses = flat.flat.clone(), torch.stack([o.loss.detach() for o in outs])
+    plan = FrameStepPlan(seq, 4, pool, bg, 2 * rasterizer.last_num_rendered, flat, use_graphs=True)
+    losses = plan.run(frames)
+    torch.cuda.synchronize()
+    status = plan.check()
+    assert all(n > 500_000 and o == 0 for n, o in status)
+    np.testing.assert_allclose(losses.cpu().numpy(), want_losses.cpu().numpy(), rtol=1e-6)
+    P = seq.xyz.shape[0]
+    got, ref = flat.flat.cpu().numpy(), want.cpu().numpy()
+    for name, lo, hi in (("xyz", 0, 3 * P), ("rot", 3 * P, 7 * P), ("scales", 7 * P, 10 * P), ("colors", 10 * P, 13 * P)):
+        assert np.abs(ref[lo:hi]).sum() > 0, name
+        assert _rel(got[lo:hi], ref[lo:hi]) < 1e-4, name
+    # a densification (here: any replacement of the parameter tensors) must stop the plan from replaying stale pointers
+    plan.invalidate("test")
+    with pytest.raises(RuntimeError, match="stale"):
+        plan.run(frames)
 
 
 @pytest.mark.parametrize("hw", [(24, 40), (61, 97), (540, 960)])

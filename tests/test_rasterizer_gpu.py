@@ -347,6 +347,42 @@ def test_argument_validation():
              scales=torch.ones(32, 3), rotations=torch.ones(32, 4))
 
 
+def test_debug_mode_results_and_backward_snapshot(tmp_path, monkeypatch):
+    """raster_settings.debug = True: per-stage synchronise-and-check in the C ABI, same results; a failing backward leaves
+    snapshot_bw.dump with the 27 positional arguments and re-raises (DGR/diff_gaussian_rasterization/__init__.py:210-233)."""
+    from soar_amd import rasterizer as R
+    monkeypatch.chdir(tmp_path)
+    scene = S.person_scene(P=400, W=96, H=64, seed=5)
+    dev = _dev()
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+    outs = {}
+    for debug in (False, True):
+        rs = S.torch_settings(scene, dev)._replace(debug=debug)
+        means = t(scene.means3D).requires_grad_(True)
+        res = R.GaussianRasterizer(rs)(means, torch.zeros_like(means, requires_grad=True), t(scene.opacities),
+                                       colors_precomp=t(scene.colors), scales=t(scene.scales), rotations=t(scene.rotations))
+        (res[0].sum() + res[2].sum()).backward()
+        outs[debug] = [x.detach().cpu() for x in res] + [means.grad.cpu()]
+    for a, b in zip(outs[False][:5], outs[True][:5]):
+        assert torch.equal(a, b)
+    assert torch.allclose(outs[False][5], outs[True][5], rtol=1e-4, atol=1e-6)     # float atomics: order differs run to run
+    assert not (tmp_path / "snapshot_fw.dump").exists() and not (tmp_path / "snapshot_bw.dump").exists()
+
+    rs = S.torch_settings(scene, dev)._replace(debug=True)
+    means = t(scene.means3D).requires_grad_(True)
+    res = R.GaussianRasterizer(rs)(means, torch.zeros_like(means, requires_grad=True), t(scene.opacities),
+                                   colors_precomp=t(scene.colors), scales=t(scene.scales), rotations=t(scene.rotations))
+
+    def broken(*a, **k):
+        raise RuntimeError("injected backward failure")
+    monkeypatch.setattr(R._C, "rasterize_gaussians_backward", broken)
+    with pytest.raises(RuntimeError, match="injected backward failure"):
+        res[0].sum().backward()
+    dump = torch.load(tmp_path / "snapshot_bw.dump")
+    assert len(dump) == 27 and torch.equal(dump[1], means.detach().cpu()) and dump[22] > 0 and dump[25] is True
+    assert all(not (isinstance(x, torch.Tensor) and x.is_cuda) for x in dump)
+
+
 def test_full_size_properties():
     """BASELINE C2-size run (50k, 540x960): size-independent properties instead of an element-wise oracle diff:
     sorted keys are non-decreasing on the masked bits, ranges partition [0,R), opacity = 1 - final_T, a second run
