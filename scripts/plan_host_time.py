@@ -41,3 +41,32 @@ for use_graphs in (True, False):
         plan.run([(20 + 4 * s + k) % 400 for k in range(4)])
         torch.cuda.synchronize()
     print(f"graphs={use_graphs}: {1e3 * (time.perf_counter() - t0) / N:.3f} ms/step when every step is synchronised", flush=True)
+
+# ---- pure host cost: the device is idle when the step is enqueued (no queue back-pressure), then the drain time
+plan = FrameStepPlan(seq, 4, targets, bg, 2 * r_seen, flat, use_graphs=True)
+for s in range(3):
+    plan.run([4 * s + k for k in range(4)])
+torch.cuda.synchronize()
+hs, ds = [], []
+for s in range(20):
+    frames = [(20 + 4 * s + k) % 400 for k in range(4)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.run(frames)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    hs.append(t1 - t0); ds.append(t2 - t0)
+hs.sort(); ds.sort()
+print(f"idle-device enqueue of one step: host {1e3 * hs[len(hs) // 2]:.3f} ms (median), step done after {1e3 * ds[len(ds) // 2]:.3f} ms", flush=True)
+def med(fn, n=20):
+    v = []
+    for _ in range(n):
+        torch.cuda.synchronize(); t = time.perf_counter(); fn(); v.append(time.perf_counter() - t)
+    v.sort(); return 1e3 * v[len(v) // 2]
+main = torch.cuda.current_stream(dev)
+idx = torch.as_tensor([0, 1, 2, 3], device=dev)
+print("host ms: as_tensor+index_select+copy %.3f | prologue replay %.3f | one frame graph replay %.3f | fan_out(4 replays) %.3f | epilogue replay %.3f" % (
+    med(lambda: (torch.index_select(seq.cano2live, 0, torch.as_tensor([0, 1, 2, 3], device=dev), out=plan.mats), plan.frame_sel.copy_(idx % 8))),
+    med(lambda: plan.graphs["prologue"].replay()), med(lambda: plan.graphs[0].replay()),
+    med(lambda: plan._fan_out(main, lambda i, s: plan.graphs[i].replay())), med(lambda: plan.graphs["epilogue"].replay())), flush=True)

@@ -56,7 +56,8 @@ def _digest(paths: List[str], flags: List[str]) -> str:
 def _compile_one(src: str, verbose: bool) -> str:
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-    flags = COMMON_FLAGS + EXTRA_FLAGS.get(src, [])
+    # SOAR_HIPCC_FLAGS: extra flags for development experiments (e.g. -DSOAR_FWD_WPE=8); part of the object's digest
+    flags = COMMON_FLAGS + EXTRA_FLAGS.get(src, []) + os.environ.get("SOAR_HIPCC_FLAGS", "").split()
     stamp = obj + ".sha"
     dig = _digest([path] + HEADERS, flags)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
