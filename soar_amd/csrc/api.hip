@@ -115,6 +115,8 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->bucket_cnt, 8192);
     take(p, out->bucket_base, 8192 + 1);
     take(p, out->blk_stats, ((n + 255) / 256) * BLK_STATS);
+    take(p, out->band_cnt, 64 * ((n + 1023) / 1024));
+    take(p, out->band_info, 128);
     out->scan_temp_bytes = scan_temp_bytes(P);
     char *tmp;
     take(p, tmp, out->scan_temp_bytes);

@@ -102,67 +102,9 @@ tile_ranges_kernel(int64_t L, const uint64_t *__restrict__ keys, uint2 *__restri
     if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
-// Longest-list-first order of the tiles (16 length classes, counting sort in one workgroup).  The blend kernels map
-// workgroup i to the i-th tile of this order, so the hardware dispatcher starts the few long tiles first and back-fills
-// with the thousands of short / empty ones instead of discovering a 4000-entry tile in the middle of the launch.
-// (LDS atomics aggregated per wavefront for the class of its first lane: 85 % of the tiles are empty and would
-// otherwise queue on one counter)
-__device__ __forceinline__ uint32_t class_slot(uint32_t *counter, int cls, bool ok)
-{
-    const unsigned long long act = __ballot(ok);
-    if (act == 0ull) return 0u;
-    const int c0 = __builtin_amdgcn_readlane(cls, (int)__builtin_ctzll(act));
-    const unsigned long long same = __ballot(ok && cls == c0);
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-    uint32_t base = 0u;
-    if (ok && cls == c0 && rank == 0) base = atomicAdd(&counter[c0], (uint32_t)__builtin_popcountll(same));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
-    if (ok && cls != c0) return atomicAdd(&counter[cls], 1u);
-    return base + (uint32_t)rank;
-}
-
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, int Tpad, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order)
 {
-    __shared__ uint32_t count[16], cursor[16];
-    const int tid = threadIdx.x;
-    if (tid < 16) count[tid] = 0u;
-    __syncthreads();
-    // eight ranges per thread in flight per trip (one load per trip would make both passes a chain of load latencies)
-    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
-        uint32_t len[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
-            len[k] = t < T ? ranges[t].y - ranges[t].x : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int cls = 15 - min(15, 32 - __clz((int)len[k]));   // class 0: >= 16384 entries ... class 15: empty
-            (void)class_slot(count, cls, t0 + k * 1024 + tid < T);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int k = 0; k < 16; k++) { cursor[k] = acc; acc += count[k]; }
-    }
-    __syncthreads();
-    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
-        uint32_t len[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
-            len[k] = t < T ? ranges[t].y - ranges[t].x : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
-            const int cls = 15 - min(15, 32 - __clz((int)len[k]));
-            const uint32_t at = class_slot(cursor, cls, t < T);
-            if (t < T) order[at] = (uint32_t)t;
-        }
-    }
-    for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
+    tile_order_block(T, Tpad, nullptr, ranges, order);
 }
 
 }  // namespace

@@ -208,22 +208,26 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     const float dN0x10 = c.dN0 * 10.f, dN1x10 = c.dN1 * 10.f, dN2x10 = c.dN2 * 10.f;          // per-pixel constants of the pair terms
     const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
+    // software pipeline over chunks (back to front): records of the chunk in front requested while this one is processed, the
+    // list ids one chunk further ahead still (the record gather never waits for its own id load)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    uint32_t rid = 0;
+    uint32_t rid = 0, rid_next = 0;
     const int cfirst = (int)((deepest - 1u) / BCHUNK) * BCHUNK;
     if (cfirst + tid < (int)deepest) {
         rid = a.point_list[range.x + cfirst + tid];
         const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
         r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
     }
+    if (cfirst >= BCHUNK) rid_next = a.point_list[range.x + cfirst - BCHUNK + tid];
     for (int cbase = cfirst; cbase >= 0; cbase -= BCHUNK) {
         const int n = min(BCHUNK, (int)deepest - cbase);
         if (tid < n) { sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3; sid[tid] = rid; }
         if (cbase >= BCHUNK) {
-            rid = a.point_list[range.x + cbase - BCHUNK + tid];
+            rid = rid_next;
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         }
+        if (cbase >= 2 * BCHUNK) rid_next = a.point_list[range.x + cbase - 2 * BCHUNK + tid];
         lds_barrier();          // LDS only: next chunk's gathers and this chunk's atomics stay in flight
 
         if (cbase < (int)deepest_wave) {

@@ -138,15 +138,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
         if (OCC) sq4[CHUNK] = make_float2(0.f, 0.f);
     }
 
-    // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended
+    // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended, and the list ids of
+    // chunk k+2 before that (the record gather of a chunk then never waits for its own id load: one global round trip per
+    // chunk off the critical path of the long tiles)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     float2 r4 = make_float2(0.f, 0.f);
+    uint32_t id_next = 0;                            // list id of this thread's entry in the chunk after the prefetched one
     if (range.x + tid < range.y) {
         const uint32_t id = a.point_list[range.x + tid];
         const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
         r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
         if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
     }
+    if (range.x + CHUNK + tid < range.y) id_next = a.point_list[range.x + CHUNK + tid];
     int parity = 0;
     for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
         const int n = min((uint32_t)CHUNK, range.y - base);
@@ -155,11 +159,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             if (OCC) sq4[tid] = r4;
         }
         if (base + CHUNK + tid < range.y) {
-            const uint32_t id = a.point_list[base + CHUNK + tid];
+            const uint32_t id = id_next;
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
             if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
         }
+        if (base + 2 * CHUNK + tid < range.y) id_next = a.point_list[base + 2 * CHUNK + tid];
         lds_barrier();           // LDS only: the gathers of the next chunk stay in flight while this one is blended
 
         if (!wave_done) {

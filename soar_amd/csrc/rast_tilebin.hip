@@ -7,16 +7,22 @@
 // (7.6e5 at 100k Gaussians / 1080p); the library sort that does this here is ~20 launch-bound kernels, 180 us.
 //
 // Same result from the structure of the problem instead:
-//   1. depth_sort_pass_kernel x4: stable LSD radix sort of the P (not R) depth keys.  One launch per 8-bit digit and
-//      no inter-workgroup protocol: every workgroup re-histograms ALL keys (P is small: 400 KB from L2) to know how
-//      many keys of each digit precede its own 4096-key block.  The first pass also splats each rectangle's four
-//      corner increments into a 2-D difference grid; the last pass also writes the rectangles in sorted order.
-//   2. tile_prefix_kernel: 2-D prefix sum of the difference grid = instances per tile, exclusive scan = `ranges`.
-//   3. bin_tiles_kernel: one workgroup per 4x4 tiles walks the depth-ordered rectangles, keeps (in order) those that
-//      touch its 4x4 tiles, and appends them to each covered tile's list with ballot-prefix compaction: every list
-//      comes out in depth order with no per-tile sort and no atomics.
-// The descending sort (back views) keeps the library path.
+//   1. bucket_count / bucket_scatter / bucket_sort: depth order of the P (not R) Gaussians -- monotone buckets of the key
+//      range (reduced by preprocess), one small sort per bucket; emits the ids and tile rectangles in depth order.
+//   2. band_count / band_place: the depth-ordered rectangles are split -- stably, by ballot-prefix compaction, no atomics --
+//      into one list per BAND of tile rows (a band = the rows of one super-tile row, or a few of them on very tall images).
+//      A super-tile only has to look at its own band's list (~1/10 of the Gaussians at 1080p) instead of all of them.
+//   3. bin_count: one workgroup per super-tile (4x4 tiles) walks its band list and counts the instances of its 16 tiles on a
+//      5x5 difference grid in LDS; tile_scan: exclusive scan of the tile counts = `ranges` (+ capacity check).
+//   4. bin_tiles: same walk; the rectangles that touch the super-tile are kept (in order) with the mask of the tiles they
+//      cover and appended to each covered tile's list with ballot-prefix compaction: every list comes out in depth order
+//      with no per-tile sort and no atomics.  One extra workgroup of the same launch builds the longest-list-first tile
+//      order of the blend kernels (it only needs the tile counts).
+// The descending sort (back views) keeps the library path (rast_binning.hip).
 #include "soar_common.h"
+
+#include <cstdio>
+#include <cstdlib>
 
 namespace soar {
 
@@ -219,12 +225,137 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(BucketSortArgs a)
     }
 }
 
+// ---- band lists -----------------------------------------------------------------------------------------------------------
+// band b = tile rows [b * band_rows, (b + 1) * band_rows).  band_count: per (band, 1024-chunk of the depth order) the number of
+// rectangles that reach into the band; band_place: exclusive scan of that matrix in (band, chunk) order = where every chunk's
+// entries of every band go, then the same ballots again to place them.  Both keep the depth order inside a band.
+constexpr int BAND_MAX = 64;            // bands (upper bound: one lane per band in the per-wavefront counts)
+constexpr int BAND_THREADS = 1024;
+constexpr int BAND_WAVES = BAND_THREADS / WAVE;
+
+struct BandArgs {
+    int nb, band_rows, nchunk;
+    uint32_t capacity;                  // entries the band arrays hold (= instances the caller's binning buffer was sized for)
+    uint32_t *header;
+    const uint2 *rect_sorted;
+    const uint32_t *ids_sorted;
+    uint32_t *band_cnt;                 // [nb][nchunk]
+    uint32_t *band_info;                // [2 * BAND_MAX]: start, length of every band's list
+    uint2 *band_rect;
+    uint32_t *band_id;
+};
+
+// bands [b0, b1] a rectangle reaches into (b1 < b0: none)
+__device__ __forceinline__ void band_span(uint2 rc, int band_rows, int &b0, int &b1)
+{
+    const int y0 = (int)(rc.y & 0xFFFFu), y1 = (int)(rc.y >> 16);
+    b0 = y0 / band_rows;
+    b1 = y1 > y0 ? (y1 - 1) / band_rows : -1;
+}
+
+// per-wavefront counts of the chunk's rectangles per band -> LDS wcnt[wave][band]
+__device__ __forceinline__ void band_wave_counts(int nb, int b0, int b1, int lane, uint32_t (*wcnt)[BAND_MAX], int wave)
+{
+    uint32_t mine = 0;
+    for (int b = 0; b < nb; b++) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(b0 <= b && b <= b1));
+        mine = lane == b ? c : mine;
+    }
+    if (lane < nb) wcnt[wave][lane] = mine;
+}
+
+__global__ void __launch_bounds__(BAND_THREADS) band_count_kernel(BandArgs a)
+{
+    __shared__ uint32_t wcnt[BAND_WAVES][BAND_MAX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nvis = (int)a.header[H_NVIS];
+    const int k = blockIdx.x * BAND_THREADS + tid;
+    int b0 = 0, b1 = -1;
+    if (k < nvis) band_span(a.rect_sorted[k], a.band_rows, b0, b1);
+    band_wave_counts(a.nb, b0, b1, lane, wcnt, wave);
+    __syncthreads();
+    if (tid < a.nb) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < BAND_WAVES; w++) t += wcnt[w][tid];
+        a.band_cnt[(size_t)tid * a.nchunk + blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(BandArgs a)
+{
+    __shared__ uint32_t wcnt[BAND_WAVES][BAND_MAX];
+    __shared__ uint32_t part[BAND_THREADS];
+    __shared__ uint32_t base[BAND_MAX];         // where this chunk's entries of every band go
+    __shared__ uint32_t total_s;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nvis = (int)a.header[H_NVIS];
+    const int k = blockIdx.x * BAND_THREADS + tid;
+    uint2 rc = make_uint2(0u, 0u);
+    int b0 = 0, b1 = -1;
+    if (k < nvis) { rc = a.rect_sorted[k]; band_span(rc, a.band_rows, b0, b1); }
+    band_wave_counts(a.nb, b0, b1, lane, wcnt, wave);
+
+    // exclusive scan of band_cnt in (band, chunk) order (every workgroup redoes it: nb * nchunk <= a few thousand words from L2)
+    const int n = a.nb * a.nchunk, per = (n + BAND_THREADS - 1) / BAND_THREADS;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; i++) sum += a.band_cnt[i];
+    // block-wide exclusive scan of the per-thread sums: wavefront scan by shuffles, then the 16 wavefront totals
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == WAVE - 1) part[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < BAND_WAVES; w++) wbase += w < wave ? part[w] : 0u;
+    if (tid == BAND_THREADS - 1) total_s = wbase + incl;
+    uint32_t run = wbase + incl - sum;
+    for (int i = i0; i < i1; i++) {
+        const int b = i / a.nchunk, c = i - b * a.nchunk;
+        if (c == (int)blockIdx.x) base[b] = run;
+        if (blockIdx.x == 0 && c == 0) a.band_info[b] = run;                    // start of band b
+        run += a.band_cnt[i];
+        if (blockIdx.x == 0 && c == a.nchunk - 1) a.band_info[BAND_MAX + b] = run;   // end of band b (turned into a length below)
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    const bool fits = total <= a.capacity;
+    if (blockIdx.x == 0) {
+        // a band list that does not fit the caller's buffer: every band is left empty, the overflow is reported like a
+        // tile-list overflow (tile_scan_kernel keeps the flag)
+        if (tid < a.nb) {
+            const uint32_t st = a.band_info[tid], en = a.band_info[BAND_MAX + tid];
+            a.band_info[BAND_MAX + tid] = fits ? en - st : 0u;
+        }
+        if (tid == 0) a.header[H_BAND_OVERFLOW] = fits ? 0u : total;
+    }
+    if (!fits) return;
+    // place: wavefront w's entries of band b follow those of the wavefronts before it
+    for (int b = 0; b < a.nb; b++) {
+        const bool in = b0 <= b && b <= b1;
+        const unsigned long long m = __ballot(in);
+        if (m == 0ull) continue;
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wcnt[w][b];
+        if (in) {
+            const uint32_t pos = base[b] + woff + (uint32_t)prefix_in_mask(m);
+            a.band_rect[pos] = rc;
+            a.band_id[pos] = a.ids_sorted[k];
+        }
+    }
+}
+
 constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile: one tile per wavefront
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_WAVES = BIN_THREADS / WAVE;
 constexpr int BIN_UNROLL = 8;           // rectangles per thread and trip (independent loads in flight)
 constexpr int BIN_CHUNK = BIN_THREADS * BIN_UNROLL;
-constexpr int BIN_CAP = 3072;           // survivors buffered between two flushes
+constexpr int BIN_CAP = BIN_CHUNK;      // survivors buffered between two flushes: a whole trip's hits always fit (64 KB of LDS)
 
 struct SuperTile {
     int tx0, ty0, tx1, ty1;
@@ -248,15 +379,24 @@ __device__ __forceinline__ bool rect_hits(uint2 rc, const SuperTile &s)
 // Pass A: instances per tile.  One workgroup per 4x4 tiles walks the depth-ordered rectangles and adds every rectangle
 // that touches its tiles to a 5x5 difference grid in LDS (4 LDS atomics per hit); the grid's 2-D prefix sum is the
 // number of instances of each of its 16 tiles.  Workgroups outside the bounding box of all rectangles leave at once.
+// band of a super-tile: its row of super-tiles, or several rows per band on very tall images
+__device__ __forceinline__ int band_of_block(int block, int gx, int band_rows)
+{
+    const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER;
+    return ((block / nsx) * BIN_SUPER) / band_rows;
+}
+
 __global__ void __launch_bounds__(BIN_THREADS)
-bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint2 *__restrict__ rect_sorted,
-                 uint32_t *__restrict__ tile_count)
+bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+                 const uint2 *__restrict__ band_rect, uint32_t *__restrict__ tile_count)
 {
     __shared__ int diff[BIN_SUPER + 1][BIN_SUPER + 1];
     const int tid = threadIdx.x;
     const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
     const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
-    const int P = (int)header[H_NVIS];
+    const int band = band_of_block(blockIdx.x, gx, band_rows);
+    const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles, depth order
+    const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
     const bool inside = P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0;
     if (tid < (BIN_SUPER + 1) * (BIN_SUPER + 1)) (&diff[0][0])[tid] = 0;
     lds_barrier();
@@ -306,24 +446,27 @@ bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
                                                          uint32_t capacity, uint32_t *__restrict__ header)
 {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t part[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int per = (T + 1023) / 1024;
     const int t0 = tid * per, t1 = min(T, t0 + per);
     uint32_t s = 0;
     for (int t = t0; t < t1; t++) s += tile_count[t];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t up = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += up;
-        __syncthreads();
+    uint32_t incl = s;                         // wavefront scan by shuffles, then the 16 wavefront totals
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
     }
-    const uint32_t total = part[1023];
-    const bool fits = total <= capacity;
-    if (tid == 0) { header[H_TOTAL] = total; header[H_OVERFLOW] = fits ? 0u : total; }
-    uint32_t run = part[tid] - s;
+    if (lane == WAVE - 1) part[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { wbase += w < wave ? part[w] : 0u; total += part[w]; }
+    const uint32_t band_over = header[H_BAND_OVERFLOW];
+    const bool fits = total <= capacity && band_over == 0u;
+    if (tid == 0) { header[H_TOTAL] = total; header[H_OVERFLOW] = fits ? 0u : max(total, band_over); }
+    uint32_t run = wbase + incl - s;
     for (int t = t0; t < t1; t++) {
         const uint32_t c = tile_count[t];
         ranges[t] = (c && fits) ? make_uint2(run, run + c) : make_uint2(0u, 0u);
@@ -346,18 +489,29 @@ __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
 // a ballot gives the number of entries, a scan over the slabs gives every slab its place in each tile's list, and
 // the ids are appended with ballot-prefix compaction: every list comes out in depth order, without atomics or sorts.
 __global__ void __launch_bounds__(BIN_THREADS)
-bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint2 *__restrict__ rect_sorted,
-                 const uint32_t *__restrict__ ids_sorted, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list)
+bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+                 const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
+                 uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
+                 uint32_t *__restrict__ tile_order, unsigned long long *__restrict__ dbg)
 {
+    const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
+    unsigned long long dbg_flush = 0;
+    int dbg_nflush = 0, dbg_hits = 0;
+    if ((int)blockIdx.x == nblocks_tiles) {
+        // the extra workgroup: longest-list-first order of the tiles for the blend launches (needs the counts only)
+        const int T = gx * gy;
+        tile_order_block(T, (T + 7) / 8 * 8, tile_count, ranges, tile_order);
+        return;
+    }
     constexpr int NT = BIN_SUPER * BIN_SUPER;
-    constexpr int MAX_SLABS = BIN_CAP / WAVE;
-    static_assert(MAX_SLABS <= WAVE, "one lane per slab in the scan");
     __shared__ uint32_t surv_mask[BIN_CAP], surv_id[BIN_CAP];
-    __shared__ uint32_t slab_at[MAX_SLABS][NT];
     __shared__ uint32_t tile_cursor[NT];
     __shared__ uint32_t wave_cnt[2][BIN_WAVES];
     __shared__ int any_s;
-    const int P = (int)header[H_NVIS];            // visible Gaussians = length of the depth-ordered list
+    const int band = band_of_block(blockIdx.x, gx, band_rows);
+    const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles / ids, depth order
+    const uint32_t *__restrict__ ids_sorted = band_id + band_info[band];
+    const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
 
@@ -373,48 +527,37 @@ bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint
     lds_barrier();
     if (!any_s) return;                           // no Gaussian touches these 16 tiles
 
+    // Flush: wavefront t owns tile t of the super-tile (16 wavefronts, 16 tiles) and walks the buffered survivors slab by
+    // slab; the entries that cover its tile are appended to the tile's list by ballot-prefix compaction at the wavefront's own
+    // running cursor -- one pass, no counting phase, no barrier between slabs; lists stay in depth order.
+    static_assert(BIN_WAVES == NT, "one wavefront per tile of the super-tile");
     int nbuf = 0;
+    uint32_t cursor = tile_cursor[wave];          // next free position of this wavefront's tile list
     auto flush = [&]() {
-        lds_barrier();
+        const unsigned long long f0 = dbg ? wall_clock64() : 0ull;
+        dbg_nflush++; dbg_hits += nbuf;
+        lds_barrier();                                // the survivors of the last trip are in LDS
         const int nslab = (nbuf + WAVE - 1) / WAVE;
-        // entries per (slab, tile)
-        for (int sl = wave; sl < nslab; sl += BIN_WAVES) {
-            const uint32_t m = sl * WAVE + lane < nbuf ? surv_mask[sl * WAVE + lane] : 0u;
-            uint32_t mine = 0;
+        constexpr int FU = 8;                          // slabs per round: their LDS reads are in flight together
+        for (int sl = 0; sl < nslab; sl += FU) {
+            uint32_t m[FU], id[FU];
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const uint32_t c = (uint32_t)__builtin_popcountll(__ballot((m >> t) & 1u));
-                mine = lane == t ? c : mine;
+            for (int u = 0; u < FU; u++) {
+                const int e = (sl + u) * WAVE + lane;
+                m[u] = e < nbuf ? surv_mask[e] : 0u;
+                id[u] = surv_id[min(e, BIN_CAP - 1)];
             }
-            if (lane < NT) slab_at[sl][lane] = mine;
-        }
-        lds_barrier();
-        // wavefront t: exclusive scan over the slabs of tile t, starting at the tile's cursor
-        if (wave < NT) {
-            const uint32_t c = lane < nslab ? slab_at[lane][wave] : 0u;
-            uint32_t incl = c;
 #pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-                if (lane >= d) incl += up;
-            }
-            const uint32_t cur = tile_cursor[wave];
-            if (lane < nslab) slab_at[lane][wave] = cur + incl - c;
-            if (lane == WAVE - 1) tile_cursor[wave] = cur + incl;
-        }
-        lds_barrier();
-        for (int sl = wave; sl < nslab; sl += BIN_WAVES) {
-            const bool ok = sl * WAVE + lane < nbuf;
-            const uint32_t m = ok ? surv_mask[sl * WAVE + lane] : 0u;
-            const uint32_t id = ok ? surv_id[sl * WAVE + lane] : 0u;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const unsigned long long bal = __ballot((m >> t) & 1u);
-                if ((m >> t) & 1u) point_list[slab_at[sl][t] + (uint32_t)prefix_in_mask(bal)] = id;
+            for (int u = 0; u < FU; u++) {
+                const bool h = (m[u] >> wave) & 1u;
+                const unsigned long long bal = __ballot(h);
+                if (h) point_list[cursor + (uint32_t)prefix_in_mask(bal)] = id[u];
+                cursor += (uint32_t)__builtin_popcountll(bal);
             }
         }
-        lds_barrier();
+        lds_barrier();                                // the buffer may be overwritten
         nbuf = 0;
+        if (dbg) dbg_flush += wall_clock64() - f0;
     };
 
     // wavefront w scans the contiguous slice [base + w*512, base + (w+1)*512) of every trip: survivors stay in depth
@@ -471,26 +614,18 @@ bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, const uint
             total += c;
         }
         if (total != 0u) {
-            if (nbuf + (int)total > BIN_CAP) flush();
-            if ((int)total <= BIN_CAP) {
-                append((uint32_t)nbuf + off, hits);
-                nbuf += (int)total;
-            } else {
-                // more hits in one trip than the buffer holds (thousands of huge splats in a row): one wavefront's slice
-                // (<= 512 hits) at a time
-                for (int w = 0; w < BIN_WAVES; w++) {
-                    const int cw = (int)wave_cnt[parity][w];
-                    if (cw == 0) continue;
-                    if (nbuf + cw > BIN_CAP) flush();
-                    if (wave == w) append((uint32_t)nbuf, hits);
-                    nbuf += cw;
-                }
-            }
+            if (nbuf + (int)total > BIN_CAP) flush();          // total <= BIN_CHUNK = BIN_CAP: after a flush a trip always fits
+            append((uint32_t)nbuf + off, hits);
+            nbuf += (int)total;
         }
 #pragma unroll
         for (int j = 0; j < BIN_UNROLL; j++) { rc[j] = nrc[j]; id[j] = nid[j]; }
     }
     flush();
+    if (dbg && tid == 0) {
+        unsigned long long *w = dbg + (size_t)blockIdx.x * 4;
+        w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits; w[3] = (unsigned long long)P;
+    }
 }
 
 }  // namespace
@@ -529,21 +664,57 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         hipLaunchKernelGGL(bucket_sort_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
     }
     SOAR_LAUNCH_OK("bucket_sort", stream, prm.debug);
+    // band lists: the band arrays live in the key / value scratch of the binning buffer (only the descending path and the key
+    // export use it for keys): at most one entry per (band, Gaussian) <= one per (tile, Gaussian) instance <= capacity
+    const int band_rows = BIN_SUPER * ((nsy + BAND_MAX - 1) / BAND_MAX);
+    BandArgs ba;
+    ba.band_rows = band_rows;
+    ba.nb = (gy + band_rows - 1) / band_rows;
+    ba.nchunk = (prm.P + BAND_THREADS - 1) / BAND_THREADS;
+    ba.capacity = (uint32_t)(capacity > 0xFFFFFFFFll ? 0xFFFFFFFFll : capacity);
+    ba.header = g.header; ba.rect_sorted = g.rect_sorted; ba.ids_sorted = g.ids_sorted; ba.band_cnt = g.band_cnt;
+    ba.band_info = g.band_info;
+    ba.band_rect = reinterpret_cast<uint2 *>(b.keys_unsorted); ba.band_id = b.vals_unsorted;
     {
         StageTimer timer(ST_RANGES, stream);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, g.rect_sorted,
-                           img.tile_count);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges,
-                           (uint32_t)(capacity > 0xFFFFFFFFll ? 0xFFFFFFFFll : capacity), g.header);
+        hipLaunchKernelGGL(band_count_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
+        hipLaunchKernelGGL(band_place_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
+                           ba.band_rect, img.tile_count);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges, ba.capacity, g.header);
     }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
     {
         StageTimer timer(ST_EMIT_KEYS, stream);
-        hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, g.rect_sorted,
-                           g.ids_sorted, img.ranges, b.vals_sorted);
+        unsigned long long *dbg = nullptr;
+        static int dbg_left = getenv("SOAR_BIN_LOG") ? 1 : 0;          // diagnostic: per-workgroup timings of ONE launch
+        if (dbg_left > 0 && prm.W >= 1920) {
+            dbg_left = 0;
+            const size_t nw = (size_t)(nsx * nsy + 1) * 4;
+            SOAR_HIP_OK(hipMalloc(&dbg, 8 * nw));
+            SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * nw, stream));
+            hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
+                               ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, dbg);
+            SOAR_HIP_OK(hipStreamSynchronize(stream));
+            unsigned long long *h = (unsigned long long *)malloc(8 * nw);
+            SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
+            (void)hipFree(dbg);
+            // the five slowest workgroups
+            for (int rep = 0; rep < 5; rep++) {
+                int best = -1;
+                for (int i = 0; i < nsx * nsy; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
+                fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, %.1f us in %llu flushes, %llu survivors of %llu band entries\n", best,
+                        h[best * 4] / 100.0, h[best * 4 + 1] / 100.0, h[best * 4 + 2] >> 32, h[best * 4 + 2] & 0xFFFFFFFFull, h[best * 4 + 3]);
+                h[best * 4] = 0;
+            }
+            free(h);
+            return 0;
+        }
+        hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
+                           ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, dbg);
     }
     SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);
-    return launch_tile_order(prm, img, stream);
+    return 0;
 }
 
 }  // namespace soar

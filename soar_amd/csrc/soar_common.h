@@ -73,6 +73,8 @@ struct GeomBuf {
     uint32_t *bucket_cnt;    // [8192] depth buckets
     uint32_t *bucket_base;   // [8192 + 1]
     uint32_t *blk_stats;     // [ceil(P/256)][BLK_STATS] per-block maxima written by preprocess
+    uint32_t *band_cnt;      // [64][ceil(P/1024)] entries per (band of tile rows, chunk of the depth order) (rast_tilebin.hip)
+    uint32_t *band_info;     // [128] start / length of every band's list
     void *scan_temp;
     size_t scan_temp_bytes;
     size_t total_bytes;
@@ -87,6 +89,7 @@ constexpr int H_NOT_X0 = 6;
 constexpr int H_NOT_Y0 = 7;
 constexpr int H_TOTAL = 8;      // instances (sum of the tile counts) found by the tile binning
 constexpr int H_OVERFLOW = 9;   // 0, or H_TOTAL when it exceeded the capacity of the caller's binning buffer
+constexpr int H_BAND_OVERFLOW = 10;   // 0, or the entries the band lists needed when they exceeded that capacity
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
     uint2 *ranges;           // [T]
@@ -213,6 +216,75 @@ __device__ __forceinline__ float mul_one_minus(float T, float alpha)
 }
 #endif
 
+#if defined(__HIPCC__)
+// Longest-list-first order of the tiles (16 length classes, counting sort in one workgroup).  The blend kernels map
+// workgroup i to the i-th tile of this order, so the hardware dispatcher starts the few long tiles first and back-fills
+// with the thousands of short / empty ones instead of discovering a 4000-entry tile in the middle of the launch.
+// (LDS atomics aggregated per wavefront for the class of its first lane: 85 % of the tiles are empty and would
+// otherwise queue on one counter)
+__device__ __forceinline__ uint32_t class_slot(uint32_t *counter, int cls, bool ok)
+{
+    const unsigned long long act = __ballot(ok);
+    if (act == 0ull) return 0u;
+    const int c0 = __builtin_amdgcn_readlane(cls, (int)__builtin_ctzll(act));
+    const unsigned long long same = __ballot(ok && cls == c0);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+    uint32_t base = 0u;
+    if (ok && cls == c0 && rank == 0) base = atomicAdd(&counter[c0], (uint32_t)__builtin_popcountll(same));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
+    if (ok && cls != c0) return atomicAdd(&counter[cls], 1u);
+    return base + (uint32_t)rank;
+}
+
+// One 1024-thread workgroup: `order` = tile ids, longest list first.  Lengths from the tile counts when given (tile binning:
+// the ranges are written by a kernel this one may run beside), else from the ranges (descending / key-sort path).
+static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const uint32_t *tile_count, const uint2 *ranges, uint32_t *order)
+{
+    __shared__ uint32_t count[16], cursor[16];
+    const int tid = threadIdx.x;
+    auto len_of = [&](int t) -> uint32_t { return tile_count ? tile_count[t] : ranges[t].y - ranges[t].x; };
+    if (tid < 16) count[tid] = 0u;
+    __syncthreads();
+    // eight lengths per thread in flight per trip (one load per trip would make both passes a chain of load latencies)
+    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
+        uint32_t len[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = t0 + k * 1024 + tid;
+            len[k] = t < T ? len_of(t) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int cls = 15 - min(15, 32 - __clz((int)len[k]));   // class 0: >= 16384 entries ... class 15: empty
+            (void)class_slot(count, cls, t0 + k * 1024 + tid < T);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 16; k++) { cursor[k] = acc; acc += count[k]; }
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
+        uint32_t len[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = t0 + k * 1024 + tid;
+            len[k] = t < T ? len_of(t) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = t0 + k * 1024 + tid;
+            const int cls = 15 - min(15, 32 - __clz((int)len[k]));
+            const uint32_t at = class_slot(cursor, cls, t < T);
+            if (t < T) order[at] = (uint32_t)t;
+        }
+    }
+    for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
+}
+
+#endif
+
 uint32_t higher_msb(uint32_t n);   // getHigherMsb, rasterizer_impl.cu:35-48
 size_t scan_temp_bytes(int32_t P);
 size_t sort_temp_bytes(int64_t R);
@@ -223,6 +295,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
                       GeomBuf &g, int32_t *radii, hipStream_t stream);
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
 int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream);
+
 int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
 int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t capacity, hipStream_t stream);
 int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R,
