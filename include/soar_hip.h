@@ -41,7 +41,11 @@ typedef struct SoarRastParams {
     int32_t prefiltered;
     int32_t render_front;
     int32_t sort_descending;
-    int32_t debug;             /* 1: synchronise + check after every stage (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:419-426) */
+    int32_t debug;             /* bit 0: synchronise + check after every stage (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:419-426);
+                                  bit 1 (backward only): order-insensitive accumulation -- the per-Gaussian gradient sums of the backward
+                                  blend go through float64 atomics instead of float32 ones (the reference's atomicAdd order,
+                                  backward.cu:845-855, is undefined; in float64 the order no longer reaches the float32 result).
+                                  Test / debugging mode: ~2x the atomic traffic */
     /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
     int32_t cfg_surface;       /* config[0] */
     int32_t cfg_normalize_depth; /* config[1] */

@@ -30,7 +30,7 @@ int check_hip(hipError_t e, const char *what, const char *file, int line)
 int post_launch(const char *what, hipStream_t stream, int debug)
 {
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && (debug & 1)) e = hipStreamSynchronize(stream);      // bit 0 of SoarRastParams.debug
     if (e == hipSuccess) return 0;
     set_error("stage '%s' failed: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
     return 1;
@@ -232,7 +232,9 @@ int soar_rast_binning_bytes(int64_t num_rendered, size_t *bytes)
 int soar_rast_backward_workspace_bytes(int32_t P, size_t *bytes)
 {
     if (!bytes || P < 0) { set_error("soar_rast_backward_workspace_bytes: bad arguments"); return 1; }
-    *bytes = align_up(sizeof(float) * ACC_STRIDE * (size_t)(P > 0 ? P : 1)) + ALIGN;
+    // float32 accumulation rows [P][16], followed by float64 rows for the order-insensitive mode (SoarRastParams.debug bit 1)
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    *bytes = align_up(sizeof(float) * ACC_STRIDE * n) + align_up(sizeof(double) * ACC_STRIDE * n) + ALIGN;
     return 0;
 }
 
@@ -430,10 +432,14 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
     carve_image(const_cast<void *>(image_buffer), prm->W, prm->H, &img);
     carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
     float *acc = static_cast<float *>(workspace);
-    SOAR_HIP_OK(hipMemsetAsync(acc, 0, sizeof(float) * ACC_STRIDE * (size_t)prm->P, stream));
-    if (num_rendered > 0) {
+    const bool wide = (prm->debug & 2) != 0;               // order-insensitive accumulation: float64 rows behind the float32 ones
+    double *acc64 = wide ? reinterpret_cast<double *>(static_cast<char *>(workspace) + align_up(sizeof(float) * ACC_STRIDE * (size_t)prm->P))
+                         : nullptr;
+    if (wide) SOAR_HIP_OK(hipMemsetAsync(acc64, 0, sizeof(double) * ACC_STRIDE * (size_t)prm->P, stream));
+    else SOAR_HIP_OK(hipMemsetAsync(acc, 0, sizeof(float) * ACC_STRIDE * (size_t)prm->P, stream));
+    if (num_rendered > 0 || wide) {
         if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
-                                   stream))
+                                   acc64, num_rendered > 0, stream))
             return 1;
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,

@@ -34,6 +34,7 @@ struct BwdArgs {
     const float *dL_dcolor, *dL_dnormal, *dL_ddepth, *dL_dopac;
     const float *grad_scale;         // optional device scalar the four image gradients are multiplied by
     float *acc;
+    double *acc64;                   // order-insensitive mode: float64 accumulation rows (same layout)
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
@@ -167,6 +168,7 @@ __global__ void selftest_wave_reduce_kernel(float *out)
     out[64 + lane] = (float)pixel_reduce16_slot(lane);
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
 {
     __shared__ float4 sq0[BCHUNK + 1], sq1[BCHUNK + 1], sq2[BCHUNK + 1], sq3[BCHUNK + 1];   // +1: all-zero record
@@ -314,7 +316,10 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     const float total = pixel_reduce16(v, lane);
                     // entries of this step with at least one live pixel: bits slot, slot+4, ... of the ballot
                     const bool entry_live = ((live_mask >> slot) & 0x1111111111111111ull) != 0ull;
-                    if (entry_live && qslot < 13) atomicAdd(a.acc + (size_t)gid * ACC_STRIDE + qslot, total);
+                    if (entry_live && qslot < 13) {
+                        if (WIDE) atomicAdd(a.acc64 + (size_t)gid * ACC_STRIDE + qslot, (double)total);
+                        else atomicAdd(a.acc + (size_t)gid * ACC_STRIDE + qslot, total);
+                    }
                 }
             }
         }
@@ -324,9 +329,18 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
 
 }  // namespace
 
+namespace {
+// order-insensitive mode: the float64 sums rounded once into the float32 rows the geometry backward reads
+__global__ void narrow_rows_kernel(size_t n, const double *__restrict__ wide, float *__restrict__ narrow)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) narrow[i] = (float)wide[i];
+}
+}  // namespace
+
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
-                           const float *grad_scale, float *acc, hipStream_t stream)
+                           const float *grad_scale, float *acc, double *acc64, bool blend, hipStream_t stream)
 {
     BwdArgs a;
     a.grad_scale = grad_scale;
@@ -337,10 +351,17 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
-    a.acc = acc;
+    a.acc = acc; a.acc64 = acc64;
     StageTimer timer(ST_RENDER_BWD, stream);
-    hipLaunchKernelGGL(render_backward_slots_kernel, dim3(4 * ((a.ntiles + 7) / 8 * 8)), dim3(256), 0, stream, a);
-    SOAR_LAUNCH_OK("render_backward", stream, prm.debug);
+    const dim3 grid(4 * ((a.ntiles + 7) / 8 * 8));
+    if (acc64) {
+        if (blend) hipLaunchKernelGGL(render_backward_slots_kernel<true>, grid, dim3(256), 0, stream, a);
+        const size_t n = (size_t)prm.P * ACC_STRIDE;
+        hipLaunchKernelGGL(narrow_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, acc64, acc);
+    } else {
+        hipLaunchKernelGGL(render_backward_slots_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
+    SOAR_LAUNCH_OK("render_backward", stream, prm.debug & 1);
     return 0;
 }
 

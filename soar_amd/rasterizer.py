@@ -31,6 +31,11 @@ from .hip_lib import SoarRastParams, check, ptr
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_views", "cpu_deep_copy_tuple",
            "_C"]
 
+# Order-insensitive accumulation in the backward blend (SoarRastParams.debug bit 1): the per-Gaussian gradient sums go through
+# float64 atomics, so the hardware's atomic order no longer reaches the float32 result.  A test / debugging switch (SURVEY.md
+# section 5.2, "deterministic-reduction test mode"); the default is the float32 path, like the reference's atomicAdd.
+DETERMINISTIC_BACKWARD = os.environ.get("SOAR_DETERMINISTIC_BACKWARD", "0") == "1"
+
 # running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
 stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
 last_num_rendered = 0        # num_rendered of the most recent forward call
@@ -181,7 +186,7 @@ class _Ctx:
         p.P, p.W, p.H = int(P), int(W), int(H)
         p.sh_degree, p.M = int(sh_degree), int(M)
         p.prefiltered, p.render_front, p.sort_descending, p.debug = int(bool(prefiltered)), int(bool(render_front)), \
-            int(bool(sort_descending)), int(bool(debug))
+            int(bool(sort_descending)), int(bool(debug)) | (2 if DETERMINISTIC_BACKWARD else 0)
         p.cfg_surface, p.cfg_normalize_depth, p.cfg_perpix_depth, p.cfg_lrn_cam = surface, norm_depth, pix_depth, lrn_cam
         p.tanfovx, p.tanfovy, p.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
         (p.bg_dev, p.viewmatrix_dev, p.projmatrix_dev, p.prcppoint_dev, p.patchbbox_dev, p.campos_dev) = \

@@ -147,7 +147,9 @@ def l2_err(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)) if b.size else 0.0
 
 
-def check_backward(scene, hip, bw, rel=REL):
+def check_backward(scene, hip, bw, rel=REL, strict=False):
+    """strict: every tensor element-wise (max-norm) and norm-wise within `rel`, no allowance for cancellation-prone tensors or
+    giant splats -- the bar of the order-insensitive accumulation mode (rasterizer.DETERMINISTIC_BACKWARD)."""
     pairs = [("dL_dmeans2D", bw.dL_dmeans2D), ("dL_dcolors", bw.dL_dcolors), ("dL_dopacity", bw.dL_dopacity),
              ("dL_dmeans3D", bw.dL_dmeans3D), ("dL_dcov3D", bw.dL_dcov3D), ("dL_dscales", bw.dL_dscales),
              ("dL_drotations", bw.dL_drotations), ("dL_dviewmat", bw.dL_dviewmat), ("dL_dprojmat", bw.dL_dprojmat),
@@ -161,7 +163,10 @@ def check_backward(scene, hip, bw, rel=REL):
         assert np.isfinite(got).all(), f"{name} has non-finite values"
         e_max, e_l2 = rel_err(got, ref), l2_err(got, ref)
         worst[name] = (e_max, e_l2)
-        if name in CONDITIONED and ref.shape[0] == hip["radii"].shape[0]:
+        if strict:
+            if e_max > rel or e_l2 > rel:
+                bad[name] = (e_max, e_l2)
+        elif name in CONDITIONED and ref.shape[0] == hip["radii"].shape[0]:
             regular = hip["radii"] <= GIANT_RADIUS
             e_reg = l2_err(got[regular], ref[regular])
             if e_reg > rel or e_l2 > CONDITIONED[name] or e_max > CONDITIONED[name]:
@@ -345,6 +350,54 @@ def test_argument_validation():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         rast(torch.as_tensor(scene.means3D), torch.zeros(32, 3), torch.ones(32, 1), colors_precomp=torch.zeros(32, 3),
              scales=torch.ones(32, 3), rotations=torch.ones(32, 4))
+
+
+def _fuzz_scene(index, seed=11):
+    """Scene number `index` of the randomised sweep tests/tools/fuzz_vs_reference.py <N> <seed> (replays its generator)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fuzz_vs_reference as fz
+    rng = np.random.default_rng(seed)
+    scene = None
+    for _ in range(index + 1):
+        scene = fz.random_scene(rng)
+    return scene
+
+
+ORDER_INSENSITIVE_SCENES = [
+    ("big_splats", lambda: S.big_splats_scene()),
+    ("blob_s1", lambda: S.blob_scene(P=800, W=97, H=61, seed=1, config=(0, 0, 0, 0))),
+    ("blob_sh3", lambda: S.blob_scene(P=600, W=80, H=64, seed=13, config=(1, 1, 1, 0), use_sh=True, sh_degree=3)),
+    ("person_close", lambda: S.person_scene(config=(1, 1, 1, 0), seed=8, opacity=None, distance=1.2)),
+    # the two scenes of the 1000-scene sweep (profiles/r01e_fuzz_vs_reference_kernels.txt, lines [165] and [335]) where the
+    # float32-atomic product was 4-16x further from the double-accumulated oracle than the reference's kernels
+    ("fuzz_165", lambda: _fuzz_scene(165)),
+    ("fuzz_335", lambda: _fuzz_scene(335)),
+]
+
+
+@pytest.mark.parametrize("name,mk", ORDER_INSENSITIVE_SCENES, ids=[n for n, _ in ORDER_INSENSITIVE_SCENES])
+def test_order_insensitive_backward_meets_the_strict_bar(name, mk, monkeypatch):
+    """SoarRastParams.debug bit 1 (rasterizer.DETERMINISTIC_BACKWARD): the backward blend's per-Gaussian sums go through float64
+    atomics, so the hardware's atomic order cannot reach the float32 result.  In that mode every gradient tensor meets 1e-4
+    element-wise against the (double-accumulating) oracle -- including the cancellation-prone tensors of screen-filling splats
+    that the default float32-atomic path is only held to 5e-4 on -- and two runs give the same bits."""
+    from soar_amd import rasterizer
+    scene = mk()
+    grads = S.upstream_grads(scene)
+    fw, bw = S.run_oracle(scene, grads, n_threads=8)
+    monkeypatch.setattr(rasterizer, "DETERMINISTIC_BACKWARD", True)
+    a = run_hip(scene, grads, export=False)
+    b = run_hip(scene, grads, export=False)
+    if not np.isfinite(bw.dL_dmeans3D).all():
+        pytest.skip("the oracle's own gradients are not finite for this scene (surface = 0 with zero-thickness surfels)")
+    check_backward(scene, a, bw, strict=True)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # ... and the default mode on the same scene stays inside the default bars
+    monkeypatch.setattr(rasterizer, "DETERMINISTIC_BACKWARD", False)
+    check_backward(scene, run_hip(scene, grads, export=False), bw)
 
 
 def test_debug_mode_results_and_backward_snapshot(tmp_path, monkeypatch):
