@@ -344,6 +344,29 @@ int soar_prof_reset(void);
 int soar_prof_stage_count(void);
 const char *soar_prof_stage_name(int stage);
 int soar_prof_read(int stage, double *total_ms, int64_t *launches);
+/* ---- step-level helpers of the frame data-parallel step (new capability, no counterpart in the reference: SURVEY.md 8e) ----
+ * soar_sum_frames: out[j] = sum_f in[f * count + j], f < n_frames (the per-frame gradient blocks of one per-Gaussian leaf summed
+ *   into that leaf's slice of the flat gradient buffer that is all-reduced over the ranks).
+ * soar_gather_step_inputs: for the n_frames frames of an optimizer step, copy row (frame_ids[f] mod num_frames_seq) of a
+ *   per-frame table [num_frames_seq, floats_per_frame] (the joint transforms cano2live [55*16]) into mats_out [n_frames, ...]
+ *   and write the frame's target-set index ((id mod n_sets), optional) -- frame_ids is a DEVICE array: a captured HIP graph
+ *   stays valid for any frames, the host refreshes n_frames integers per step. */
+int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_dev, float *out_dev, void *stream);
+/* soar_sum_frames_when_last: the same sums for up to 8 leaves at once, but enqueued at the END OF EVERY FRAME CHAIN of a step
+ *   (each chain on its own stream): one thread draws a ticket from *counter_dev (zeroed by the caller before the chains start);
+ *   only the chain that draws the last of n_frames tickets -- by then every other chain's gradient blocks are complete --
+ *   performs the sums (in frame order: the result does not depend on which chain finishes last); the others return at once.
+ *   src_dev / dst_dev / counts are HOST arrays of n_leaves device pointers / element counts; is_last_dev: one word per chain. */
+int soar_sum_frames_when_last(int32_t n_frames, int32_t n_leaves, const float *const *src_dev, float *const *dst_dev,
+                              const int64_t *counts, uint32_t *counter_dev, uint32_t *is_last_dev, void *stream);
+int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
+                            const int32_t *frame_ids_dev, const float *table_dev, float *mats_out_dev,
+                            int32_t *set_index_out_dev, void *stream);
+
+/* soar_prof_timestamp: one-thread kernel that appends {tag, device wall clock (100 MHz ticks)} to a ring in device memory when
+ * `stream` gets there: ring[0] counts the stamps, stamp n lies at ring[1 + 2 (n mod capacity)].  Timelines of launch chains
+ * without host synchronisation; capturable in a HIP graph (every replay appends). */
+int soar_prof_timestamp(unsigned long long *ring_dev, int64_t capacity, int64_t tag, void *stream);
 
 /* ---- device self-test of the 16-value transpose-reduce of the backward blend (sum over the 16 pixel-lanes of each slot,
  * lane = 4 * pixel + slot).  out128_dev [128] floats: [0..63] the total each lane ends up with, [64..127] the value index

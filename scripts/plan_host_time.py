@@ -59,14 +59,3 @@ for s in range(20):
     hs.append(t1 - t0); ds.append(t2 - t0)
 hs.sort(); ds.sort()
 print(f"idle-device enqueue of one step: host {1e3 * hs[len(hs) // 2]:.3f} ms (median), step done after {1e3 * ds[len(ds) // 2]:.3f} ms", flush=True)
-def med(fn, n=20):
-    v = []
-    for _ in range(n):
-        torch.cuda.synchronize(); t = time.perf_counter(); fn(); v.append(time.perf_counter() - t)
-    v.sort(); return 1e3 * v[len(v) // 2]
-main = torch.cuda.current_stream(dev)
-idx = torch.as_tensor([0, 1, 2, 3], device=dev)
-print("host ms: as_tensor+index_select+copy %.3f | prologue replay %.3f | one frame graph replay %.3f | fan_out(4 replays) %.3f | epilogue replay %.3f" % (
-    med(lambda: (torch.index_select(seq.cano2live, 0, torch.as_tensor([0, 1, 2, 3], device=dev), out=plan.mats), plan.frame_sel.copy_(idx % 8))),
-    med(lambda: plan.graphs["prologue"].replay()), med(lambda: plan.graphs[0].replay()),
-    med(lambda: plan._fan_out(main, lambda i, s: plan.graphs[i].replay())), med(lambda: plan.graphs["epilogue"].replay())), flush=True)

@@ -202,6 +202,23 @@ int soar_prof_read(int stage, double *total_ms, int64_t *launches)
 }
 int soar_abi_version(void) { return SOAR_HIP_ABI_VERSION; }
 
+// device wall clock (100 MHz, common to all CUs) written to *dst when the stream reaches this point: a timeline of chains of
+// launches that needs no host synchronisation and can be captured in a HIP graph
+// ring[0] = number of stamps taken so far; stamp n goes to ring[1 + 2 * (n % capacity)] = {tag, clock}
+__global__ void timestamp_kernel(unsigned long long *ring, unsigned long long capacity, unsigned long long tag)
+{
+    const unsigned long long n = atomicAdd(ring, 1ull);
+    ring[1 + 2 * (n % capacity)] = tag;
+    ring[2 + 2 * (n % capacity)] = wall_clock64();
+}
+int soar_prof_timestamp(unsigned long long *ring_dev, int64_t capacity, int64_t tag, void *stream_)
+{
+    if (!ring_dev || capacity <= 0) { set_error("soar_prof_timestamp: bad arguments"); return 1; }
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), ring_dev,
+                       (unsigned long long)capacity, (unsigned long long)tag);
+    return 0;
+}
+
 int soar_rast_geometry_bytes(int32_t P, int32_t M, size_t *bytes)
 {
     if (!bytes || P < 0) { set_error("soar_rast_geometry_bytes: bad arguments"); return 1; }

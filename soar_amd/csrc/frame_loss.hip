@@ -163,3 +163,127 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
     SOAR_LAUNCH_OK("frame_loss", stream, 0);
     return 0;
 }
+
+
+// ---- step-level helpers of the frame data-parallel step (soar_amd/step_plan.py) -------------------------------------------------
+namespace soar {
+namespace {
+// out[j] = sum over the frames of in[f][j]: the per-frame gradient blocks of one leaf -> its slice of the flat gradient buffer
+// (VEC = 4: 16-byte aligned blocks of a multiple of 4 floats; VEC = 1: anything)
+template <int VEC>
+__global__ void __launch_bounds__(256) sum_frames_kernel(int n_frames, size_t count, const float *__restrict__ in, float *__restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (i >= count) return;
+    if (VEC == 4) {
+        float4 acc = *reinterpret_cast<const float4 *>(in + i);
+        for (int f = 1; f < n_frames; f++) {
+            const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)f * count + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i) = acc;
+    } else {
+        float acc = in[i];
+        for (int f = 1; f < n_frames; f++) acc += in[(size_t)f * count + i];
+        out[i] = acc;
+    }
+}
+// "the frame chain that finishes last sums": every chain ends with ticket_kernel (one thread draws a ticket from a counter the
+// step's prologue zeroed) and sum_frames_if_last_kernel, which returns at once unless its chain drew the last ticket -- then all
+// the other chains' gradient blocks are complete (their kernels ended before their ticket was drawn) and it sums them in frame
+// order.  No join + extra launch on the caller's stream, and the sum keeps a fixed order whichever chain runs it.
+struct SumLeaves {
+    int n_leaves;
+    const float *src[8];
+    float *dst[8];
+    unsigned long long count[8], start[9];          // start: prefix of ceil(count / 4) work items
+};
+__global__ void ticket_kernel(uint32_t *counter, uint32_t n_frames, uint32_t *is_last)
+{
+    const uint32_t t = atomicAdd(counter, 1u);
+    *is_last = (t + 1u == n_frames) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) sum_frames_if_last_kernel(int n_frames, SumLeaves L, const uint32_t *__restrict__ is_last)
+{
+    if (*is_last == 0u) return;
+    const unsigned long long w = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= L.start[L.n_leaves]) return;
+    int leaf = 0;
+    while (leaf + 1 < L.n_leaves && w >= L.start[leaf + 1]) leaf++;
+    const unsigned long long i = (w - L.start[leaf]) * 4, count = L.count[leaf];
+    const float *in = L.src[leaf];
+    float *out = L.dst[leaf];
+    for (unsigned long long j = i; j < min(i + 4, count); j++) {
+        float acc = in[j];
+        for (int f = 1; f < n_frames; f++) acc += in[(size_t)f * count + j];
+        out[j] = acc;
+    }
+}
+// the per-step inputs of a plan: joint transforms of the step's frames gathered from the sequence table, target-set index of
+// every frame.  frame_ids live in device memory (the host only refreshes those few integers per step).
+__global__ void gather_step_inputs_kernel(int n_frames, int num_frames_seq, int floats_per_frame, int n_sets,
+                                          const int32_t *__restrict__ frame_ids, const float *__restrict__ table,
+                                          float *__restrict__ mats_out, int32_t *__restrict__ set_out)
+{
+    const int f = blockIdx.x;
+    int id = frame_ids[f] % num_frames_seq;
+    if (id < 0) id += num_frames_seq;
+    for (int k = threadIdx.x; k < floats_per_frame; k += blockDim.x) mats_out[(size_t)f * floats_per_frame + k] = table[(size_t)id * floats_per_frame + k];
+    if (threadIdx.x == 0 && set_out) set_out[f] = n_sets > 0 ? id % n_sets : 0;
+}
+}  // namespace
+}  // namespace soar
+
+extern "C" int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_dev, float *out_dev, void *stream_)
+{
+    using namespace soar;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_frames <= 0 || count < 0 || !in_dev || !out_dev) { set_error("soar_sum_frames: bad arguments"); return 1; }
+    if (count == 0) return 0;
+    const bool vec = ((((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0) && ((count & 3) == 0);
+    if (vec) hipLaunchKernelGGL(sum_frames_kernel<4>, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, stream, n_frames, (size_t)count, in_dev, out_dev);
+    else hipLaunchKernelGGL(sum_frames_kernel<1>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, n_frames, (size_t)count, in_dev, out_dev);
+    SOAR_LAUNCH_OK("sum_frames", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_sum_frames_when_last(int32_t n_frames, int32_t n_leaves, const float *const *src_dev, float *const *dst_dev,
+                                         const int64_t *counts, uint32_t *counter_dev, uint32_t *is_last_dev, void *stream_)
+{
+    using namespace soar;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_frames <= 0 || n_leaves <= 0 || n_leaves > 8 || !src_dev || !dst_dev || !counts || !counter_dev || !is_last_dev) {
+        set_error("soar_sum_frames_when_last: bad arguments");
+        return 1;
+    }
+    SumLeaves L;
+    L.n_leaves = n_leaves;
+    L.start[0] = 0;
+    for (int k = 0; k < n_leaves; k++) {
+        if (!src_dev[k] || !dst_dev[k] || counts[k] < 0) { set_error("soar_sum_frames_when_last: bad leaf %d", k); return 1; }
+        L.src[k] = src_dev[k]; L.dst[k] = dst_dev[k]; L.count[k] = (unsigned long long)counts[k];
+        L.start[k + 1] = L.start[k] + (L.count[k] + 3) / 4;
+    }
+    hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(1), 0, stream, counter_dev, (uint32_t)n_frames, is_last_dev);
+    const unsigned long long items = L.start[n_leaves];
+    if (items > 0)
+        hipLaunchKernelGGL(sum_frames_if_last_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, n_frames, L, is_last_dev);
+    SOAR_LAUNCH_OK("sum_frames_when_last", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
+                                       const int32_t *frame_ids_dev, const float *table_dev, float *mats_out_dev,
+                                       int32_t *set_index_out_dev, void *stream_)
+{
+    using namespace soar;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_frames <= 0 || num_frames_seq <= 0 || floats_per_frame <= 0 || !frame_ids_dev || !table_dev || !mats_out_dev) {
+        set_error("soar_gather_step_inputs: bad arguments");
+        return 1;
+    }
+    hipLaunchKernelGGL(gather_step_inputs_kernel, dim3(n_frames), dim3(256), 0, stream, n_frames, num_frames_seq, floats_per_frame, n_sets,
+                       frame_ids_dev, table_dev, mats_out_dev, set_index_out_dev);
+    SOAR_LAUNCH_OK("gather_step_inputs", stream, 0);
+    return 0;
+}

@@ -95,6 +95,10 @@ SIGNATURES = {
     "soar_prof_stage_count": (C.c_int, []),
     "soar_prof_stage_name": (C.c_char_p, [C.c_int]),
     "soar_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
+    "soar_sum_frames_when_last": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -58,7 +58,12 @@ class FrameStepPlan:
             self.targets = None
         else:
             self.targets = [targets[k].to(**f).contiguous() for k in ("color", "mask", "normal")]
-        self.frame_sel = torch.zeros((self.n,), dtype=torch.int32, device=dev)   # static input: target set of each slot's frame
+        self.frame_sel = torch.zeros((self.n,), dtype=torch.int32, device=dev)   # target set of each slot's frame (device side)
+        # static input: the step's frame ids.  The host stages them in pinned memory, one small asynchronous copy per step;
+        # mats / frame_sel follow on the device (soar_gather_step_inputs, first launch of the prologue)
+        self.frame_ids = torch.zeros((self.n,), dtype=torch.int32, device=dev)
+        self.done = torch.zeros((1 + self.n,), dtype=torch.int32, device=dev)    # ticket counter of the step + "drew the last ticket" per chain
+        self._ids_pinned = torch.zeros((64, self.n), dtype=torch.int32).pin_memory()
         self.mats = torch.empty((self.n, 55, 4, 4), **f)                 # static input: joint transforms of the step's frames
         self.blend_weights = torch.empty((P, seq.lbs_weights.shape[1]), **f)
         self.ones = torch.ones((P, 1), **f)
@@ -94,10 +99,19 @@ class FrameStepPlan:
         self.knn_order = torch.empty((P,), dtype=torch.int32, device=dev)     # query order of the KNN, refreshed every few steps
         self.knn_ws = seq.knn_grid.query_workspace(P)        # query scratch owned by THIS plan (its graphs hold the pointer)
         self.steps = 0
+        # SOAR_PLAN_TIMESTAMPS=1 (diagnostic): {tag, device wall clock} stamps at the start / end of the prologue (tags 0, 1), of
+        # frame chain i (2 + 2 i, 3 + 2 i) and of the epilogue (2 n + 2, 2 n + 3), appended to a ring on every replay
+        # (soar_prof_timestamp; scripts/plan_phases.py reads it)
+        self.STAMP_CAP = 8192
+        self.stamps = torch.zeros((1 + 2 * self.STAMP_CAP,), dtype=torch.int64, device=dev) if os.environ.get("SOAR_PLAN_TIMESTAMPS") == "1" else None
         self.stale = None
         self._baked = self._leaf_signature()
-        # frame 0 stays on the caller's stream, the others get their own (4 hardware queues in all for 4 frames)
-        self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)]
+        # every frame chain on a stream of its own; the caller's stream only carries the prologue, the joins and the epilogue
+        # (measured with device timestamps, scripts/plan_phases.py: with a frame on the caller's stream that chain starts ~70 us
+        # behind the others and ends last; SOAR_PLAN_MAIN_FRAME=1 restores that layout)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n)]
+        if os.environ.get("SOAR_PLAN_MAIN_FRAME", "0") == "1":
+            self.streams[0] = None
         self.graphs = None
         if use_graphs:
             if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
@@ -124,14 +138,24 @@ class FrameStepPlan:
     # ---- the three pieces -------------------------------------------------------------------------------------------
     RESORT_EVERY = 8      # steps between two sorts of the KNN query order (lbs.KnnGrid.RESORT_EVERY)
 
+    def _stamp(self, k: int, stream: int) -> None:
+        if self.stamps is not None:
+            check(self.L.soar_prof_timestamp(self.stamps.data_ptr(), self.STAMP_CAP, k, stream), "timestamp")
+
     def _prologue(self, stream: int, resort: bool = True) -> None:
         L, s = self.L, self.seq
+        self._stamp(0, stream)
+        self.done.zero_()                      # (on the prologue's stream: torch's current stream while it is enqueued / captured)
+        n_sets = int(self.pool.shape[0]) if self.pool is not None else 0
+        check(L.soar_gather_step_inputs(self.n, s.num_frames, 55 * 16, n_sets, ptr(self.frame_ids), ptr(s.cano2live), ptr(self.mats),
+                                        ptr(self.frame_sel), stream), "gather_step_inputs")
         # (the flat gradient buffer is not zeroed here: the epilogue overwrites every registered slice, and the previous
         # step's second all-reduce bucket may still be reading it)
         check(L.soar_lbs_knn_query_ordered(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
                                            ptr(s.xyz.detach()), self.P, 30, ptr(self.knn_order), int(resort),
                                            ptr(self.blend_weights), None, ptr(self.knn_ws), self.knn_ws.numel(), stream),
               "knn_query")
+        self._stamp(1, stream)
 
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
@@ -140,6 +164,7 @@ class FrameStepPlan:
         J = int(self.blend_weights.shape[1])
         mats = self.mats[i]
         xyz, rot = s.xyz.detach(), s.rot.detach()
+        self._stamp(2 + 2 * i, stream)
         check(L.soar_lbs_warp_forward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, None, P, J, ptr(v["xyz_p"]),
                                       ptr(v["rot_p"]), None, stream), "warp_forward")
         check(L.soar_rast_forward_geometry(prm, ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
@@ -166,18 +191,28 @@ class FrameStepPlan:
                                    ptr(v["work"]), v["work"].numel(), stream), "backward")
         check(L.soar_lbs_warp_backward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, P, J, ptr(v["g_means3D"]),
                                        ptr(v["g_rot_p"]), ptr(self.g_xyz[i]), ptr(self.g_rot[i]), stream), "warp_backward")
+        # the chain that finishes last sums the frames' gradient blocks into the flat buffer (no join + launch on the caller's stream)
+        fv = self.flat.views
+        blocks = ((self.g_xyz, "xyz"), (self.g_rot, "rot"), (self.g_scales, "scales"), (self.g_colors, "colors"))
+        src = (C.c_void_p * 4)(*[ptr(t) for t, _ in blocks])
+        dst = (C.c_void_p * 4)(*[ptr(fv[name]) for _, name in blocks])
+        cnt = (C.c_int64 * 4)(*[t[0].numel() for t, _ in blocks])
+        check(L.soar_sum_frames_when_last(self.n, 4, src, dst, cnt, ptr(self.done[0:1]), ptr(self.done[1 + i:2 + i]), stream),
+              "sum_frames_when_last")
+        self._stamp(3 + 2 * i, stream)
 
     def _epilogue(self) -> None:
-        fv = self.flat.views
-        torch.sum(self.g_xyz, dim=0, out=fv["xyz"])
-        torch.sum(self.g_rot, dim=0, out=fv["rot"])
-        torch.sum(self.g_scales, dim=0, out=fv["scales"])
-        torch.sum(self.g_colors, dim=0, out=fv["colors"])
+        """Nothing left to launch: the last frame chain has summed the gradients (soar_sum_frames_when_last); the caller's stream
+        has joined every chain in `_fan_out`."""
+        if self.stamps is not None:
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            self._stamp(2 * self.n + 2, cur)
+            self._stamp(2 * self.n + 3, cur)
 
     # ---- graphs -------------------------------------------------------------------------------------------------------
     def _capture(self) -> None:
         dev = self.device
-        self.mats.copy_(self.seq.cano2live[: self.n] if self.seq.num_frames >= self.n else self.seq.cano2live[[0] * self.n])
+        self.frame_ids.copy_(torch.arange(self.n, dtype=torch.int32) % max(self.seq.num_frames, 1))
         self._run_eager()                       # warm-up: lazy workspaces, code objects
         torch.cuda.synchronize(dev)
         cap = torch.cuda.Stream(device=dev)
@@ -193,10 +228,6 @@ class FrameStepPlan:
                 with torch.cuda.graph(g, stream=cap):
                     self._frame(i, cap.cuda_stream)
                 graphs[i] = g
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
-                self._epilogue()
-            graphs["epilogue"] = g
         torch.cuda.synchronize(dev)
         self.graphs = graphs
 
@@ -212,19 +243,29 @@ class FrameStepPlan:
         self.steps += 1
 
     def _fan_out(self, main, fn) -> None:
-        """frames 1.. on their own streams (forked from `main`), frame 0 on `main`, then join"""
+        """frames with a stream of their own are forked from `main` (and joined again), the others run on `main`"""
         ev = torch.cuda.Event()
         ev.record(main)
         done = []
-        for i in range(1, self.n):
+        first_main = os.environ.get("SOAR_PLAN_MAIN_FIRST", "0") == "1"
+        if first_main:
+            for i in range(self.n):
+                if self.streams[i] is None:
+                    fn(i, main)
+        for i in range(self.n):
             s = self.streams[i]
+            if s is None:
+                continue
             s.wait_event(ev)
             with torch.cuda.stream(s):
                 fn(i, s)
             e = torch.cuda.Event()
             e.record(s)
             done.append(e)
-        fn(0, main)
+        if not first_main:
+            for i in range(self.n):
+                if self.streams[i] is None:
+                    fn(i, main)
         for e in done:
             main.wait_event(e)
 
@@ -235,10 +276,12 @@ class FrameStepPlan:
             raise ValueError(f"the plan was built for {self.n} frames per step, got {len(frames)}")
         self._check_fresh()
         dev = self.device
-        idx = torch.as_tensor([f % self.seq.num_frames for f in frames], device=dev)
-        torch.index_select(self.seq.cano2live, 0, idx, out=self.mats)
-        if self.pool is not None:
-            self.frame_sel.copy_(idx % int(self.pool.shape[0]))
+        # the step's only host -> device traffic: n frame ids, through a ring of pinned slots (the host runs steps ahead of the
+        # device; a slot is reused 64 steps later)
+        slot = self._ids_pinned[self.steps % self._ids_pinned.shape[0]]
+        for k, f in enumerate(frames):
+            slot[k] = int(f) % self.seq.num_frames
+        self.frame_ids.copy_(slot, non_blocking=True)
         if self.graphs is None:
             self._run_eager()
             return self.losses
@@ -250,7 +293,7 @@ class FrameStepPlan:
         self.graphs["prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"].replay()
         self.flat.wait_all()
         self._fan_out(main, lambda i, s: self.graphs[i].replay())
-        self.graphs["epilogue"].replay()
+        self._epilogue()
         self.steps += 1
         return self.losses
 
