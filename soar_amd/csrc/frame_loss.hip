@@ -7,6 +7,8 @@
 // frame; here every pixel is read once and its four gradient planes are written once.
 #include "soar_common.h"
 
+#include <type_traits>
+
 namespace soar {
 
 namespace {
@@ -20,6 +22,8 @@ struct LossArgs {
     float *sums;                 // [4] un-normalised sums of the four terms
     const int *set_index;        // optional: the targets are set (*set_index mod n_sets) of a resident pool [n_sets][7][n]
     int n_sets;
+    const uint32_t *n_contrib;   // optional [n]: the forward blend's contributor count; gradients of pixels nothing contributed to
+                                 // are never read by the backward blend (its walk starts at n_contrib) and are not written
 };
 
 __device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -39,6 +43,8 @@ __device__ __forceinline__ float4 ld(const float4 *p, int i) { return p[i]; }
 __device__ __forceinline__ float4 ld(const float *p, int i) { return make_float4(p[i], 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void st(float4 *p, int i, float4 v) { p[i] = v; }
 __device__ __forceinline__ void st(float *p, int i, float4 v) { p[i] = v.x; }
+__device__ __forceinline__ bool any_contrib(const uint4 *p, int i) { const uint4 v = p[i]; return (v.x | v.y | v.z | v.w) != 0u; }
+__device__ __forceinline__ bool any_contrib(const uint32_t *p, int i) { return p[i] != 0u; }
 
 template <int V>
 __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
@@ -52,7 +58,9 @@ __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
     float s_c = 0.f, s_m = 0.f, s_n = 0.f, s_d = 0.f;
     const float gc = a.wc / (3.f * a.n), gm = a.wm / a.n, gn = a.wn / (3.f * a.n), gd = a.wd / a.n;
     const float4 pad = V == 4 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(1.f, 0.f, 0.f, 0.f);   // lanes that exist
+    typedef typename std::conditional<V == 4, uint4, uint32_t>::type U;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
+        const bool wr = !a.n_contrib || any_contrib(reinterpret_cast<const U *>(a.n_contrib), i);     // someone will read the gradients
         float4 nsum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -60,22 +68,22 @@ __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
             const float4 t = ld(reinterpret_cast<const T *>(a.t_color + (size_t)ch * a.n), i);
             const float4 d = make_float4(c.x - t.x, c.y - t.y, c.z - t.z, c.w - t.w);
             s_c += (fabsf(d.x) + fabsf(d.y)) + (fabsf(d.z) + fabsf(d.w));
-            st(reinterpret_cast<T *>(a.dcolor + (size_t)ch * a.n), i,
-               make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w)));
+            if (wr) st(reinterpret_cast<T *>(a.dcolor + (size_t)ch * a.n), i,
+                       make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w)));
             const float4 nr = ld(reinterpret_cast<const T *>(a.normal + (size_t)ch * a.n), i);
             const float4 nt = ld(reinterpret_cast<const T *>(a.t_normal + (size_t)ch * a.n), i);
             nsum.x += nr.x * nt.x; nsum.y += nr.y * nt.y; nsum.z += nr.z * nt.z; nsum.w += nr.w * nt.w;
-            st(reinterpret_cast<T *>(a.dnormal + (size_t)ch * a.n), i, make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w));
+            if (wr) st(reinterpret_cast<T *>(a.dnormal + (size_t)ch * a.n), i, make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w));
         }
         s_n += (nsum.x + nsum.y) + (nsum.z + nsum.w);
         const float4 o = ld(reinterpret_cast<const T *>(a.opac), i);
         const float4 m = ld(reinterpret_cast<const T *>(a.t_mask), i);
         const float4 e = make_float4(o.x - m.x, o.y - m.y, o.z - m.z, o.w - m.w);
         s_m += (fabsf(e.x) + fabsf(e.y)) + (fabsf(e.z) + fabsf(e.w));
-        st(reinterpret_cast<T *>(a.dopac), i, make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w)));
+        if (wr) st(reinterpret_cast<T *>(a.dopac), i, make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w)));
         const float4 dp = ld(reinterpret_cast<const T *>(a.depth), i);
         s_d += (dp.x + dp.y) + (dp.z + dp.w);
-        st(reinterpret_cast<T *>(a.ddepth), i, make_float4(gd * pad.x, gd * pad.y, gd * pad.z, gd * pad.w));
+        if (wr) st(reinterpret_cast<T *>(a.ddepth), i, make_float4(gd * pad.x, gd * pad.y, gd * pad.z, gd * pad.w));
     }
     __shared__ float part[4][4];
     s_c = wave_sum(s_c); s_m = wave_sum(s_m); s_n = wave_sum(s_n); s_d = wave_sum(s_d);
@@ -105,16 +113,16 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
                              const float *target_color, const float *target_mask, const float *target_normal,
                              const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
                              float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                             float *dL_dopac, hipStream_t stream);
+                             float *dL_dopac, const void *image_buffer, hipStream_t stream);
 
 extern "C" int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                                const float *opac, const float *target_color, const float *target_mask,
                                const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
                                float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                               float *dL_dopac, void *stream_)
+                               float *dL_dopac, const void *image_buffer, void *stream_)
 {
     return frame_loss_launch(W, H, color, normal, depth, opac, target_color, target_mask, target_normal, nullptr, 1, w_color,
-                             w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac,
+                             w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac, image_buffer,
                              static_cast<hipStream_t>(stream_));
 }
 
@@ -122,19 +130,19 @@ extern "C" int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, 
                                       const float *opac, const float *target_pool, int32_t n_sets,
                                       const int32_t *set_index_dev, float w_color, float w_mask, float w_normal, float w_depth,
                                       float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                                      float *dL_dopac, void *stream_)
+                                      float *dL_dopac, const void *image_buffer, void *stream_)
 {
     if (n_sets <= 0 || !set_index_dev) { set_error("soar_frame_loss_pooled: need n_sets > 0 and a device index"); return 1; }
     return frame_loss_launch(W, H, color, normal, depth, opac, target_pool, target_pool, target_pool, set_index_dev, n_sets,
                              w_color, w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac,
-                             static_cast<hipStream_t>(stream_));
+                             image_buffer, static_cast<hipStream_t>(stream_));
 }
 
 static int frame_loss_launch(int32_t W, int32_t H, const float *color, const float *normal, const float *depth, const float *opac,
                              const float *target_color, const float *target_mask, const float *target_normal,
                              const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
                              float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                             float *dL_dopac, hipStream_t stream)
+                             float *dL_dopac, const void *image_buffer, hipStream_t stream)
 {
     if (W <= 0 || H <= 0) { set_error("soar_frame_loss: bad image size %dx%d", W, H); return 1; }
     if (!color || !normal || !depth || !opac || !target_color || !target_mask || !target_normal || !loss_out || !sums4 ||
@@ -150,9 +158,15 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
     a.dcolor = dL_dcolor; a.dnormal = dL_dnormal; a.ddepth = dL_ddepth; a.dopac = dL_dopac;
     a.sums = sums4;
     a.set_index = set_index_dev; a.n_sets = n_sets;
+    a.n_contrib = nullptr;
+    if (image_buffer) {                      // the rasterizer's image buffer of these outputs: gate the gradient planes by n_contrib
+        ImageBuf img;
+        carve_image(const_cast<void *>(image_buffer), W, H, &img);
+        a.n_contrib = img.n_contrib;
+    }
     SOAR_HIP_OK(hipMemsetAsync(sums4, 0, 4 * sizeof(float), stream));
     StageTimer timer(ST_FRAME_LOSS, stream);
-    const bool vec4 = (a.n & 3) == 0 && (((uintptr_t)color | (uintptr_t)normal | (uintptr_t)depth | (uintptr_t)opac | (uintptr_t)target_color |
+    const bool vec4 = (a.n & 3) == 0 && (((uintptr_t)a.n_contrib | (uintptr_t)color | (uintptr_t)normal | (uintptr_t)depth | (uintptr_t)opac | (uintptr_t)target_color |
                                           (uintptr_t)target_mask | (uintptr_t)target_normal | (uintptr_t)dL_dcolor | (uintptr_t)dL_dnormal |
                                           (uintptr_t)dL_ddepth | (uintptr_t)dL_dopac) & 15) == 0;
     const int blocks = min(2048, max(1, (a.n / (vec4 ? 4 : 1) + 255) / 256));

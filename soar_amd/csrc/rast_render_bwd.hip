@@ -71,7 +71,9 @@ __device__ __forceinline__ void load_pixel(const BwdArgs &a, int px, int py, boo
     const float D_final = (inside && a.normalize_depth) ? a.final_D[pix] : 0.f;
     float dO = 0.f;
     c.dC0 = c.dC1 = c.dC2 = c.dN0 = c.dN1 = c.dN2 = c.dD = 0.f;
-    if (inside) {
+    // a pixel nothing was blended into takes no part in the walk (it starts at n_contrib): its upstream gradients are not even
+    // read -- producers may leave them unwritten (soar_frame_loss with an image buffer does)
+    if (inside && c.last != 0u) {
         const float gs = a.grad_scale ? *a.grad_scale : 1.f;
         c.dC0 = gs * a.dL_dcolor[pix]; c.dC1 = gs * a.dL_dcolor[hw + pix]; c.dC2 = gs * a.dL_dcolor[2 * hw + pix];
         c.dN0 = gs * a.dL_dnormal[pix]; c.dN1 = gs * a.dL_dnormal[hw + pix]; c.dN2 = gs * a.dL_dnormal[2 * hw + pix];
