@@ -5,7 +5,9 @@ reference rasterizer, see rasterizer_oracle.c).  Only ``tests/``, ``__graft_entr
 and ``bench.py``'s ``cpu_baseline`` leg may import this module; nothing under ``soar_amd/``
 does.
 
-PARITY STATUS: pinned on the reference's own kernels built for gfx950 (see rasterizer_oracle.h, oracle/ref_build/).
+PARITY STATUS: parity unpinned by the rules of this build (no golden vectors in the reference, its CUDA toolchain absent);
+checked against the reference's own kernel sources translated by hipify-perl and built for gfx950 (oracle/_ref,
+oracle/ref_build/build_ref.sh, tests/test_reference_build_gpu.py) -- see rasterizer_oracle.c and DESIGN.md section 3.
 """
 from __future__ import annotations
 
