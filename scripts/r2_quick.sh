@@ -1,5 +1,7 @@
-# quick GPU check: rasterizer parity tests + default bench summary
+# quick GPU check: rasterizer parity tests + default bench summary; extra env assignments as arguments (e.g. SOAR_FWD_PIXEL=1)
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-r2q}
+shift
+for kv in "$@"; do export "$kv"; done
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_rasterizer_gpu.py tests/test_reference_build_gpu.py -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $out/pytest.log
