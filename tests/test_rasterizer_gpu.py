@@ -223,6 +223,17 @@ def test_binning_stress_scenes(mk):
     check_forward(scene, hip, fw)
 
 
+def test_binning_band_lists_on_a_very_tall_image():
+    """More than 64 rows of super-tiles (H = 4300 px: 269 tile rows, 68 super-tile rows): a band of the tile binning then spans two
+    super-tile rows (at most 64 bands fit the per-wavefront counters).  Per-tile lists, ranges, contributor counts bit for bit."""
+    scene = S.person_scene(P=8000, W=48, H=4300, seed=12, config=(1, 1, 1, 0), opacity=None, distance=0.5)
+    fw, _ = S.run_oracle(scene, n_threads=8)
+    assert fw.num_rendered > 2000 and (fw.ranges[:, 1] > fw.ranges[:, 0]).sum() > 400
+    rows = np.nonzero(fw.ranges[:, 1] > fw.ranges[:, 0])[0] // 3           # 3 tiles per row
+    assert rows.max() - rows.min() > 80                                     # the lists span many bands
+    check_forward(scene, run_hip(scene), fw)
+
+
 def test_camera_gradients_when_lrn_cam():
     scene = S.blob_scene(config=(1, 1, 1, 1), seed=11, P=600, use_sh=True, sh_degree=2)
     grads = S.upstream_grads(scene)
