@@ -64,17 +64,63 @@ __device__ __forceinline__ uint32_t quad_move_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
+// background values of a tile no Gaussian touches (what the blend's epilogue writes for T = 1, forward.cu:618-633)
+template <bool OCC>
+__device__ __forceinline__ void fill_tile(const FwdArgs &a, int tile, int tid, int nthreads)
+{
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const size_t hw = (size_t)a.H * a.W;
+    const float Tc = (float)(1 - 0.000001);
+    const bool vec = (a.W & 3) == 0;
+    for (int i = tid; i < 14 * 64; i += nthreads) {
+        const int plane = i >> 6, r = i & 63;
+        const int x = tx * TILE + (r & 3) * 4, y = ty * TILE + (r >> 2);
+        float v = 0.f;
+        float *dst = nullptr;
+        switch (plane) {
+        case 0: dst = a.final_T; v = Tc; break;
+        case 1: dst = reinterpret_cast<float *>(a.n_contrib); v = 0.f; break;        // bits of 0u
+        case 2: case 3: case 4: dst = a.out_color + (plane - 2) * hw; v = 0.f + Tc * a.bg[plane - 2]; break;
+        case 5: case 6: case 7: dst = a.out_normal + (plane - 5) * hw; v = 0.f; break;
+        case 8: dst = a.out_depth; v = a.normalize_depth ? 0.f / (1.f - Tc) : 0.f + Tc * 10.f; break;
+        case 9: dst = a.out_opac; v = 1.f - Tc; break;
+        case 10: if (a.normalize_depth) { dst = a.final_D; v = 0.f; } break;
+        case 11: case 12: case 13: if (OCC) { dst = a.out_occ + (plane - 11) * hw; v = 0.f + Tc * a.bg[plane - 11]; } break;
+        default: break;
+        }
+        if (!dst || y >= a.H || x >= a.W) continue;
+        float *p = dst + (size_t)a.W * y + x;
+        if (vec) {
+            *reinterpret_cast<float4 *>(p) = make_float4(v, v, v, v);
+        } else {
+            for (int k = 0; k < 4 && x + k < a.W; k++) p[k] = v;
+        }
+    }
+}
+
+// v[slot] for four wave-replicated values, with per-lane bit masks: four bit operations, no predicates (a select chain on
+// `slot` costs compares or scalar mask registers inside the hot loop)
+__device__ __forceinline__ float pick_by_slot(float v0, float v1, float v2, float v3, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
+{
+    uint32_t r = __float_as_uint(v0) & k0;
+    r |= __float_as_uint(v1) & k1;
+    r |= __float_as_uint(v2) & k2;
+    r |= __float_as_uint(v3) & k3;
+    return __uint_as_float(r);
+}
+
 // OCC = true additionally blends, in the same walk of the list, what a second rasterization with render_front = 1 and
 // colours = occ_values would produce (TS/renderer/diff_gaussian_rasterizer.py:281-291): the per-pixel sequence of
 // camera-facing entries is the same subsequence of this list (preprocess differs between the two passes only by the
 // back-face cull, forward.cu:262-266), so a second transmittance chain that ignores the back-facing entries reproduces
 // that pass without a second preprocess / sort / blend.
 template <bool LOG, bool OCC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) render_forward_kernel(FwdArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) render_forward_kernel(FwdArgs a)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
     __shared__ int wave_alive[2][4];
+    __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: LDS slots of a sub-chunk's relevant entries
     unsigned long long t_start = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
 
@@ -83,6 +129,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     // order, four consecutive workgroups of an XCD = the four quads of one tile (one L2 serves the tile's records)
     const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
     const int rank = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    // tiles no Gaussian touches (85 % of a 1080p frame of one person) sit behind the first n_work ranks of the order: one
+    // workgroup of the four fills the whole tile with its background values, the other three leave at once
+    const int Tpad = (a.ntiles + 7) / 8 * 8;
+    if (!LOG && rank >= (int)a.tile_order[Tpad]) {
+        if (quad != 0) return;
+        const uint32_t empty_tile = a.tile_order[rank];
+        if (empty_tile != 0xFFFFFFFFu) fill_tile<OCC>(a, (int)empty_tile, tid, 256);
+        return;
+    }
     const uint32_t tile_u = a.tile_order[rank];
     if (tile_u == 0xFFFFFFFFu) return;
     const int tile = (int)tile_u, seq = rank * 4 + quad;
@@ -92,45 +147,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     const int pxl = lane >> 2, slot = lane & 3;
     const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
     const bool inside = px < a.W && py < a.H;
+    // all-ones for this lane's slot, zero for the others (pick_by_slot)
+    const uint32_t k0 = slot == 0 ? ~0u : 0u, k1 = slot == 1 ? ~0u : 0u, k2 = slot == 2 ? ~0u : 0u, k3 = slot == 3 ? ~0u : 0u;
     const float fx = (float)px, fy = (float)py;
 
     const uint2 range = a.ranges[tile];
     set_wave_priority_by_length(range.y - range.x);
 
-    // tiles no Gaussian touches (most of the image): the 8x8 quad gets its background values with one aligned float4
-    // store per thread instead of walking the blend loop's prologue / epilogue in four wavefronts
-    {
-        const int qx0 = tx * TILE + (quad & 1) * 8, qy0 = ty * TILE + (quad >> 1) * 8;
-        if (!LOG && range.x == range.y && qx0 + 8 <= a.W && qy0 + 8 <= a.H && (a.W & 3) == 0) {
-            const int plane = tid >> 4, r = tid & 15;
-            const size_t hw = (size_t)a.H * a.W;
-            const size_t at = (size_t)a.W * (qy0 + (r >> 1)) + qx0 + (r & 1) * 4;
-            const float Tc = (float)(1 - 0.000001);            // the epilogue's clamp of T = 1 (forward.cu:618-633)
-            float v = 0.f;
-            float *dst = nullptr;
-            switch (plane) {
-            case 0: dst = a.final_T; v = Tc; break;
-            case 1: dst = reinterpret_cast<float *>(a.n_contrib); v = 0.f; break;        // bits of 0u
-            case 2: case 3: case 4: dst = a.out_color + (plane - 2) * hw; v = 0.f + Tc * a.bg[plane - 2]; break;
-            case 5: case 6: case 7: dst = a.out_normal + (plane - 5) * hw; v = 0.f; break;
-            case 8: dst = a.out_depth; v = a.normalize_depth ? 0.f / (1.f - Tc) : 0.f + Tc * 10.f; break;
-            case 9: dst = a.out_opac; v = 1.f - Tc; break;
-            case 10: if (a.normalize_depth) { dst = a.final_D; v = 0.f; } break;
-            case 11: case 12: case 13: if (OCC) { dst = a.out_occ + (plane - 11) * hw; v = 0.f + Tc * a.bg[plane - 11]; } break;
-            default: break;
-            }
-            if (dst) *reinterpret_cast<float4 *>(dst + at) = make_float4(v, v, v, v);
-            return;
-        }
-    }
-
     float T = 1.0f;                                  // replicated in the four lanes of a pixel
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
     uint32_t last_contributor = 0;                   // per-slot, folded with max at the end
-    bool done = !inside;                             // replicated
+    // 1 while the pixel blends, 0 once it has stopped (replicated in its four lanes).  Kept as a number, not a predicate:
+    // a per-lane bool that lives across the loop becomes a 64-bit mask in scalar registers, merged with three scalar
+    // instructions at every join -- and one SIMD issues a scalar instruction only every ~4 cycles, half the vector rate
+    float alive = inside ? 1.f : 0.f;
     float T_o = 1.0f, Co = 0.f;                      // occlusion pass: transmittance (replicated), per-slot sum
-    bool done_o = !inside || !OCC;
-    bool wave_done = (__ballot(!done) == 0ull);
+    float alive_o = (inside && OCC) ? 1.f : 0.f;
+    bool wave_done = (__ballot(alive != 0.f) == 0ull);
 
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -173,7 +206,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
             // pixels long after the covered ones have saturated; entries that touch only finished pixels are dropped).
             float rx0 = (float)bx0, ry0 = (float)by0, rex = 3.f, rey = 3.f;
             {
-                const unsigned long long am = __ballot(!(done && done_o));                // 4 lanes per pixel, pixel = lane >> 2
+                const unsigned long long am = __ballot(alive + alive_o != 0.f);           // 4 lanes per pixel, pixel = lane >> 2
                 uint32_t cols = 0, rows = 0;                                               // active columns / rows of the block
 #pragma unroll
                 for (int pp = 0; pp < 16; pp++) {
@@ -193,19 +226,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
                     relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[sub + lane].w, rx0, ry0, rex, rey);
                 }
-                unsigned long long todo = __ballot(relevant);
-                const uint32_t contrib0 = base - range.x + (uint32_t)sub;       // list entries before this sub-chunk
+                // the relevant entries' LDS slots, compacted in list order into the wavefront's ring (ballot-prefix ranks);
+                // three pad entries behind them point at the zero record, so the last step needs no special case
+                const unsigned long long todo = __ballot(relevant);
+                const int n_todo = (int)__builtin_popcountll(todo);
+                if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(sub + lane);
+                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)CHUNK;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t contrib1 = base - range.x + 1u;                  // list position + 1 of LDS slot 0
 
                 // phase B -- lanes = (pixel, slot): four surviving entries per step, in list order
-                while (todo != 0ull) {
+                for (int it = 0; it < n_todo; it += 4) {
                     if (LOG) n_iter++;
-                    int jj[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        jj[k] = todo ? (sub + (int)__builtin_ctzll(todo)) : CHUNK;      // CHUNK: the zero record
-                        todo = todo ? (todo & (todo - 1ull)) : 0ull;
-                    }
-                    const int j = slot == 0 ? jj[0] : slot == 1 ? jj[1] : slot == 2 ? jj[2] : jj[3];
+                    const int j = todo_ring[wave][it + slot];
                     const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
                     // x,y,A,B | C,opacity,depth,plane_a | plane_b,r,g,b | nx,ny,nz,-
                     const float dx = q0.x - fx, dy = q0.y - fy;
@@ -214,8 +249,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     // skip rules (:512, :545) zero the effective alpha of this lane's entry
                     float a_live = (power > 0.0f) ? 0.f : alpha;
                     a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
-                    if (LOG) n_useful += (unsigned long long)__builtin_popcountll(__ballot(a_live > 0.f && !done));
-                    const float a_eff = done ? 0.f : a_live;
+                    if (LOG) n_useful += (unsigned long long)__builtin_popcountll(__ballot(a_live * alive > 0.f));
+                    const float a_eff = a_live * alive;                                   // x 1 or x 0: exact
                     // running transmittance through the four slots, reference order (:548-553, :602).
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
                     const float om = 1.f - a_eff;
@@ -226,8 +261,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed
                     const float t0 = mul_keep(T, om0), p1 = mul_keep(t0, om1), p2 = mul_keep(p1, om2), p3 = mul_keep(p2, om3);
                     float w;
+                    bool some_stop = false;                                               // wave-uniform
                     if (__ballot(p3 < 0.0001f) == 0ull) {
-                        const float T_mine = slot == 0 ? T : slot == 1 ? t0 : slot == 2 ? p1 : p2;
+                        const float T_mine = pick_by_slot(T, t0, p1, p2, k0, k1, k2, k3);
                         w = a_eff * T_mine;
                         T = p3;
                     } else {
@@ -246,7 +282,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                         const bool stopped = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
                         w = stopped ? 0.f : a_eff * T_mine;
                         T = s3 ? T3 : t3;
-                        done = done || s3;
+                        alive = s3 ? 0.f : alive;
+                        some_stop = true;
                     }
                     const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
                     const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
@@ -257,18 +294,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                     N0 = __builtin_fmaf(q3.x, w, N0);
                     N1 = __builtin_fmaf(q3.y, w, N1);
                     N2 = __builtin_fmaf(q3.z, w, N2);
-                    last_contributor = blend ? contrib0 + (uint32_t)(j - sub) + 1u : last_contributor;
+                    last_contributor = blend ? contrib1 + (uint32_t)j : last_contributor;
                     if (OCC) {
                         // the same chain over the camera-facing entries only, with its own transmittance and stop
                         const float2 e4 = sq4[j];
-                        const float a_o = (done_o || e4.y == 0.f) ? 0.f : a_live;
+                        const float a_o = a_live * e4.y * alive_o;                        // camera-facing flag and liveness are 0 / 1
                         const float mo = 1.f - a_o;
                         const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
                                     mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
                         const float u0 = mul_keep(T_o, mo0), v1 = mul_keep(u0, mo1), v2 = mul_keep(v1, mo2), v3 = mul_keep(v2, mo3);
                         float w_o;
                         if (__ballot(v3 < 0.0001f) == 0ull) {
-                            const float U_mine = slot == 0 ? T_o : slot == 1 ? u0 : slot == 2 ? v1 : v2;
+                            const float U_mine = pick_by_slot(T_o, u0, v1, v2, k0, k1, k2, k3);
                             w_o = a_o * U_mine;
                             T_o = v3;
                         } else {
@@ -286,11 +323,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
                             const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
                             w_o = stopped_o ? 0.f : a_o * U_mine;
                             T_o = z3 ? U3 : u3;
-                            done_o = done_o || z3;
+                            alive_o = z3 ? 0.f : alive_o;
+                            some_stop = true;
                         }
                         Co = __builtin_fmaf(e4.x, w_o, Co);
                     }
-                    if (__ballot(!(done && done_o)) == 0ull) { wave_done = true; break; }
+                    if (some_stop && __ballot(alive + alive_o != 0.f) == 0ull) { wave_done = true; break; }
                 }
                 if (wave_done) break;
             }

@@ -96,7 +96,8 @@ struct ImageBuf {
     float *final_T;          // [pix]
     uint32_t *n_contrib;     // [pix]
     float *final_D;          // [pix]
-    uint32_t *tile_order;    // [T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding)
+    uint32_t *tile_order;    // [Tpad = T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding); [Tpad]: the
+                             // number of tiles with a non-empty list (the first ones of the order)
     uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
     size_t total_bytes;
 };
@@ -281,6 +282,7 @@ static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const u
         }
     }
     for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
+    if (tid == 0) order[Tpad] = (uint32_t)T - count[15];                 // tiles with a non-empty list (class 15 = empty)
 }
 
 #endif
