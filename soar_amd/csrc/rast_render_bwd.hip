@@ -170,16 +170,17 @@ __global__ void selftest_wave_reduce_kernel(float *out)
     out[64 + lane] = (float)pixel_reduce16_slot(lane);
 }
 
+constexpr int BWD_GRID_RANKS = 2048;   // tiles one pass of the grid covers
+
 template <bool WIDE>
-__global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
+__device__ __forceinline__ void backward_quad(const BwdArgs &a, const int rank, const int quad)
 {
     __shared__ float4 sq0[BCHUNK + 1], sq1[BCHUNK + 1], sq2[BCHUNK + 1], sq3[BCHUNK + 1];   // +1: all-zero record
     __shared__ uint32_t sid[BCHUNK + 1];
     __shared__ uint32_t wave_deep[4];
+    __shared__ unsigned short todo_ring[4][WAVE + 4];       // per wavefront: [0..3] the zero record, then the LDS slots of a sub-chunk's relevant entries
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;         // same longest-first mapping as the forward kernel
-    const int rank = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const uint32_t tile_u = a.tile_order[rank];
     if (tile_u == 0xFFFFFFFFu) return;
     const int tile = (int)tile_u;
@@ -199,6 +200,7 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     float P = 0.f;                               // (blend of everything behind) . (upstream gradient), replicated
     const uint32_t deepest_wave = wave_max_u32(c.last);
     if (lane == 0) wave_deep[wave] = deepest_wave;
+    if (lane < 4) todo_ring[wave][lane] = (unsigned short)BCHUNK;
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         sq0[BCHUNK] = z; sq1[BCHUNK] = z; sq2[BCHUNK] = z; sq3[BCHUNK] = z;
@@ -243,18 +245,20 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
                     const float4 e0 = sq0[e], e1 = sq1[e];
                     relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[e].w, (float)bx0, (float)by0, 3.f);
                 }
-                unsigned long long todo = __ballot(relevant);
+                // the relevant entries' LDS slots, compacted in list order behind the four pad entries of the wavefront's ring
+                // (ballot-prefix ranks): a scalar walk of the ballot's bits costs ~30 scalar instructions per step, and one SIMD
+                // issues a scalar instruction only every ~4 cycles
+                const unsigned long long todo = __ballot(relevant);
+                const int n_todo = (int)__builtin_popcountll(todo);
+                if (relevant) todo_ring[wave][4 + __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)e;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-                // phase B -- lanes = (pixel, slot): the four deepest remaining entries per step, slot 3 = deepest
-                while (todo != 0ull) {
-                    int jj[4];
-#pragma unroll
-                    for (int k = 3; k >= 0; k--) {
-                        const int b = todo ? 63 - (int)__builtin_clzll(todo) : -1;
-                        jj[k] = b >= 0 ? sub + b : BCHUNK;                         // BCHUNK: the zero record
-                        todo = b >= 0 ? (todo & ~(1ull << b)) : 0ull;
-                    }
-                    const int j = slot == 0 ? jj[0] : slot == 1 ? jj[1] : slot == 2 ? jj[2] : jj[3];
+                // phase B -- lanes = (pixel, slot): the four deepest remaining entries per step, slot 3 = deepest; the last step
+                // of a sub-chunk reaches into the pads (the zero record)
+                for (int top = n_todo; top > 0; top -= 4) {
+                    const int j = todo_ring[wave][top + slot];
                     const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
                     const uint32_t gid = sid[j];
                     Splat g;
@@ -329,6 +333,21 @@ __global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
     }
 }
 
+// Same small grid and rank-stride walk of the longest-first tile order as the forward kernel (render_forward_kernel,
+// rast_render_fwd.hip): the tiles behind the first n_work ranks have nothing to differentiate and are never visited.
+template <bool WIDE>
+__global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
+{
+    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
+    const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
+    for (int rank = rank0; rank < n_work; rank += stride) {
+        backward_quad<WIDE>(a, rank, quad);
+        lds_barrier();                                       // the next item's staging overwrites this one's LDS image
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -355,7 +374,8 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc; a.acc64 = acc64;
     StageTimer timer(ST_RENDER_BWD, stream);
-    const dim3 grid(4 * ((a.ntiles + 7) / 8 * 8));
+    static const int grid_ranks = getenv("SOAR_BLEND_GRID_RANKS") ? atoi(getenv("SOAR_BLEND_GRID_RANKS")) / 8 * 8 : BWD_GRID_RANKS;   // development switch
+    const dim3 grid(4 * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
         if (blend) hipLaunchKernelGGL(render_backward_slots_kernel<true>, grid, dim3(256), 0, stream, a);
         const size_t n = (size_t)prm.P * ACC_STRIDE;

@@ -31,6 +31,7 @@ namespace soar {
 namespace {
 
 constexpr int CHUNK = 256;          // list entries staged per workgroup iteration (one per thread)
+constexpr int FWD_GRID_RANKS = 2048; // tiles one pass of the grid covers (see render_forward_kernel)
 
 struct FwdArgs {
     int W, H, gx, gy, ntiles;
@@ -52,6 +53,7 @@ struct FwdArgs {
 
 constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST1 = 0x55, DPP_QUAD_BCAST2 = 0xAA, DPP_QUAD_BCAST3 = 0xFF;
 constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
+constexpr int DPP_QUAD_SHIFT1 = 0x90;          // quad_perm [0,0,1,2]: lane k reads lane k - 1 of its quad (lane 0 itself)
 
 template <int CTRL>
 __device__ __forceinline__ float quad_move(float v)
@@ -98,15 +100,17 @@ __device__ __forceinline__ void fill_tile(const FwdArgs &a, int tile, int tid, i
     }
 }
 
-// v[slot] for four wave-replicated values, with per-lane bit masks: four bit operations, no predicates (a select chain on
-// `slot` costs compares or scalar mask registers inside the hot loop)
-__device__ __forceinline__ float pick_by_slot(float v0, float v1, float v2, float v3, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
+// Running products of one pixel's four slots: T is replicated in the quad, m is this lane's factor; lane k returns
+// ((T m_0) m_1 ...) m_k -- every product a plain rounded multiply, in list order.  Pass k makes lane k final (lane 0 is
+// final after the first multiply and is carried through the passes with the factor 1).
+__device__ __forceinline__ float quad_scan_products(float T, float m, bool first_slot)
 {
-    uint32_t r = __float_as_uint(v0) & k0;
-    r |= __float_as_uint(v1) & k1;
-    r |= __float_as_uint(v2) & k2;
-    r |= __float_as_uint(v3) & k3;
-    return __uint_as_float(r);
+    const float m_pass = first_slot ? 1.0f : m;
+    float x = mul_keep(T, m);
+    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
+    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
+    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
+    return x;
 }
 
 // OCC = true additionally blends, in the same walk of the list, what a second rasterization with render_front = 1 and
@@ -115,7 +119,7 @@ __device__ __forceinline__ float pick_by_slot(float v0, float v1, float v2, floa
 // back-face cull, forward.cu:262-266), so a second transmittance chain that ignores the back-facing entries reproduces
 // that pass without a second preprocess / sort / blend.
 template <bool LOG, bool OCC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) render_forward_kernel(FwdArgs a)
+__device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, const int quad)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
@@ -125,19 +129,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (LOG) t_start = wall_clock64();
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // workgroups are dealt round-robin over the 8 XCDs: XCD x takes the tiles of rank x, x+8, ... of the longest-first
-    // order, four consecutive workgroups of an XCD = the four quads of one tile (one L2 serves the tile's records)
-    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
-    const int rank = (kth >> 2) * 8 + xcd, quad = kth & 3;
-    // tiles no Gaussian touches (85 % of a 1080p frame of one person) sit behind the first n_work ranks of the order: one
-    // workgroup of the four fills the whole tile with its background values, the other three leave at once
-    const int Tpad = (a.ntiles + 7) / 8 * 8;
-    if (!LOG && rank >= (int)a.tile_order[Tpad]) {
-        if (quad != 0) return;
-        const uint32_t empty_tile = a.tile_order[rank];
-        if (empty_tile != 0xFFFFFFFFu) fill_tile<OCC>(a, (int)empty_tile, tid, 256);
-        return;
-    }
     const uint32_t tile_u = a.tile_order[rank];
     if (tile_u == 0xFFFFFFFFu) return;
     const int tile = (int)tile_u, seq = rank * 4 + quad;
@@ -147,8 +138,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     const int pxl = lane >> 2, slot = lane & 3;
     const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
     const bool inside = px < a.W && py < a.H;
-    // all-ones for this lane's slot, zero for the others (pick_by_slot)
-    const uint32_t k0 = slot == 0 ? ~0u : 0u, k1 = slot == 1 ? ~0u : 0u, k2 = slot == 2 ? ~0u : 0u, k3 = slot == 3 ? ~0u : 0u;
     const float fx = (float)px, fy = (float)py;
 
     const uint2 range = a.ranges[tile];
@@ -254,19 +243,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
                     // running transmittance through the four slots, reference order (:548-553, :602).
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
                     const float om = 1.f - a_eff;
-                    const float om0 = quad_move<DPP_QUAD_BCAST0>(om), om1 = quad_move<DPP_QUAD_BCAST1>(om),
-                                om2 = quad_move<DPP_QUAD_BCAST2>(om), om3 = quad_move<DPP_QUAD_BCAST3>(om);
                     // unclamped running products first: transmittances only shrink, so some slot stops the pixel in
                     // this step iff the last product is below the threshold -- and in most steps no pixel of the
-                    // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed
-                    const float t0 = mul_keep(T, om0), p1 = mul_keep(t0, om1), p2 = mul_keep(p1, om2), p3 = mul_keep(p2, om3);
+                    // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed.
+                    // The products run through the quad as a scan (lane k <- lane k - 1, three fused DPP multiplies): lane k
+                    // ends with ((T om_0) om_1 ...) om_k, the reference's order of roundings
+                    float x = quad_scan_products(T, om, slot == 0);
+                    const float p3 = quad_move<DPP_QUAD_BCAST3>(x);
                     float w;
                     bool some_stop = false;                                               // wave-uniform
                     if (__ballot(p3 < 0.0001f) == 0ull) {
-                        const float T_mine = pick_by_slot(T, t0, p1, p2, k0, k1, k2, k3);
-                        w = a_eff * T_mine;
+                        const float T_prev = quad_move<DPP_QUAD_SHIFT1>(x);               // the product in front of my entry
+                        w = a_eff * (slot == 0 ? T : T_prev);
                         T = p3;
                     } else {
+                        const float om0 = quad_move<DPP_QUAD_BCAST0>(om), om1 = quad_move<DPP_QUAD_BCAST1>(om),
+                                    om2 = quad_move<DPP_QUAD_BCAST2>(om), om3 = quad_move<DPP_QUAD_BCAST3>(om);
+                        const float t0 = mul_keep(T, om0);
                         const bool s0 = t0 < 0.0001f;
                         const float T1 = s0 ? T : t0;
                         const float t1 = mul_keep(T1, om1);
@@ -300,15 +293,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
                         const float2 e4 = sq4[j];
                         const float a_o = a_live * e4.y * alive_o;                        // camera-facing flag and liveness are 0 / 1
                         const float mo = 1.f - a_o;
-                        const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
-                                    mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
-                        const float u0 = mul_keep(T_o, mo0), v1 = mul_keep(u0, mo1), v2 = mul_keep(v1, mo2), v3 = mul_keep(v2, mo3);
+                        float y = quad_scan_products(T_o, mo, slot == 0);
+                        const float v3 = quad_move<DPP_QUAD_BCAST3>(y);
                         float w_o;
                         if (__ballot(v3 < 0.0001f) == 0ull) {
-                            const float U_mine = pick_by_slot(T_o, u0, v1, v2, k0, k1, k2, k3);
-                            w_o = a_o * U_mine;
+                            const float U_prev = quad_move<DPP_QUAD_SHIFT1>(y);
+                            w_o = a_o * (slot == 0 ? T_o : U_prev);
                             T_o = v3;
                         } else {
+                            const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
+                                        mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
+                            const float u0 = mul_keep(T_o, mo0);
                             const bool z0 = u0 < 0.0001f;
                             const float U1 = z0 ? T_o : u0;
                             const float u1 = mul_keep(U1, mo1);
@@ -381,6 +376,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     }
 }
 
+// The launch covers the first gridDim.x / 4 ranks of the longest-first tile order, four workgroups (quads) per tile; the
+// ranks are dealt round-robin over the 8 XCDs with the four quads of a tile on one XCD (one L2 serves the tile's records).
+// The grid is much smaller than the tile count: only ~10 % of the tiles of a 1080p frame of one person have any work, and
+// the dispatcher needs ~2 ns per workgroup even for one that exits at once -- four frames in flight paid ~100 us per step
+// for empty workgroups.  Tiles with work beyond the grid (a denser scene) are reached by the rank-stride loop; the tiles no
+// Gaussian touches sit behind the first n_work ranks and are filled with their background values, whole tiles, by all
+// workgroups once their blending is done.
+template <bool LOG, bool OCC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) render_forward_kernel(FwdArgs a)
+{
+    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
+    const int Tpad = (a.ntiles + 7) / 8 * 8;
+    const int n_work = LOG ? Tpad : (int)a.tile_order[Tpad];
+    for (int rank = rank0; rank < n_work; rank += stride) {
+        blend_quad<LOG, OCC>(a, rank, quad);
+        lds_barrier();                                       // the next item's staging overwrites this one's LDS image
+    }
+    if (!LOG)
+        for (int rank = n_work + (int)blockIdx.x; rank < a.ntiles; rank += (int)gridDim.x)
+            fill_tile<OCC>(a, (int)a.tile_order[rank], (int)threadIdx.x, 256);
+}
+
 }  // namespace
 
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
@@ -397,9 +416,11 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
     a.wave_log = nullptr;
-    const int nblocks = 4 * ((a.ntiles + 7) / 8 * 8);
-    StageTimer timer(ST_RENDER_FWD, stream);
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
+    static const int grid_ranks = getenv("SOAR_BLEND_GRID_RANKS") ? atoi(getenv("SOAR_BLEND_GRID_RANKS")) / 8 * 8 : FWD_GRID_RANKS;   // development switch
+    const int Tpad = (a.ntiles + 7) / 8 * 8;
+    const int nblocks = 4 * (log_path ? Tpad : min(Tpad, grid_ranks));
+    StageTimer timer(ST_RENDER_FWD, stream);
     static int logged = 0;
     if (log_path && !logged && prm.render_front == 0) {
         logged = 1;

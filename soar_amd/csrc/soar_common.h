@@ -154,6 +154,7 @@ __device__ __forceinline__ void set_wave_priority_by_length(uint32_t len)
     if (len > 2048u) __builtin_amdgcn_s_setprio(3);
     else if (len > 768u) __builtin_amdgcn_s_setprio(2);
     else if (len > 256u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);                  // (a workgroup may take a short tile after a long one)
 }
 
 // Gaussian falloff exponent exactly as the reference writes it (forward.cu:507-508, backward.cu:663-664), evaluated

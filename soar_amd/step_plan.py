@@ -103,7 +103,8 @@ class FrameStepPlan:
         # frame chain i (2 + 2 i, 3 + 2 i) and of the epilogue (2 n + 2, 2 n + 3), appended to a ring on every replay
         # (soar_prof_timestamp; scripts/plan_phases.py reads it)
         self.STAMP_CAP = 8192
-        self.stamps = torch.zeros((1 + 2 * self.STAMP_CAP,), dtype=torch.int64, device=dev) if os.environ.get("SOAR_PLAN_TIMESTAMPS") == "1" else None
+        self.stamps = torch.zeros((1 + 2 * self.STAMP_CAP,), dtype=torch.int64, device=dev) if os.environ.get("SOAR_PLAN_TIMESTAMPS") in ("1", "2") else None
+        self.fine_stamps = os.environ.get("SOAR_PLAN_TIMESTAMPS") == "2"
         self.stale = None
         self._baked = self._leaf_signature()
         # every frame chain on a stream of its own; the caller's stream only carries the prologue, the joins and the epilogue
@@ -142,6 +143,11 @@ class FrameStepPlan:
         if self.stamps is not None:
             check(self.L.soar_prof_timestamp(self.stamps.data_ptr(), self.STAMP_CAP, k, stream), "timestamp")
 
+    def _stage_stamp(self, i: int, stage: int, stream: int) -> None:
+        """SOAR_PLAN_TIMESTAMPS=2: one more stamp behind every call of a frame chain (tag 100 + 10 * frame + stage)"""
+        if self.stamps is not None and self.fine_stamps:
+            self._stamp(100 + 10 * i + stage, stream)
+
     def _prologue(self, stream: int, resort: bool = True) -> None:
         L, s = self.L, self.seq
         self._stamp(0, stream)
@@ -167,11 +173,14 @@ class FrameStepPlan:
         self._stamp(2 + 2 * i, stream)
         check(L.soar_lbs_warp_forward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, None, P, J, ptr(v["xyz_p"]),
                                       ptr(v["rot_p"]), None, stream), "warp_forward")
+        self._stage_stamp(i, 0, stream)
         check(L.soar_rast_forward_geometry(prm, ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
                                            ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream), "geometry")
+        self._stage_stamp(i, 1, stream)
         check(L.soar_rast_forward_render_occ(prm, ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
                                              ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
                                              ptr(v["occ"]), stream), "render")
+        self._stage_stamp(i, 2, stream)
         wc, wm, wn, wd = self.weights
         if self.pool is not None:
             check(L.soar_frame_loss_pooled(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
@@ -183,12 +192,14 @@ class FrameStepPlan:
             check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
                                     wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
                                     ptr(v["gO"]), ptr(v["img"]), stream), "frame_loss")
+        self._stage_stamp(i, 3, stream)
         check(L.soar_rast_backward(prm, ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()), ptr(s.scales.detach()),
                                    ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
                                    ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
                                    ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]), ptr(v["g_cov3D"]), None,
                                    ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
                                    ptr(v["work"]), v["work"].numel(), stream), "backward")
+        self._stage_stamp(i, 4, stream)
         check(L.soar_lbs_warp_backward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, P, J, ptr(v["g_means3D"]),
                                        ptr(v["g_rot_p"]), ptr(self.g_xyz[i]), ptr(self.g_rot[i]), stream), "warp_backward")
         # the chain that finishes last sums the frames' gradient blocks into the flat buffer (no join + launch on the caller's stream)
