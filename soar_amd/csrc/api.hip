@@ -36,6 +36,39 @@ int post_launch(const char *what, hipStream_t stream, int debug)
     return 1;
 }
 
+namespace {
+struct ZeroArgs { uint32_t *ptr[4]; size_t words[4]; size_t first_block[5]; };
+__global__ void __launch_bounds__(256) zero_ranges_kernel(ZeroArgs z)
+{
+    int r = 0;
+    while (r < 3 && blockIdx.x >= z.first_block[r + 1]) r++;
+    const size_t w0 = ((size_t)blockIdx.x - z.first_block[r]) * 1024 + threadIdx.x * 4;
+    uint32_t *p = z.ptr[r];
+    const size_t n = z.words[r];
+    if (w0 + 3 < n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(p + w0) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int k = 0; k < 4; k++) if (w0 + k < n) p[w0 + k] = 0u;
+    }
+}
+}  // namespace
+
+int launch_zero_ranges(const ZeroRange *ranges, int count, hipStream_t stream)
+{
+    ZeroArgs z;
+    size_t blocks = 0;
+    for (int r = 0; r < 4; r++) {
+        z.first_block[r] = blocks;
+        z.ptr[r] = r < count ? static_cast<uint32_t *>(ranges[r].ptr) : nullptr;
+        z.words[r] = r < count ? ranges[r].bytes / 4 : 0;
+        blocks += (z.words[r] + 1023) / 1024;
+    }
+    z.first_block[4] = blocks;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z);
+    return post_launch("zero_ranges", stream, 0);
+}
+
 // ---- per-stage event timing -----------------------------------------------------------------------
 namespace {
 struct ProfSlot { hipEvent_t a, b; int stage; bool open; };
@@ -283,8 +316,10 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     GeomBuf g;
     carve_geom(geom_buffer, prm->P, prm->M, &g);
     // header (kmin / kmax / n_vis) and the depth-bucket counters start from zero
-    SOAR_HIP_OK(hipMemsetAsync(g.header, 0, 64 * sizeof(uint32_t), stream));
-    SOAR_HIP_OK(hipMemsetAsync(g.bucket_cnt, 0, 8192 * sizeof(uint32_t), stream));
+    {
+        const ZeroRange zr[2] = {{g.header, 64 * sizeof(uint32_t)}, {g.bucket_cnt, 8192 * sizeof(uint32_t)}};
+        if (launch_zero_ranges(zr, 2, stream)) return 1;
+    }
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
     if (!prm->sort_descending && launch_depth_buckets(*prm, g, stream)) return 1;
@@ -452,8 +487,12 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
     const bool wide = (prm->debug & 2) != 0;               // order-insensitive accumulation: float64 rows behind the float32 ones
     double *acc64 = wide ? reinterpret_cast<double *>(static_cast<char *>(workspace) + align_up(sizeof(float) * ACC_STRIDE * (size_t)prm->P))
                          : nullptr;
-    if (wide) SOAR_HIP_OK(hipMemsetAsync(acc64, 0, sizeof(double) * ACC_STRIDE * (size_t)prm->P, stream));
-    else SOAR_HIP_OK(hipMemsetAsync(acc, 0, sizeof(float) * ACC_STRIDE * (size_t)prm->P, stream));
+    {
+        // accumulation rows and the camera gradients (atomic sums of the two backward kernels) in one launch
+        const ZeroRange zr[4] = {{wide ? (void *)acc64 : (void *)acc, (wide ? sizeof(double) : sizeof(float)) * ACC_STRIDE * (size_t)prm->P},
+                                 {dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)}};
+        if (launch_zero_ranges(zr, 4, stream)) return 1;
+    }
     if (num_rendered > 0 || wide) {
         if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
                                    acc64, num_rendered > 0, stream))
@@ -461,7 +500,7 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
                                  dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat,
-                                 dL_dprojmat, dL_dcampos, stream))
+                                 dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/false, stream))
         return 1;
     return 0;
 }

@@ -349,7 +349,7 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
-                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, hipStream_t stream)
+                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream)
 {
     GeomBwdArgs a;
     a.P = prm.P; a.D = prm.sh_degree; a.M = prm.M; a.W = prm.W; a.H = prm.H;
@@ -366,9 +366,10 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
     a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity; a.dL_dmeans3D = dL_dmeans3D;
     a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations;
     a.dL_dviewmat = dL_dviewmat; a.dL_dprojmat = dL_dprojmat; a.dL_dcampos = dL_dcampos;
-    SOAR_HIP_OK(hipMemsetAsync(dL_dviewmat, 0, 16 * sizeof(float), stream));
-    SOAR_HIP_OK(hipMemsetAsync(dL_dprojmat, 0, 16 * sizeof(float), stream));
-    SOAR_HIP_OK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+    if (zero_camera_grads) {
+        const ZeroRange zr[3] = {{dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)}};
+        if (launch_zero_ranges(zr, 3, stream)) return 1;
+    }
     StageTimer timer(ST_GEOM_BWD, stream);
     hipLaunchKernelGGL(geometry_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("geometry_backward", stream, prm.debug);

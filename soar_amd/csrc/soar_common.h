@@ -297,6 +297,10 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
                       const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
                       GeomBuf &g, int32_t *radii, hipStream_t stream);
 int launch_scan(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
+// one launch that zeroes up to four 4-byte-aligned ranges (a hipMemsetAsync each is a kernel launch of its own: ~5 us on the
+// critical path of a frame)
+struct ZeroRange { void *ptr; size_t bytes; };
+int launch_zero_ranges(const ZeroRange *ranges, int count, hipStream_t stream);
 int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stream);
 
 int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream);
@@ -313,6 +317,6 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
-                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, hipStream_t stream);
+                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream);
 
 }  // namespace soar
