@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SOAR_HIP_ABI_VERSION 2
+#define SOAR_HIP_ABI_VERSION 3
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
@@ -45,7 +45,11 @@ typedef struct SoarRastParams {
                                   bit 1 (backward only): order-insensitive accumulation -- the per-Gaussian gradient sums of the backward
                                   blend go through float64 atomics instead of float32 ones (the reference's atomicAdd order,
                                   backward.cu:845-855, is undefined; in float64 the order no longer reaches the float32 result).
-                                  Test / debugging mode: ~2x the atomic traffic */
+                                  Test / debugging mode: ~2x the atomic traffic;
+                                  bit 2 (forward blend only): the caller states that image_buffer AND every output plane are the ones of
+                                  the previous forward call with this image_buffer, untouched since, and that the background colour has
+                                  not changed: tiles without Gaussians in both calls are not written again (their pixels already hold the
+                                  background values).  Never set it on the first call with an image_buffer. */
     /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
     int32_t cfg_surface;       /* config[0] */
     int32_t cfg_normalize_depth; /* config[1] */
@@ -239,15 +243,17 @@ int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
  *      four-output loss of section 8(d):  L = wc mean|color - tc| + wm mean|opac - tm| + wn mean(normal . tn) + wd mean(depth);
  *      same per-pixel structure as the reference's frame losses, TS/system/gaussian_surfel_mvdream.py:311-330,622-630).
  *   color/normal/target_color/target_normal [3,H,W], depth/opac/target_mask [1,H,W] (16-byte accesses when W*H is a multiple of 4 and the planes are aligned).
- *   loss_out [1], sums4 [4] (scratch: the four un-normalised sums), dL_d* = gradient of L w.r.t. the four images.
+ *   loss_out [1], scratch [SOAR_FRAME_LOSS_SCRATCH_FLOATS] (per-workgroup partial sums of the four terms, added up in a fixed
+ *   order: the loss value does not depend on the order in which workgroups finish), dL_d* = gradient of L w.r.t. the four images.
  *   image_buffer (optional, may be NULL): the rasterizer image buffer that belongs to these outputs.  When given, the gradient
  *   planes are only written at pixels with n_contrib > 0 -- the backward blend starts its walk at n_contrib
  *   (backward.cu:604,653), so the gradients of pixels nothing was blended into (85 % of a 1080p frame of one person) are
  *   never read; the loss value always covers every pixel. */
+#define SOAR_FRAME_LOSS_SCRATCH_FLOATS (4 * 2048)
 int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                     const float *opac, const float *target_color, const float *target_mask,
                     const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
-                    float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
+                    float *loss_out, float *scratch, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
                     float *dL_dopac, const void *image_buffer, void *stream);
 
 /* Same loss with the frame data resident in HBM: target_pool [n_sets][7][H*W] (colour 3, mask 1, normal 3 planes per
@@ -255,7 +261,7 @@ int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *norma
  * HIP graph for another frame (the host only rewrites the 4-byte index). */
 int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                            const float *opac, const float *target_pool, int32_t n_sets, const int32_t *set_index_dev,
-                           float w_color, float w_mask, float w_normal, float w_depth, float *loss_out, float *sums4,
+                           float w_color, float w_mask, float w_normal, float w_depth, float *loss_out, float *scratch,
                            float *dL_dcolor, float *dL_dnormal, float *dL_ddepth, float *dL_dopac, const void *image_buffer,
                            void *stream);
 

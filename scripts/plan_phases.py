@@ -23,7 +23,7 @@ for s in range(3):
     r_seen = max(r_seen, rasterizer.last_num_rendered)
 torch.cuda.synchronize()
 for n in ((4,) if os.environ.get("SOAR_ONLY4") == "1" else (1, 2, 3, 4)):
-    plan = FrameStepPlan(seq, n, targets, bg, 2 * r_seen, flat, use_graphs=True)
+    plan = FrameStepPlan(seq, n, targets, bg, 2 * r_seen, flat, use_graphs=os.environ.get("SOAR_PHASES_EAGER") != "1")
     for s in range(10):
         plan.run([(4 * s + k) % 400 for k in range(n)])
     torch.cuda.synchronize()

@@ -19,7 +19,7 @@ struct LossArgs {
     const float *t_color, *t_mask, *t_normal;              // [3,n] [n] [3,n]
     float wc, wm, wn, wd;
     float *dcolor, *dnormal, *ddepth, *dopac;
-    float *sums;                 // [4] un-normalised sums of the four terms
+    float *sums;                 // [gridDim.x][4] per-workgroup un-normalised sums of the four terms
     const int *set_index;        // optional: the targets are set (*set_index mod n_sets) of a resident pool [n_sets][7][n]
     int n_sets;
     const uint32_t *n_contrib;   // optional [n]: the forward blend's contributor count; gradients of pixels nothing contributed to
@@ -90,17 +90,36 @@ __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { part[wave][0] = s_c; part[wave][1] = s_m; part[wave][2] = s_n; part[wave][3] = s_d; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        atomicAdd(a.sums + threadIdx.x, v);
-    }
+    if (threadIdx.x < 4)
+        a.sums[4 * blockIdx.x + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// loss = wc*sums[0]/(3n) + wm*sums[1]/n + wn*sums[2]/(3n) + wd*sums[3]/n
-__global__ void frame_loss_finish_kernel(const float *sums, int n, float wc, float wm, float wn, float wd, float *loss)
+// loss = wc*S[0]/(3n) + wm*S[1]/n + wn*S[2]/(3n) + wd*S[3]/n,  S = the workgroups' partial sums added in a fixed order (thread t
+// takes workgroups t, t + 256, ...; then a fixed tree): no atomics, the value does not depend on who finished first
+__global__ void __launch_bounds__(256) frame_loss_finish_kernel(const float *sums, int blocks, int n, float wc, float wm, float wn, float wd,
+                                                                float *loss)
 {
-    if (threadIdx.x == 0)
-        *loss = (wc * sums[0] / (3.f * n) + wm * sums[1] / n) + (wn * sums[2] / (3.f * n) + wd * sums[3] / n);
+    __shared__ float4 red[256];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+        const float4 v = reinterpret_cast<const float4 *>(sums)[b];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float4 o = red[threadIdx.x + off];
+            float4 m = red[threadIdx.x];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float4 S = red[0];
+        *loss = (wc * S.x / (3.f * n) + wm * S.y / n) + (wn * S.z / (3.f * n) + wd * S.w / n);
+    }
 }
 
 }  // namespace
@@ -164,15 +183,14 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
         carve_image(const_cast<void *>(image_buffer), W, H, &img);
         a.n_contrib = img.n_contrib;
     }
-    SOAR_HIP_OK(hipMemsetAsync(sums4, 0, 4 * sizeof(float), stream));
     StageTimer timer(ST_FRAME_LOSS, stream);
     const bool vec4 = (a.n & 3) == 0 && (((uintptr_t)a.n_contrib | (uintptr_t)color | (uintptr_t)normal | (uintptr_t)depth | (uintptr_t)opac | (uintptr_t)target_color |
                                           (uintptr_t)target_mask | (uintptr_t)target_normal | (uintptr_t)dL_dcolor | (uintptr_t)dL_dnormal |
                                           (uintptr_t)dL_ddepth | (uintptr_t)dL_dopac) & 15) == 0;
-    const int blocks = min(2048, max(1, (a.n / (vec4 ? 4 : 1) + 255) / 256));
+    const int blocks = min(SOAR_FRAME_LOSS_SCRATCH_FLOATS / 4, max(1, (a.n / (vec4 ? 4 : 1) + 255) / 256));
     if (vec4) hipLaunchKernelGGL(frame_loss_kernel<4>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(frame_loss_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(64), 0, stream, sums4, a.n, w_color, w_mask, w_normal, w_depth,
+    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, sums4, blocks, a.n, w_color, w_mask, w_normal, w_depth,
                        loss_out);
     SOAR_LAUNCH_OK("frame_loss", stream, 0);
     return 0;

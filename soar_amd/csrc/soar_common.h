@@ -99,6 +99,9 @@ struct ImageBuf {
     uint32_t *tile_order;    // [Tpad = T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding); [Tpad]: the
                              // number of tiles with a non-empty list (the first ones of the order)
     uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
+    uint32_t *bg_tiles;      // [T] 1: every output plane of the tile holds the background values of the last forward blend.
+                             // One 32-bit word per tile, written with agent-scope stores: workgroups on different XCDs (one L2
+                             // each) update neighbouring tiles in the same launch, and narrower flags sharing a word lost updates
     size_t total_bytes;
 };
 struct BinBuf {

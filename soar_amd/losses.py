@@ -36,7 +36,7 @@ class _FrameLoss(torch.autograd.Function):
             if t.numel() != ch * H * W:
                 raise ValueError(f"{name} must have {ch}x{H}x{W} elements, got {tuple(t.shape)}")
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        sums = torch.empty((4,), dtype=torch.float32, device=dev)
+        sums = torch.empty((hip_lib.FRAME_LOSS_SCRATCH_FLOATS,), dtype=torch.float32, device=dev)
         gc, gn, gd, go = torch.empty_like(c), torch.empty_like(n), torch.empty_like(d), torch.empty_like(o)
         wc, wm, wn, wd = (float(w) for w in weights)
         with torch.cuda.device(dev):

@@ -514,7 +514,7 @@ class _RasterizeViews(torch.autograd.Function):
                 tg = frame_loss["targets"][i] if isinstance(frame_loss["targets"], (list, tuple)) else frame_loss["targets"]
                 f = dict(dtype=torch.float32, device=dev)
                 st["loss"] = torch.empty((), **f)
-                st["loss_sums"] = torch.empty((4,), **f)
+                st["loss_sums"] = torch.empty((hip_lib.FRAME_LOSS_SCRATCH_FLOATS,), **f)
                 st["loss_grads"] = [torch.empty((3, H, W), **f), torch.empty((3, H, W), **f), torch.empty((1, H, W), **f),
                                     torch.empty((1, H, W), **f)]
                 st["loss_targets"] = [_dev_f32(tg["color"], dev, "target color"), _dev_f32(tg["mask"], dev, "target mask"),

@@ -82,7 +82,7 @@ class FrameStepPlan:
                 color=torch.empty((3, H, W), **f), normal=torch.empty((3, H, W), **f), depth=torch.empty((1, H, W), **f),
                 opac=torch.empty((1, H, W), **f), occ=torch.empty((3, H, W), **f),
                 geom=torch.empty(geom_b, **u8), img=torch.empty(img_b, **u8), binning=torch.empty(bin_b, **u8),
-                work=torch.empty(work_b, **u8), loss=torch.empty((), **f), sums=torch.empty((4,), **f),
+                work=torch.empty(work_b, **u8), loss=torch.empty((), **f), sums=torch.empty((hip_lib.FRAME_LOSS_SCRATCH_FLOATS,), **f),
                 gC=torch.empty((3, H, W), **f), gN=torch.empty((3, H, W), **f), gD=torch.empty((1, H, W), **f),
                 gO=torch.empty((1, H, W), **f),
                 g_means2D=torch.empty((P, 3), **f), g_colors=torch.empty((P, 3), **f), g_opacity=torch.empty((P, 1), **f),
@@ -252,6 +252,9 @@ class FrameStepPlan:
             self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
             self._epilogue()
         self.steps += 1
+        # every later forward blend of a chain writes the same image buffer and output planes again, with the same background:
+        # tiles that stay empty keep their pixels (SoarRastParams.debug bit 2, include/soar_hip.h)
+        self.ctx.params.debug |= 4
 
     def _fan_out(self, main, fn) -> None:
         """frames with a stream of their own are forked from `main` (and joined again), the others run on `main`"""

@@ -396,6 +396,34 @@ def test_step_plan_matches_autograd(use_graphs, pooled):
         assert _rel(flat.flat.cpu().numpy(), want.cpu().numpy()) < 1e-4
 
 
+def test_step_plan_keeps_background_of_empty_tiles_only():
+    """From its second step on the plan asks the forward blend not to rewrite tiles that stay empty (SoarRastParams.debug bit 2:
+    85 % of the output bytes of a 1080p frame).  With the allocator's free blocks full of junk, and frames whose silhouettes
+    move between steps, every image of every chain must stay bit-identical to a render into fresh buffers."""
+    import bench
+    from soar_amd import rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+    junk = [torch.full((64 << 20,), 0xA5, dtype=torch.uint8, device=DEV) for _ in range(8)]
+    del junk
+    seq, pool, _ = bench.build_sequence("C3", DEV)
+    flat = FlatGradBuffer(seq.leaves())
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    bench.run_step(seq, pool, flat, [0, 1, 2, 3], bg)
+    plan = FrameStepPlan(seq, 4, pool, bg, 2 * rasterizer.last_num_rendered, flat, use_graphs=True)
+    for frames in ([40, 41, 42, 43], [200, 7, 42, 120], [3, 2, 1, 0], [3, 2, 1, 0]):
+        plan.run(frames)
+        torch.cuda.synchronize()
+        assert all(o == 0 for _, o in plan.check())
+        with torch.no_grad():
+            seq.refresh_blend_weights()
+            outs = seq.render_frames(frames, bg)
+        for i, o in enumerate(outs):
+            v = plan.views[i]
+            for name, want in (("color", o.render), ("opac", o.mask), ("depth", o.depth), ("normal", o.normal), ("occ", o.occ)):
+                assert torch.equal(v[name].reshape(want.shape), want), (frames, i, name)
+
+
 def test_step_plan_matches_autograd_at_c3_size():
     """BASELINE config C3 at full size (100k Gaussians, 1080x1920, batch = 4 frames): one FrameStepPlan step (HIP graphs, four
     streams, sync-free binning) against the autograd path on the same four frames -- the bench's timed step is this object."""
