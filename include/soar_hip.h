@@ -248,13 +248,16 @@ int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
  *   image_buffer (optional, may be NULL): the rasterizer image buffer that belongs to these outputs.  When given, the gradient
  *   planes are only written at pixels with n_contrib > 0 -- the backward blend starts its walk at n_contrib
  *   (backward.cu:604,653), so the gradients of pixels nothing was blended into (85 % of a 1080p frame of one person) are
- *   never read; the loss value always covers every pixel. */
+ *   never read; the loss value always covers every pixel.
+ *   background (optional device [3], only with image_buffer) + normalize_depth (SoarRastParams.cfg_normalize_depth of that forward):
+ *   the background colour the images were blended over.  When given, the four images are not READ at pixels with n_contrib == 0
+ *   either: what the blend wrote there are its background constants (forward.cu:618-633), recomputed here bit for bit. */
 #define SOAR_FRAME_LOSS_SCRATCH_FLOATS (4 * 2048)
 int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                     const float *opac, const float *target_color, const float *target_mask,
                     const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
                     float *loss_out, float *scratch, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                    float *dL_dopac, const void *image_buffer, void *stream);
+                    float *dL_dopac, const void *image_buffer, const float *background, int32_t normalize_depth, void *stream);
 
 /* Same loss with the frame data resident in HBM: target_pool [n_sets][7][H*W] (colour 3, mask 1, normal 3 planes per
  * frame), the set is chosen on the DEVICE as *set_index_dev mod n_sets -- the launch stays valid when it is replayed from a
@@ -263,7 +266,7 @@ int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float
                            const float *opac, const float *target_pool, int32_t n_sets, const int32_t *set_index_dev,
                            float w_color, float w_mask, float w_normal, float w_depth, float *loss_out, float *scratch,
                            float *dL_dcolor, float *dL_dnormal, float *dL_ddepth, float *dL_dopac, const void *image_buffer,
-                           void *stream);
+                           const float *background, int32_t normalize_depth, void *stream);
 
 /* ---- SSIM (TS/utils/loss_utils.py:36-76: 11x11 Gaussian window, sigma 1.5, zero padding):
  *      mean SSIM of img1, img2 [C,H,W] and, when dssim_dimg1 != NULL, its gradient w.r.t. img1 -- one kernel per

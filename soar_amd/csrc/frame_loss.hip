@@ -22,6 +22,9 @@ struct LossArgs {
     float *sums;                 // [gridDim.x][4] per-workgroup un-normalised sums of the four terms
     const int *set_index;        // optional: the targets are set (*set_index mod n_sets) of a resident pool [n_sets][7][n]
     int n_sets;
+    const float *bg;             // optional [3] (with n_contrib): background colour of the forward blend that wrote the images --
+                                 // pixels nothing contributed to are not read, their values are the blend's background constants
+    int normalize_depth;
     const uint32_t *n_contrib;   // optional [n]: the forward blend's contributor count; gradients of pixels nothing contributed to
                                  // are never read by the backward blend (its walk starts at n_contrib) and are not written
 };
@@ -59,29 +62,36 @@ __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
     const float gc = a.wc / (3.f * a.n), gm = a.wm / a.n, gn = a.wn / (3.f * a.n), gd = a.wd / a.n;
     const float4 pad = V == 4 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(1.f, 0.f, 0.f, 0.f);   // lanes that exist
     typedef typename std::conditional<V == 4, uint4, uint32_t>::type U;
+    // what the blend writes where nothing contributed (T = 1; forward.cu:618-633, the same expressions as its epilogue)
+    const float Tc = (float)(1 - 0.000001);
+    const bool known = a.n_contrib && a.bg;
+    float bgc[3] = {0.f, 0.f, 0.f};
+    if (known) { bgc[0] = 0.f + Tc * a.bg[0]; bgc[1] = 0.f + Tc * a.bg[1]; bgc[2] = 0.f + Tc * a.bg[2]; }
+    const float bg_depth = a.normalize_depth ? 0.f / (1.f - Tc) : 0.f + Tc * 10.f, bg_opac = 1.f - Tc;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
         const bool wr = !a.n_contrib || any_contrib(reinterpret_cast<const U *>(a.n_contrib), i);     // someone will read the gradients
+        const bool rd = wr || !known;                                                                  // the images have to be read
         float4 nsum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float4 c = ld(reinterpret_cast<const T *>(a.color + (size_t)ch * a.n), i);
+            const float4 c = rd ? ld(reinterpret_cast<const T *>(a.color + (size_t)ch * a.n), i) : make_float4(bgc[ch], bgc[ch], bgc[ch], bgc[ch]);
             const float4 t = ld(reinterpret_cast<const T *>(a.t_color + (size_t)ch * a.n), i);
             const float4 d = make_float4(c.x - t.x, c.y - t.y, c.z - t.z, c.w - t.w);
             s_c += (fabsf(d.x) + fabsf(d.y)) + (fabsf(d.z) + fabsf(d.w));
             if (wr) st(reinterpret_cast<T *>(a.dcolor + (size_t)ch * a.n), i,
                        make_float4(gc * sign_of(d.x), gc * sign_of(d.y), gc * sign_of(d.z), gc * sign_of(d.w)));
-            const float4 nr = ld(reinterpret_cast<const T *>(a.normal + (size_t)ch * a.n), i);
+            const float4 nr = rd ? ld(reinterpret_cast<const T *>(a.normal + (size_t)ch * a.n), i) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 nt = ld(reinterpret_cast<const T *>(a.t_normal + (size_t)ch * a.n), i);
             nsum.x += nr.x * nt.x; nsum.y += nr.y * nt.y; nsum.z += nr.z * nt.z; nsum.w += nr.w * nt.w;
             if (wr) st(reinterpret_cast<T *>(a.dnormal + (size_t)ch * a.n), i, make_float4(gn * nt.x, gn * nt.y, gn * nt.z, gn * nt.w));
         }
         s_n += (nsum.x + nsum.y) + (nsum.z + nsum.w);
-        const float4 o = ld(reinterpret_cast<const T *>(a.opac), i);
+        const float4 o = rd ? ld(reinterpret_cast<const T *>(a.opac), i) : make_float4(bg_opac, bg_opac, bg_opac, bg_opac);
         const float4 m = ld(reinterpret_cast<const T *>(a.t_mask), i);
         const float4 e = make_float4(o.x - m.x, o.y - m.y, o.z - m.z, o.w - m.w);
         s_m += (fabsf(e.x) + fabsf(e.y)) + (fabsf(e.z) + fabsf(e.w));
         if (wr) st(reinterpret_cast<T *>(a.dopac), i, make_float4(gm * sign_of(e.x), gm * sign_of(e.y), gm * sign_of(e.z), gm * sign_of(e.w)));
-        const float4 dp = ld(reinterpret_cast<const T *>(a.depth), i);
+        const float4 dp = rd ? ld(reinterpret_cast<const T *>(a.depth), i) : make_float4(bg_depth, bg_depth, bg_depth, bg_depth);
         s_d += (dp.x + dp.y) + (dp.z + dp.w);
         if (wr) st(reinterpret_cast<T *>(a.ddepth), i, make_float4(gd * pad.x, gd * pad.y, gd * pad.z, gd * pad.w));
     }
@@ -132,36 +142,38 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
                              const float *target_color, const float *target_mask, const float *target_normal,
                              const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
                              float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                             float *dL_dopac, const void *image_buffer, hipStream_t stream);
+                             float *dL_dopac, const void *image_buffer, const float *background, int32_t normalize_depth, hipStream_t stream);
 
 extern "C" int soar_frame_loss(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                                const float *opac, const float *target_color, const float *target_mask,
                                const float *target_normal, float w_color, float w_mask, float w_normal, float w_depth,
                                float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                               float *dL_dopac, const void *image_buffer, void *stream_)
+                               float *dL_dopac, const void *image_buffer, const float *background, int32_t normalize_depth,
+                               void *stream_)
 {
     return frame_loss_launch(W, H, color, normal, depth, opac, target_color, target_mask, target_normal, nullptr, 1, w_color,
                              w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac, image_buffer,
-                             static_cast<hipStream_t>(stream_));
+                             background, normalize_depth, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float *normal, const float *depth,
                                       const float *opac, const float *target_pool, int32_t n_sets,
                                       const int32_t *set_index_dev, float w_color, float w_mask, float w_normal, float w_depth,
                                       float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                                      float *dL_dopac, const void *image_buffer, void *stream_)
+                                      float *dL_dopac, const void *image_buffer, const float *background,
+                                      int32_t normalize_depth, void *stream_)
 {
     if (n_sets <= 0 || !set_index_dev) { set_error("soar_frame_loss_pooled: need n_sets > 0 and a device index"); return 1; }
     return frame_loss_launch(W, H, color, normal, depth, opac, target_pool, target_pool, target_pool, set_index_dev, n_sets,
                              w_color, w_mask, w_normal, w_depth, loss_out, sums4, dL_dcolor, dL_dnormal, dL_ddepth, dL_dopac,
-                             image_buffer, static_cast<hipStream_t>(stream_));
+                             image_buffer, background, normalize_depth, static_cast<hipStream_t>(stream_));
 }
 
 static int frame_loss_launch(int32_t W, int32_t H, const float *color, const float *normal, const float *depth, const float *opac,
                              const float *target_color, const float *target_mask, const float *target_normal,
                              const int32_t *set_index_dev, int32_t n_sets, float w_color, float w_mask, float w_normal,
                              float w_depth, float *loss_out, float *sums4, float *dL_dcolor, float *dL_dnormal, float *dL_ddepth,
-                             float *dL_dopac, const void *image_buffer, hipStream_t stream)
+                             float *dL_dopac, const void *image_buffer, const float *background, int32_t normalize_depth, hipStream_t stream)
 {
     if (W <= 0 || H <= 0) { set_error("soar_frame_loss: bad image size %dx%d", W, H); return 1; }
     if (!color || !normal || !depth || !opac || !target_color || !target_mask || !target_normal || !loss_out || !sums4 ||
@@ -178,6 +190,7 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
     a.sums = sums4;
     a.set_index = set_index_dev; a.n_sets = n_sets;
     a.n_contrib = nullptr;
+    a.bg = image_buffer ? background : nullptr; a.normalize_depth = normalize_depth;
     if (image_buffer) {                      // the rasterizer's image buffer of these outputs: gate the gradient planes by n_contrib
         ImageBuf img;
         carve_image(const_cast<void *>(image_buffer), W, H, &img);

@@ -86,9 +86,9 @@ SIGNATURES = {
     "soar_cos_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp]),
     "soar_cos_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "soar_frame_loss": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float,
-                                  C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "soar_frame_loss_pooled": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_float, C.c_float, C.c_float,
-                                         C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                         C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "soar_selftest_exp": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "soar_selftest_wave_reduce": (C.c_int, [_vp, _vp]),
     "soar_prof_enable": (C.c_int, [C.c_int]),

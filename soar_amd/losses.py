@@ -41,7 +41,8 @@ class _FrameLoss(torch.autograd.Function):
         wc, wm, wn, wd = (float(w) for w in weights)
         with torch.cuda.device(dev):
             check(L.soar_frame_loss(W, H, ptr(c), ptr(n), ptr(d), ptr(o), ptr(tc), ptr(tm), ptr(tn), wc, wm, wn, wd, ptr(loss),
-                                    ptr(sums), ptr(gc), ptr(gn), ptr(gd), ptr(go), None, torch.cuda.current_stream(dev).cuda_stream),
+                                    ptr(sums), ptr(gc), ptr(gn), ptr(gd), ptr(go), None, None, 0,
+                                    torch.cuda.current_stream(dev).cuda_stream),
                   "soar_frame_loss")
         ctx.save_for_backward(gc, gn, gd, go)
         ctx.shapes = (color.shape, normal.shape, depth.shape, opac.shape)

@@ -535,7 +535,8 @@ class _RasterizeViews(torch.autograd.Function):
                     with torch.cuda.device(st["device"]):
                         check(L.soar_frame_loss(st["W"], st["H"], ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(t[0]), ptr(t[1]),
                                                 ptr(t[2]), wc, wm, wn, wd, ptr(st["loss"]), ptr(st["loss_sums"]), ptr(g[0]),
-                                                ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(st["img"]), stream), "soar_frame_loss")
+                                                ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(st["img"]), st["ctx"].params.bg_dev,
+                                                int(st["ctx"].params.cfg_normalize_depth), stream), "soar_frame_loss")
                 if calls is not None:
                     calls.append(loss_launch)
                 else:

@@ -185,13 +185,15 @@ class FrameStepPlan:
         if self.pool is not None:
             check(L.soar_frame_loss_pooled(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
                                            int(self.pool.shape[0]), ptr(self.frame_sel[i]), wc, wm, wn, wd, ptr(self.losses[i]),
-                                           ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["img"]), stream),
+                                           ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["img"]),
+                                           self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
                   "frame_loss_pooled")
         else:
             tc, tm, tn = self.targets
             check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
                                     wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
-                                    ptr(v["gO"]), ptr(v["img"]), stream), "frame_loss")
+                                    ptr(v["gO"]), ptr(v["img"]), self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
+                  "frame_loss")
         self._stage_stamp(i, 3, stream)
         check(L.soar_rast_backward(prm, ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()), ptr(s.scales.detach()),
                                    ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
