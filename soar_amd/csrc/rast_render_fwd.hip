@@ -385,8 +385,11 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
 // for empty workgroups.  Tiles with work beyond the grid (a denser scene) are reached by the rank-stride loop; the tiles no
 // Gaussian touches sit behind the first n_work ranks and are filled with their background values, whole tiles, by all
 // workgroups once their blending is done.
+#ifndef SOAR_FWD_WPE
+#define SOAR_FWD_WPE 6
+#endif
 template <bool LOG, bool OCC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) render_forward_kernel(FwdArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_FWD_WPE, 8))) render_forward_kernel(FwdArgs a)
 {
     const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;

@@ -154,6 +154,9 @@ __device__ __forceinline__ void lds_barrier()
 // of short ones sharing their SIMD (the hardware arbiter serves higher s_setprio levels first).
 __device__ __forceinline__ void set_wave_priority_by_length(uint32_t len)
 {
+#ifdef SOAR_NO_SETPRIO
+    return;
+#endif
     if (len > 2048u) __builtin_amdgcn_s_setprio(3);
     else if (len > 768u) __builtin_amdgcn_s_setprio(2);
     else if (len > 256u) __builtin_amdgcn_s_setprio(1);
