@@ -47,9 +47,10 @@ typedef struct SoarRastParams {
                                   backward.cu:845-855, is undefined; in float64 the order no longer reaches the float32 result).
                                   Test / debugging mode: ~2x the atomic traffic;
                                   bit 2 (forward blend only): the caller states that image_buffer AND every output plane are the ones of
-                                  the previous forward call with this image_buffer, untouched since, and that the background colour has
-                                  not changed: tiles without Gaussians in both calls are not written again (their pixels already hold the
-                                  background values).  Never set it on the first call with an image_buffer. */
+                                  the previous forward call with this image_buffer, untouched since: tiles without Gaussians in both calls
+                                  are not written again (their pixels already hold the background values; a background colour or
+                                  normalize-depth switch that differs from the previous call's is noticed on the device and every tile is
+                                  written).  Never set it on the first call with an image_buffer. */
     /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
     int32_t cfg_surface;       /* config[0] */
     int32_t cfg_normalize_depth; /* config[1] */

@@ -169,6 +169,7 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->final_D, pix > 0 ? pix : 1);
     take(p, out->tile_order, (tiles + 7) / 8 * 8 + 8);
     take(p, out->tile_count, tiles > 0 ? tiles : 1);
+    take(p, out->bg_state, 8);
     take(p, out->bg_tiles, tiles > 0 ? tiles : 1);
     out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
     return 0;

@@ -49,6 +49,7 @@ struct FwdArgs {
     const float *front;              // [P] 1 = camera-facing (preprocess)
     float *out_occ;                  // [3,H,W]
     uint32_t *bg_tiles;              // ImageBuf::bg_tiles
+    const uint32_t *bg_state;        // ImageBuf::bg_state
     int keep_background;             // SoarRastParams.debug bit 2
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
 };
@@ -405,12 +406,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_F
     // A tile that was empty in the previous forward blend into the SAME output planes with the same background still holds its
     // values (the caller says so: SoarRastParams.debug bit 2): 85 % of the output bytes of a 1080p frame of one person, which
     // would otherwise be written again -- and written back from the L2s when the kernel ends
+    // (the caller's promise covers the buffers; that the background VALUES are those of the previous forward is checked on the
+    // device: tile_order_block compared them one launch ago)
+    const bool keep = a.keep_background && a.bg_state[4] == 0u;
     if (!LOG)
         for (int rank = n_work + (int)blockIdx.x; rank < a.ntiles; rank += (int)gridDim.x) {
             const int tile = (int)a.tile_order[rank];
             const uint32_t holds_background = __hip_atomic_load(a.bg_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_barrier();                                   // every wavefront has read the flag before the first one may set it below
-            if (a.keep_background && holds_background == 1u) continue;
+            if (keep && holds_background == 1u) continue;
             fill_tile<OCC>(a, tile, (int)threadIdx.x, 256);
             if (threadIdx.x == 0) __hip_atomic_store(a.bg_tiles + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -431,7 +435,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
-    a.bg_tiles = img.bg_tiles; a.keep_background = (prm.debug & 4) ? 1 : 0;
+    a.bg_tiles = img.bg_tiles; a.bg_state = img.bg_state; a.keep_background = (prm.debug & 4) ? 1 : 0;
     a.wave_log = nullptr;
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     static const int grid_ranks = getenv("SOAR_BLEND_GRID_RANKS") ? atoi(getenv("SOAR_BLEND_GRID_RANKS")) / 8 * 8 : FWD_GRID_RANKS;   // development switch

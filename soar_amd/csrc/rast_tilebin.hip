@@ -492,7 +492,8 @@ __global__ void __launch_bounds__(BIN_THREADS)
 bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
                  uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
-                 uint32_t *__restrict__ tile_order, unsigned long long *__restrict__ dbg)
+                 uint32_t *__restrict__ tile_order, const float *__restrict__ bg, int normalize_depth,
+                 uint32_t *__restrict__ bg_state, unsigned long long *__restrict__ dbg)
 {
     const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
     unsigned long long dbg_flush = 0;
@@ -500,7 +501,7 @@ bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_r
     if ((int)blockIdx.x == nblocks_tiles) {
         // the extra workgroup: longest-list-first order of the tiles for the blend launches (needs the counts only)
         const int T = gx * gy;
-        tile_order_block(T, (T + 7) / 8 * 8, tile_count, ranges, tile_order);
+        tile_order_block(T, (T + 7) / 8 * 8, tile_count, ranges, tile_order, bg, normalize_depth, bg_state);
         return;
     }
     constexpr int NT = BIN_SUPER * BIN_SUPER;
@@ -694,7 +695,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             SOAR_HIP_OK(hipMalloc(&dbg, 8 * nw));
             SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * nw, stream));
             hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
-                               ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, dbg);
+                               ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg);
             SOAR_HIP_OK(hipStreamSynchronize(stream));
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
             SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
@@ -711,7 +712,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             return 0;
         }
         hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
-                           ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, dbg);
+                           ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg);
     }
     SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);
     return 0;

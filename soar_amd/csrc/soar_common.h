@@ -99,6 +99,7 @@ struct ImageBuf {
     uint32_t *tile_order;    // [Tpad = T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding); [Tpad]: the
                              // number of tiles with a non-empty list (the first ones of the order)
     uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
+    uint32_t *bg_state;      // [8] {background bits x3, normalize_depth} of the last forward, [4]: they differ from the one before
     uint32_t *bg_tiles;      // [T] 1: every output plane of the tile holds the background values of the last forward blend.
                              // One 32-bit word per tile, written with agent-scope stores: workgroups on different XCDs (one L2
                              // each) update neighbouring tiles in the same launch, and narrower flags sharing a word lost updates
@@ -246,7 +247,8 @@ __device__ __forceinline__ uint32_t class_slot(uint32_t *counter, int cls, bool 
 
 // One 1024-thread workgroup: `order` = tile ids, longest list first.  Lengths from the tile counts when given (tile binning:
 // the ranges are written by a kernel this one may run beside), else from the ranges (descending / key-sort path).
-static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const uint32_t *tile_count, const uint2 *ranges, uint32_t *order)
+static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const uint32_t *tile_count, const uint2 *ranges, uint32_t *order,
+                                                        const float *bg, int normalize_depth, uint32_t *bg_state)
 {
     __shared__ uint32_t count[16], cursor[16];
     const int tid = threadIdx.x;
@@ -290,6 +292,13 @@ static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const u
     }
     for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
     if (tid == 0) order[Tpad] = (uint32_t)T - count[15];                 // tiles with a non-empty list (class 15 = empty)
+    // is the background of this frame the one the flagged tiles (ImageBuf::bg_tiles) were filled with?  Decided here, one
+    // launch before the forward blend reads it, so that no workgroup of the blend sees the state change under it
+    if (tid == 0 && bg_state) {
+        const uint32_t now[4] = {__float_as_uint(bg[0]), __float_as_uint(bg[1]), __float_as_uint(bg[2]), (uint32_t)normalize_depth};
+        bg_state[4] = (now[0] != bg_state[0]) | (now[1] != bg_state[1]) | (now[2] != bg_state[2]) | (now[3] != bg_state[3]);
+        bg_state[0] = now[0]; bg_state[1] = now[1]; bg_state[2] = now[2]; bg_state[3] = now[3];
+    }
 }
 
 #endif

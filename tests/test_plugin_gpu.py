@@ -399,7 +399,8 @@ def test_step_plan_matches_autograd(use_graphs, pooled):
 def test_step_plan_keeps_background_of_empty_tiles_only():
     """From its second step on the plan asks the forward blend not to rewrite tiles that stay empty (SoarRastParams.debug bit 2:
     85 % of the output bytes of a 1080p frame).  With the allocator's free blocks full of junk, and frames whose silhouettes
-    move between steps, every image of every chain must stay bit-identical to a render into fresh buffers."""
+    move between steps, every image of every chain must stay bit-identical to a render into fresh buffers -- also when the
+    background colour changes in place between two steps."""
     import bench
     from soar_amd import rasterizer
     from soar_amd.frame_dp import FlatGradBuffer
@@ -411,7 +412,9 @@ def test_step_plan_keeps_background_of_empty_tiles_only():
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     bench.run_step(seq, pool, flat, [0, 1, 2, 3], bg)
     plan = FrameStepPlan(seq, 4, pool, bg, 2 * rasterizer.last_num_rendered, flat, use_graphs=True)
-    for frames in ([40, 41, 42, 43], [200, 7, 42, 120], [3, 2, 1, 0], [3, 2, 1, 0]):
+    for step, frames in enumerate(([40, 41, 42, 43], [200, 7, 42, 120], [3, 2, 1, 0], [3, 2, 1, 0], [5, 6, 7, 8])):
+        if step == 3:
+            bg.copy_(torch.tensor([0.9, 0.1, 0.4], device=DEV))      # a new background colour in place: noticed on the device
         plan.run(frames)
         torch.cuda.synchronize()
         assert all(o == 0 for _, o in plan.check())
