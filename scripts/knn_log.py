@@ -24,3 +24,9 @@ coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
 print("fit dur_us = %.4f*cand + %.4f*blend + %.3f*pairs + %.2f" % tuple(coef))
 i = np.argsort(-dur)[:5]
 print("slowest:", [(float(dur[k]), int(a[k, 2]), int(a[k, 3]), int(a[k, 4])) for k in i])
+q = np.argsort(start)
+for lo, hi in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
+    sel = q[int(lo * len(q)):int(hi * len(q))]
+    print("waves starting in quartile %.2f-%.2f: start %.1f..%.1f us, mean dur %.1f us, mean cand %.0f" % (lo, hi, start[sel].min(), start[sel].max(), dur[sel].mean(), a[sel, 3].mean()))
+heavy = a[:, 3] > 450
+print("heavy waves (cand > 450):", int(heavy.sum()), "start pct [10,50,90]:", np.percentile(start[heavy], [10, 50, 90]), "end max", end[heavy].max())

@@ -347,13 +347,89 @@ __device__ __forceinline__ void chain_insert(float (&best)[K], float d)
     best[0] = fminf(best[0], d);
 }
 
+// Heaviest-first order of the (chunk, slot) work items of the launch below.  An item's time grows with the vertices in the 3x3x3
+// cell box of its segments' cells (pass 1) and with its number of queries (pass 2): at C3 126 of the 2217 workgroups with work
+// scan 450+ candidates and run twice as long as the median, and a tenth of them used to start at 75 us of a 158 us launch (the
+// second segment of a chunk sat in gridDim.y, behind every first segment).  Items without a segment go last, in one block: an
+// empty workgroup in every second or fourth position would leave the CUs the dispatcher deals them to idle.
+constexpr uint32_t KNN_ORDER_STAMP = 0x534F4152u;
+// one wavefront per chunk, lane = query: cost of the chunk's (up to) KNN_SLOTS items, 0 = no segment
+__global__ void __launch_bounds__(WAVE)
+item_cost_kernel(const uint32_t *__restrict__ q_keys, int P, const GridMeta *__restrict__ meta, const uint2 *__restrict__ cell_range,
+                 uint32_t *__restrict__ cost)
+{
+    const int lane = threadIdx.x, chunk = blockIdx.x, q = chunk * WAVE + lane;
+    const bool valid = q < P;
+    const uint32_t key = valid ? q_keys[q] : 0xFFFFFFFFu;
+    const GridMeta m = *meta;
+    uint32_t item[KNN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < KNN_SLOTS; k++) item[k] = 0u;
+    unsigned long long remaining = __ballot(valid);
+    for (int seg = 0; remaining != 0ull; seg++) {                       // the same segments as knn_cell_kernel
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(remaining));
+        const unsigned long long mine = __ballot(valid && key == c);
+        remaining &= ~mine;
+        const int cx = (int)(c % GRID_MAX), cy = (int)((c / GRID_MAX) % GRID_MAX), cz = (int)(c / (GRID_MAX * GRID_MAX));
+        uint32_t n = 0;                                                  // lane < 27: one cell of the box
+        if (lane < 27) {
+            const int gx = cx + lane % 3 - 1, gy = cy + (lane / 3) % 3 - 1, gz = cz + lane / 9 - 1;
+            if (gx >= 0 && gx < m.nx && gy >= 0 && gy < m.ny && gz >= 0 && gz < m.nz) {
+                const uint2 rg = cell_range[(gz * GRID_MAX + gy) * GRID_MAX + gx];
+                n = rg.y - rg.x;
+            }
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n += (uint32_t)__shfl_xor((int)n, off);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+        if (n < 2u * KNN_K) {                                            // a sparse box will grow: count the 5x5x5 one
+            uint32_t n5 = 0;
+            for (int t = lane; t < 125; t += WAVE) {
+                const int gx = cx + t % 5 - 2, gy = cy + (t / 5) % 5 - 2, gz = cz + t / 25 - 2;
+                if (gx >= 0 && gx < m.nx && gy >= 0 && gy < m.ny && gz >= 0 && gz < m.nz) {
+                    const uint2 rg = cell_range[(gz * GRID_MAX + gy) * GRID_MAX + gx];
+                    n5 += rg.y - rg.x;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) n5 += (uint32_t)__shfl_xor((int)n5, off);
+            n += (uint32_t)__builtin_amdgcn_readfirstlane((int)n5);      // both boxes are scanned
+        }
+        // measured: ~0.08 us per candidate + ~0.7 us per query + 12 us per segment (scripts/knn_log.py)
+        const uint32_t us100 = 8u * n + 70u * (uint32_t)__builtin_popcountll(mine) + 1200u;
+#pragma unroll
+        for (int k = 0; k < KNN_SLOTS; k++) item[k] += (seg % KNN_SLOTS) == k ? us100 : 0u;
+    }
+    if (lane < KNN_SLOTS) cost[chunk * KNN_SLOTS + lane] = lane == 0 ? item[0] : lane == 1 ? item[1] : lane == 2 ? item[2] : item[3];
+}
+// counting sort of the items into 32 cost classes, heaviest first, items without work last (one workgroup; the order inside a
+// class is whatever the LDS atomics give: it only schedules)
+__global__ void __launch_bounds__(1024) item_order_kernel(const uint32_t *__restrict__ cost, int n_items, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t count[33], cursor[33];
+    const int tid = threadIdx.x;
+    if (tid < 33) count[tid] = 0u;
+    __syncthreads();
+    auto class_of = [&](uint32_t c) -> int { return c == 0u ? 32 : 31 - (int)min(31u, c / 400u); };     // 4 us per class
+    for (int i = tid; i < n_items; i += 1024) atomicAdd(&count[class_of(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 33; k++) { cursor[k] = acc; acc += count[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_items; i += 1024) order[atomicAdd(&cursor[class_of(cost[i])], 1u)] = (uint32_t)i;
+    if (tid == 0) order[n_items] = KNN_ORDER_STAMP ^ (uint32_t)n_items;      // "this workspace holds an order for n_items items"
+}
+
 template <bool WITH_IDX, bool LOG = false>
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
 knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__restrict__ meta,
                 const uint2 *__restrict__ cell_range, const float4 *__restrict__ sorted_verts,
                 const uint32_t *__restrict__ q_keys, const uint32_t *__restrict__ q_ids,
                 const float *__restrict__ rows_padded, int J, float *__restrict__ weights_out,
-                int32_t *__restrict__ knn_idx_out, unsigned long long *__restrict__ wave_log = nullptr)
+                int32_t *__restrict__ knn_idx_out, const uint32_t *__restrict__ item_order,
+                unsigned long long *__restrict__ wave_log = nullptr)
 {
     constexpr int K = KNN_K;
     __shared__ float4 cand[KNN_CAND];                      // {x, y, z, sorted position}
@@ -368,27 +444,35 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
     if (LOG) t_start = wall_clock64();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * WAVE + lane;
+    // heaviest items first -- when the workspace holds an order for this launch (a call that keeps a stored query order on a
+    // workspace no sort has been through finds no stamp and takes the items in place)
+    const uint32_t n_items = gridDim.x;
+    const bool ordered = item_order && item_order[n_items] == (KNN_ORDER_STAMP ^ n_items);
+    // (in place = every chunk's first segment, then every second one, ...: never an idle workgroup in a periodic position)
+    const uint32_t n_chunks = n_items / KNN_SLOTS;
+    const uint32_t item = ordered ? min(item_order[blockIdx.x], n_items - 1u) : (blockIdx.x % n_chunks) * KNN_SLOTS + blockIdx.x / n_chunks;
+    const int chunk = (int)(item / KNN_SLOTS), slot = (int)(item % KNN_SLOTS);
+    const int q = chunk * WAVE + lane;
     const bool valid = q < P;
     const uint32_t key = valid ? q_keys[q] : 0xFFFFFFFFu;
-    // the chunk's queries are sorted by cell: a segment = the lanes of one cell; this workgroup takes segments
-    // slot, slot + KNN_SLOTS, ... so that a chunk that straddles many sparse cells is shared by several workgroups
-    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
-    unsigned long long seg_heads = __ballot(valid && (lane == 0 || key != prev));
-    const int slot = blockIdx.y;
-    if ((int)__builtin_popcountll(seg_heads) <= slot) return;
+    // a segment = ALL the lanes of the chunk that share one cell (adjacent when the query order is fresh; with a reused order the
+    // same cell can come back later in the chunk -- one segment all the same, or two workgroups would blend the same queries);
+    // this workgroup takes segments slot, slot + KNN_SLOTS, ... so that a chunk that straddles many sparse cells is shared by
+    // several workgroups
+    unsigned long long remaining = __ballot(valid);
+    if (remaining == 0ull) return;
 
     const int p = valid ? (int)q_ids[q] : 0;
     const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
     const GridMeta m = *meta;
     const float qx = x - m.minx, qy = y - m.miny, qz = z - m.minz;
 
-    for (int seg = 0; seg_heads != 0ull; seg++) {
-        const int head = (int)__builtin_ctzll(seg_heads);
-        seg_heads &= seg_heads - 1ull;
-        if ((seg % KNN_SLOTS) != slot) continue;
+    for (int seg = 0; remaining != 0ull; seg++) {
+        const int head = (int)__builtin_ctzll(remaining);
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, head);
         const bool active = valid && key == c;
+        remaining &= ~__ballot(active);
+        if ((seg % KNN_SLOTS) != slot) continue;
         const int cx = (int)(c % GRID_MAX), cy = (int)((c / GRID_MAX) % GRID_MAX), cz = (int)(c / (GRID_MAX * GRID_MAX));
         if (LOG) n_pairs++;
 
@@ -542,7 +626,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
         }
     }
     if (LOG && lane == 0) {
-        unsigned long long *w = wave_log + (((size_t)blockIdx.x * KNN_SLOTS + slot) * KNN_WAVES + wave) * 8;
+        unsigned long long *w = wave_log + ((size_t)blockIdx.x * KNN_WAVES + wave) * 8;
         w[0] = t_start; w[1] = wall_clock64(); w[2] = n_pairs; w[3] = n_cand; w[4] = n_blend;
     }
 }
@@ -610,8 +694,10 @@ int knn_build(const float *verts, int32_t V, const float *vert_weights, int32_t 
 struct QueryWs {
     size_t sort_bytes, total;
     uint32_t *qk0, *qk1, *qv0, *qv1;
+    uint32_t *item_cost, *item_order; // [KNN_SLOTS * ceil(P / 64) (+ 1)] cost and heaviest-first order of the (chunk, slot) work items
+                                      // (kept between re-sorts)
 };
-// layout of the caller-owned query workspace: [rocPRIM sort temp | qk0 | qk1 | qv0 | qv1], each 256-byte aligned
+// layout of the caller-owned query workspace: [rocPRIM sort temp | qk0 | qk1 | qv0 | qv1 | item costs | item order], each 256-byte aligned
 int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
 {
     size_t qsort_bytes = 0;
@@ -622,13 +708,15 @@ int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = align_up(off + n); return o; };
     const size_t o_tmp = carve(qsort_bytes), o_qk0 = carve(4 * (size_t)P), o_qk1 = carve(4 * (size_t)P),
-                 o_qv0 = carve(4 * (size_t)P), o_qv1 = carve(4 * (size_t)P);
+                 o_qv0 = carve(4 * (size_t)P), o_qv1 = carve(4 * (size_t)P), o_cost = carve(4 * KNN_SLOTS * (((size_t)P + WAVE - 1) / WAVE)),
+                 o_ord = carve(4 * (KNN_SLOTS * (((size_t)P + WAVE - 1) / WAVE) + 1));
     (void)o_tmp;
     char *b = static_cast<char *>(base);
     out->sort_bytes = qsort_bytes;
     out->total = off;
     out->qk0 = reinterpret_cast<uint32_t *>(b + o_qk0); out->qk1 = reinterpret_cast<uint32_t *>(b + o_qk1);
     out->qv0 = reinterpret_cast<uint32_t *>(b + o_qv0); out->qv1 = reinterpret_cast<uint32_t *>(b + o_qv1);
+    out->item_cost = reinterpret_cast<uint32_t *>(b + o_cost); out->item_order = reinterpret_cast<uint32_t *>(b + o_ord);
     return 0;
 }
 
@@ -662,16 +750,21 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
         SOAR_HIP_OK(rocprim::radix_sort_pairs(b + o_tmp, qsort_bytes, qk0, qk1, qv0, order ? order : qv1, (size_t)P, 0u, 18u,
                                               stream));
         if (order) qv1 = order;
+        // the item order is rebuilt with every sort and reused by the calls that keep the stored query order
+        const int nchunks = (P + WAVE - 1) / WAVE;
+        hipLaunchKernelGGL(item_cost_kernel, dim3(nchunks), dim3(WAVE), 0, stream, qk1, P, g.meta, g.cell_range, ws.item_cost);
+        hipLaunchKernelGGL(item_order_kernel, dim3(1), dim3(1024), 0, stream, ws.item_cost, nchunks * KNN_SLOTS, ws.item_order);
     }
-    const dim3 grid((P + WAVE - 1) / WAVE, KNN_SLOTS);
+    const dim3 grid(((P + WAVE - 1) / WAVE) * KNN_SLOTS);
+    const uint32_t *chunk_order = getenv("SOAR_KNN_NO_ORDER") ? nullptr : ws.item_order;         // development switch
     const char *log_path = getenv("SOAR_KNN_LOG");            // diagnostic: per-wave timeline of one launch
     if (log_path && !knn_idx_out) {
         unsigned long long *log_dev = nullptr;
-        const size_t nbytes = sizeof(unsigned long long) * 8 * (size_t)grid.x * KNN_SLOTS * KNN_WAVES;
+        const size_t nbytes = sizeof(unsigned long long) * 8 * (size_t)grid.x * KNN_WAVES;
         SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
         hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, log_dev);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, log_dev);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
@@ -683,10 +776,10 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
     }
     if (knn_idx_out)
         hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order);
     else
         hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order);
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
     return 0;
 }
