@@ -448,10 +448,26 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *
 {
     __shared__ uint32_t part[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int per = (T + 1023) / 1024;
+    // every thread owns `per` consecutive tiles (a multiple of 4: 16-byte loads, several in flight -- one load per trip made this
+    // one-workgroup kernel a chain of load latencies: 51 us for the 32 400 tiles of a 4K frame); the counts stay in registers
+    // between the two passes when they fit (per <= 32: images up to 4K)
+    const int per = ((T + 1023) / 1024 + 3) / 4 * 4;
     const int t0 = tid * per, t1 = min(T, t0 + per);
+    constexpr int KEEP = 32;
+    uint32_t cnt[KEEP];
+    const bool keep = per <= KEEP && (T & 3) == 0;           // (whole uint4 groups: t1 - t0 is a multiple of 4 as well)
     uint32_t s = 0;
-    for (int t = t0; t < t1; t++) s += tile_count[t];
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k += 4) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k < per && t0 + k < t1) v = *reinterpret_cast<const uint4 *>(tile_count + t0 + k);
+            cnt[k] = v.x; cnt[k + 1] = v.y; cnt[k + 2] = v.z; cnt[k + 3] = v.w;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int t = t0; t < t1; t++) s += tile_count[t];
+    }
     uint32_t incl = s;                         // wavefront scan by shuffles, then the 16 wavefront totals
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -467,10 +483,24 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *
     const bool fits = total <= capacity && band_over == 0u;
     if (tid == 0) { header[H_TOTAL] = total; header[H_OVERFLOW] = fits ? 0u : max(total, band_over); }
     uint32_t run = wbase + incl - s;
-    for (int t = t0; t < t1; t++) {
-        const uint32_t c = tile_count[t];
-        ranges[t] = (c && fits) ? make_uint2(run, run + c) : make_uint2(0u, 0u);
-        run += c;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k += 2) {
+            if (k < per && t0 + k < t1) {                     // two ranges = one 16-byte store
+                const uint32_t c0 = cnt[k], c1 = cnt[k + 1];
+                const uint2 r0 = (c0 && fits) ? make_uint2(run, run + c0) : make_uint2(0u, 0u);
+                run += c0;
+                const uint2 r1 = (c1 && fits) ? make_uint2(run, run + c1) : make_uint2(0u, 0u);
+                run += c1;
+                *reinterpret_cast<uint4 *>(ranges + t0 + k) = make_uint4(r0.x, r0.y, r1.x, r1.y);
+            }
+        }
+    } else {
+        for (int t = t0; t < t1; t++) {
+            const uint32_t c = tile_count[t];
+            ranges[t] = (c && fits) ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+            run += c;
+        }
     }
 }
 
