@@ -506,3 +506,58 @@ def test_module_accepts_noncontiguous_and_double_inputs():
     for a, b in zip(want, got64):
         assert torch.equal(a, b.to(a.dtype))
     assert g64["means3D"].dtype == torch.float64 and rel_err(g64["means3D"].cpu().numpy(), gw["means3D"].cpu().numpy()) < 1e-4
+
+
+def test_persistent_outputs_keep_only_what_is_still_background():
+    """SoarRastParams.debug bit 2 through the C ABI, on an image whose width is not a multiple of 4 (scalar fill path) and whose
+    height is not a multiple of the tile size: the same buffers -- handed over full of junk -- rendered three times with the person
+    at different places and finally over another background must equal a render into fresh buffers, every plane bit for bit."""
+    from soar_amd import hip_lib
+    from soar_amd.rasterizer import _Ctx
+    from soar_amd.hip_lib import check, ptr
+    dev = _dev()
+    L = hip_lib.lib()
+    W, H, P = 203, 150, 4000
+    scenes = [S.person_scene(P=P, W=W, H=H, seed=4, azimuth=az, distance=d) for az, d in ((0.3, 3.0), (1.4, 4.5), (-0.8, 2.2), (-0.8, 2.2))]
+    f = dict(dtype=torch.float32, device=dev)
+    nb = C.c_size_t(0)
+    check(L.soar_rast_geometry_bytes(P, 0, C.byref(nb)), "geometry_bytes"); geom_b = nb.value
+    check(L.soar_rast_image_bytes(W, H, C.byref(nb)), "image_bytes"); img_b = nb.value
+    cap = 400_000
+    check(L.soar_rast_binning_bytes(cap, C.byref(nb)), "binning_bytes"); bin_b = nb.value
+
+    def buffers():
+        junk = lambda *shape: torch.full(shape, float("nan"), **f)
+        return dict(geom=torch.full((geom_b,), 0xA5, dtype=torch.uint8, device=dev), img=torch.full((img_b,), 0xA5, dtype=torch.uint8, device=dev),
+                    binning=torch.empty(bin_b, dtype=torch.uint8, device=dev), radii=torch.empty((P,), dtype=torch.int32, device=dev),
+                    color=junk(3, H, W), normal=junk(3, H, W), depth=junk(1, H, W), opac=junk(1, H, W), occ=junk(3, H, W))
+
+    def render(scene, b, bg, keep):
+        st = S.torch_settings(scene, dev)
+        ctx = _Ctx(P, 0, H, W, st.tanfovx, st.tanfovy, st.scale_modifier, 0, False, False, False, False, bg, st.viewmatrix,
+                   st.projmatrix, st.prcppoint, st.patch_bbox, st.campos, st.config, dev)
+        if keep:
+            ctx.params.debug |= 4
+        t = lambda a: torch.as_tensor(a, **f).contiguous()
+        means, cols, opac, scl, rot = t(scene.means3D), t(scene.colors), t(scene.opacities), t(scene.scales), t(scene.rotations)
+        occ_vals = t(np.linspace(0.0, 1.0, P, dtype=np.float32))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        prm = C.byref(ctx.params)
+        check(L.soar_rast_forward_geometry(prm, ptr(means), None, ptr(cols), ptr(opac), ptr(scl), ptr(rot), None, ptr(b["geom"]),
+                                           ptr(b["radii"]), None, stream), "geometry")
+        check(L.soar_rast_forward_render_occ(prm, ptr(b["radii"]), ptr(b["geom"]), ptr(b["binning"]), ptr(b["img"]), cap, ptr(b["color"]),
+                                             ptr(b["normal"]), ptr(b["depth"]), ptr(b["opac"]), ptr(occ_vals), ptr(b["occ"]), stream),
+              "render")
+        torch.cuda.synchronize()
+        return {k: b[k].clone() for k in ("color", "normal", "depth", "opac", "occ")}
+
+    bg0 = torch.tensor([0.2, 0.5, 0.7], **f)
+    bg1 = torch.tensor([0.9, 0.1, 0.3], **f)
+    kept = buffers()
+    for k, scene in enumerate(scenes):
+        bg = bg1 if k == 3 else bg0
+        got = render(scene, kept, bg, keep=k > 0)                 # never on the first call with a buffer
+        want = render(scene, buffers(), bg, keep=False)
+        for name in want:
+            assert torch.equal(got[name], want[name]), (k, name)
+        assert float(want["opac"].max()) > 0.5 and float((want["opac"] < 1e-5).float().mean()) > 0.3   # a person and plenty of background
