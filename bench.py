@@ -50,18 +50,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip
 # stage timer name (soar_prof_stage_name) -> kernels it brackets.  The first kernel of each list is the one whose HBM counters
 # (profiles/*_hbm_traffic.json) are reported as `roofline.traffic` when that stage dominates.
 STAGE_KERNELS = {
-    "preprocess": ["preprocess_kernel"],
+    "preprocess": ["preprocess_kernel", "zero_ranges_kernel"],
     "scan": ["rocprim inclusive_scan (synchronous form / key export only)"],
     "depth_order": ["bucket_sort_kernel", "bucket_count_kernel", "bucket_scatter_kernel"],
-    "tile_ranges": ["bin_count_kernel", "tile_scan_kernel"],
-    "tile_lists": ["bin_tiles_kernel", "tile_order_kernel"],
+    "tile_ranges": ["bin_count_kernel", "tile_scan_kernel", "band_count_kernel", "band_place_kernel"],
+    "tile_lists": ["bin_tiles_kernel", "(its last workgroup builds the tile order)"],
     "render_forward": ["render_forward_kernel"],
-    "render_backward": ["render_backward_slots_kernel"],
+    "render_backward": ["render_backward_slots_kernel", "zero_ranges_kernel"],
     "geometry_backward": ["geometry_backward_kernel"],
-    "lbs_knn_weights": ["knn_cell_kernel"],
+    "lbs_knn_weights": ["knn_cell_kernel", "query_cells_ordered_kernel", "item_cost_kernel + item_order_kernel (with every re-sort)"],
     "lbs_warp_forward": ["warp_forward_kernel"],
     "lbs_warp_backward": ["warp_backward_kernel"],
-    "frame_loss": ["frame_loss_kernel"],
+    "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel"],
 }
 
 

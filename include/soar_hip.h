@@ -199,7 +199,10 @@ int soar_lbs_knn_weights(const float *xyz, int32_t P, const float *verts, int32_
  * training, TS/utils/smpl.py:508-511): build the vertex grid once, query it every optimizer step.
  *   grid_buffer: soar_lbs_knn_grid_bytes(V) bytes of 256-byte aligned device memory, owned by the caller.
  *   query_workspace: soar_lbs_knn_query_bytes(P) bytes, owned by the caller (one per concurrent query / per step plan;
- *   a plan that captures the query in a HIP graph keeps it alive as long as the graph). */
+ *   a plan that captures the query in a HIP graph keeps it alive as long as the graph).  Besides the sort scratch it holds the
+ *   heaviest-first order of the query kernel's work items, rebuilt with every sort: a call that reuses a stored query order
+ *   (soar_lbs_knn_query_ordered, resort = 0) should pass the workspace of the call that sorted (any other one is accepted: the
+ *   items are then taken in place). */
 int soar_lbs_knn_grid_bytes(int32_t V, size_t *bytes);
 int soar_lbs_knn_query_bytes(int32_t P, size_t *bytes);
 int soar_lbs_knn_build_grid(const float *verts, int32_t V, const float *vert_weights, int32_t J, void *grid_buffer,

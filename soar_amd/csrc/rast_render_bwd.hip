@@ -8,7 +8,8 @@
 // to front from the deepest contributor of the wavefront's pixels in staged chunks, four surviving entries per step; the 13
 // gradient terms of a step are summed over the 16 pixels with a transpose-reduce (v_permlane32/16_swap + DPP) and leave as
 // ONE global_atomic_add_f32 wave-instruction into the 64-byte accumulation rows acc[gaussian][16], which
-// geometry_backward_kernel (rast_geom_bwd.hip) consumes.  Details at the kernel below.
+// geometry_backward_kernel (rast_geom_bwd.hip) consumes.  Same small fixed grid with a rank-stride walk of the tile order and the
+// same LDS ring of survivors as the forward kernel (rast_render_fwd.hip).  Details at the kernel below.
 //
 // Two earlier layouts were measured and retired (profiles/README.md, negative results): per-lane entry pointers with
 // ds_add_f32 accumulation rows (2190 us: neighbouring pixels pop the same entry in the same step and the LDS atomics

@@ -11,16 +11,22 @@
 //  * workgroup = one 8x8 pixel quad of a 16x16 tile (4 workgroups per tile), wavefront = one 4x4 pixel block;
 //  * lane = (pixel p = lane >> 2, slot s = lane & 3): the four lanes of a pixel take FOUR consecutive surviving
 //    entries of the list at once.  Each lane evaluates its own alpha (falloff + exp: the long part), then the
-//    running transmittance is carried through the four slots with wavefront-level quad broadcasts (DPP quad_perm), in
+//    running transmittance runs through the four slots as a quad scan (three fused v_mul_f32_dpp, lane k <- lane k - 1), in
 //    exactly the reference's order of multiplications -- including "stop before the entry that would drop T below
 //    1e-4" -- so T, n_contrib and the set of blended entries are those of the sequential loop.  Colour / normal /
 //    depth sums are kept per slot and folded once per pixel at the end;
 //  * the list is staged per workgroup in chunks of 256 entries: thread t gathers the 64-byte record of entry t
 //    (software-pipelined one chunk ahead) into LDS as four float4 arrays; every wavefront then tests its 64-entry
-//    sub-chunks against ITS 4x4 block (lanes = entries, conservative bound splat_may_touch_rect) and only walks the
-//    set bits of the resulting ballot;
-//  * workgroups follow the longest-list-first tile order built by tile_order_kernel (rast_binning.hip), dealt
-//    round-robin to the XCDs with the four quads of a tile on one XCD: the long tiles start first, everywhere.
+//    sub-chunks against ITS 4x4 block (lanes = entries, conservative bound splat_may_touch_rect) and compacts the
+//    survivors' LDS slots, in list order, into a ring of its own (ballot-prefix ranks) that the steps read;
+//  * scalar instructions are kept out of the loops: one SIMD of gfx950 issues a scalar instruction only every ~4 cycles
+//    whatever the number of resident wavefronts (tests/tools/issue_model).  Liveness of a pixel is a 0 / 1 number folded
+//    into alpha, not a predicate (a per-lane bool that lives across the loop is a 64-bit scalar mask merged at every join);
+//  * a fixed grid of 4 x 2048 workgroups walks the longest-list-first tile order of tile_order_block (soar_common.h) with
+//    a rank stride, ranks dealt round-robin to the XCDs with the four quads of a tile on one XCD: the long tiles start
+//    first, everywhere, and the dispatcher never sees the ~29 000 workgroups of tiles without work (~2 ns each).  The
+//    tiles no Gaussian touches are filled with their background values by all workgroups at the end -- unless they
+//    already hold them (SoarRastParams.debug bit 2: same outputs as the previous call).
 #include "soar_common.h"
 
 #include <cstdio>
