@@ -664,7 +664,7 @@ bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_r
 static int bucket_count_for(int32_t P)
 {
     int B = 256;
-    while (B < BKT_MAX && B * 32 < P) B <<= 1;          // ~32 Gaussians per bucket
+    while (B < BKT_MAX && B * 16 < P) B <<= 1;          // ~16 Gaussians per bucket
     return B;
 }
 
