@@ -336,8 +336,13 @@ __device__ __forceinline__ void backward_quad(const BwdArgs &a, const int rank, 
 
 // Same small grid and rank-stride walk of the longest-first tile order as the forward kernel (render_forward_kernel,
 // rast_render_fwd.hip): the tiles behind the first n_work ranks have nothing to differentiate and are never visited.
+#ifdef SOAR_BWD_WPE
+#define SOAR_BWD_OCC __attribute__((amdgpu_waves_per_eu(SOAR_BWD_WPE, 8)))
+#else
+#define SOAR_BWD_OCC
+#endif
 template <bool WIDE>
-__global__ void __launch_bounds__(256) render_backward_slots_kernel(BwdArgs a)
+__global__ void __launch_bounds__(256) SOAR_BWD_OCC render_backward_slots_kernel(BwdArgs a)
 {
     const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;

@@ -24,7 +24,8 @@
 //    into alpha, not a predicate (a per-lane bool that lives across the loop is a 64-bit scalar mask merged at every join);
 //  * a fixed grid of 4 x 2048 workgroups walks the longest-list-first tile order of tile_order_block (soar_common.h) with
 //    a rank stride, ranks dealt round-robin to the XCDs with the four quads of a tile on one XCD: the long tiles start
-//    first, everywhere, and the dispatcher never sees the ~29 000 workgroups of tiles without work (~2 ns each).  The
+//    first, everywhere, and the ~29 000 workgroups of tiles without work (a slot, two loads and ~100 instructions each) are
+//    never launched.  The
 //    tiles no Gaussian touches are filled with their background values by all workgroups at the end -- unless they
 //    already hold them (SoarRastParams.debug bit 2: same outputs as the previous call).
 #include "soar_common.h"
@@ -36,7 +37,10 @@ namespace soar {
 
 namespace {
 
-constexpr int CHUNK = 256;          // list entries staged per workgroup iteration (one per thread)
+#ifndef SOAR_FWD_CHUNK
+#define SOAR_FWD_CHUNK 256
+#endif
+constexpr int CHUNK = SOAR_FWD_CHUNK;   // list entries staged per workgroup iteration (one per thread)
 constexpr int FWD_GRID_RANKS = 2048; // tiles one pass of the grid covers (see render_forward_kernel)
 
 struct FwdArgs {
@@ -388,8 +392,8 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
 // The launch covers the first gridDim.x / 4 ranks of the longest-first tile order, four workgroups (quads) per tile; the
 // ranks are dealt round-robin over the 8 XCDs with the four quads of a tile on one XCD (one L2 serves the tile's records).
 // The grid is much smaller than the tile count: only ~10 % of the tiles of a 1080p frame of one person have any work, and
-// the dispatcher needs ~2 ns per workgroup even for one that exits at once -- four frames in flight paid ~100 us per step
-// for empty workgroups.  Tiles with work beyond the grid (a denser scene) are reached by the rank-stride loop; the tiles no
+// even a workgroup that exits at once costs ~0.6 ns all told (slot, loads, ~100 instructions) -- four frames in flight paid
+// ~100 us per step for empty workgroups.  Tiles with work beyond the grid (a denser scene) are reached by the rank-stride loop; the tiles no
 // Gaussian touches sit behind the first n_work ranks and are filled with their background values, whole tiles, by all
 // workgroups once their blending is done.
 #ifndef SOAR_FWD_WPE
