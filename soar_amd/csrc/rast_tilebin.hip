@@ -98,15 +98,26 @@ bucket_scatter_kernel(int P, int B, const uint32_t *__restrict__ depth_key, uint
         const int b = tid * per + k;
         if (b < B) s += bucket_cnt[b];
     }
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t up = tid >= d ? part[tid - d] : 0u;
+    // inclusive scan over the 1024 threads: wavefront shuffles, then the 16 wavefront totals (two barriers instead of twenty)
+    uint32_t incl = s;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == WAVE - 1) part[wave] = incl;
         __syncthreads();
-        part[tid] += up;
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) wbase += w < wave ? part[w] : 0u;
+        incl += wbase;
+        __syncthreads();
+        part[tid] = incl;                                   // (part[1023] = the total, read below)
         __syncthreads();
     }
-    uint32_t run = part[tid] - s;
+    uint32_t run = incl - s;
     for (int k = 0; k < per; k++) {
         const int b = tid * per + k;
         if (b < B) {
