@@ -239,6 +239,18 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
                            const float *dL_dxyz_out, const float *dL_drot_out,
                            float *dL_dxyz, float *dL_drot, void *stream);
 
+/* The warps of the n frames of one optimizer step, one launch each way (no reference counterpart: the reference warps frame by
+ * frame).  The canonical model (xyz, rot) and the blend weights are shared; joint_mats [n][J][16]; xyz_out / dL_dxyz_out
+ * [n][P][3], rot_out / dL_drot_out [n][P][4] (frame-major).  The backward form returns the SUM over the frames, added in frame
+ * order: dL_dxyz [P][3], dL_drot [P][4]; on the way it can sum up to two more per-frame gradient blocks of the same points
+ * (extra_src[e] = [n][P][extra_width[e]] -> extra_dst[e] = [P][extra_width[e]]; host arrays of device pointers). */
+int soar_lbs_warp_forward_batch(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t n,
+                                int32_t P, int32_t J, float *xyz_out, float *rot_out, void *stream);
+int soar_lbs_warp_backward_sum(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t n,
+                               int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out, float *dL_dxyz,
+                               float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                               const int32_t *extra_width, void *stream);
+
 /* ---- simple-knn distCUDA2 (call sites TS/geometry/surfel_base.py:499-503, gaussian_base.py:585-588):
  *   out[i] = mean of the 3 smallest squared distances from point i to the other points. */
 int soar_dist2_knn3(const float *points, int32_t N, float *out, void *stream);
@@ -370,13 +382,6 @@ int soar_prof_read(int stage, double *total_ms, int64_t *launches);
  *   and write the frame's target-set index ((id mod n_sets), optional) -- frame_ids is a DEVICE array: a captured HIP graph
  *   stays valid for any frames, the host refreshes n_frames integers per step. */
 int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_dev, float *out_dev, void *stream);
-/* soar_sum_frames_when_last: the same sums for up to 8 leaves at once, but enqueued at the END OF EVERY FRAME CHAIN of a step
- *   (each chain on its own stream): one thread draws a ticket from *counter_dev (zeroed by the caller before the chains start);
- *   only the chain that draws the last of n_frames tickets -- by then every other chain's gradient blocks are complete --
- *   performs the sums (in frame order: the result does not depend on which chain finishes last); the others return at once.
- *   src_dev / dst_dev / counts are HOST arrays of n_leaves device pointers / element counts; is_last_dev: one word per chain. */
-int soar_sum_frames_when_last(int32_t n_frames, int32_t n_leaves, const float *const *src_dev, float *const *dst_dev,
-                              const int64_t *counts, uint32_t *counter_dev, uint32_t *is_last_dev, void *stream);
 int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
                             const int32_t *frame_ids_dev, const float *table_dev, float *mats_out_dev,
                             int32_t *set_index_out_dev, void *stream);

@@ -233,37 +233,6 @@ __global__ void __launch_bounds__(256) sum_frames_kernel(int n_frames, size_t co
         out[i] = acc;
     }
 }
-// "the frame chain that finishes last sums": every chain ends with ticket_kernel (one thread draws a ticket from a counter the
-// step's prologue zeroed) and sum_frames_if_last_kernel, which returns at once unless its chain drew the last ticket -- then all
-// the other chains' gradient blocks are complete (their kernels ended before their ticket was drawn) and it sums them in frame
-// order.  No join + extra launch on the caller's stream, and the sum keeps a fixed order whichever chain runs it.
-struct SumLeaves {
-    int n_leaves;
-    const float *src[8];
-    float *dst[8];
-    unsigned long long count[8], start[9];          // start: prefix of ceil(count / 4) work items
-};
-__global__ void ticket_kernel(uint32_t *counter, uint32_t n_frames, uint32_t *is_last)
-{
-    const uint32_t t = atomicAdd(counter, 1u);
-    *is_last = (t + 1u == n_frames) ? 1u : 0u;
-}
-__global__ void __launch_bounds__(256) sum_frames_if_last_kernel(int n_frames, SumLeaves L, const uint32_t *__restrict__ is_last)
-{
-    if (*is_last == 0u) return;
-    const unsigned long long w = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= L.start[L.n_leaves]) return;
-    int leaf = 0;
-    while (leaf + 1 < L.n_leaves && w >= L.start[leaf + 1]) leaf++;
-    const unsigned long long i = (w - L.start[leaf]) * 4, count = L.count[leaf];
-    const float *in = L.src[leaf];
-    float *out = L.dst[leaf];
-    for (unsigned long long j = i; j < min(i + 4, count); j++) {
-        float acc = in[j];
-        for (int f = 1; f < n_frames; f++) acc += in[(size_t)f * count + j];
-        out[j] = acc;
-    }
-}
 // the per-step inputs of a plan: joint transforms of the step's frames gathered from the sequence table, target-set index of
 // every frame.  frame_ids live in device memory (the host only refreshes those few integers per step).
 __global__ void gather_step_inputs_kernel(int n_frames, int num_frames_seq, int floats_per_frame, int n_sets,
@@ -289,31 +258,6 @@ extern "C" int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_
     if (vec) hipLaunchKernelGGL(sum_frames_kernel<4>, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, stream, n_frames, (size_t)count, in_dev, out_dev);
     else hipLaunchKernelGGL(sum_frames_kernel<1>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, n_frames, (size_t)count, in_dev, out_dev);
     SOAR_LAUNCH_OK("sum_frames", stream, 0);
-    return 0;
-}
-
-extern "C" int soar_sum_frames_when_last(int32_t n_frames, int32_t n_leaves, const float *const *src_dev, float *const *dst_dev,
-                                         const int64_t *counts, uint32_t *counter_dev, uint32_t *is_last_dev, void *stream_)
-{
-    using namespace soar;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n_frames <= 0 || n_leaves <= 0 || n_leaves > 8 || !src_dev || !dst_dev || !counts || !counter_dev || !is_last_dev) {
-        set_error("soar_sum_frames_when_last: bad arguments");
-        return 1;
-    }
-    SumLeaves L;
-    L.n_leaves = n_leaves;
-    L.start[0] = 0;
-    for (int k = 0; k < n_leaves; k++) {
-        if (!src_dev[k] || !dst_dev[k] || counts[k] < 0) { set_error("soar_sum_frames_when_last: bad leaf %d", k); return 1; }
-        L.src[k] = src_dev[k]; L.dst[k] = dst_dev[k]; L.count[k] = (unsigned long long)counts[k];
-        L.start[k + 1] = L.start[k] + (L.count[k] + 3) / 4;
-    }
-    hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(1), 0, stream, counter_dev, (uint32_t)n_frames, is_last_dev);
-    const unsigned long long items = L.start[n_leaves];
-    if (items > 0)
-        hipLaunchKernelGGL(sum_frames_if_last_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, n_frames, L, is_last_dev);
-    SOAR_LAUNCH_OK("sum_frames_when_last", stream, 0);
     return 0;
 }
 

@@ -9,6 +9,10 @@
 //  * dist2_knn3_kernel    : simple-knn distCUDA2 semantics (mean of the 3 smallest squared distances, self excluded).
 #include "soar_common.h"
 
+// Products and sums contract to FMAs within one expression only, as written: the same point has to come out bit-identical
+// from the single-frame kernels and from the all-frames ones, whatever each kernel's surroundings let the backend fuse.
+#pragma clang fp contract(on)
+
 namespace soar {
 
 namespace {
@@ -55,7 +59,22 @@ struct WarpArgs {
     float *xyz_out, *rot_out, *pt_mats_out;
     const float *g_xyz_out, *g_rot_out;
     float *g_xyz, *g_rot;
+    // batch of frames (blockIdx.y): the canonical model and the blend weights are shared, joint transforms and outputs per frame
+    size_t mats_stride, xyz_stride, rot_stride;      // floats between two frames (0: one frame)
 };
+
+__device__ __forceinline__ void select_frame(WarpArgs &a)
+{
+    const size_t f = blockIdx.y;
+    if (f == 0) return;
+    a.joint_mats += f * a.mats_stride;
+    if (a.xyz_out) a.xyz_out += f * a.xyz_stride;
+    if (a.rot_out) a.rot_out += f * a.rot_stride;
+    if (a.g_xyz_out) a.g_xyz_out += f * a.xyz_stride;
+    if (a.g_rot_out) a.g_rot_out += f * a.rot_stride;
+    if (a.g_xyz) a.g_xyz += f * a.xyz_stride;
+    if (a.g_rot) a.g_rot += f * a.rot_stride;
+}
 
 constexpr int WARP_THREADS = 256;
 constexpr int WARP_MAXJ = 64;
@@ -63,6 +82,7 @@ constexpr int WARP_MAXJ = 64;
 // blended 3x4 transform of one Gaussian: M[r*4+c] = sum_j w_j * A_j[r][c]; weights via LDS (coalesced tile load).
 // With a.weights == nullptr, a.joint_mats holds one ready-made 4x4 per Gaussian (the pt_mats tensor that
 // SMPL_Guidance.__call__ returns) and is simply loaded.
+__device__ __forceinline__ void blend_frame_matrix(const float *wrow, const float *mats, int J, float M[12]);
 __device__ __forceinline__ void blend_matrix(const WarpArgs &a, float *wtile, int p0, int tid, float M[12])
 {
     const int J = a.J;
@@ -82,43 +102,12 @@ __device__ __forceinline__ void blend_matrix(const WarpArgs &a, float *wtile, in
     __syncthreads();
     for (int t = tid; t < nrows * J; t += WARP_THREADS) wtile[t] = a.weights[(size_t)p0 * J + t];
     __syncthreads();
-    if (tid < nrows) {
-        const float *wrow = wtile + tid * J;           // stride J = 55 floats: odd => conflict-free
-        for (int j = 0; j < J; j++) {
-            const float w = wrow[j];
-            const float *A = a.joint_mats + 16 * j;    // wave-uniform address -> scalar loads
-#pragma unroll
-            for (int c = 0; c < 12; c++) M[c] += w * A[c];
-        }
-    }
+    if (tid < nrows) blend_frame_matrix(wtile + tid * J, a.joint_mats, J, M);      // row stride J = 55 floats: odd => conflict-free
 }
 
-__global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
+// the warp of one Gaussian given its blended 3x4 transform M
+__device__ __forceinline__ void forward_point(const WarpArgs &a, int p, const float M[12], float *xyz_out, float *rot_out)
 {
-    extern __shared__ float wtile[];
-    const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * WARP_THREADS;
-    const int p = p0 + tid;
-    float M[12];
-    blend_matrix(a, wtile, p0, tid, M);
-    if (p >= a.P) return;
-
-    if (a.pt_mats_out && a.weights) {
-        float4 *o = reinterpret_cast<float4 *>(a.pt_mats_out + (size_t)p * 16);
-        // bottom row is the blend of the joints' [0,0,0,1] rows = sum of weights
-        float wsum = 0.f;
-        const float *wrow = wtile + tid * a.J;
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        for (int j = 0; j < a.J; j++) {
-            const float *A = a.joint_mats + 16 * j + 12;
-            b0 += wrow[j] * A[0]; b1 += wrow[j] * A[1]; b2 += wrow[j] * A[2]; wsum += wrow[j] * A[3];
-        }
-        o[0] = make_float4(M[0], M[1], M[2], M[3]);
-        o[1] = make_float4(M[4], M[5], M[6], M[7]);
-        o[2] = make_float4(M[8], M[9], M[10], M[11]);
-        o[3] = make_float4(b0, b1, b2, wsum);
-    }
-
     // position: p' = M3 p + t (+ offsets), then optional axis permutation p' <- p' T
     const float x = a.xyz[3 * p], y = a.xyz[3 * p + 1], z = a.xyz[3 * p + 2];
     float px = M[0] * x + M[1] * y + M[2] * z + M[3];
@@ -150,7 +139,7 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
 #pragma unroll
         for (int k = 0; k < 9; k++) Rp[k] = Rt[k];
     }
-    a.xyz_out[3 * p] = px; a.xyz_out[3 * p + 1] = py; a.xyz_out[3 * p + 2] = pz;
+    xyz_out[3 * p] = px; xyz_out[3 * p + 1] = py; xyz_out[3 * p + 2] = pz;
 
     // q' = normalize(standardize(matrix_to_quaternion(R')))
     float cand[4], a_best, x_best;
@@ -159,12 +148,13 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
     float o[4] = {cand[0] * inv, cand[1] * inv, cand[2] * inv, cand[3] * inv};
     if (o[0] < 0.f) { o[0] = -o[0]; o[1] = -o[1]; o[2] = -o[2]; o[3] = -o[3]; }
     const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]), 1e-12f);
-    reinterpret_cast<float4 *>(a.rot_out)[p] = make_float4(o[0] / nrm, o[1] / nrm, o[2] / nrm, o[3] / nrm);
+    reinterpret_cast<float4 *>(rot_out)[p] = make_float4(o[0] / nrm, o[1] / nrm, o[2] / nrm, o[3] / nrm);
 }
 
-__global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
+__global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
 {
     extern __shared__ float wtile[];
+    select_frame(a);
     const int tid = threadIdx.x;
     const int p0 = blockIdx.x * WARP_THREADS;
     const int p = p0 + tid;
@@ -172,18 +162,41 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
     blend_matrix(a, wtile, p0, tid, M);
     if (p >= a.P) return;
 
+    if (a.pt_mats_out && a.weights) {
+        float4 *o = reinterpret_cast<float4 *>(a.pt_mats_out + (size_t)p * 16);
+        // bottom row is the blend of the joints' [0,0,0,1] rows = sum of weights
+        float wsum = 0.f;
+        const float *wrow = wtile + tid * a.J;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int j = 0; j < a.J; j++) {
+            const float *A = a.joint_mats + 16 * j + 12;
+            b0 += wrow[j] * A[0]; b1 += wrow[j] * A[1]; b2 += wrow[j] * A[2]; wsum += wrow[j] * A[3];
+        }
+        o[0] = make_float4(M[0], M[1], M[2], M[3]);
+        o[1] = make_float4(M[4], M[5], M[6], M[7]);
+        o[2] = make_float4(M[8], M[9], M[10], M[11]);
+        o[3] = make_float4(b0, b1, b2, wsum);
+    }
+
+    forward_point(a, p, M, a.xyz_out, a.rot_out);
+}
+
+// gradient of one Gaussian's canonical position / quaternion given its blended 3x4 transform M and the upstream gradients
+__device__ __forceinline__ void backward_point(const WarpArgs &a, int p, const float M[12], const float *g_xyz_out, const float *g_rot_out,
+                                              float dxyz[3], float4 &drot)
+{
     const float *T = a.axis_perm;
     // ---- position: dL/dp = M3^T (T g)
-    float gx = a.g_xyz_out[3 * p], gy = a.g_xyz_out[3 * p + 1], gz = a.g_xyz_out[3 * p + 2];
+    float gx = g_xyz_out[3 * p], gy = g_xyz_out[3 * p + 1], gz = g_xyz_out[3 * p + 2];
     if (T) {
         const float tx = T[0] * gx + T[1] * gy + T[2] * gz;
         const float ty = T[3] * gx + T[4] * gy + T[5] * gz;
         const float tz = T[6] * gx + T[7] * gy + T[8] * gz;
         gx = tx; gy = ty; gz = tz;
     }
-    a.g_xyz[3 * p + 0] = M[0] * gx + M[4] * gy + M[8] * gz;
-    a.g_xyz[3 * p + 1] = M[1] * gx + M[5] * gy + M[9] * gz;
-    a.g_xyz[3 * p + 2] = M[2] * gx + M[6] * gy + M[10] * gz;
+    dxyz[0] = M[0] * gx + M[4] * gy + M[8] * gz;
+    dxyz[1] = M[1] * gx + M[5] * gy + M[9] * gz;
+    dxyz[2] = M[2] * gx + M[6] * gy + M[10] * gz;
 
     // ---- rotation: recompute the forward
     const float4 qv = reinterpret_cast<const float4 *>(a.rot)[p];
@@ -208,7 +221,7 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
     const float sgn = (o[0] < 0.f) ? -1.f : 1.f;
     float u[4] = {sgn * o[0], sgn * o[1], sgn * o[2], sgn * o[3]};
     const float un = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
-    const float4 gq = reinterpret_cast<const float4 *>(a.g_rot_out)[p];
+    const float4 gq = reinterpret_cast<const float4 *>(g_rot_out)[p];
     float g[4] = {gq.x, gq.y, gq.z, gq.w};
     // through F.normalize: g_u = (g - (g.n) n) / |u|   (eps branch: plain scale)
     float gu[4];
@@ -270,8 +283,121 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
     const float di = j * G[1] + k * G[2] + j * G[3] - 2 * i * G[4] - r * G[5] + k * G[6] + r * G[7] - 2 * i * G[8];
     const float dj = -2 * j * G[0] + i * G[1] + r * G[2] + i * G[3] + k * G[5] - r * G[6] + k * G[7] - 2 * j * G[8];
     const float dk = -2 * k * G[0] - r * G[1] + i * G[2] + r * G[3] - 2 * k * G[4] + j * G[5] + i * G[6] + j * G[7];
-    reinterpret_cast<float4 *>(a.g_rot)[p] =
+    drot =
         make_float4(s * dr - s * s * r * GQ, s * di - s * s * i * GQ, s * dj - s * s * j * GQ, s * dk - s * s * k * GQ);
+}
+
+__global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
+{
+    extern __shared__ float wtile[];
+    select_frame(a);
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * WARP_THREADS;
+    const int p = p0 + tid;
+    float M[12];
+    blend_matrix(a, wtile, p0, tid, M);
+    if (p >= a.P) return;
+
+    float dxyz[3];
+    float4 drot;
+    backward_point(a, p, M, a.g_xyz_out, a.g_rot_out, dxyz, drot);
+    a.g_xyz[3 * p] = dxyz[0]; a.g_xyz[3 * p + 1] = dxyz[1]; a.g_xyz[3 * p + 2] = dxyz[2];
+    reinterpret_cast<float4 *>(a.g_rot)[p] = drot;
+}
+
+// ---- all frames of a step in one launch: a workgroup takes 64 Gaussians, its wavefront k the frames k, k + WARP_NF, ...  The
+//      weights rows of the 64 Gaussians are staged once and serve every frame; the joint transforms are wavefront-uniform
+//      (scalar loads), exactly as in the single-frame kernels -- per wavefront this IS the single-frame kernel's work, with
+//      WARP_NF times the wavefronts in flight to hide its latencies behind.  The backward form adds the frames' gradients in
+//      frame order (through LDS) and can sum other per-frame gradient blocks of the same points on the way.
+constexpr int WARP_NF = WARP_THREADS / WAVE;                 // frames in flight per workgroup
+struct FrameSums {
+    int n_extra;
+    const float *src[2];         // [n][P][width]
+    float *dst[2];               // [P][width]
+    int width[2];
+};
+__device__ __forceinline__ void stage_weight_rows(const WarpArgs &a, float *wtile, int tid, int p0)
+{
+    // p0 * J * 4 bytes is a multiple of 16 (p0 is one of 64): float4 copies, the odd tail of the last workgroup one by one
+    const int count = min(WAVE, a.P - p0) * a.J;
+    const float *src = a.weights + (size_t)p0 * a.J;
+    for (int t = tid; t < count / 4; t += WARP_THREADS) reinterpret_cast<float4 *>(wtile)[t] = reinterpret_cast<const float4 *>(src)[t];
+    if (tid < count % 4) wtile[count - 1 - tid] = src[count - 1 - tid];
+    __syncthreads();
+}
+__device__ __forceinline__ void blend_frame_matrix(const float *wrow, const float *mats, int J, float M[12])
+{
+#pragma unroll
+    for (int c = 0; c < 12; c++) M[c] = 0.f;
+    for (int j = 0; j < J; j++) {
+        const float w = wrow[j];
+        const float *A = mats + 16 * j;                // wavefront-uniform address -> scalar loads
+#pragma unroll
+        for (int c = 0; c < 12; c++) M[c] += w * A[c];
+    }
+}
+__global__ void __launch_bounds__(WARP_THREADS) warp_forward_frames_kernel(WarpArgs a, int n)
+{
+    extern __shared__ float wtile[];
+    const int tid = threadIdx.x, k = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE;
+    const int p0 = blockIdx.x * WAVE, p = p0 + lane;
+    stage_weight_rows(a, wtile, tid, p0);
+    const int f = blockIdx.y * WARP_NF + k;               // no loop over frame groups: a store before the matrix loads of a
+    if (p >= a.P || f >= n) return;                       // later group would turn them into vector loads
+    float M[12];
+    blend_frame_matrix(wtile + lane * a.J, a.joint_mats + (size_t)f * a.mats_stride, a.J, M);
+    forward_point(a, p, M, a.xyz_out + (size_t)f * a.xyz_stride, a.rot_out + (size_t)f * a.rot_stride);
+}
+__global__ void __launch_bounds__(WARP_THREADS) warp_backward_frames_kernel(WarpArgs a, int n, FrameSums fs)
+{
+    extern __shared__ float wtile[];
+    float *red = wtile + WAVE * a.J;                             // [WARP_NF][7][WAVE]
+    const int tid = threadIdx.x, k = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE;
+    const int p0 = blockIdx.x * WAVE, p = p0 + lane;
+    stage_weight_rows(a, wtile, tid, p0);
+    float acc[2] = {0.f, 0.f};                                   // thread tid owns outputs tid and tid + WARP_THREADS of the 7 x 64
+    for (int f0 = 0; f0 < n; f0 += WARP_NF) {
+        const int f = f0 + k;
+        float d[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p < a.P && f < n) {
+            float M[12], dx[3];
+            float4 dq;
+            blend_frame_matrix(wtile + lane * a.J, a.joint_mats + (size_t)f * a.mats_stride, a.J, M);
+            backward_point(a, p, M, a.g_xyz_out + (size_t)f * a.xyz_stride, a.g_rot_out + (size_t)f * a.rot_stride, dx, dq);
+            d[0] = dx[0]; d[1] = dx[1]; d[2] = dx[2]; d[3] = dq.x; d[4] = dq.y; d[5] = dq.z; d[6] = dq.w;
+        }
+        if (f0) __syncthreads();                                 // the previous group's sums have been read
+#pragma unroll
+        for (int c = 0; c < 7; c++) red[(k * 7 + c) * WAVE + lane] = d[c];
+        __syncthreads();
+        // frame order: (((acc + g_f0) + g_f0+1) + g_f0+2) + g_f0+3 (frames past n contribute exact zeros)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int o = tid + h * WARP_THREADS;
+            if (o < 7 * WAVE)
+#pragma unroll
+                for (int kk = 0; kk < WARP_NF; kk++) acc[h] += red[kk * 7 * WAVE + o];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int o = tid + h * WARP_THREADS, c = o / WAVE, q = p0 + o % WAVE;
+        if (o < 7 * WAVE && q < a.P) {
+            if (c < 3) a.g_xyz[3 * q + c] = acc[h];
+            else a.g_rot[4 * q + c - 3] = acc[h];
+        }
+    }
+    if (p < a.P && k >= 1 && k - 1 < fs.n_extra) {                // wavefronts 1, 2: the extra blocks of these points
+        const int e = k - 1, w = fs.width[e];
+        const size_t count = (size_t)a.P * w;
+        for (int c = 0; c < w; c++) {
+            const size_t at = (size_t)p * w + c;
+            float s = fs.src[e][at];
+            for (int f = 1; f < n; f++) s += fs.src[e][(size_t)f * count + at];
+            fs.dst[e][at] = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,6 +480,61 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
     StageTimer timer(ST_LBS_WARP_BWD, stream);
     hipLaunchKernelGGL(warp_backward_kernel, dim3((P + WARP_THREADS - 1) / WARP_THREADS), dim3(WARP_THREADS), lds, stream, a);
     SOAR_LAUNCH_OK("lbs_warp_backward", stream, 0);
+    return 0;
+}
+
+// The warps of the n frames of a step in one launch each way (soar_amd/step_plan.py): the canonical model and the blend weights are
+// shared (the weights tile is staged once per workgroup), joint_mats [n][J][16], xyz_out / dL_dxyz_out [n][P][3],
+// rot_out / dL_drot_out [n][P][4].  The backward form returns the SUM over the frames (frame order), dL_dxyz [P][3] and
+// dL_drot [P][4], and adds up to two more per-frame gradient blocks of the same points on the way (extra_src[e] = [n][P][width],
+// extra_dst[e] = [P][width]).
+int soar_lbs_warp_forward_batch(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t n,
+                                int32_t P, int32_t J, float *xyz_out, float *rot_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n <= 0 || !weights) { set_error("soar_lbs_warp_forward_batch: need n > 0 and blend weights"); return 1; }
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!xyz_out || !rot_out) { set_error("soar_lbs_warp_forward_batch: NULL output"); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats;
+    a.xyz_out = xyz_out; a.rot_out = rot_out;
+    a.mats_stride = (size_t)J * 16; a.xyz_stride = (size_t)P * 3; a.rot_stride = (size_t)P * 4;
+    const size_t lds = sizeof(float) * WAVE * (size_t)J;      // the weights rows of 64 Gaussians
+    StageTimer timer(ST_LBS_WARP_FWD, stream);
+    hipLaunchKernelGGL(warp_forward_frames_kernel, dim3((P + WAVE - 1) / WAVE, (n + WARP_NF - 1) / WARP_NF), dim3(WARP_THREADS), lds, stream, a, (int)n);
+    SOAR_LAUNCH_OK("lbs_warp_forward_batch", stream, 0);
+    return 0;
+}
+
+int soar_lbs_warp_backward_sum(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t n,
+                               int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out, float *dL_dxyz,
+                               float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                               const int32_t *extra_width, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n <= 0 || !weights) { set_error("soar_lbs_warp_backward_sum: need n > 0 and blend weights"); return 1; }
+    if (n_extra < 0 || n_extra > 2 || (n_extra > 0 && (!extra_src || !extra_dst || !extra_width))) {
+        set_error("soar_lbs_warp_backward_sum: at most two extra blocks");
+        return 1;
+    }
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!dL_dxyz_out || !dL_drot_out || !dL_dxyz || !dL_drot) { set_error("soar_lbs_warp_backward_sum: NULL pointer"); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats;
+    a.g_xyz_out = dL_dxyz_out; a.g_rot_out = dL_drot_out; a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
+    a.mats_stride = (size_t)J * 16; a.xyz_stride = (size_t)P * 3; a.rot_stride = (size_t)P * 4;
+    FrameSums fs{};
+    fs.n_extra = n_extra;
+    for (int e = 0; e < n_extra; e++) {
+        if (!extra_src[e] || !extra_dst[e] || extra_width[e] <= 0) { set_error("soar_lbs_warp_backward_sum: bad extra block %d", e); return 1; }
+        fs.src[e] = extra_src[e]; fs.dst[e] = extra_dst[e]; fs.width[e] = extra_width[e];
+    }
+    const size_t lds = sizeof(float) * (WAVE * (size_t)J + WARP_NF * 7 * WAVE);
+    StageTimer timer(ST_LBS_WARP_BWD, stream);
+    hipLaunchKernelGGL(warp_backward_frames_kernel, dim3((P + WAVE - 1) / WAVE), dim3(WARP_THREADS), lds, stream, a, (int)n, fs);
+    SOAR_LAUNCH_OK("lbs_warp_backward_sum", stream, 0);
     return 0;
 }
 

@@ -65,6 +65,8 @@ SIGNATURES = {
                                              _vp, C.c_size_t, _vp]),
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
+    "soar_lbs_warp_forward_batch": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 3),
+    "soar_lbs_warp_backward_sum": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp, _vp, _vp, _vp]),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
     "soar_depth2normal": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "soar_depth2normal_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp,
@@ -97,7 +99,6 @@ SIGNATURES = {
     "soar_prof_stage_name": (C.c_char_p, [C.c_int]),
     "soar_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
-    "soar_sum_frames_when_last": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
 }

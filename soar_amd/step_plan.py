@@ -1,18 +1,21 @@
 """One optimizer step of the per-frame path as an explicit launch plan (no autograd in the loop).
 
 ``AvatarSequence.render_frames`` + ``loss.backward()`` is the general form: any loss, any graph.  For the fixed training
-step of the avatar stage -- KNN blend weights, then for every frame of the batch LBS warp -> rasterize (main + fused
-occlusion pass) -> per-frame image loss -> rasterizer backward -> warp backward, then sum the frames' gradients -- every
-operation is a call of the C ABI whose backward is another call of the C ABI, so the step can be laid out once:
+step of the avatar stage -- KNN blend weights, LBS warp of every frame of the batch, then per frame rasterize (main +
+fused occlusion pass) -> per-frame image loss -> rasterizer backward, then warp backward and the sum of the frames'
+gradients -- every operation is a call of the C ABI whose backward is another call of the C ABI, so the step can be laid
+out once:
 
 * all buffers are allocated when the plan is built (a C3 step holds ~0.8 GB of them; with 288 GB of HBM per GPU nothing
   is recycled between frames);
-* each frame's forward+backward chain is a straight line of ~20 launches on the frame's own HIP stream, independent of
-  the other frames (they only share read-only inputs), captured as ONE HIP graph per frame;
-* a prologue (zero gradients, KNN blend weights) and an epilogue (sum of the per-frame gradients into the flat
-  gradient buffer) run on the caller's stream.
+* each frame's rasterizer forward + loss + backward chain is a straight line of ~17 launches on the frame's own HIP
+  stream, independent of the other frames (they only share read-only inputs), captured as ONE HIP graph per frame;
+* on the caller's stream: a prologue (KNN blend weights; it does not need the reduced gradients of the previous step's
+  second bucket), the warp of ALL frames in one launch (soar_lbs_warp_forward_batch, behind the all-reduces), and after
+  the chains an epilogue of one launch (soar_lbs_warp_backward_sum: the warp backward of all frames, their sum in frame
+  order and the sums of the frames' scale / colour gradients, written straight into the flat gradient buffer).
 
-Per step the host replays 2 + n_frames graphs instead of enqueueing ~105 launches through autograd, and the frames'
+Per step the host replays 3 + n_frames graphs instead of enqueueing ~105 launches through autograd, and the frames'
 chains overlap by ordinary stream semantics (a single captured graph with four branches was measured to be released
 one branch at a time by the graph executor).  The kernels and their results are those of the autograd path
 (``tests/test_plugin_gpu.py::test_step_plan_matches_autograd``).
@@ -62,7 +65,6 @@ class FrameStepPlan:
         # static input: the step's frame ids.  The host stages them in pinned memory, one small asynchronous copy per step;
         # mats / frame_sel follow on the device (soar_gather_step_inputs, first launch of the prologue)
         self.frame_ids = torch.zeros((self.n,), dtype=torch.int32, device=dev)
-        self.done = torch.zeros((1 + self.n,), dtype=torch.int32, device=dev)    # ticket counter of the step + "drew the last ticket" per chain
         self._ids_pinned = torch.zeros((64, self.n), dtype=torch.int32).pin_memory()
         self.mats = torch.empty((self.n, 55, 4, 4), **f)                 # static input: joint transforms of the step's frames
         self.blend_weights = torch.empty((P, seq.lbs_weights.shape[1]), **f)
@@ -75,10 +77,13 @@ class FrameStepPlan:
         check(L.soar_rast_binning_bytes(self.capacity, C.byref(nbytes)), "binning_bytes"); bin_b = nbytes.value
         check(L.soar_rast_backward_workspace_bytes(P, C.byref(nbytes)), "workspace_bytes"); work_b = nbytes.value
         u8 = dict(dtype=torch.uint8, device=dev)
+        # warped model and its upstream gradients of all frames, frame-major: one launch warps (un-warps) the n frames of a step
+        self.xyz_p_all, self.rot_p_all = torch.empty((self.n, P, 3), **f), torch.empty((self.n, P, 4), **f)
+        self.g_means3D_all, self.g_rot_p_all = torch.empty((self.n, P, 3), **f), torch.empty((self.n, P, 4), **f)
         self.views: List[dict] = []
-        for _ in range(self.n):
+        for i in range(self.n):
             v = dict(
-                xyz_p=torch.empty((P, 3), **f), rot_p=torch.empty((P, 4), **f), radii=torch.empty((P,), dtype=torch.int32, device=dev),
+                xyz_p=self.xyz_p_all[i], rot_p=self.rot_p_all[i], radii=torch.empty((P,), dtype=torch.int32, device=dev),
                 color=torch.empty((3, H, W), **f), normal=torch.empty((3, H, W), **f), depth=torch.empty((1, H, W), **f),
                 opac=torch.empty((1, H, W), **f), occ=torch.empty((3, H, W), **f),
                 geom=torch.empty(geom_b, **u8), img=torch.empty(img_b, **u8), binning=torch.empty(bin_b, **u8),
@@ -86,8 +91,8 @@ class FrameStepPlan:
                 gC=torch.empty((3, H, W), **f), gN=torch.empty((3, H, W), **f), gD=torch.empty((1, H, W), **f),
                 gO=torch.empty((1, H, W), **f),
                 g_means2D=torch.empty((P, 3), **f), g_colors=torch.empty((P, 3), **f), g_opacity=torch.empty((P, 1), **f),
-                g_means3D=torch.empty((P, 3), **f), g_cov3D=torch.empty((P, 6), **f), g_scales=torch.empty((P, 3), **f),
-                g_rot_p=torch.empty((P, 4), **f), g_view=torch.empty((4, 4), **f), g_proj=torch.empty((4, 4), **f),
+                g_means3D=self.g_means3D_all[i], g_cov3D=torch.empty((P, 6), **f), g_scales=torch.empty((P, 3), **f),
+                g_rot_p=self.g_rot_p_all[i], g_view=torch.empty((4, 4), **f), g_proj=torch.empty((4, 4), **f),
                 g_campos=torch.empty((3,), **f))
             self.views.append(v)
         # per-frame gradients of the leaves, frame-major so that one reduction per leaf sums them
@@ -151,7 +156,6 @@ class FrameStepPlan:
     def _prologue(self, stream: int, resort: bool = True) -> None:
         L, s = self.L, self.seq
         self._stamp(0, stream)
-        self.done.zero_()                      # (on the prologue's stream: torch's current stream while it is enqueued / captured)
         n_sets = int(self.pool.shape[0]) if self.pool is not None else 0
         check(L.soar_gather_step_inputs(self.n, s.num_frames, 55 * 16, n_sets, ptr(self.frame_ids), ptr(s.cano2live), ptr(self.mats),
                                         ptr(self.frame_sel), stream), "gather_step_inputs")
@@ -163,6 +167,15 @@ class FrameStepPlan:
               "knn_query")
         self._stamp(1, stream)
 
+    def _warp_all(self, stream: int) -> None:
+        """The forward warps of all frames in one launch on the caller's stream (in a chain of its own each was 18 us of kernel
+        behind a fork: 54 us with four chains in flight).  It reads every warped parameter, so it sits behind `flat.wait_all()`
+        -- the KNN prologue in front of it only needs the positions."""
+        L, s = self.L, self.seq
+        J = int(self.blend_weights.shape[1])
+        check(L.soar_lbs_warp_forward_batch(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
+                                            self.P, J, ptr(self.xyz_p_all), ptr(self.rot_p_all), stream), "warp_forward_batch")
+
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
         L, s, v, P, W, H = self.L, self.seq, self.views[i], self.P, self.W, self.H
@@ -171,8 +184,6 @@ class FrameStepPlan:
         mats = self.mats[i]
         xyz, rot = s.xyz.detach(), s.rot.detach()
         self._stamp(2 + 2 * i, stream)
-        check(L.soar_lbs_warp_forward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, None, P, J, ptr(v["xyz_p"]),
-                                      ptr(v["rot_p"]), None, stream), "warp_forward")
         self._stage_stamp(i, 0, stream)
         check(L.soar_rast_forward_geometry(prm, ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
                                            ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream), "geometry")
@@ -202,25 +213,22 @@ class FrameStepPlan:
                                    ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
                                    ptr(v["work"]), v["work"].numel(), stream), "backward")
         self._stage_stamp(i, 4, stream)
-        check(L.soar_lbs_warp_backward(ptr(xyz), ptr(rot), ptr(self.blend_weights), ptr(mats), None, P, J, ptr(v["g_means3D"]),
-                                       ptr(v["g_rot_p"]), ptr(self.g_xyz[i]), ptr(self.g_rot[i]), stream), "warp_backward")
-        # the chain that finishes last sums the frames' gradient blocks into the flat buffer (no join + launch on the caller's stream)
-        fv = self.flat.views
-        blocks = ((self.g_xyz, "xyz"), (self.g_rot, "rot"), (self.g_scales, "scales"), (self.g_colors, "colors"))
-        src = (C.c_void_p * 4)(*[ptr(t) for t, _ in blocks])
-        dst = (C.c_void_p * 4)(*[ptr(fv[name]) for _, name in blocks])
-        cnt = (C.c_int64 * 4)(*[t[0].numel() for t, _ in blocks])
-        check(L.soar_sum_frames_when_last(self.n, 4, src, dst, cnt, ptr(self.done[0:1]), ptr(self.done[1 + i:2 + i]), stream),
-              "sum_frames_when_last")
         self._stamp(3 + 2 * i, stream)
 
-    def _epilogue(self) -> None:
-        """Nothing left to launch: the last frame chain has summed the gradients (soar_sum_frames_when_last); the caller's stream
-        has joined every chain in `_fan_out`."""
-        if self.stamps is not None:
-            cur = torch.cuda.current_stream(self.device).cuda_stream
-            self._stamp(2 * self.n + 2, cur)
-            self._stamp(2 * self.n + 3, cur)
+    def _epilogue(self, stream: int) -> None:
+        """Behind the join, on the caller's stream, ONE launch: the backward warps of all frames, added in frame order, straight
+        into the flat buffer's xyz / rot slices, and the frames' scale / colour gradient blocks summed on the way."""
+        L, s = self.L, self.seq
+        self._stamp(2 * self.n + 2, stream)
+        J = int(self.blend_weights.shape[1])
+        fv = self.flat.views
+        src = (C.c_void_p * 2)(ptr(self.g_scales), ptr(self.g_colors))
+        dst = (C.c_void_p * 2)(ptr(fv["scales"]), ptr(fv["colors"]))
+        width = (C.c_int32 * 2)(3, 3)
+        check(L.soar_lbs_warp_backward_sum(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
+                                           self.P, J, ptr(self.g_means3D_all), ptr(self.g_rot_p_all), ptr(fv["xyz"]), ptr(fv["rot"]),
+                                           2, src, dst, width, stream), "warp_backward_sum")
+        self._stamp(2 * self.n + 3, stream)
 
     # ---- graphs -------------------------------------------------------------------------------------------------------
     def _capture(self) -> None:
@@ -241,6 +249,11 @@ class FrameStepPlan:
                 with torch.cuda.graph(g, stream=cap):
                     self._frame(i, cap.cuda_stream)
                 graphs[i] = g
+            for name, fn in (("warp", self._warp_all), ("epilogue", self._epilogue)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    fn(cap.cuda_stream)
+                graphs[name] = g
         torch.cuda.synchronize(dev)
         self.graphs = graphs
 
@@ -251,8 +264,9 @@ class FrameStepPlan:
             self.flat.wait_bucket(0)
             self._prologue(main.cuda_stream, self.steps % self.RESORT_EVERY == 0)
             self.flat.wait_all()
+            self._warp_all(main.cuda_stream)
             self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
-            self._epilogue()
+            self._epilogue(main.cuda_stream)
         self.steps += 1
         # every later forward blend of a chain writes the same image buffer and output planes again, with the same background:
         # tiles that stay empty keep their pixels (SoarRastParams.debug bit 2, include/soar_hip.h)
@@ -308,8 +322,9 @@ class FrameStepPlan:
         self.flat.wait_bucket(0)
         self.graphs["prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"].replay()
         self.flat.wait_all()
+        self.graphs["warp"].replay()
         self._fan_out(main, lambda i, s: self.graphs[i].replay())
-        self._epilogue()
+        self.graphs["epilogue"].replay()
         self.steps += 1
         return self.losses
 

@@ -83,6 +83,59 @@ def test_warp_ragged_and_empty():
     assert p.shape == (0, 3) and q.shape == (0, 4)
 
 
+@pytest.mark.parametrize("n,P", [(1, 300), (3, 257), (4, 3000), (6, 1001)])
+def test_warp_of_all_frames_in_one_launch_is_the_per_frame_warp(n, P):
+    """soar_lbs_warp_forward_batch / soar_lbs_warp_backward_sum (the step plan's forms: every frame of a step in one launch, the
+    backward one adding the frames' gradients in frame order and summing two more per-frame blocks on the way) against the
+    per-frame entry points, bit for bit."""
+    from soar_amd import hip_lib
+    L = hip_lib.lib()
+    ptr = hip_lib.ptr
+    s, bm, cano2live = _setup(P=P, seed=3, V=2048)
+    gen = torch.Generator().manual_seed(11)
+    w = lo.query_weights(s.xyz, bm.v_template, bm.lbs_weights).to(DEV).contiguous()
+    J = w.shape[1]
+    mats = torch.stack([cano2live + 0.01 * k * torch.randn(cano2live.shape, generator=gen) for k in range(n)]).to(DEV).contiguous()
+    xyz = s.xyz.to(DEV).contiguous()
+    rot = (s.rot * (0.5 + torch.rand(P, 1, generator=gen))).to(DEV).contiguous()
+    g_p = torch.randn(n, P, 3, generator=gen).to(DEV)
+    g_q = torch.randn(n, P, 4, generator=gen).to(DEV)
+    extra = [torch.randn(n, P, 3, generator=gen).to(DEV), torch.randn(n, P, 1, generator=gen).to(DEV)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    p_all = torch.full((n, P, 3), float("nan"), device=DEV)
+    q_all = torch.full((n, P, 4), float("nan"), device=DEV)
+    assert L.soar_lbs_warp_forward_batch(ptr(xyz), ptr(rot), ptr(w), ptr(mats), n, P, J, ptr(p_all), ptr(q_all), stream) == 0
+    d_p = torch.full((P, 3), float("nan"), device=DEV)
+    d_q = torch.full((P, 4), float("nan"), device=DEV)
+    sums = [torch.full((P, 3), float("nan"), device=DEV), torch.full((P, 1), float("nan"), device=DEV)]
+    src = torch.tensor([e.data_ptr() for e in extra], dtype=torch.int64)
+    dst = torch.tensor([e.data_ptr() for e in sums], dtype=torch.int64)
+    width = torch.tensor([3, 1], dtype=torch.int32)
+    assert L.soar_lbs_warp_backward_sum(ptr(xyz), ptr(rot), ptr(w), ptr(mats), n, P, J, ptr(g_p), ptr(g_q), ptr(d_p), ptr(d_q),
+                                        2, src.data_ptr(), dst.data_ptr(), width.data_ptr(), stream) == 0
+    want_dp = torch.zeros(P, 3, device=DEV)
+    want_dq = torch.zeros(P, 4, device=DEV)
+    for f in range(n):
+        p_f = torch.empty(P, 3, device=DEV)
+        q_f = torch.empty(P, 4, device=DEV)
+        assert L.soar_lbs_warp_forward(ptr(xyz), ptr(rot), ptr(w), ptr(mats[f]), None, None, P, J, ptr(p_f), ptr(q_f), None, stream) == 0
+        assert torch.equal(p_all[f], p_f) and torch.equal(q_all[f], q_f), f
+        dp_f = torch.empty(P, 3, device=DEV)
+        dq_f = torch.empty(P, 4, device=DEV)
+        assert L.soar_lbs_warp_backward(ptr(xyz), ptr(rot), ptr(w), ptr(mats[f]), None, P, J, ptr(g_p[f]), ptr(g_q[f]), ptr(dp_f),
+                                        ptr(dq_f), stream) == 0
+        want_dp = want_dp + dp_f
+        want_dq = want_dq + dq_f
+    torch.cuda.synchronize()
+    assert torch.equal(d_p, want_dp) and torch.equal(d_q, want_dq)
+    for e, got in zip(extra, sums):
+        want = e[0].clone()
+        for f in range(1, n):
+            want = want + e[f]
+        assert torch.equal(got, want)
+
+
 def test_dist2_knn3_matches_oracle():
     from soar_amd import lbs
     gen = torch.Generator().manual_seed(3)

@@ -597,3 +597,18 @@ def test_masked_l1_and_cos_loss_kernels(shape):
     assert torch.isnan(masked_l1(a.to(DEV), b.to(DEV), torch.zeros(H, W, dtype=torch.bool, device=DEV)))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         masked_l1(a, b, m)
+
+
+@pytest.mark.parametrize("n,count", [(1, 7), (4, 300000), (3, 100001)])
+def test_sum_frames_adds_in_frame_order(n, count):
+    """soar_sum_frames: the per-frame gradient blocks of one leaf summed in frame order (vector and scalar forms)."""
+    from soar_amd import hip_lib
+    L = hip_lib.lib()
+    x = torch.randn(n, count, device=DEV)
+    out = torch.full((count,), float("nan"), device=DEV)
+    assert L.soar_sum_frames(n, count, hip_lib.ptr(x), hip_lib.ptr(out), torch.cuda.current_stream().cuda_stream) == 0
+    want = x[0].clone()
+    for f in range(1, n):
+        want = want + x[f]
+    assert torch.equal(out, want)
+    assert L.soar_sum_frames(0, count, hip_lib.ptr(x), hip_lib.ptr(out), None) != 0
