@@ -365,6 +365,21 @@ int soar_normal2curv(int32_t W, int32_t H, const float *normal, const uint8_t *m
 int soar_normal2curv_backward(int32_t W, int32_t H, const float *normal, const uint8_t *mask, const float *dL_dcurv,
                               float *dL_dnormal, void *stream);
 
+/* soar_view_finish[_backward]: everything DiffGaussian.forward does to a view behind the rasterizer
+ *   (TS/renderer/diff_gaussian_rasterizer.py:292-303) in one launch each way -- mask = opac > 1e-5;
+ *   normal_out = (normal * (1,-1,-1) + 1) / 2 with gradient inside the mask only (the torch.where of :294);
+ *   curv = normal2curv(normal * (1,-1,-1), mask); pred_normal = (depth2normal(depth, mask) * (1,-1,-1) + 1) / 2 -- the same
+ *   values as the separate entry points above give.  prcppoint_dev: the camera's principal point, 2 floats in DEVICE memory
+ *   (no host read of a device tensor per frame).  Backward: each incoming gradient may be NULL; dL_ddepth_direct is the
+ *   gradient that reaches the depth image itself; the result is ONE block [4][H][W] = dL/dnormal [3] then dL/ddepth [1]. */
+int soar_view_finish(int32_t W, int32_t H, const float *normal, const float *depth, const float *opac,
+                     const float *prcppoint_dev, float focal_k00, float focal_k11, float *normal_out, float *curv_out,
+                     float *pred_normal_out, void *stream);
+int soar_view_finish_backward(int32_t W, int32_t H, const float *normal, const float *depth, const float *opac,
+                              const float *prcppoint_dev, float focal_k00, float focal_k11, const float *dL_dnormal_out,
+                              const float *dL_dcurv, const float *dL_dpred_normal, const float *dL_ddepth_direct,
+                              float *dL_dnormal_and_depth, void *stream);
+
 /* ---- per-stage timing (no reference counterpart; used by bench.py for the roofline figure) ----
  * When enabled, every kernel stage is bracketed by two hipEvents recorded on the launch stream.
  * soar_prof_read synchronises the pending events and returns the accumulated device time and launch count of

@@ -135,6 +135,101 @@ __global__ void __launch_bounds__(256) normal2curv_kernel(N2CArgs a)
     }
 }
 
+// ---- everything the renderer plugin does to a view behind the rasterizer (TS/renderer/diff_gaussian_rasterizer.py:292-303)
+//      in one pass each way: mask = opac > 1e-5;  normal' = (normal * (1,-1,-1) + 1) / 2 (gradient only inside the mask);
+//      curv = normal2curv(normal * (1,-1,-1), mask) -- the sign flips cancel inside the absolute values --;
+//      pred_normal = (depth2normal(depth, mask) * (1,-1,-1) + 1) / 2.  The principal point is read from device memory.
+struct ViewArgs {
+    int W, H;
+    float inv_k00, inv_k11;
+    const float *prcp;             // device, 2 floats
+    const float *normal, *depth, *opac;
+    float *normal_out, *curv_out, *pred_out;                                   // forward
+    const float *g_normal_out, *g_curv, *g_pred, *g_depth_direct;              // backward in (each may be null)
+    float *g_normal, *g_depth;                                                 // backward out, zero-filled before the launch
+};
+__device__ __forceinline__ Stencil stencil_of_opac(int x, int y, int W, int H, const float *opac)
+{
+    Stencil s;
+    const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    s.ip = y * W + x; s.iu = yu * W + x; s.ib = yb * W + x; s.il = y * W + xl; s.ir = y * W + xr;
+    s.mp = opac[s.ip] > 1e-5f ? 1.f : 0.f; s.mu = opac[s.iu] > 1e-5f ? 1.f : 0.f; s.ml = opac[s.il] > 1e-5f ? 1.f : 0.f;
+    s.mb = opac[s.ib] > 1e-5f ? 1.f : 0.f; s.mr = opac[s.ir] > 1e-5f ? 1.f : 0.f;
+    return s;
+}
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) view_finish_kernel(ViewArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const Stencil s = stencil_of_opac(x, y, a.W, a.H, a.opac);
+    const size_t hw = (size_t)a.W * a.H;
+    const float cxW = a.prcp[0] * a.W, cyH = a.prcp[1] * a.H;
+    // ---- curvature of the normal image
+    auto nat = [&](int i) -> V3 { return {a.normal[i], a.normal[hw + i], a.normal[2 * hw + i]}; };
+    const V3 nc_raw = nat(s.ip);
+    const V3 nc = nc_raw * s.mp;
+    const V3 lap = ((nat(s.iu) - nc) * s.mu + (nat(s.il) - nc) * s.ml + (nat(s.ib) - nc) * s.mb + (nat(s.ir) - nc) * s.mr) * s.mp;
+    // ---- normal of the depth image (same order of operations as depth2normal_kernel)
+    auto ray = [&](int idx) -> V3 {
+        const int px = idx % a.W, py = idx / a.W;
+        return {((float)px - cxW) * a.inv_k00, ((float)py - cyH) * a.inv_k11, 1.f};
+    };
+    auto point = [&](int idx) -> V3 {
+        const float d = a.depth[idx];
+        const int px = idx % a.W, py = idx / a.W;
+        return {(((float)px - cxW) * d) * a.inv_k00, (((float)py - cyH) * d) * a.inv_k11, d};
+    };
+    const V3 c = point(s.ip) * s.mp;
+    const V3 u = (point(s.iu) - c) * s.mu, l = (point(s.il) - c) * s.ml;
+    const V3 b = (point(s.ib) - c) * s.mb, r = (point(s.ir) - c) * s.mr;
+    const V3 N = cross(u, l) + cross(r, u) + cross(b, r) + cross(l, b);
+    const float len = sqrtf(dot(N, N)), inv = 1.f / fmaxf(len, 1e-12f);
+    const V3 n = N * inv;
+    if (!BACKWARD) {
+        a.normal_out[s.ip] = (nc_raw.x + 1.f) * 0.5f;
+        a.normal_out[hw + s.ip] = (-nc_raw.y + 1.f) * 0.5f;
+        a.normal_out[2 * hw + s.ip] = (-nc_raw.z + 1.f) * 0.5f;
+        a.curv_out[s.ip] = fabsf(lap.x) + fabsf(lap.y) + fabsf(lap.z);
+        a.pred_out[s.ip] = (n.x * s.mp + 1.f) * 0.5f;
+        a.pred_out[hw + s.ip] = (-(n.y * s.mp) + 1.f) * 0.5f;
+        a.pred_out[2 * hw + s.ip] = (-(n.z * s.mp) + 1.f) * 0.5f;
+        return;
+    }
+    if (a.g_depth_direct) atomicAdd(&a.g_depth[s.ip], a.g_depth_direct[s.ip]);
+    if (a.g_normal_out && s.mp != 0.f) {
+        atomicAdd(&a.g_normal[s.ip], a.g_normal_out[s.ip] * 0.5f);
+        atomicAdd(&a.g_normal[hw + s.ip], -(a.g_normal_out[hw + s.ip] * 0.5f));
+        atomicAdd(&a.g_normal[2 * hw + s.ip], -(a.g_normal_out[2 * hw + s.ip] * 0.5f));
+    }
+    if (a.g_curv) {
+        const float g = a.g_curv[s.ip] * s.mp;
+        auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+        const V3 ds = {g * sgn(lap.x), g * sgn(lap.y), g * sgn(lap.z)};
+        const float wc = -(s.mu + s.ml + s.mb + s.mr) * s.mp;
+        const int idx[5] = {s.ip, s.iu, s.il, s.ib, s.ir};
+        const float w[5] = {wc, s.mu, s.ml, s.mb, s.mr};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (w[k] == 0.f) continue;
+            atomicAdd(&a.g_normal[idx[k]], ds.x * w[k]);
+            atomicAdd(&a.g_normal[hw + idx[k]], ds.y * w[k]);
+            atomicAdd(&a.g_normal[2 * hw + idx[k]], ds.z * w[k]);
+        }
+    }
+    if (a.g_pred && len > 1e-12f) {                      // (see depth2normal_kernel for the pixels whose N vanishes)
+        const V3 g = {a.g_pred[s.ip] * 0.5f * s.mp, -(a.g_pred[hw + s.ip] * 0.5f) * s.mp, -(a.g_pred[2 * hw + s.ip] * 0.5f) * s.mp};
+        const V3 gN = (g - n * dot(n, g)) * inv;
+        const V3 du = cross(l - r, gN) * s.mu, dl = cross(b - u, gN) * s.ml, db = cross(r - l, gN) * s.mb, dr = cross(u - b, gN) * s.mr;
+        const V3 dc = (du + dl + db + dr) * -1.f;
+        atomicAdd(&a.g_depth[s.ip], dot(ray(s.ip), dc) * s.mp);
+        atomicAdd(&a.g_depth[s.iu], dot(ray(s.iu), du));
+        atomicAdd(&a.g_depth[s.il], dot(ray(s.il), dl));
+        atomicAdd(&a.g_depth[s.ib], dot(ray(s.ib), db));
+        atomicAdd(&a.g_depth[s.ir], dot(ray(s.ir), dr));
+    }
+}
+
 dim3 pix_grid(int W, int H) { return dim3((W + 31) / 32, (H + 7) / 8); }
 
 }  // namespace
@@ -195,5 +290,47 @@ extern "C" int soar_normal2curv_backward(int32_t W, int32_t H, const float *norm
     StageTimer timer(ST_POSTOPS, stream);
     hipLaunchKernelGGL(normal2curv_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("normal2curv_backward", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_view_finish(int32_t W, int32_t H, const float *normal, const float *depth, const float *opac,
+                                const float *prcppoint_dev, float focal_k00, float focal_k11, float *normal_out, float *curv_out,
+                                float *pred_normal_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !normal || !depth || !opac || !prcppoint_dev || !normal_out || !curv_out || !pred_normal_out) {
+        set_error("soar_view_finish: bad arguments");
+        return 1;
+    }
+    ViewArgs a = {};
+    a.W = W; a.H = H; a.inv_k00 = 1.f / focal_k00; a.inv_k11 = 1.f / focal_k11; a.prcp = prcppoint_dev;
+    a.normal = normal; a.depth = depth; a.opac = opac;
+    a.normal_out = normal_out; a.curv_out = curv_out; a.pred_out = pred_normal_out;
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(view_finish_kernel<false>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("view_finish", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_view_finish_backward(int32_t W, int32_t H, const float *normal, const float *depth, const float *opac,
+                                         const float *prcppoint_dev, float focal_k00, float focal_k11, const float *dL_dnormal_out,
+                                         const float *dL_dcurv, const float *dL_dpred_normal, const float *dL_ddepth_direct,
+                                         float *dL_dnormal_and_depth, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (W <= 0 || H <= 0 || !normal || !depth || !opac || !prcppoint_dev || !dL_dnormal_and_depth) {
+        set_error("soar_view_finish_backward: bad arguments");
+        return 1;
+    }
+    const size_t hw = (size_t)W * H;
+    ViewArgs a = {};
+    a.W = W; a.H = H; a.inv_k00 = 1.f / focal_k00; a.inv_k11 = 1.f / focal_k11; a.prcp = prcppoint_dev;
+    a.normal = normal; a.depth = depth; a.opac = opac;
+    a.g_normal_out = dL_dnormal_out; a.g_curv = dL_dcurv; a.g_pred = dL_dpred_normal; a.g_depth_direct = dL_ddepth_direct;
+    a.g_normal = dL_dnormal_and_depth; a.g_depth = dL_dnormal_and_depth + 3 * hw;
+    SOAR_HIP_OK(hipMemsetAsync(dL_dnormal_and_depth, 0, sizeof(float) * 4 * hw, stream));
+    StageTimer timer(ST_POSTOPS, stream);
+    hipLaunchKernelGGL(view_finish_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("view_finish_backward", stream, 0);
     return 0;
 }

@@ -73,6 +73,9 @@ SIGNATURES = {
                                              _vp]),
     "soar_normal2curv": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "soar_normal2curv_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "soar_view_finish": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "soar_view_finish_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
+                                            _vp, _vp]),
     "soar_ssim_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_ssim": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_densify_stats": (C.c_int, [C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

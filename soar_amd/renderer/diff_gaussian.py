@@ -15,6 +15,7 @@ per-Gaussian matrices.  Both rasterizations run through ``soar_amd.rasterizer``.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -26,7 +27,11 @@ from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rast
 from . import registry
 from .batch import GaussianBatchRenderer
 from .cameras import device_constant
+from .fused_view import render_view
 from .postops import depth2normal, normal2curv
+
+# SOAR_FUSED_VIEW=0: always take the composed path (separate autograd ops), e.g. to compare the two
+FUSED_VIEW = os.environ.get("SOAR_FUSED_VIEW", "1") != "0"
 
 _DIR2VEC = {"+x": (1, 0, 0), "+y": (0, 1, 0), "+z": (0, 0, 1), "-x": (-1, 0, 0), "-y": (0, -1, 0), "-z": (0, 0, -1)}
 
@@ -38,7 +43,9 @@ def axis_permutation(dirs: str, device) -> torch.Tensor:
         if d not in _DIR2VEC:
             raise ValueError(f"Invalid direction: {d}")
         T[:, i] = _DIR2VEC[d]
-    return torch.from_numpy(T).float().to(device)
+    if torch.device(device).type == "cpu":
+        return torch.from_numpy(T).float()
+    return device_constant(T.reshape(-1), device).reshape(3, 3)          # one host-to-device copy per distinct matrix, not per view
 
 
 def transform_point_cloud(xyz: torch.Tensor, dirs: str):
@@ -94,6 +101,32 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
             _, mat, _ = guide(points, idx=idx, zero_out=True) if zero_out else guide(points, idx=idx)
         return lbs.lbs_warp(points, rot, None, mat[0].detach(), offsets, axis_perm)
 
+    def _forward_fused(self, pc, cam, bg_color, scaling_modifier, points, rot, offsets, axis_perm, attribute_color,
+                       attribute_scale, zero_out, kwargs):
+        """The whole view as one autograd node (soar_amd/renderer/fused_view.py): full patch, fused occlusion pass, fixed
+        camera.  Same outputs as the composed path below."""
+        guide = pc.smpl_guidance
+        idx, a_smpl = kwargs.get("gt_index"), kwargs.get("gt_a_smpl")
+        with torch.no_grad():
+            mats = guide.joint_mats(smpl_parms_in=a_smpl, idx=None if a_smpl is not None else idx, zero_out=zero_out)
+            w = guide.blend_weights(points)
+        # a leaf whose gradient is the screen-space mean gradient used by densification (:155-164)
+        screenspace_points = torch.zeros((points.shape[0], 3), dtype=points.dtype, device=points.device, requires_grad=True)
+        H, W = int(cam.image_height), int(cam.image_width)
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+            patch_bbox=cam.random_patch(float("inf"), float("inf")), prcppoint=cam.prcppoint, sh_degree=pc.active_sh_degree,
+            campos=cam.camera_center, prefiltered=False, render_front=False, sort_descending=False, debug=False, config=pc.config)
+        (image, normal, depth, pred_normal, opac, occ, curv, radii) = render_view(
+            points, rot, pc.get_colors if self.cfg.use_explicit else attribute_color,
+            pc.get_scaling if self.cfg.use_explicit else attribute_scale, screenspace_points, pc.get_occ, w, mats, offsets,
+            axis_perm, rs, cam)
+        return {
+            "render": image, "normal": normal, "depth": depth, "pred_normal": pred_normal, "mask": opac, "occ": occ, "curv": curv,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+        }
+
     def forward(self, viewpoint_camera, bg_color: torch.Tensor, patch_size: list = [float("inf"), float("inf")],
                 scaling_modifier=1.0, override_color=None, gt=False, render_front=True, stage=0, **kwargs):
         """Render one view.  Background tensor (bg_color) must be on the GPU."""
@@ -104,14 +137,26 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         fields = pc.attribute_field(points.detach()) if not gt else pc.attribute_field(points.detach(), z=None)
         attribute_color, attribute_scale, attribute_offsets = fields["shs"], fields["scales"], fields["offsets"]
         offsets = attribute_offsets if self.cfg.offset else None
-        if not gt:
-            # SDS pose views: global orientation / translation zeroed and the "+z,+x,+y" axis permutation (:77-114)
-            T = axis_permutation("+z,+x,+y", points.device)
-            points, rot = self._warp(pc, points, rot, offsets, T, True, kwargs)
-        else:
-            points, rot = self._warp(pc, points, rot, offsets, None, False, kwargs)     # video frame (:116-149)
-            if not self.training:
-                bg_color = torch.ones_like(bg_color)
+        if gt and not self.training:
+            bg_color = torch.ones_like(bg_color)
+        # SDS pose views: global orientation / translation zeroed and the "+z,+x,+y" axis permutation (:77-114);
+        # video frames (gt): the frame's pose as it is (:116-149)
+        axis_perm = None if gt else axis_permutation("+z,+x,+y", points.device)
+
+        full_patch = patch_size[0] >= viewpoint_camera.image_height and patch_size[1] >= viewpoint_camera.image_width
+        cam_leaf = any(getattr(t, "requires_grad", False) for t in (viewpoint_camera.world_view_transform,
+                                                                    viewpoint_camera.full_proj_transform,
+                                                                    viewpoint_camera.camera_center))
+        # The reference hands `pc.get_occ.repeat(1, 3)` UNDETACHED to the occlusion pass (:280-291): `rendered_occ` carries
+        # gradient to the occlusion parameter (loss_occ, TS/system/gaussian_surfel_mvdream.py:412-417).  The fused blend
+        # produces the occlusion image without a backward, so it is only taken when no such gradient can be asked for.
+        occ_needs_grad = torch.is_grad_enabled() and bool(getattr(pc.get_occ, "requires_grad", False))
+        guide = pc.smpl_guidance
+        fused_blend = render_front and full_patch and not cam_leaf and not occ_needs_grad
+        if fused_blend and FUSED_VIEW and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights"):
+            return self._forward_fused(pc, viewpoint_camera, bg_color, scaling_modifier, points, rot, offsets, axis_perm,
+                                       attribute_color, attribute_scale, not gt, kwargs)
+        points, rot = self._warp(pc, points, rot, offsets, axis_perm, not gt, kwargs)
 
         # zero tensor whose gradient is the screen-space mean gradient used by densification (:155-164)
         screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device="cuda") + 0
@@ -139,15 +184,7 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         colors_precomp = pc.get_colors if self.cfg.use_explicit else attribute_color
         ones = torch.ones_like(opacity)
 
-        full_patch = patch_size[0] >= viewpoint_camera.image_height and patch_size[1] >= viewpoint_camera.image_width
-        cam_leaf = any(getattr(t, "requires_grad", False) for t in (viewpoint_camera.world_view_transform,
-                                                                    viewpoint_camera.full_proj_transform,
-                                                                    viewpoint_camera.camera_center))
-        # The reference hands `pc.get_occ.repeat(1, 3)` UNDETACHED to the occlusion pass (:280-291): `rendered_occ` carries
-        # gradient to the occlusion parameter (loss_occ, TS/system/gaussian_surfel_mvdream.py:412-417).  The fused blend
-        # produces the occlusion image without a backward, so it is only taken when no such gradient can be asked for.
-        occ_needs_grad = torch.is_grad_enabled() and bool(getattr(pc.get_occ, "requires_grad", False))
-        if render_front and full_patch and not cam_leaf and not occ_needs_grad:
+        if fused_blend:
             # main pass sorted front-to-back and both passes on the same (full) patch: the occlusion pass (:193-211,
             # :281-291) is a subsequence of the main one and is blended in the same kernel launch
             (rendered_image, rendered_normal, rendered_depth, rendered_opac, radii, rendered_occ) = rasterize_views(

@@ -127,6 +127,42 @@ def test_plugin_video_frame_matches_oracle_chain(world):
         t.grad = None
 
 
+@pytest.mark.parametrize("gt", [True, False])
+def test_fused_view_matches_the_composed_path(world, gt):
+    """The view as ONE autograd node (soar_amd/renderer/fused_view.py: warp -> rasterize -> soar_view_finish, and back) against
+    the same view composed from the separate autograd ops: identical images, gradients to float-atomic order."""
+    from soar_amd.renderer import diff_gaussian as dg
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    gen = torch.Generator().manual_seed(3)
+    wts = {k: torch.randn(c, H, W, generator=gen).to(DEV) for k, c in (("render", 3), ("normal", 3), ("depth", 1), ("pred_normal", 3),
+                                                                       ("mask", 1), ("curv", 1))}
+    res = {}
+    for fused in (True, False):
+        dg.FUSED_VIEW = fused
+        try:
+            out = w.renderer(w.cam, bg, gt=gt, gt_index=5)
+        finally:
+            dg.FUSED_VIEW = True
+        sum(((out[k] * wts[k]).sum() for k in wts)).backward()
+        leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color, out["viewspace_points"])
+        res[fused] = ({k: v.detach().clone() for k, v in out.items()}, [t.grad.clone() for t in leaves])
+        for t in leaves[:4]:
+            t.grad = None
+    (fo, fg), (co, cg) = res[True], res[False]
+    for k in fo:
+        assert torch.equal(fo[k], co[k]), k
+    for a, b, name in zip(fg, cg, ("xyz", "rot", "scale", "color", "means2D")):
+        assert torch.isfinite(a).all() and b.abs().max() > 0, name
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), name
+    # unused outputs: no gradient planes are made up for them
+    out = w.renderer(w.cam, bg, gt=gt, gt_index=5)
+    out["render"].mean().backward()
+    assert torch.isfinite(w.pc._xyz.grad).all() and w.pc._xyz.grad.abs().sum() > 0
+    for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
+        t.grad = None
+
+
 def test_plugin_occlusion_image_carries_gradient_to_the_occ_parameter(world):
     """The reference passes `pc.get_occ.repeat(1,3)` undetached (:280-291) and trains `_occ` with
     loss_occ = (1 - comp_occ[mask]).mean() (gaussian_surfel_mvdream.py:412-417): d loss / d _occ must be the occlusion pass's
