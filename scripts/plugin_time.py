@@ -7,7 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from soar_amd import synthetic as syn
-from soar_amd.losses import cos_loss, masked_l1, recon_loss
+from soar_amd.losses import avatar_stage_loss, cos_loss, masked_l1, recon_loss
 from soar_amd.renderer import cameras, registry
 from soar_amd.smpl_guidance import SMPLGuidance
 import soar_amd.renderer  # noqa: F401
@@ -38,7 +38,9 @@ def step(f, with_loss=True):
     out = renderer(cam, bg, gt=True, gt_index=f)
     t = syn.pool_targets(pool, f)
     mask = t["mask"][0] > 0.5
-    if with_loss:
+    if with_loss == "fused":
+        loss = avatar_stage_loss(out, t["color"], t["mask"], t["normal"] * 0.5 + 0.5, mask, lambda_depth=0.01, lambda_curv=0.01)
+    elif with_loss:
         loss = (recon_loss(out["render"], t["color"], t["color"], mask) + 0.2 * cos_loss(out["normal"], t["normal"] * 0.5 + 0.5, mask)
                 + masked_l1(out["mask"], t["mask"]) + 0.01 * out["depth"].mean() + 0.01 * out["curv"].mean())
     else:
@@ -47,19 +49,36 @@ def step(f, with_loss=True):
     opt.step()
 
 
-for name, wl in (("render + avatar-stage losses (SSIM, masked L1, cosine) + backward + Adam", True), ("render + mean losses + backward + Adam", False)):
+VARIANTS = (("render + avatar-stage losses (SSIM, masked L1, cosine) composed the reference's way + backward + Adam", True),
+            ("render + losses.avatar_stage_loss (the same terms as one autograd node) + backward + Adam", "fused"),
+            ("render + mean losses + backward + Adam", False))
+if os.environ.get("SOAR_PLUGIN_TIME_IMPORT_ONLY") == "1":       # scripts/plugin_host_split.py reuses the scene
+    VARIANTS = ()
+def timed(name, wl, n=40):
     for f in range(4):
         step(f, wl)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 40
     for f in range(n):
         step(f, wl)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"plugin path, {name}: {dt * 1e3:.2f} ms per frame = {1 / dt:.0f} frames/s", flush=True)
 
-if os.environ.get("SOAR_PROFILE_HOST") == "1":
+
+for name, wl in VARIANTS:
+    timed(name, wl)
+if VARIANTS:
+    # opt-in, not in the reference: no read-back of the instance count per forward call (Config.binning_capacity)
+    from soar_amd import rasterizer
+    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 2 * rasterizer.last_num_rendered},
+                                                          geometry=pc)
+    timed("avatar_stage_loss, Config.binning_capacity set (no host read-back per frame)", "fused")
+    print("   binning status (instances, overflow):", rasterizer.check_binning())
+    opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4, fused=True)
+    timed("avatar_stage_loss, binning_capacity and torch.optim.Adam(fused=True)", "fused")
+
+if os.environ.get("SOAR_PROFILE_HOST") == "1" and VARIANTS:
     import cProfile, pstats
     pr = cProfile.Profile()
     pr.enable()

@@ -114,7 +114,8 @@ def _loss_common(img, gt, mask, name):
         m = mask.detach().to(device=dev).reshape(-1)
         if m.numel() != a.shape[1] * a.shape[2]:
             raise ValueError(f"{name}: mask must have H*W = {a.shape[1] * a.shape[2]} elements, got {m.numel()}")
-        m = (m != 0).to(torch.uint8).contiguous()
+        # a bool mask already is one byte of 0 / 1 per pixel: no conversion launches
+        m = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else (m != 0).to(torch.uint8).contiguous()
     import ctypes as C
     n = C.c_size_t(0)
     check(hip_lib.lib().soar_image_loss_scratch_floats(C.byref(n)), "soar_image_loss_scratch_floats")
@@ -132,7 +133,7 @@ class _MaskedL1(torch.autograd.Function):
             check(hip_lib.lib().soar_masked_l1(Cn, H, W, ptr(a), ptr(b), ptr(m), ptr(stats), ptr(scratch),
                                                torch.cuda.current_stream(a.device).cuda_stream), "soar_masked_l1")
         ctx.saved = (a, b, m, stats)
-        return stats[0].clone()
+        return stats[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -157,7 +158,7 @@ class _CosLoss(torch.autograd.Function):
             check(hip_lib.lib().soar_cos_loss(Cn, H, W, ptr(a), ptr(b), ptr(m), ct, wt, ptr(stats), ptr(scratch),
                                               torch.cuda.current_stream(a.device).cuda_stream), "soar_cos_loss")
         ctx.saved = (a, b, m, stats, ct, wt)
-        return stats[0].clone()
+        return stats[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -188,3 +189,116 @@ def recon_loss(comp_rgb: torch.Tensor, gt_rgb: torch.Tensor, gt_blended: torch.T
     """The reference's photometric term: 0.8 l1_loss_w(comp_rgb[mask], gt_rgb[mask]) + 0.2 (1 - ssim(comp_rgb, gt_blended))
     (TS/system/gaussian_surfel_mvdream.py:311-320), channel-first images."""
     return 0.8 * masked_l1(comp_rgb, gt_rgb, mask) + 0.2 * (1.0 - ssim(comp_rgb, gt_blended))
+
+
+class _AvatarStageLoss(torch.autograd.Function):
+    """The image-loss block of the avatar stage's training step (TS/system/gaussian_surfel_mvdream.py:305-371) as ONE autograd
+    node: the same four kernels as ``recon_loss`` / ``masked_l1`` / ``cos_loss`` above, but none of the ~25 scalar torch ops and
+    graph nodes between them (composed the reference's way, the block costs the host ~0.8 ms per frame; here ~0.25 ms)."""
+
+    @staticmethod
+    def forward(ctx, render, mask_out, normal, depth, curv, gt_rgb, gt_blended, gt_mask, gt_normal, sel, normal_sel, lam):
+        import ctypes as C
+        L = hip_lib.lib()
+        dev = render.device
+        if not render.is_cuda:
+            raise RuntimeError("avatar_stage_loss runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        byte = lambda m: None if m is None else (m.detach().to(dev).reshape(-1).contiguous().view(torch.uint8) if m.dtype == torch.bool
+                                                 else (m.detach().to(dev).reshape(-1) != 0).to(torch.uint8))
+        r, mo, n = f(render), f(mask_out), f(normal)
+        tr, tb, tm, tn = f(gt_rgb), f(gt_blended), f(gt_mask).reshape(mo.shape), f(gt_normal)
+        Cn, H, W = r.shape
+        m_sel, m_nrm = byte(sel), byte(normal_sel)
+        for t, name in ((m_sel, "mask"), (m_nrm, "normal mask")):
+            if t is not None and t.numel() != H * W:
+                raise ValueError(f"avatar_stage_loss: {name} must have H*W = {H * W} elements, got {t.numel()}")
+        k = C.c_size_t(0)
+        check(L.soar_image_loss_scratch_floats(C.byref(k)), "soar_image_loss_scratch_floats")
+        n_loss = int(k.value)
+        check(L.soar_ssim_scratch_floats(Cn, H, W, C.byref(k)), "soar_ssim_scratch_floats")
+        scratch = torch.empty((max(n_loss, int(k.value)),), dtype=torch.float32, device=dev)
+        # terms[0..5] = masked L1 (colour), SSIM, L1 (mask), cosine, mean depth, mean curvature; stats: {loss, count} per L1 / cosine
+        terms = torch.zeros((6,), dtype=torch.float32, device=dev)
+        stats = torch.empty((3, 2), dtype=torch.float32, device=dev)
+        g_ssim = torch.empty_like(r)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), ptr(stats[0]), ptr(scratch), stream), "soar_masked_l1")
+            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), ptr(terms[1:]), ptr(scratch), ptr(g_ssim), stream), "soar_ssim")
+            check(L.soar_masked_l1(1, H, W, ptr(mo), ptr(tm), None, ptr(stats[1]), ptr(scratch), stream), "soar_masked_l1")
+            check(L.soar_cos_loss(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, ptr(stats[2]), ptr(scratch), stream), "soar_cos_loss")
+        terms[0:1] = stats[0, 0:1]
+        terms[2:4] = stats[1:, 0]
+        if depth is not None and lam["depth"] != 0.0:
+            terms[4] = depth.detach().mean()
+        if curv is not None and lam["curv"] != 0.0:
+            terms[5] = curv.detach().mean()
+        # loss = l_recon (0.8 L1 + 0.2 (1 - ssim)) + l_mask L1(mask) + l_normal 0.2 cos + l_depth mean(depth) + l_curv mean(curv)
+        coef = (0.8 * lam["recon"], -0.2 * lam["recon"], lam["mask"], 0.2 * lam["normal"], lam["depth"], lam["curv"])
+        ctx.coef, ctx.shapes = coef, (render.shape, mask_out.shape, normal.shape, None if depth is None else depth.shape,
+                                      None if curv is None else curv.shape)
+        ctx.saved = (r, mo, n, tr, tm, tn, m_sel, m_nrm, stats, g_ssim)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(terms)
+        return terms @ _coef_tensor(coef, dev) + 0.2 * lam["recon"], terms
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        if g is None:
+            return (None,) * 12
+        L = hip_lib.lib()
+        r, mo, n, tr, tm, tn, m_sel, m_nrm, stats, g_ssim = ctx.saved
+        dev = r.device
+        Cn, H, W = r.shape
+        coef = ctx.coef
+        up = g.detach().to(device=dev, dtype=torch.float32).reshape(1) * _coef_tensor(coef, dev)     # upstream scalar of every term
+        g_r, g_mo, g_n = torch.empty_like(r), torch.empty_like(mo), torch.empty_like(n)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            check(L.soar_masked_l1_backward(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), ptr(stats[0]), ptr(up[0:]), ptr(g_r), stream),
+                  "soar_masked_l1_backward")
+            check(L.soar_masked_l1_backward(1, H, W, ptr(mo), ptr(tm), None, ptr(stats[1]), ptr(up[2:]), ptr(g_mo), stream),
+                  "soar_masked_l1_backward")
+            check(L.soar_cos_loss_backward(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, ptr(stats[2]), ptr(up[3:]), ptr(g_n), stream),
+                  "soar_cos_loss_backward")
+        g_r.addcmul_(g_ssim, up[1])
+        sr, sm, sn, sd, sc = ctx.shapes
+        g_d = None if sd is None or coef[4] == 0.0 else (up[4] / float(torch.Size(sd).numel())).expand(sd)
+        g_c = None if sc is None or coef[5] == 0.0 else (up[5] / float(torch.Size(sc).numel())).expand(sc)
+        return (g_r.view(sr), g_mo.view(sm), g_n.view(sn), g_d, g_c) + (None,) * 7
+
+
+_coef_cache = {}
+
+
+def _coef_tensor(coef, dev) -> torch.Tensor:
+    key = (coef, str(dev))
+    t = _coef_cache.get(key)
+    if t is None:
+        if len(_coef_cache) > 64:
+            _coef_cache.clear()
+        t = _coef_cache[key] = torch.tensor(coef, dtype=torch.float32, device=dev)
+    return t
+
+
+def avatar_stage_loss(out: Dict[str, torch.Tensor], gt_rgb: torch.Tensor, gt_mask: torch.Tensor, gt_normal: torch.Tensor,
+                      mask: torch.Tensor, normal_mask: Optional[torch.Tensor] = None, gt_rgb_blended: Optional[torch.Tensor] = None,
+                      lambda_recon: float = 1.0, lambda_mask: float = 1.0, lambda_normal: float = 1.0, lambda_depth: float = 0.0,
+                      lambda_curv: float = 0.0, return_terms: bool = False):
+    """The image losses of the avatar stage on one rendered frame ``out`` (the renderer plugin's dict, channel-first images):
+
+        lambda_recon  * (0.8 l1_loss_w(render[mask], gt_rgb[mask]) + 0.2 (1 - ssim(render, gt_rgb_blended)))     (:311-320)
+      + lambda_mask   * mean|out["mask"] - gt_mask|                                                                 (:322-327)
+      + lambda_normal * 0.2 cos_loss(out["normal"], gt_normal, normal_mask, thrsh=0, weight=1)                      (:329-338)
+      + lambda_depth  * mean(out["depth"]) + lambda_curv * mean(out["curv"])
+
+    -- the value ``recon_loss`` / ``masked_l1`` / ``cos_loss`` give when composed by hand, as one autograd node.  (The LPIPS terms
+    of :339-352 need the external VGG network and stay with the caller.)  ``return_terms``: also the detached vector
+    [L1 colour, SSIM, L1 mask, cosine, mean depth, mean curvature] for logging."""
+    lam = {"recon": float(lambda_recon), "mask": float(lambda_mask), "normal": float(lambda_normal), "depth": float(lambda_depth),
+           "curv": float(lambda_curv)}
+    loss, terms = _AvatarStageLoss.apply(out["render"], out["mask"], out["normal"], out.get("depth"), out.get("curv"), gt_rgb,
+                                         gt_rgb if gt_rgb_blended is None else gt_rgb_blended, gt_mask, gt_normal, mask,
+                                         mask if normal_mask is None else normal_mask, lam)
+    return (loss, terms.detach()) if return_terms else loss

@@ -74,6 +74,11 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         back_ground_color: Tuple[float, float, float] = (1, 1, 1)
         offset: bool = False
         use_explicit: bool = False
+        # not in the reference: > 0 = upper bound of the (tile, Gaussian) instances of a view.  The reference blocks the host
+        # in every forward call to read that count back (rasterizer_impl.cu:250); with a bound the binning buffer is sized by
+        # it, nothing is read back and the host runs ahead of the device.  The device checks the bound:
+        # ``soar_amd.rasterizer.check_binning()`` (e.g. once per step or per epoch) raises if it was exceeded.
+        binning_capacity: int = 0
 
     cfg: Config
 
@@ -121,7 +126,7 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         (image, normal, depth, pred_normal, opac, occ, curv, radii) = render_view(
             points, rot, pc.get_colors if self.cfg.use_explicit else attribute_color,
             pc.get_scaling if self.cfg.use_explicit else attribute_scale, screenspace_points, pc.get_occ, w, mats, offsets,
-            axis_perm, rs, cam)
+            axis_perm, rs, cam, capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None)
         return {
             "render": image, "normal": normal, "depth": depth, "pred_normal": pred_normal, "mask": opac, "occ": occ, "curv": curv,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,

@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from .. import hip_lib
+from .. import hip_lib, rasterizer
 from ..hip_lib import check, ptr
 from ..rasterizer import _NativeOps, _dev_f32, _stream
 from .postops import fov2focal
@@ -46,7 +46,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 class _RenderView(torch.autograd.Function):
     # outputs: render, normal, depth, pred_normal, mask, occ, curv, radii
     @staticmethod
-    def forward(ctx, xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal):
+    def forward(ctx, xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal, capacity):
         L = hip_lib.lib()
         dev = xyz.device
         x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
@@ -66,7 +66,9 @@ class _RenderView(torch.autograd.Function):
         st = _NativeOps._geometry_stage(rs.bg, xyz_p, cols, _ones_column(P, dev), scales3, rot_p, rs.scale_modifier, None,
                                         rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, H, W,
                                         None, rs.sh_degree, rs.campos, rs.prefiltered, False, False, rs.debug, rs.config)
-        R = _NativeOps._render_stage(st, occ)
+        R = _NativeOps._render_stage(st, occ, capacity=capacity)
+        if capacity is not None:
+            rasterizer._last_batch = [(st["geom"], P, 0, dev)]            # what rasterizer.check_binning() reads
         color, normal, depth, opac = st["out"]
         f = dict(dtype=torch.float32, device=dev)
         normal_out, curv, pred = torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((3, H, W), **f)
@@ -121,11 +123,14 @@ class _RenderView(torch.autograd.Function):
         g_off = None
         if ctx.off_grad:
             g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
-        return g_xyz, g_rot, g_colors, g_scale, g_means2D, None, None, None, g_off, None, None, None
+        return g_xyz, g_rot, g_colors, g_scale, g_means2D, None, None, None, g_off, None, None, None, None
 
 
 def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets: Optional[torch.Tensor], axis_perm, rs,
-                camera):
-    """-> (render, normal, depth, pred_normal, mask, occ, curv, radii) of one view; see the module docstring."""
+                camera, capacity: Optional[int] = None):
+    """-> (render, normal, depth, pred_normal, mask, occ, curv, radii) of one view; see the module docstring.
+    capacity: the sync-free form of ``rasterizer.rasterize_views`` (binning buffer sized by this bound, nothing read back;
+    ``rasterizer.check_binning()`` afterwards)."""
     focal = (float(fov2focal(float(camera.FoVy), camera.image_height)), float(fov2focal(float(camera.FoVx), camera.image_width)))
-    return _RenderView.apply(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal)
+    return _RenderView.apply(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal,
+                             int(capacity) if capacity else None)

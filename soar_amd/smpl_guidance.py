@@ -46,6 +46,7 @@ class SMPLGuidance:
         Tm = torch.einsum("vj,jxy->vxy", self.ori_lbs[0], A_cano[0])
         self.cano_vertices = (torch.einsum("vxy,vy->vx", Tm[:, :3, :3], v_shaped) + Tm[:, :3, 3]).contiguous()
         self._w_cache = None
+        self._mats_cache, self._mats_cache_src = {}, None
         self._knn_grid = lbs.KnnGrid(self.cano_vertices, self.ori_lbs[0])         # canonical vertices are static
 
     # ---- parameter plumbing -------------------------------------------------------------------------------------
@@ -85,9 +86,29 @@ class SMPLGuidance:
     # ---- fast path ------------------------------------------------------------------------------------------------
     def joint_mats(self, smpl_parms_in=None, idx=None, zero_out=False) -> torch.Tensor:
         """cano2live_jnt_mats = A_live @ inv(A_cano)  [55,4,4]   (:601-609)"""
+        key = None
+        if not smpl_parms_in and idx is not None:
+            # a frame of the stored sequence: the transforms only change when a stored parameter tensor is replaced or
+            # written in place (an optimizer step on the poses bumps its version) -- video training revisits every frame
+            # thousands of times, so the joint chain (parameter slicing, two concatenations, one launch) runs once per change.
+            # The cache keeps the tensors it was filled from alive, so "same object" cannot be a recycled id.
+            src = tuple(t for t in self.smpl_parms.values() if isinstance(t, torch.Tensor))
+            stamp = tuple(t._version for t in src)
+            held = self._mats_cache_src
+            if held is None or len(held[0]) != len(src) or any(a is not b for a, b in zip(held[0], src)) or held[1] != stamp \
+                    or len(self._mats_cache) >= 8192:
+                self._mats_cache.clear()
+                self._mats_cache_src = (src, stamp)
+            key = (int(idx) % len(self.smpl_parms["body_pose"]), bool(zero_out))
+            hit = self._mats_cache.get(key)
+            if hit is not None:
+                return hit
         betas, pose, transl = self._select(smpl_parms_in, idx, zero_out)
         # one launch: Rodrigues, the 55-joint chain, transl and the product with inv(A_cano)  (csrc/smplx_joints.hip)
-        return self._jt.hip(betas, pose, transl, right=self.inv_mats[0])[0]
+        mats = self._jt.hip(betas, pose, transl, right=self.inv_mats[0])[0]
+        if key is not None:
+            self._mats_cache[key] = mats
+        return mats
 
     def blend_weights(self, points: torch.Tensor, refresh: bool = False) -> torch.Tensor:
         """query_weights_smpl cached on (storage, version) of `points`: the weights depend on the canonical positions

@@ -163,6 +163,48 @@ def test_fused_view_matches_the_composed_path(world, gt):
         t.grad = None
 
 
+def test_guidance_joint_transform_cache_follows_the_parameters():
+    """SMPLGuidance.joint_mats keeps the transforms of a stored frame until a parameter tensor is written in place or replaced."""
+    from soar_amd.smpl_guidance import SMPLGuidance
+    body = syn.make_body_model(0)
+    guide = SMPLGuidance(body, _smpl_parms(syn.make_pose_sequence(6, 0)), device=DEV)
+    a = guide.joint_mats(idx=2)
+    assert guide.joint_mats(idx=2) is a and guide.joint_mats(idx=8) is a            # same frame (6 frames: 8 -> 2)
+    assert not torch.equal(guide.joint_mats(idx=3), a) and not torch.equal(guide.joint_mats(idx=2, zero_out=True), a)
+    guide.smpl_parms["body_pose"][2, 4] += 0.3                                       # in place: version bump
+    b = guide.joint_mats(idx=2)
+    assert b is not a and not torch.equal(a, b)
+    guide._mats_cache.clear()
+    assert torch.equal(guide.joint_mats(idx=2), b)                                   # the cached value is the computed one
+    guide.smpl_parms["transl"] = guide.smpl_parms["transl"] + 0.5                    # replaced tensor
+    c = guide.joint_mats(idx=2)
+    assert c is not b and not torch.equal(c, b)
+
+
+def test_plugin_binning_capacity_config_renders_without_read_back(world):
+    """Config.binning_capacity (not in the reference): the view's binning buffer is sized by the bound, the instance count is not
+    read back; same images, and rasterizer.check_binning() reports the count / raises when the bound was too small."""
+    from soar_amd import rasterizer
+    from soar_amd.renderer import registry
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    want = w.renderer(w.cam, bg, gt=True, gt_index=4)
+    n = rasterizer.last_num_rendered
+    free = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 2 * n}, geometry=w.pc)
+    got = free(w.cam, bg, gt=True, gt_index=4)
+    for k in ("render", "normal", "depth", "pred_normal", "mask", "occ", "curv", "radii"):
+        assert torch.equal(got[k], want[k]), k
+    assert rasterizer.check_binning() == [(n, 0)]
+    got["render"].mean().backward()
+    assert torch.isfinite(w.pc._xyz.grad).all() and w.pc._xyz.grad.abs().sum() > 0
+    small = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": n // 2}, geometry=w.pc)
+    small(w.cam, bg, gt=True, gt_index=4)
+    with pytest.raises(RuntimeError, match="binning capacity exceeded"):
+        rasterizer.check_binning()
+    for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
+        t.grad = None
+
+
 def test_plugin_occlusion_image_carries_gradient_to_the_occ_parameter(world):
     """The reference passes `pc.get_occ.repeat(1,3)` undetached (:280-291) and trains `_occ` with
     loss_occ = (1 - comp_occ[mask]).mean() (gaussian_surfel_mvdream.py:412-417): d loss / d _occ must be the occlusion pass's
@@ -648,3 +690,39 @@ def test_sum_frames_adds_in_frame_order(n, count):
         want = want + x[f]
     assert torch.equal(out, want)
     assert L.soar_sum_frames(0, count, hip_lib.ptr(x), hip_lib.ptr(out), None) != 0
+
+
+@pytest.mark.parametrize("hw", [(37, 53), (128, 200)])
+def test_avatar_stage_loss_is_the_composed_losses_in_one_node(hw):
+    """losses.avatar_stage_loss against recon_loss + masked_l1 + cos_loss + means composed by hand (the reference's way)."""
+    from soar_amd.losses import avatar_stage_loss, cos_loss, masked_l1, recon_loss
+    Hh, Ww = hw
+    gen = torch.Generator().manual_seed(Hh)
+    rnd = lambda *s: torch.rand(*s, generator=gen).to(DEV)
+    gt_rgb, gt_blend, gt_mask, gt_normal = rnd(3, Hh, Ww), rnd(3, Hh, Ww), (rnd(1, Hh, Ww) > 0.4).float(), rnd(3, Hh, Ww)
+    mask, nmask = gt_mask[0] > 0.5, rnd(Hh, Ww) > 0.3
+    lam = dict(lambda_recon=1.3, lambda_mask=0.7, lambda_normal=0.9, lambda_depth=0.01, lambda_curv=0.02)
+    res = []
+    for fused in (True, False):
+        g2 = torch.Generator().manual_seed(7)
+        out = {k: torch.rand(c, Hh, Ww, generator=g2).to(DEV).requires_grad_(True)
+               for k, c in (("render", 3), ("mask", 1), ("normal", 3), ("depth", 1), ("curv", 1))}
+        if fused:
+            loss, terms = avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, mask, nmask, gt_blend, return_terms=True, **lam)
+            assert terms.shape == (6,) and not terms.requires_grad
+        else:
+            loss = (lam["lambda_recon"] * recon_loss(out["render"], gt_rgb, gt_blend, mask)
+                    + lam["lambda_mask"] * masked_l1(out["mask"], gt_mask)
+                    + lam["lambda_normal"] * 0.2 * cos_loss(out["normal"], gt_normal, nmask)
+                    + lam["lambda_depth"] * out["depth"].mean() + lam["lambda_curv"] * out["curv"].mean())
+        (loss * 1.7).backward()
+        res.append((loss.item(), {k: v.grad.clone() for k, v in out.items()}))
+    (lf, gf), (lc, gc) = res
+    assert abs(lf - lc) <= 2e-6 * abs(lc)
+    for k in gf:
+        assert (gf[k] - gc[k]).abs().max().item() <= 1e-5 * gc[k].abs().max().item() + 1e-12, k
+    # terms that are switched off get no gradient at all
+    out = {k: torch.rand(c, Hh, Ww, generator=gen).to(DEV).requires_grad_(True)
+           for k, c in (("render", 3), ("mask", 1), ("normal", 3), ("depth", 1), ("curv", 1))}
+    avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, mask).backward()
+    assert out["depth"].grad is None and out["curv"].grad is None and out["render"].grad.abs().sum() > 0
