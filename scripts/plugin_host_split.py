@@ -24,7 +24,7 @@ def timed(cls, meth, name, static=True):
 
 from soar_amd import losses as LS, rasterizer as RZ
 from soar_amd.renderer import fused_view as FV
-for cls, nm in ((FV._RenderView, "RenderView"), (LS._Ssim, "Ssim"), (LS._MaskedL1, "MaskedL1"), (LS._CosLoss, "CosLoss")):
+for cls, nm in ((FV._RenderView, "RenderView"), (LS._AvatarStageLoss, "AvatarStageLoss")):
     timed(cls, "backward", f"  [{nm}.backward]")
     timed(cls, "forward", f"  [{nm}.forward]")
 timed(RZ._NativeOps, "_geometry_stage", "    [geometry_stage]")
@@ -39,8 +39,12 @@ def step(f):
     out = PT.renderer(PT.cam, PT.bg, gt=True, gt_index=f); t = tick("render forward", t)
     tg = PT.syn.pool_targets(PT.pool, f)
     mask = tg["mask"][0] > 0.5; t = tick("targets + mask", t)
-    loss = (PT.recon_loss(out["render"], tg["color"], tg["color"], mask) + 0.2 * PT.cos_loss(out["normal"], tg["normal"] * 0.5 + 0.5, mask)
-            + PT.masked_l1(out["mask"], tg["mask"]) + 0.01 * out["depth"].mean() + 0.01 * out["curv"].mean()); t = tick("losses", t)
+    if os.environ.get("SOAR_SPLIT_COMPOSED") == "1":
+        loss = (PT.recon_loss(out["render"], tg["color"], tg["color"], mask) + 0.2 * PT.cos_loss(out["normal"], tg["normal"] * 0.5 + 0.5, mask)
+                + PT.masked_l1(out["mask"], tg["mask"]) + 0.01 * out["depth"].mean() + 0.01 * out["curv"].mean())
+    else:
+        loss = PT.avatar_stage_loss(out, tg["color"], tg["mask"], tg["normal"] * 0.5 + 0.5, mask, lambda_depth=0.01, lambda_curv=0.01)
+    t = tick("losses", t)
     loss.backward(); t = tick("backward", t)
     PT.opt.step(); t = tick("adam", t)
 

@@ -55,7 +55,7 @@ VARIANTS = (("render + avatar-stage losses (SSIM, masked L1, cosine) composed th
 if os.environ.get("SOAR_PLUGIN_TIME_IMPORT_ONLY") == "1":       # scripts/plugin_host_split.py reuses the scene
     VARIANTS = ()
 def timed(name, wl, n=40):
-    for f in range(4):
+    for f in range(F + 4):               # every frame of the sequence once (per-frame caches, allocator) before the clock starts
         step(f, wl)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -191,82 +191,118 @@ def recon_loss(comp_rgb: torch.Tensor, gt_rgb: torch.Tensor, gt_blended: torch.T
     return 0.8 * masked_l1(comp_rgb, gt_rgb, mask) + 0.2 * (1.0 - ssim(comp_rgb, gt_blended))
 
 
+def _as_f32(t: torch.Tensor, dev) -> torch.Tensor:
+    """the tensor itself when a kernel can read it as it is (the usual case), else an fp32 contiguous copy on `dev`"""
+    if t.dtype is torch.float32 and t.device == dev and t.is_contiguous():
+        return t
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _as_bytes(m: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if m is None:
+        return None
+    if m.dtype is torch.bool and m.device == dev and m.is_contiguous():
+        return m.view(torch.uint8)
+    m = m.detach().to(dev)
+    return (m.contiguous().view(torch.uint8) if m.dtype is torch.bool else (m != 0).to(torch.uint8)).reshape(-1)
+
+
 class _AvatarStageLoss(torch.autograd.Function):
     """The image-loss block of the avatar stage's training step (TS/system/gaussian_surfel_mvdream.py:305-371) as ONE autograd
     node: the same four kernels as ``recon_loss`` / ``masked_l1`` / ``cos_loss`` above, but none of the ~25 scalar torch ops and
     graph nodes between them (composed the reference's way, the block costs the host ~0.8 ms per frame; here ~0.25 ms)."""
 
+    # slots of the term vector: {loss, count} of the colour L1, of the mask L1, of the cosine loss; SSIM; mean depth; mean
+    # curvature; a constant 1 (the "1 -" of the SSIM term)
+    L1, L1M, COS, SSIM, DEPTH, CURV, ONE, N = 0, 2, 4, 6, 7, 8, 9, 10
+
     @staticmethod
     def forward(ctx, render, mask_out, normal, depth, curv, gt_rgb, gt_blended, gt_mask, gt_normal, sel, normal_sel, lam):
         import ctypes as C
+        S = _AvatarStageLoss
         L = hip_lib.lib()
         dev = render.device
         if not render.is_cuda:
             raise RuntimeError("avatar_stage_loss runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
-        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        byte = lambda m: None if m is None else (m.detach().to(dev).reshape(-1).contiguous().view(torch.uint8) if m.dtype == torch.bool
-                                                 else (m.detach().to(dev).reshape(-1) != 0).to(torch.uint8))
-        r, mo, n = f(render), f(mask_out), f(normal)
-        tr, tb, tm, tn = f(gt_rgb), f(gt_blended), f(gt_mask).reshape(mo.shape), f(gt_normal)
+        r, mo, n = _as_f32(render, dev), _as_f32(mask_out, dev), _as_f32(normal, dev)
+        tr, tb, tm, tn = _as_f32(gt_rgb, dev), _as_f32(gt_blended, dev), _as_f32(gt_mask, dev), _as_f32(gt_normal, dev)
         Cn, H, W = r.shape
-        m_sel, m_nrm = byte(sel), byte(normal_sel)
-        for t, name in ((m_sel, "mask"), (m_nrm, "normal mask")):
-            if t is not None and t.numel() != H * W:
-                raise ValueError(f"avatar_stage_loss: {name} must have H*W = {H * W} elements, got {t.numel()}")
+        m_sel, m_nrm = _as_bytes(sel, dev), _as_bytes(normal_sel, dev)
+        for t, name, count in ((m_sel, "mask", H * W), (m_nrm, "normal mask", H * W), (tm, "gt_mask", H * W), (mo, "mask image", H * W),
+                               (tr, "gt_rgb", Cn * H * W), (tb, "gt_rgb_blended", Cn * H * W), (n, "normal", 3 * H * W),
+                               (tn, "gt_normal", 3 * H * W)):
+            if t is not None and t.numel() != count:
+                raise ValueError(f"avatar_stage_loss: {name} must have {count} elements, got {tuple(t.shape)}")
         k = C.c_size_t(0)
         check(L.soar_image_loss_scratch_floats(C.byref(k)), "soar_image_loss_scratch_floats")
         n_loss = int(k.value)
         check(L.soar_ssim_scratch_floats(Cn, H, W, C.byref(k)), "soar_ssim_scratch_floats")
         scratch = torch.empty((max(n_loss, int(k.value)),), dtype=torch.float32, device=dev)
-        # terms[0..5] = masked L1 (colour), SSIM, L1 (mask), cosine, mean depth, mean curvature; stats: {loss, count} per L1 / cosine
-        terms = torch.zeros((6,), dtype=torch.float32, device=dev)
-        stats = torch.empty((3, 2), dtype=torch.float32, device=dev)
+        terms = _unit_terms(dev).clone()                            # zeros, a one in the last slot
         g_ssim = torch.empty_like(r)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        at = lambda i: terms.data_ptr() + 4 * i
         with torch.cuda.device(dev):
-            check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), ptr(stats[0]), ptr(scratch), stream), "soar_masked_l1")
-            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), ptr(terms[1:]), ptr(scratch), ptr(g_ssim), stream), "soar_ssim")
-            check(L.soar_masked_l1(1, H, W, ptr(mo), ptr(tm), None, ptr(stats[1]), ptr(scratch), stream), "soar_masked_l1")
-            check(L.soar_cos_loss(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, ptr(stats[2]), ptr(scratch), stream), "soar_cos_loss")
-        terms[0:1] = stats[0, 0:1]
-        terms[2:4] = stats[1:, 0]
+            check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(S.L1), ptr(scratch), stream), "soar_masked_l1")
+            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), at(S.SSIM), ptr(scratch), ptr(g_ssim), stream), "soar_ssim")
+            check(L.soar_masked_l1(1, H, W, ptr(mo), ptr(tm), None, at(S.L1M), ptr(scratch), stream), "soar_masked_l1")
+            check(L.soar_cos_loss(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(S.COS), ptr(scratch), stream), "soar_cos_loss")
+        coef = [0.0] * S.N
+        coef[S.L1], coef[S.SSIM], coef[S.ONE] = 0.8 * lam["recon"], -0.2 * lam["recon"], 0.2 * lam["recon"]
+        coef[S.L1M], coef[S.COS] = lam["mask"], 0.2 * lam["normal"]
+        back = list(coef)                                            # upstream factor of every term; the means spread over their pixels
         if depth is not None and lam["depth"] != 0.0:
-            terms[4] = depth.detach().mean()
+            torch.mean(depth.detach().reshape(-1), dim=0, out=terms[S.DEPTH])
+            coef[S.DEPTH], back[S.DEPTH] = lam["depth"], lam["depth"] / depth.numel()
         if curv is not None and lam["curv"] != 0.0:
-            terms[5] = curv.detach().mean()
-        # loss = l_recon (0.8 L1 + 0.2 (1 - ssim)) + l_mask L1(mask) + l_normal 0.2 cos + l_depth mean(depth) + l_curv mean(curv)
-        coef = (0.8 * lam["recon"], -0.2 * lam["recon"], lam["mask"], 0.2 * lam["normal"], lam["depth"], lam["curv"])
-        ctx.coef, ctx.shapes = coef, (render.shape, mask_out.shape, normal.shape, None if depth is None else depth.shape,
-                                      None if curv is None else curv.shape)
-        ctx.saved = (r, mo, n, tr, tm, tn, m_sel, m_nrm, stats, g_ssim)
+            torch.mean(curv.detach().reshape(-1), dim=0, out=terms[S.CURV])
+            coef[S.CURV], back[S.CURV] = lam["curv"], lam["curv"] / curv.numel()
+        ctx.back = tuple(back)
+        ctx.shapes = (render.shape, mask_out.shape, normal.shape, None if depth is None else depth.shape,
+                      None if curv is None else curv.shape)
+        ctx.saved = (r, mo, n, tr, tm, tn, m_sel, m_nrm, terms, g_ssim)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(terms)
-        return terms @ _coef_tensor(coef, dev) + 0.2 * lam["recon"], terms
+        return torch.dot(terms, _coef_tensor(tuple(coef), dev)), terms
 
     @staticmethod
     def backward(ctx, g, _g_terms):
         if g is None:
             return (None,) * 12
+        S = _AvatarStageLoss
         L = hip_lib.lib()
-        r, mo, n, tr, tm, tn, m_sel, m_nrm, stats, g_ssim = ctx.saved
+        r, mo, n, tr, tm, tn, m_sel, m_nrm, terms, g_ssim = ctx.saved
         dev = r.device
         Cn, H, W = r.shape
-        coef = ctx.coef
-        up = g.detach().to(device=dev, dtype=torch.float32).reshape(1) * _coef_tensor(coef, dev)     # upstream scalar of every term
+        back = ctx.back
+        up = _as_f32(g, dev).reshape(1) * _coef_tensor(back, dev)            # upstream scalar of every term (device side)
         g_r, g_mo, g_n = torch.empty_like(r), torch.empty_like(mo), torch.empty_like(n)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        at = lambda t, i: t.data_ptr() + 4 * i
         with torch.cuda.device(dev):
-            check(L.soar_masked_l1_backward(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), ptr(stats[0]), ptr(up[0:]), ptr(g_r), stream),
+            check(L.soar_masked_l1_backward(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(terms, S.L1), at(up, S.L1), ptr(g_r), stream),
                   "soar_masked_l1_backward")
-            check(L.soar_masked_l1_backward(1, H, W, ptr(mo), ptr(tm), None, ptr(stats[1]), ptr(up[2:]), ptr(g_mo), stream),
+            check(L.soar_masked_l1_backward(1, H, W, ptr(mo), ptr(tm), None, at(terms, S.L1M), at(up, S.L1M), ptr(g_mo), stream),
                   "soar_masked_l1_backward")
-            check(L.soar_cos_loss_backward(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, ptr(stats[2]), ptr(up[3:]), ptr(g_n), stream),
-                  "soar_cos_loss_backward")
-        g_r.addcmul_(g_ssim, up[1])
+            check(L.soar_cos_loss_backward(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(terms, S.COS), at(up, S.COS), ptr(g_n),
+                                           stream), "soar_cos_loss_backward")
+        g_r.addcmul_(g_ssim, up[S.SSIM])
         sr, sm, sn, sd, sc = ctx.shapes
-        g_d = None if sd is None or coef[4] == 0.0 else (up[4] / float(torch.Size(sd).numel())).expand(sd)
-        g_c = None if sc is None or coef[5] == 0.0 else (up[5] / float(torch.Size(sc).numel())).expand(sc)
+        g_d = None if sd is None or back[S.DEPTH] == 0.0 else up[S.DEPTH].expand(sd)
+        g_c = None if sc is None or back[S.CURV] == 0.0 else up[S.CURV].expand(sc)
         return (g_r.view(sr), g_mo.view(sm), g_n.view(sn), g_d, g_c) + (None,) * 7
+
+
+_unit = {}
+
+
+def _unit_terms(dev) -> torch.Tensor:
+    t = _unit.get(str(dev))
+    if t is None:
+        v = [0.0] * _AvatarStageLoss.N
+        v[_AvatarStageLoss.ONE] = 1.0
+        t = _unit[str(dev)] = torch.tensor(v, dtype=torch.float32, device=dev)
+    return t
 
 
 _coef_cache = {}
@@ -294,8 +330,8 @@ def avatar_stage_loss(out: Dict[str, torch.Tensor], gt_rgb: torch.Tensor, gt_mas
       + lambda_depth  * mean(out["depth"]) + lambda_curv * mean(out["curv"])
 
     -- the value ``recon_loss`` / ``masked_l1`` / ``cos_loss`` give when composed by hand, as one autograd node.  (The LPIPS terms
-    of :339-352 need the external VGG network and stay with the caller.)  ``return_terms``: also the detached vector
-    [L1 colour, SSIM, L1 mask, cosine, mean depth, mean curvature] for logging."""
+    of :339-352 need the external VGG network and stay with the caller.)  ``return_terms``: also the detached term vector for
+    logging (slots ``_AvatarStageLoss.L1 / L1M / COS`` = {value, selected pixels}, ``SSIM``, ``DEPTH``, ``CURV``)."""
     lam = {"recon": float(lambda_recon), "mask": float(lambda_mask), "normal": float(lambda_normal), "depth": float(lambda_depth),
            "curv": float(lambda_curv)}
     loss, terms = _AvatarStageLoss.apply(out["render"], out["mask"], out["normal"], out.get("depth"), out.get("curv"), gt_rgb,

@@ -11,7 +11,7 @@ from typing import Dict, List
 
 import torch
 
-from .cameras import Camera, get_cam_info_gaussian_cxcy, sample_camera
+from .cameras import Camera, device_constant, get_cam_info_gaussian_cxcy, sample_camera
 
 _KEYMAP = (("depth", "depths"), ("mask", "masks"), ("occ", "occs"), ("curv", "curvs"), ("comp_bg", "comp_bgs"))
 
@@ -48,9 +48,9 @@ class GaussianBatchRenderer:
         ncx, ncy = float(batch["gt_normal_cx"][0]), float(batch["gt_normal_cy"][0])
         w2c_n, proj_n, cam_p_n = get_cam_info_gaussian_cxcy(c2w=c2w, fovx=nfx, fovy=nfy, znear=0.1, zfar=100,
                                                             cxcy=(ncx, ncy), img_wh=(res, res), device=dev)
-        prcp = torch.tensor([float(batch["gt_cx"][0]) / batch["gt_width"], float(batch["gt_cy"][0]) / batch["gt_height"]],
-                            device=dev)
-        half = torch.tensor([0.5, 0.5], device=dev)
+        # (small constants through the per-value cache: a tensor built from Python numbers is a pageable copy that drains the stream)
+        prcp = device_constant((float(batch["gt_cx"][0]) / batch["gt_width"], float(batch["gt_cy"][0]) / batch["gt_height"]), dev)
+        half = device_constant((0.5, 0.5), dev)
         cam_rgb = Camera(FoVx=fovx, FoVy=fovy, image_width=batch["gt_width"], image_height=batch["gt_height"],
                          world_view_transform=w2c, full_proj_transform=proj, camera_center=cam_p, prcppoint=prcp)
         cam_n = Camera(FoVx=nfx, FoVy=nfy, image_width=res, image_height=res, world_view_transform=w2c_n,
@@ -87,7 +87,7 @@ class GaussianBatchRenderer:
                                                           device=dev)
             cam = Camera(FoVx=fovy, FoVy=fovy, image_width=batch["width"], image_height=batch["height"],
                          world_view_transform=w2c, full_proj_transform=proj, camera_center=cam_p,
-                         prcppoint=torch.tensor([0.5, 0.5], device=dev))
+                         prcppoint=device_constant((0.5, 0.5), dev))
             with torch.autocast("cuda", enabled=False):
                 pkg = self.forward(cam, torch.zeros_like(self.background_tensor) * 0.5, mode=mode, head_flag=head_flag,
                                    stage=stage, **batch)

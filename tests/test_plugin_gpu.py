@@ -709,7 +709,7 @@ def test_avatar_stage_loss_is_the_composed_losses_in_one_node(hw):
                for k, c in (("render", 3), ("mask", 1), ("normal", 3), ("depth", 1), ("curv", 1))}
         if fused:
             loss, terms = avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, mask, nmask, gt_blend, return_terms=True, **lam)
-            assert terms.shape == (6,) and not terms.requires_grad
+            assert terms.shape == (10,) and not terms.requires_grad and terms[9].item() == 1.0
         else:
             loss = (lam["lambda_recon"] * recon_loss(out["render"], gt_rgb, gt_blend, mask)
                     + lam["lambda_mask"] * masked_l1(out["mask"], gt_mask)
