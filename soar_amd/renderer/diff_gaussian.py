@@ -107,9 +107,9 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         return lbs.lbs_warp(points, rot, None, mat[0].detach(), offsets, axis_perm)
 
     def _forward_fused(self, pc, cam, bg_color, scaling_modifier, points, rot, offsets, axis_perm, attribute_color,
-                       attribute_scale, zero_out, kwargs):
-        """The whole view as one autograd node (soar_amd/renderer/fused_view.py): full patch, fused occlusion pass, fixed
-        camera.  Same outputs as the composed path below."""
+                       attribute_scale, zero_out, back, kwargs):
+        """The whole view as one autograd node (soar_amd/renderer/fused_view.py): full patch, fixed camera, no gradient asked of
+        the occlusion image.  Same outputs as the composed path below."""
         guide = pc.smpl_guidance
         idx, a_smpl = kwargs.get("gt_index"), kwargs.get("gt_a_smpl")
         with torch.no_grad():
@@ -126,7 +126,7 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         (image, normal, depth, pred_normal, opac, occ, curv, radii) = render_view(
             points, rot, pc.get_colors if self.cfg.use_explicit else attribute_color,
             pc.get_scaling if self.cfg.use_explicit else attribute_scale, screenspace_points, pc.get_occ, w, mats, offsets,
-            axis_perm, rs, cam, capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None)
+            axis_perm, rs, cam, capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None, back=back)
         return {
             "render": image, "normal": normal, "depth": depth, "pred_normal": pred_normal, "mask": opac, "occ": occ, "curv": curv,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
@@ -157,10 +157,11 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         # produces the occlusion image without a backward, so it is only taken when no such gradient can be asked for.
         occ_needs_grad = torch.is_grad_enabled() and bool(getattr(pc.get_occ, "requires_grad", False))
         guide = pc.smpl_guidance
-        fused_blend = render_front and full_patch and not cam_leaf and not occ_needs_grad
-        if fused_blend and FUSED_VIEW and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights"):
+        one_node = full_patch and not cam_leaf and not occ_needs_grad
+        fused_blend = render_front and one_node
+        if one_node and FUSED_VIEW and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights"):
             return self._forward_fused(pc, viewpoint_camera, bg_color, scaling_modifier, points, rot, offsets, axis_perm,
-                                       attribute_color, attribute_scale, not gt, kwargs)
+                                       attribute_color, attribute_scale, not gt, not render_front, kwargs)
         points, rot = self._warp(pc, points, rot, offsets, axis_perm, not gt, kwargs)
 
         # zero tensor whose gradient is the screen-space mean gradient used by densification (:155-164)

@@ -46,7 +46,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 class _RenderView(torch.autograd.Function):
     # outputs: render, normal, depth, pred_normal, mask, occ, curv, radii
     @staticmethod
-    def forward(ctx, xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal, capacity):
+    def forward(ctx, xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal, capacity, back):
         L = hip_lib.lib()
         dev = xyz.device
         x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
@@ -63,12 +63,25 @@ class _RenderView(torch.autograd.Function):
         scales3 = _f32(scale_src).repeat(1, 3)                      # :233-234
         scales3[..., -1] = -1e10
         cols = _f32(colors)
-        st = _NativeOps._geometry_stage(rs.bg, xyz_p, cols, _ones_column(P, dev), scales3, rot_p, rs.scale_modifier, None,
-                                        rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, H, W,
-                                        None, rs.sh_degree, rs.campos, rs.prefiltered, False, False, rs.debug, rs.config)
-        R = _NativeOps._render_stage(st, occ, capacity=capacity)
-        if capacity is not None:
-            rasterizer._last_batch = [(st["geom"], P, 0, dev)]            # what rasterizer.check_binning() reads
+        ones = _ones_column(P, dev)
+        geometry = lambda colours, front, descending: _NativeOps._geometry_stage(
+            rs.bg, xyz_p, colours, ones, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
+            rs.patch_bbox, rs.tanfovx, rs.tanfovy, H, W, None, rs.sh_degree, rs.campos, rs.prefiltered, front, descending, rs.debug,
+            rs.config)
+        if not back:
+            # main pass front-to-back: the occlusion pass (:193-211, :281-291) is a subsequence of it, blended in the same launch
+            st = geometry(cols, False, False)
+            R = _NativeOps._render_stage(st, occ, capacity=capacity)
+            if capacity is not None:
+                rasterizer._last_batch = [(st["geom"], P, 0, dev)]        # what rasterizer.check_binning() reads
+            occ_img = st["occ"]
+        else:
+            # render_front=False: main pass sorted back-to-front (:173-191); the occlusion pass is a rasterization of its own
+            st = geometry(cols, False, True)
+            st_occ = geometry(_f32(occ).reshape(P, 1).repeat(1, 3), True, False)      # both geometry stages in front of the read-backs
+            R = _NativeOps._render_stage(st, None)
+            _NativeOps._render_stage(st_occ, None)
+            occ_img = st_occ["out"][0]
         color, normal, depth, opac = st["out"]
         f = dict(dtype=torch.float32, device=dev)
         normal_out, curv, pred = torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((3, H, W), **f)
@@ -82,7 +95,6 @@ class _RenderView(torch.autograd.Function):
         empty = torch.empty((0,), **f)
         ctx.save_for_backward(x, q, w, A, T if T is not None else empty, cols, scales3, xyz_p, rot_p, st["radii"], st["geom"],
                               st["binning"], st["img"], normal, depth, opac, prcp)
-        occ_img = st.get("occ", empty)
         ctx.mark_non_differentiable(st["radii"], occ_img)
         ctx.set_materialize_grads(False)
         return color, normal_out, depth, pred, opac, occ_img, curv, st["radii"]
@@ -123,14 +135,15 @@ class _RenderView(torch.autograd.Function):
         g_off = None
         if ctx.off_grad:
             g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
-        return g_xyz, g_rot, g_colors, g_scale, g_means2D, None, None, None, g_off, None, None, None, None
+        return g_xyz, g_rot, g_colors, g_scale, g_means2D, None, None, None, g_off, None, None, None, None, None
 
 
 def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets: Optional[torch.Tensor], axis_perm, rs,
-                camera, capacity: Optional[int] = None):
+                camera, capacity: Optional[int] = None, back: bool = False):
     """-> (render, normal, depth, pred_normal, mask, occ, curv, radii) of one view; see the module docstring.
     capacity: the sync-free form of ``rasterizer.rasterize_views`` (binning buffer sized by this bound, nothing read back;
-    ``rasterizer.check_binning()`` afterwards)."""
+    ``rasterizer.check_binning()`` afterwards).  back: the ``render_front=False`` form (main pass sorted back-to-front, occlusion
+    pass rasterized separately; always with the read-back)."""
     focal = (float(fov2focal(float(camera.FoVy), camera.image_height)), float(fov2focal(float(camera.FoVx), camera.image_width)))
     return _RenderView.apply(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal,
-                             int(capacity) if capacity else None)
+                             int(capacity) if capacity and not back else None, bool(back))

@@ -268,22 +268,26 @@ class CameraSpec:
         return math.tan(self.fovy * 0.5)
 
 
+def make_c2w(distance: float = 3.0, elevation: float = 0.0, azimuth: float = 0.0, target=(0.0, -0.1, 0.0)) -> torch.Tensor:
+    """OpenGL-style camera-to-world matrix of a camera looking at `target` from `distance` m (along its -z, y up)."""
+    tgt = torch.tensor(target)
+    pos = tgt + distance * torch.tensor([math.cos(elevation) * math.sin(azimuth), math.sin(elevation),
+                                         math.cos(elevation) * math.cos(azimuth)])
+    zc = torch.nn.functional.normalize(pos - tgt, dim=0)
+    xc = torch.nn.functional.normalize(torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), zc), dim=0)
+    yc = torch.linalg.cross(zc, xc)
+    c2w = torch.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = xc, yc, zc, pos
+    return c2w
+
+
 def make_camera(width: int, height: int, distance: float = 3.0, elevation: float = 0.0, azimuth: float = 0.0,
                 target=(0.0, -0.1, 0.0)) -> CameraSpec:
     """Pinhole with fy = 1.2 H, fx = fy, principal point (0.5,0.5), looking at the person from `distance` m."""
     fy = 1.2 * height
     fovy = 2 * math.atan(height / (2 * fy))
     fovx = 2 * math.atan(width / (2 * fy))
-    tgt = torch.tensor(target)
-    pos = tgt + distance * torch.tensor([math.cos(elevation) * math.sin(azimuth), math.sin(elevation),
-                                         math.cos(elevation) * math.cos(azimuth)])
-    # OpenGL-style c2w: camera looks along its -z, y up
-    zc = torch.nn.functional.normalize(pos - tgt, dim=0)
-    xc = torch.nn.functional.normalize(torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), zc), dim=0)
-    yc = torch.linalg.cross(zc, xc)
-    c2w = torch.eye(4)
-    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = xc, yc, zc, pos
-    wv, full, center = camera_from_c2w(c2w, fovx, fovy)
+    wv, full, center = camera_from_c2w(make_c2w(distance, elevation, azimuth, target), fovx, fovy)
     return CameraSpec(width, height, fovx, fovy, wv, full, center, torch.tensor([0.5, 0.5]))
 
 

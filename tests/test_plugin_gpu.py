@@ -127,8 +127,8 @@ def test_plugin_video_frame_matches_oracle_chain(world):
         t.grad = None
 
 
-@pytest.mark.parametrize("gt", [True, False])
-def test_fused_view_matches_the_composed_path(world, gt):
+@pytest.mark.parametrize("gt,front", [(True, True), (False, True), (True, False)])
+def test_fused_view_matches_the_composed_path(world, gt, front):
     """The view as ONE autograd node (soar_amd/renderer/fused_view.py: warp -> rasterize -> soar_view_finish, and back) against
     the same view composed from the separate autograd ops: identical images, gradients to float-atomic order."""
     from soar_amd.renderer import diff_gaussian as dg
@@ -141,7 +141,7 @@ def test_fused_view_matches_the_composed_path(world, gt):
     for fused in (True, False):
         dg.FUSED_VIEW = fused
         try:
-            out = w.renderer(w.cam, bg, gt=gt, gt_index=5)
+            out = w.renderer(w.cam, bg, gt=gt, gt_index=5, render_front=front)
         finally:
             dg.FUSED_VIEW = True
         sum(((out[k] * wts[k]).sum() for k in wts)).backward()
@@ -156,7 +156,7 @@ def test_fused_view_matches_the_composed_path(world, gt):
         assert torch.isfinite(a).all() and b.abs().max() > 0, name
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), name
     # unused outputs: no gradient planes are made up for them
-    out = w.renderer(w.cam, bg, gt=gt, gt_index=5)
+    out = w.renderer(w.cam, bg, gt=gt, gt_index=5, render_front=front)
     out["render"].mean().backward()
     assert torch.isfinite(w.pc._xyz.grad).all() and w.pc._xyz.grad.abs().sum() > 0
     for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
@@ -258,6 +258,34 @@ def test_plugin_back_view_descending_and_unfused_occ(world):
     assert np.abs(out["render"].detach().cpu().numpy() - fw.out_color).mean() < 1e-5
     occ_fw = _oracle_frame(w, 1, True, np.repeat(w.pc.get_occ.cpu().numpy(), 3, 1))
     assert np.abs(out["occ"].cpu().numpy() - occ_fw.out_color).mean() < 1e-5
+
+
+def test_gt_forward_renders_the_three_views_of_a_video_frame(world):
+    """GaussianBatchRenderer.gt_forward (TS/renderer/gaussian_batch_renderer.py:96-220): the frame at video resolution plus the
+    normal view and the back normal view (render_front=False) at gt_normal_res, stacked channel-last under the reference's keys."""
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    res = 96
+    nf = 2 * math.atan(0.5 / 1.1)
+    batch = dict(gt_fovx=w.spec.fovx, gt_fovy=w.spec.fovy, gt_c2w=syn.make_c2w(3.0, 0.1, 0.4)[None], gt_normal_fovx=nf, gt_normal_fovy=nf,
+                 gt_normal_res=res, gt_normal_cx=torch.tensor([res / 2.0]), gt_normal_cy=torch.tensor([res / 2.0]),
+                 gt_cx=torch.tensor([W / 2.0]), gt_cy=torch.tensor([H / 2.0]), gt_width=W, gt_height=H, rand_bg_color=bg, gt_index=3)
+    out = w.renderer.gt_forward(batch)
+    assert out["comp_rgb"].shape == (1, H, W, 3) and out["comp_mask"].shape == (1, H, W, 1) and out["comp_occ"].shape == (1, H, W, 3)
+    assert out["comp_normal"].shape == (2, res, res, 3) and out["comp_pred_normal"].shape == (2, res, res, 3)
+    assert out["comp_normal_mask"].shape == (2, res, res, 1) and out["comp_depth"].shape == (1, H, W, 1)
+    assert len(out["viewspace_points"]) == 3 and len(out["radii"]) == 3
+    # the RGB view is the plugin's own render of that frame through the same camera
+    one = w.renderer(w.cam, bg, gt=True, gt_index=3)
+    assert torch.equal(out["comp_rgb"][0].permute(2, 0, 1), one["render"]) and torch.equal(out["comp_mask"][0].permute(2, 0, 1), one["mask"])
+    # front and back normal views see the body from the same camera: same silhouette, different surfaces
+    m_front, m_back = out["comp_normal_mask"][0] > 0.5, out["comp_normal_mask"][1] > 0.5
+    assert (m_front != m_back).float().mean() < 0.02 and m_front.float().mean() > 0.02
+    assert (out["comp_normal"][0] - out["comp_normal"][1]).abs()[m_front.expand(-1, -1, 3)].mean() > 0.05
+    (out["comp_rgb"].mean() + out["comp_normal"].mean() + out["comp_normal_mask"].mean()).backward()
+    for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
+        t.grad = None
 
 
 def test_reference_style_guidance_gives_same_frame(world):
