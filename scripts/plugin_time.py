@@ -45,6 +45,8 @@ def step(f, with_loss=True):
                 + masked_l1(out["mask"], t["mask"]) + 0.01 * out["depth"].mean() + 0.01 * out["curv"].mean())
     else:
         loss = out["render"].mean() + out["normal"].mean() + out["depth"].mean() + out["mask"].mean()
+    if TRAIN_OCC:                                     # loss_occ of the shipped configs (lambda_occ 0.1, gaussian_surfel_mvdream.py:412-417)
+        loss = loss + 0.1 * (1 - out["occ"][mask.expand(3, -1, -1)]).mean()
     loss.backward()
     opt.step()
 
@@ -54,6 +56,9 @@ VARIANTS = (("render + avatar-stage losses (SSIM, masked L1, cosine) composed th
             ("render + mean losses + backward + Adam", False))
 if os.environ.get("SOAR_PLUGIN_TIME_IMPORT_ONLY") == "1":       # scripts/plugin_host_split.py reuses the scene
     VARIANTS = ()
+TRAIN_OCC = False
+
+
 def timed(name, wl, n=40):
     for f in range(F + 4):               # every frame of the sequence once (per-frame caches, allocator) before the clock starts
         step(f, wl)
@@ -69,9 +74,20 @@ def timed(name, wl, n=40):
 for name, wl in VARIANTS:
     timed(name, wl)
 if VARIANTS:
-    # opt-in, not in the reference: no read-back of the instance count per forward call (Config.binning_capacity)
     from soar_amd import rasterizer
-    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 2 * rasterizer.last_num_rendered},
+    capacity = 3 * rasterizer.last_num_rendered        # of the main pass of the last frame (the model moves under Adam: generous bound)
+    # the occlusion parameter trained, as in the reference's configs: the occlusion pass is then a rasterization of its own with
+    # a backward of its own (the fused blend gives the occlusion image without a gradient)
+    pc._occ.requires_grad_(True)
+    opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color, pc._occ], lr=1e-4)
+    TRAIN_OCC = True
+    timed("avatar_stage_loss + loss_occ, occlusion parameter trained (separate occlusion pass with backward)", "fused")
+    TRAIN_OCC = False
+    pc._occ.requires_grad_(False)
+    pc._occ.grad = None
+    opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4)
+    # opt-in, not in the reference: no read-back of the instance count per forward call (Config.binning_capacity)
+    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": capacity},
                                                           geometry=pc)
     timed("avatar_stage_loss, Config.binning_capacity set (no host read-back per frame)", "fused")
     print("   binning status (instances, overflow):", rasterizer.check_binning())

@@ -108,8 +108,8 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
 
     def _forward_fused(self, pc, cam, bg_color, scaling_modifier, points, rot, offsets, axis_perm, attribute_color,
                        attribute_scale, zero_out, back, kwargs):
-        """The whole view as one autograd node (soar_amd/renderer/fused_view.py): full patch, fixed camera, no gradient asked of
-        the occlusion image.  Same outputs as the composed path below."""
+        """The whole view as one autograd node (soar_amd/renderer/fused_view.py): full patch, fixed camera.  Same outputs as the
+        composed path below."""
         guide = pc.smpl_guidance
         idx, a_smpl = kwargs.get("gt_index"), kwargs.get("gt_a_smpl")
         with torch.no_grad():
@@ -157,8 +157,8 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         # produces the occlusion image without a backward, so it is only taken when no such gradient can be asked for.
         occ_needs_grad = torch.is_grad_enabled() and bool(getattr(pc.get_occ, "requires_grad", False))
         guide = pc.smpl_guidance
-        one_node = full_patch and not cam_leaf and not occ_needs_grad
-        fused_blend = render_front and one_node
+        one_node = full_patch and not cam_leaf
+        fused_blend = render_front and one_node and not occ_needs_grad
         if one_node and FUSED_VIEW and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights"):
             return self._forward_fused(pc, viewpoint_camera, bg_color, scaling_modifier, points, rot, offsets, axis_perm,
                                        attribute_color, attribute_scale, not gt, not render_front, kwargs)

@@ -68,7 +68,9 @@ class _RenderView(torch.autograd.Function):
             rs.bg, xyz_p, colours, ones, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
             rs.patch_bbox, rs.tanfovx, rs.tanfovy, H, W, None, rs.sh_degree, rs.campos, rs.prefiltered, front, descending, rs.debug,
             rs.config)
-        if not back:
+        occ_grad = bool(ctx.needs_input_grad[5])             # the occlusion parameter is trained
+        st_occ = None
+        if not back and not occ_grad:
             # main pass front-to-back: the occlusion pass (:193-211, :281-291) is a subsequence of it, blended in the same launch
             st = geometry(cols, False, False)
             R = _NativeOps._render_stage(st, occ, capacity=capacity)
@@ -76,11 +78,14 @@ class _RenderView(torch.autograd.Function):
                 rasterizer._last_batch = [(st["geom"], P, 0, dev)]        # what rasterizer.check_binning() reads
             occ_img = st["occ"]
         else:
-            # render_front=False: main pass sorted back-to-front (:173-191); the occlusion pass is a rasterization of its own
-            st = geometry(cols, False, True)
-            st_occ = geometry(_f32(occ).reshape(P, 1).repeat(1, 3), True, False)      # both geometry stages in front of the read-backs
+            # render_front=False: main pass sorted back-to-front (:173-191); or the occlusion parameter is trained (loss_occ,
+            # TS/system/gaussian_surfel_mvdream.py:412-417): the fused blend has no backward for the occlusion chain.  Either
+            # way the occlusion pass is a rasterization of its own, as in the reference (:193-211, :281-291)
+            st = geometry(cols, False, back)
+            occ3 = _f32(occ).reshape(P, 1).repeat(1, 3)
+            st_occ = geometry(occ3, True, False)                      # both geometry stages in front of the read-backs
             R = _NativeOps._render_stage(st, None)
-            _NativeOps._render_stage(st_occ, None)
+            R_occ = _NativeOps._render_stage(st_occ, None)
             occ_img = st_occ["out"][0]
         color, normal, depth, opac = st["out"]
         f = dict(dtype=torch.float32, device=dev)
@@ -93,16 +98,24 @@ class _RenderView(torch.autograd.Function):
         ctx.scale_shape = tuple(scale_src.shape)
         ctx.off_grad = offsets is not None and offsets.requires_grad
         empty = torch.empty((0,), **f)
+        ctx.occ_shape = None
+        occ_state = ()
+        if occ_grad and st_occ is not None:
+            ctx.occ_shape, ctx.R_occ = tuple(occ.shape), R_occ
+            occ_state = (occ3, st_occ["radii"], st_occ["geom"], st_occ["binning"], st_occ["img"])
         ctx.save_for_backward(x, q, w, A, T if T is not None else empty, cols, scales3, xyz_p, rot_p, st["radii"], st["geom"],
-                              st["binning"], st["img"], normal, depth, opac, prcp)
-        ctx.mark_non_differentiable(st["radii"], occ_img)
+                              st["binning"], st["img"], normal, depth, opac, prcp, *occ_state)
+        if ctx.occ_shape is None:
+            ctx.mark_non_differentiable(st["radii"], occ_img)
+        else:
+            ctx.mark_non_differentiable(st["radii"])
         ctx.set_materialize_grads(False)
         return color, normal_out, depth, pred, opac, occ_img, curv, st["radii"]
 
     @staticmethod
-    def backward(ctx, g_color, g_normal_out, g_depth, g_pred, g_opac, _g_occ, g_curv, _g_radii):
+    def backward(ctx, g_color, g_normal_out, g_depth, g_pred, g_opac, g_occ_img, g_curv, _g_radii):
         L = hip_lib.lib()
-        (x, q, w, A, T, cols, scales3, xyz_p, rot_p, radii, geom, binning, img, normal, depth, opac, prcp) = ctx.saved_tensors
+        (x, q, w, A, T, cols, scales3, xyz_p, rot_p, radii, geom, binning, img, normal, depth, opac, prcp) = ctx.saved_tensors[:17]
         rs, dev = ctx.rs, x.device
         H, W = int(rs.image_height), int(rs.image_width)
         P = x.shape[0]
@@ -135,7 +148,17 @@ class _RenderView(torch.autograd.Function):
         g_off = None
         if ctx.off_grad:
             g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
-        return g_xyz, g_rot, g_colors, g_scale, g_means2D, None, None, None, g_off, None, None, None, None, None
+        g_occ = None
+        if ctx.occ_shape is not None and g_occ_img is not None:
+            # the occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient
+            occ3, radii_o, geom_o, binning_o, img_o = ctx.saved_tensors[17:]
+            z3, z1 = torch.zeros((3, H, W), **f), torch.zeros((1, H, W), **f)
+            g_occ3 = _NativeOps.rasterize_gaussians_backward(
+                rs.bg, xyz_p, radii_o, occ3, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
+                rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_occ_img, z3, z1, z1, None, rs.sh_degree, rs.campos, geom_o, ctx.R_occ,
+                binning_o, img_o, rs.debug, rs.config)[1]
+            g_occ = g_occ3.sum(1, keepdim=True).reshape(ctx.occ_shape)
+        return g_xyz, g_rot, g_colors, g_scale, g_means2D, g_occ, None, None, g_off, None, None, None, None, None
 
 
 def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets: Optional[torch.Tensor], axis_perm, rs,

@@ -127,8 +127,8 @@ def test_plugin_video_frame_matches_oracle_chain(world):
         t.grad = None
 
 
-@pytest.mark.parametrize("gt,front", [(True, True), (False, True), (True, False)])
-def test_fused_view_matches_the_composed_path(world, gt, front):
+@pytest.mark.parametrize("gt,front,occ_trained", [(True, True, False), (False, True, False), (True, False, False), (True, True, True)])
+def test_fused_view_matches_the_composed_path(world, gt, front, occ_trained):
     """The view as ONE autograd node (soar_amd/renderer/fused_view.py: warp -> rasterize -> soar_view_finish, and back) against
     the same view composed from the separate autograd ops: identical images, gradients to float-atomic order."""
     from soar_amd.renderer import diff_gaussian as dg
@@ -136,23 +136,32 @@ def test_fused_view_matches_the_composed_path(world, gt, front):
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     gen = torch.Generator().manual_seed(3)
     wts = {k: torch.randn(c, H, W, generator=gen).to(DEV) for k, c in (("render", 3), ("normal", 3), ("depth", 1), ("pred_normal", 3),
-                                                                       ("mask", 1), ("curv", 1))}
+                                                                       ("mask", 1), ("curv", 1), ("occ", 3))}
+    if not occ_trained:
+        del wts["occ"]
+    occ0 = w.pc._occ
     res = {}
-    for fused in (True, False):
-        dg.FUSED_VIEW = fused
-        try:
-            out = w.renderer(w.cam, bg, gt=gt, gt_index=5, render_front=front)
-        finally:
-            dg.FUSED_VIEW = True
-        sum(((out[k] * wts[k]).sum() for k in wts)).backward()
-        leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color, out["viewspace_points"])
-        res[fused] = ({k: v.detach().clone() for k, v in out.items()}, [t.grad.clone() for t in leaves])
-        for t in leaves[:4]:
-            t.grad = None
+    try:
+        if occ_trained:                                  # loss_occ trains the occlusion parameter: the occ image carries gradient
+            w.pc._occ = occ0.clone().requires_grad_(True)
+        for fused in (True, False):
+            dg.FUSED_VIEW = fused
+            try:
+                out = w.renderer(w.cam, bg, gt=gt, gt_index=5, render_front=front)
+            finally:
+                dg.FUSED_VIEW = True
+            assert out["occ"].requires_grad == occ_trained
+            sum(((out[k] * wts[k]).sum() for k in wts)).backward()
+            leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color, out["viewspace_points"]) + ((w.pc._occ,) if occ_trained else ())
+            res[fused] = ({k: v.detach().clone() for k, v in out.items()}, [t.grad.clone() for t in leaves])
+            for t in leaves[:4] + leaves[5:]:
+                t.grad = None
+    finally:
+        w.pc._occ = occ0
     (fo, fg), (co, cg) = res[True], res[False]
     for k in fo:
         assert torch.equal(fo[k], co[k]), k
-    for a, b, name in zip(fg, cg, ("xyz", "rot", "scale", "color", "means2D")):
+    for a, b, name in zip(fg, cg, ("xyz", "rot", "scale", "color", "means2D", "occ")):
         assert torch.isfinite(a).all() and b.abs().max() > 0, name
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), name
     # unused outputs: no gradient planes are made up for them
