@@ -144,6 +144,15 @@ int soar_rast_backward(const SoarRastParams *prm,
                        float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos,
                        void *workspace, size_t workspace_bytes,
                        void *stream);
+/* soar_rast_occ_backward: gradient of the occlusion image of soar_rast_forward_render_occ w.r.t. the per-Gaussian occlusion
+ * values: dL_docc[i] = sum over pixels of (g_0 + g_1 + g_2) alpha_i T_occ,i -- what the reference gets as dL_dcolors (summed over
+ * the three equal channels) of its separate occlusion pass, whose colours are occ.repeat(1, 3) and whose geometry is detached
+ * (TS/renderer/diff_gaussian_rasterizer.py:281-291; loss_occ, TS/system/gaussian_surfel_mvdream.py:412-417).  One walk of the
+ * MAIN pass's lists (its geom / binning / image buffers: render_front = 0, sort_descending = 0) over the camera-facing entries,
+ * same arithmetic as the forward's occlusion chain.  dL_dout_occ [3,H,W]; dL_docc [P], overwritten. */
+int soar_rast_occ_backward(const SoarRastParams *prm, const void *geom_buffer, const void *binning_buffer,
+                           const void *image_buffer, int64_t num_rendered, const float *dL_dout_occ, float *dL_docc,
+                           void *stream);
 /* Same, with the four image gradients multiplied by the device scalar *grad_scale_dev while they are loaded (the
  * upstream gradient of a scalar image loss whose gradient planes soar_frame_loss wrote): no scaling pass. */
 int soar_rast_backward_scaled(const SoarRastParams *prm,

@@ -45,8 +45,11 @@ def step(f, with_loss=True):
                 + masked_l1(out["mask"], t["mask"]) + 0.01 * out["depth"].mean() + 0.01 * out["curv"].mean())
     else:
         loss = out["render"].mean() + out["normal"].mean() + out["depth"].mean() + out["mask"].mean()
-    if TRAIN_OCC:                                     # loss_occ of the shipped configs (lambda_occ 0.1, gaussian_surfel_mvdream.py:412-417)
-        loss = loss + 0.1 * (1 - out["occ"][mask.expand(3, -1, -1)]).mean()
+    if TRAIN_OCC == "indexed":                        # loss_occ of the shipped configs (lambda_occ 0.1, gaussian_surfel_mvdream.py:412-417)
+        loss = loss + 0.1 * (1 - out["occ"][mask.expand(3, -1, -1)]).mean()         # as written there: boolean indexing blocks the host
+    elif TRAIN_OCC:                                   # the same value as a masked mean: nothing is read back
+        m3 = mask.expand(3, -1, -1)
+        loss = loss + 0.1 * ((1 - out["occ"]) * m3).sum() / m3.sum()
     loss.backward()
     opt.step()
 
@@ -81,7 +84,9 @@ if VARIANTS:
     pc._occ.requires_grad_(True)
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color, pc._occ], lr=1e-4)
     TRAIN_OCC = True
-    timed("avatar_stage_loss + loss_occ, occlusion parameter trained (separate occlusion pass with backward)", "fused")
+    timed("avatar_stage_loss + loss_occ as a masked mean, occlusion parameter trained (soar_rast_occ_backward)", "fused")
+    TRAIN_OCC = "indexed"
+    timed("avatar_stage_loss + loss_occ by boolean indexing as the reference writes it (a host read-back per frame)", "fused")
     TRAIN_OCC = False
     pc._occ.requires_grad_(False)
     pc._occ.grad = None

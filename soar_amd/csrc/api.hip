@@ -429,6 +429,28 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
     return 0;
 }
 
+int soar_rast_occ_backward(const SoarRastParams *prm, const void *geom_buffer, const void *binning_buffer, const void *image_buffer,
+                           int64_t num_rendered, const float *dL_dout_occ, float *dL_docc, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (prm->P == 0) return 0;
+    if (!dL_dout_occ || !dL_docc) { set_error("soar_rast_occ_backward: a required pointer is NULL"); return 1; }
+    if (prm->sort_descending || prm->render_front) {
+        set_error("soar_rast_occ_backward: the fused occlusion pass belongs to a main pass with render_front = 0 and sort_descending = 0");
+        return 1;
+    }
+    if (check_aligned(geom_buffer, "geom_buffer") || check_aligned(image_buffer, "image_buffer")) return 1;
+    if (num_rendered > 0 && check_aligned(binning_buffer, "binning_buffer")) return 1;
+    GeomBuf g;
+    ImageBuf img;
+    BinBuf b;
+    carve_geom(const_cast<void *>(geom_buffer), prm->P, prm->M, &g);
+    carve_image(const_cast<void *>(image_buffer), prm->W, prm->H, &img);
+    carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
+    return launch_occ_backward(*prm, g, b, img, dL_dout_occ, dL_docc, stream);
+}
+
 int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
                        const float *colors_precomp, const float *scales, const float *rotations,
                        const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,

@@ -430,6 +430,187 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_F
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Gradient of the fused occlusion image w.r.t. the per-Gaussian occlusion values (the reference trains them: loss_occ,
+// TS/system/gaussian_surfel_mvdream.py:412-417, through an occlusion pass whose colours are occ.repeat(1, 3) and whose geometry is
+// detached, TS/renderer/diff_gaussian_rasterizer.py:281-291):
+//     dL/docc_i = sum over pixels of (g_0 + g_1 + g_2)(pixel) * alpha_i(pixel) * T_occ,i(pixel)
+// The weights alpha * T_occ are those of the occlusion chain of blend_quad<.., OCC = true>; this kernel walks the same lists
+// with the same arithmetic for that chain only (same roundings, same stops) and, instead of blending a colour, adds up
+// weight x upstream gradient over the 16 pixels of a wavefront's 4x4 block per surviving entry -- one atomic per (wavefront,
+// entry) that contributed.  Pixels whose upstream gradient is zero never start (loss_occ masks the person's pixels).
+struct OccGradArgs {
+    int W, H, gx, gy, ntiles;
+    const uint2 *ranges;
+    const uint32_t *tile_order;
+    const uint32_t *point_list;
+    const GaussRec *rec;
+    const float *front;              // [P] 1 = camera-facing (preprocess)
+    const float *g_occ;              // [3,H,W] upstream gradient of the occlusion image
+    float *g_values;                 // [P] out, zero-filled before the launch
+};
+
+__device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int rank, const int quad)
+{
+    __shared__ float4 sq0[CHUNK + 1];                                                    // x, y, A, B
+    __shared__ float4 sq1[CHUNK + 1];                                                    // C, opacity, cull threshold, camera-facing
+    __shared__ uint32_t sid[CHUNK + 1];
+    __shared__ int wave_alive[2][4];
+    __shared__ unsigned short todo_ring[4][WAVE + 4];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t tile_u = a.tile_order[rank];
+    if (tile_u == 0xFFFFFFFFu) return;
+    const int tile = (int)tile_u;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
+    const int pxl = lane >> 2, slot = lane & 3;
+    const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
+    const bool inside = px < a.W && py < a.H;
+    const float fx = (float)px, fy = (float)py;
+    const uint2 range = a.ranges[tile];
+
+    float G = 0.f;
+    if (inside) {
+        const size_t pix = (size_t)a.W * py + px, hw = (size_t)a.H * a.W;
+        G = a.g_occ[pix] + a.g_occ[hw + pix] + a.g_occ[2 * hw + pix];
+    }
+    float T_o = 1.0f;
+    float alive_o = (inside && G != 0.f) ? 1.f : 0.f;
+    bool wave_done = (__ballot(alive_o != 0.f) == 0ull);
+
+    if (tid == 0) {
+        sq0[CHUNK] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sq1[CHUNK] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sid[CHUNK] = 0u;
+    }
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    uint32_t rid = 0, id_next = 0;
+    if (range.x + tid < range.y) {
+        rid = a.point_list[range.x + tid];
+        const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
+        r0 = src[0];
+        const float4 t1 = src[1];
+        r1 = make_float4(t1.x, t1.y, src[3].w, a.front[rid]);
+    }
+    if (range.x + CHUNK + tid < range.y) id_next = a.point_list[range.x + CHUNK + tid];
+    int parity = 0;
+    for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
+        const int n = min((uint32_t)CHUNK, range.y - base);
+        if (tid < n) { sq0[tid] = r0; sq1[tid] = r1; sid[tid] = rid; }
+        if (base + CHUNK + tid < range.y) {
+            rid = id_next;
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + rid);
+            r0 = src[0];
+            const float4 t1 = src[1];
+            r1 = make_float4(t1.x, t1.y, src[3].w, a.front[rid]);
+        }
+        if (base + 2 * CHUNK + tid < range.y) id_next = a.point_list[base + 2 * CHUNK + tid];
+        lds_barrier();
+
+        if (!wave_done) {
+            float rx0 = (float)bx0, ry0 = (float)by0, rex = 3.f, rey = 3.f;             // bounding box of the pixels still walking
+            {
+                const unsigned long long am = __ballot(alive_o != 0.f);
+                uint32_t cols = 0, rows = 0;
+#pragma unroll
+                for (int pp = 0; pp < 16; pp++) {
+                    const uint32_t on = (uint32_t)((am >> (4 * pp)) & 1ull);
+                    cols |= on << (pp & 3);
+                    rows |= on << (pp >> 2);
+                }
+                if (cols) {
+                    const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), q0 = __builtin_ctz(rows), q1 = 31 - __builtin_clz(rows);
+                    rx0 = (float)(bx0 + c0); ry0 = (float)(by0 + q0); rex = (float)(c1 - c0); rey = (float)(q1 - q0);
+                }
+            }
+            for (int sub = 0; sub < n; sub += WAVE) {
+                bool relevant = false;
+                if (sub + lane < n) {
+                    const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
+                    relevant = e1.w != 0.f && splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, e1.z, rx0, ry0, rex, rey);
+                }
+                const unsigned long long todo = __ballot(relevant);
+                const int n_todo = (int)__builtin_popcountll(todo);
+                if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(sub + lane);
+                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)CHUNK;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                for (int it = 0; it < n_todo; it += 4) {
+                    const int j = todo_ring[wave][it + slot];
+                    const float4 q0 = sq0[j], q1 = sq1[j];
+                    const float dx = q0.x - fx, dy = q0.y - fy;
+                    const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);
+                    const float alpha = fminf(0.99f, q1.y * exp_nonpositive(power));
+                    float a_live = (power > 0.0f) ? 0.f : alpha;
+                    a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
+                    const float a_o = a_live * q1.w * alive_o;                           // (back-facing entries never enter the ring; the
+                    const float mo = 1.f - a_o;                                          //  pad record has flag 0)
+                    float y = quad_scan_products(T_o, mo, slot == 0);
+                    const float v3 = quad_move<DPP_QUAD_BCAST3>(y);
+                    float w_o;
+                    bool some_stop = false;
+                    if (__ballot(v3 < 0.0001f) == 0ull) {
+                        const float U_prev = quad_move<DPP_QUAD_SHIFT1>(y);
+                        w_o = a_o * (slot == 0 ? T_o : U_prev);
+                        T_o = v3;
+                    } else {
+                        const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
+                                    mo2 = quad_move<DPP_QUAD_BCAST2>(mo), mo3 = quad_move<DPP_QUAD_BCAST3>(mo);
+                        const float u0 = mul_keep(T_o, mo0);
+                        const bool z0 = u0 < 0.0001f;
+                        const float U1 = z0 ? T_o : u0;
+                        const float u1 = mul_keep(U1, mo1);
+                        const bool z1 = z0 || (u1 < 0.0001f);
+                        const float U2 = z1 ? U1 : u1;
+                        const float u2 = mul_keep(U2, mo2);
+                        const bool z2 = z1 || (u2 < 0.0001f);
+                        const float U3 = z2 ? U2 : u2;
+                        const float u3 = mul_keep(U3, mo3);
+                        const bool z3 = z2 || (u3 < 0.0001f);
+                        const float U_mine = slot == 0 ? T_o : slot == 1 ? U1 : slot == 2 ? U2 : U3;
+                        const bool stopped_o = slot == 0 ? z0 : slot == 1 ? z1 : slot == 2 ? z2 : z3;
+                        w_o = stopped_o ? 0.f : a_o * U_mine;
+                        T_o = z3 ? U3 : u3;
+                        alive_o = z3 ? 0.f : alive_o;
+                        some_stop = true;
+                    }
+                    if (__ballot(w_o != 0.f) != 0ull) {
+                        // sum over the 16 pixels of the block, per slot (lanes with the same lane & 3)
+                        float c = w_o * G;
+                        c += __shfl_xor(c, 4);
+                        c += __shfl_xor(c, 8);
+                        c += __shfl_xor(c, 16);
+                        c += __shfl_xor(c, 32);
+                        if (lane < 4 && c != 0.f) atomicAdd(a.g_values + sid[j], c);
+                    }
+                    if (some_stop && __ballot(alive_o != 0.f) == 0ull) { wave_done = true; break; }
+                }
+                if (wave_done) break;
+            }
+        }
+        if (lane == 0) wave_alive[parity][wave] = wave_done ? 0 : 1;
+        lds_barrier();
+        if ((wave_alive[parity][0] | wave_alive[parity][1] | wave_alive[parity][2] | wave_alive[parity][3]) == 0) break;
+    }
+}
+
+__global__ void __launch_bounds__(256) occ_backward_kernel(OccGradArgs a)
+{
+    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
+    const int stride = (int)(gridDim.x >> 2);
+    const int Tpad = (a.ntiles + 7) / 8 * 8;
+    const int n_work = (int)a.tile_order[Tpad];
+    for (int rank = rank0; rank < n_work; rank += stride) {
+        occ_grad_quad(a, rank, quad);
+        lds_barrier();
+    }
+}
+
 }  // namespace
 
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
@@ -472,6 +653,24 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     if (out_occ) hipLaunchKernelGGL((render_forward_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
+    return 0;
+}
+
+int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img, const float *dL_dout_occ,
+                        float *dL_docc, hipStream_t stream)
+{
+    OccGradArgs a;
+    a.W = prm.W; a.H = prm.H;
+    a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
+    a.ntiles = a.gx * a.gy;
+    a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.front = g.front;
+    a.g_occ = dL_dout_occ; a.g_values = dL_docc;
+    const int Tpad = (a.ntiles + 7) / 8 * 8;
+    const int nblocks = 4 * min(Tpad, FWD_GRID_RANKS);
+    SOAR_HIP_OK(hipMemsetAsync(dL_docc, 0, sizeof(float) * (size_t)prm.P, stream));
+    StageTimer timer(ST_RENDER_BWD, stream);
+    hipLaunchKernelGGL(occ_backward_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("occ_backward", stream, prm.debug);
     return 0;
 }
 

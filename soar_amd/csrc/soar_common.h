@@ -325,6 +325,8 @@ int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &i
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
                           float *out_color, float *out_normal, float *out_depth, float *out_opac,
                           const float *occ_values, float *out_occ, hipStream_t stream);
+int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img, const float *dL_dout_occ,
+                        float *dL_docc, hipStream_t stream);
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
                            const float *grad_scale, float *acc, double *acc64, bool blend, hipStream_t stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
                            + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_backward_scaled": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 5
                                   + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
+    "soar_rast_occ_backward": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_rast_export_state": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64] + [_vp] * 17 + [_vp]),
     "soar_lbs_knn_weights_bytes": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

@@ -12,7 +12,7 @@ path except for the post-op glue, which ``soar_view_finish`` folds into the two 
 """
 from __future__ import annotations
 
-import ctypes as C  # noqa: F401  (kept for symmetry with the other host modules)
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -70,18 +70,18 @@ class _RenderView(torch.autograd.Function):
             rs.config)
         occ_grad = bool(ctx.needs_input_grad[5])             # the occlusion parameter is trained
         st_occ = None
-        if not back and not occ_grad:
+        if not back:
             # main pass front-to-back: the occlusion pass (:193-211, :281-291) is a subsequence of it, blended in the same launch
+            # (its gradient w.r.t. the occlusion values, when they are trained: soar_rast_occ_backward, one more walk of the lists)
             st = geometry(cols, False, False)
             R = _NativeOps._render_stage(st, occ, capacity=capacity)
             if capacity is not None:
                 rasterizer._last_batch = [(st["geom"], P, 0, dev)]        # what rasterizer.check_binning() reads
             occ_img = st["occ"]
         else:
-            # render_front=False: main pass sorted back-to-front (:173-191); or the occlusion parameter is trained (loss_occ,
-            # TS/system/gaussian_surfel_mvdream.py:412-417): the fused blend has no backward for the occlusion chain.  Either
-            # way the occlusion pass is a rasterization of its own, as in the reference (:193-211, :281-291)
-            st = geometry(cols, False, back)
+            # render_front=False: main pass sorted back-to-front (:173-191), the occlusion pass is a rasterization of its own, as
+            # in the reference (:193-211, :281-291)
+            st = geometry(cols, False, True)
             occ3 = _f32(occ).reshape(P, 1).repeat(1, 3)
             st_occ = geometry(occ3, True, False)                      # both geometry stages in front of the read-backs
             R = _NativeOps._render_stage(st, None)
@@ -100,9 +100,11 @@ class _RenderView(torch.autograd.Function):
         empty = torch.empty((0,), **f)
         ctx.occ_shape = None
         occ_state = ()
-        if occ_grad and st_occ is not None:
-            ctx.occ_shape, ctx.R_occ = tuple(occ.shape), R_occ
-            occ_state = (occ3, st_occ["radii"], st_occ["geom"], st_occ["binning"], st_occ["img"])
+        if occ_grad:
+            ctx.occ_shape, ctx.back = tuple(occ.shape), back
+            if back:
+                ctx.R_occ = R_occ
+                occ_state = (occ3, st_occ["radii"], st_occ["geom"], st_occ["binning"], st_occ["img"])
         ctx.save_for_backward(x, q, w, A, T if T is not None else empty, cols, scales3, xyz_p, rot_p, st["radii"], st["geom"],
                               st["binning"], st["img"], normal, depth, opac, prcp, *occ_state)
         if ctx.occ_shape is None:
@@ -120,36 +122,49 @@ class _RenderView(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         P = x.shape[0]
         f = dict(dtype=torch.float32, device=dev)
-        g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
-        opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
-        gn, gc, gp, gd = opt(g_normal_out), opt(g_curv), opt(g_pred), opt(g_depth)
-        with torch.cuda.device(dev):
-            check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), ctx.focal[0], ctx.focal[1],
-                                              ptr(gn), ptr(gc), ptr(gp), ptr(gd), ptr(g_nd), _stream(dev)), "soar_view_finish_backward")
-        g_color = g_color if g_color is not None else torch.zeros((3, H, W), **f)
-        g_opac = g_opac if g_opac is not None else torch.zeros((1, H, W), **f)
-        (g_means2D, g_colors, _g_opacity, g_means3D, _g_cov, _g_sh, g_scales3, g_rot_p, _gv, _gpj, _gcam) = \
-            _NativeOps.rasterize_gaussians_backward(
-                rs.bg, xyz_p, radii, cols, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
-                rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_nd[:3], g_nd[3:], g_opac, None, rs.sh_degree, rs.campos, geom,
-                ctx.R, binning, img, rs.debug, rs.config)
-        g_xyz, g_rot = torch.empty_like(x), torch.empty_like(q)
-        with torch.cuda.device(dev):
-            check(L.soar_lbs_warp_backward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(T) if T.numel() else None, P, ctx.J, ptr(g_means3D),
-                                           ptr(g_rot_p), ptr(g_xyz), ptr(g_rot), _stream(dev)), "soar_lbs_warp_backward")
-        # scales3 = scale_src.repeat(1, 3) with the last column overwritten
-        k = ctx.scale_shape[1]
-        if k == 1:
-            g_scale = g_scales3[:, 0:1] + g_scales3[:, 1:2]
-        else:
-            g3 = g_scales3.clone()
-            g3[..., -1] = 0
-            g_scale = g3.reshape(P, 3, k).sum(1)
-        g_off = None
-        if ctx.off_grad:
-            g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
+        g_xyz = g_rot = g_colors = g_scale = g_means2D = g_off = None
+        if any(g is not None for g in (g_color, g_normal_out, g_depth, g_pred, g_opac, g_curv)):        # else: only the occlusion image was used
+            g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
+            opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
+            gn, gc, gp, gd = opt(g_normal_out), opt(g_curv), opt(g_pred), opt(g_depth)
+            with torch.cuda.device(dev):
+                check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), ctx.focal[0], ctx.focal[1],
+                                                  ptr(gn), ptr(gc), ptr(gp), ptr(gd), ptr(g_nd), _stream(dev)), "soar_view_finish_backward")
+            g_color = g_color if g_color is not None else torch.zeros((3, H, W), **f)
+            g_opac = g_opac if g_opac is not None else torch.zeros((1, H, W), **f)
+            (g_means2D, g_colors, _g_opacity, g_means3D, _g_cov, _g_sh, g_scales3, g_rot_p, _gv, _gpj, _gcam) = \
+                _NativeOps.rasterize_gaussians_backward(
+                    rs.bg, xyz_p, radii, cols, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
+                    rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_nd[:3], g_nd[3:], g_opac, None, rs.sh_degree, rs.campos, geom,
+                    ctx.R, binning, img, rs.debug, rs.config)
+            g_xyz, g_rot = torch.empty_like(x), torch.empty_like(q)
+            with torch.cuda.device(dev):
+                check(L.soar_lbs_warp_backward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(T) if T.numel() else None, P, ctx.J, ptr(g_means3D),
+                                               ptr(g_rot_p), ptr(g_xyz), ptr(g_rot), _stream(dev)), "soar_lbs_warp_backward")
+            # scales3 = scale_src.repeat(1, 3) with the last column overwritten
+            k = ctx.scale_shape[1]
+            if k == 1:
+                g_scale = g_scales3[:, 0:1] + g_scales3[:, 1:2]
+            else:
+                g3 = g_scales3.clone()
+                g3[..., -1] = 0
+                g_scale = g3.reshape(P, 3, k).sum(1)
+            g_off = None
+            if ctx.off_grad:
+                g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
         g_occ = None
-        if ctx.occ_shape is not None and g_occ_img is not None:
+        if ctx.occ_shape is not None and g_occ_img is not None and not ctx.back:
+            # the occlusion image came out of the main pass's blend: one more walk of its lists for dL/docc
+            from ..rasterizer import _Ctx
+            c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, False, rs.debug, rs.bg,
+                     rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
+            g_flat = torch.empty((P,), **f)
+            go = _dev_f32(g_occ_img, dev, "gradient of the occlusion image")
+            with torch.cuda.device(dev):
+                check(L.soar_rast_occ_backward(C.byref(c.params), ptr(geom), ptr(binning), ptr(img), int(ctx.R), ptr(go), ptr(g_flat),
+                                               _stream(dev)), "soar_rast_occ_backward")
+            g_occ = g_flat.reshape(ctx.occ_shape)
+        elif ctx.occ_shape is not None and g_occ_img is not None:
             # the occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient
             occ3, radii_o, geom_o, binning_o, img_o = ctx.saved_tensors[17:]
             z3, z1 = torch.zeros((3, H, W), **f), torch.zeros((1, H, W), **f)
