@@ -244,6 +244,12 @@ class FrameStepPlan:
                 with torch.cuda.graph(g, stream=cap):
                     self._prologue(cap.cuda_stream, resort)
                 graphs[name] = g
+                # nothing to wait for between the two (one rank, or the reductions are already done): one graph, one launch gap less
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    self._prologue(cap.cuda_stream, resort)
+                    self._warp_all(cap.cuda_stream)
+                graphs[name + "+warp"] = g
             for i in range(self.n):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=cap):
@@ -320,9 +326,13 @@ class FrameStepPlan:
         # prologue depends on the positions only -> it waits for the xyz bucket (where an optimizer's update of xyz sits);
         # the frames read every parameter -> they wait for the rest.  Stream-side waits, no host block; no-ops on one rank.
         self.flat.wait_bucket(0)
-        self.graphs["prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"].replay()
-        self.flat.wait_all()
-        self.graphs["warp"].replay()
+        name = "prologue_resort" if self.steps % self.RESORT_EVERY == 0 else "prologue"
+        if any(p is not None for p in self.flat.pending):
+            self.graphs[name].replay()
+            self.flat.wait_all()
+            self.graphs["warp"].replay()
+        else:
+            self.graphs[name + "+warp"].replay()
         self._fan_out(main, lambda i, s: self.graphs[i].replay())
         self.graphs["epilogue"].replay()
         self.steps += 1
