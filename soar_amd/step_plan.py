@@ -15,7 +15,7 @@ out once:
   the chains an epilogue of one launch (soar_lbs_warp_backward_sum: the warp backward of all frames, their sum in frame
   order and the sums of the frames' scale / colour gradients, written straight into the flat gradient buffer).
 
-Per step the host replays 3 + n_frames graphs instead of enqueueing ~105 launches through autograd, and the frames'
+Per step the host replays 2 + n_frames graphs (one more while a gradient reduction is pending between the KNN and the warp) instead of enqueueing ~105 launches through autograd, and the frames'
 chains overlap by ordinary stream semantics (a single captured graph with four branches was measured to be released
 one branch at a time by the graph executor).  The kernels and their results are those of the autograd path
 (``tests/test_plugin_gpu.py::test_step_plan_matches_autograd``).
