@@ -9,7 +9,8 @@
 // positions and skinning rows are wave-uniform (scalar) loads, there is no divergence and no per-lane gather.
 //   pass 1: every lane keeps the K smallest squared distances in registers (median-of-3 insertion chain, no
 //           indices); the four wavefronts of a workgroup each scan a quarter of the LDS-staged candidates and merge
-//           their lists; the box grows until, for every lane, the K-th distance is provably final (distance to the
+//           their lists (two sorted lists -> min against the reversed other = a bitonic sequence of the 32 smallest, five
+//           compare-exchange stages; the last merge only needs the K-th value); the box grows until, for every lane, the K-th distance is provably final (distance to the
 //           nearest open face of the box) -- the search is exact;
 //   pass 2: one query at a time per wavefront: lanes = candidates pick those below the query's K-th distance (ties at
 //           the K-th place in list order until K are reached), then lanes = joints blend their skinning rows, so row
@@ -347,6 +348,49 @@ __device__ __forceinline__ void chain_insert(float (&best)[K], float d)
     best[0] = fminf(best[0], d);
 }
 
+// Two ascending lists of K distances -> the K smallest of their union, ascending.  Elementwise min of one list against the other
+// reversed (both padded to 32 with +inf) is a bitonic sequence that holds the 32 smallest; five compare-exchange stages sort it
+// (80 min/max pairs instead of the 900 median steps of K chain insertions).  `other`: the second list, element k at other[k * stride].
+template <int K>
+__device__ __forceinline__ void merge_sorted(float (&best)[K], const float *other, int stride)
+{
+    static_assert(K <= 32 && K >= 16, "padded to 32");
+    float m[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const float a = k < K ? best[k] : 3.0e38f;
+        const float b = (31 - k) < K ? other[(31 - k) * stride] : 3.0e38f;
+        m[k] = fminf(a, b);
+    }
+#pragma unroll
+    for (int j = 16; j >= 1; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            if ((i & j) == 0) {
+                const float lo = fminf(m[i], m[i + j]), hi = fmaxf(m[i], m[i + j]);
+                m[i] = lo; m[i + j] = hi;
+            }
+#pragma unroll
+    for (int k = 0; k < K; k++) best[k] = m[k];
+}
+// The same union when only its K-th smallest value and the number of elements strictly below it are wanted (the last merge):
+// no sort at all.  Returns tau; need = how many elements AT tau belong to the K.
+template <int K>
+__device__ __forceinline__ float merge_sorted_kth(const float (&best)[K], const float *other, int stride, int &need)
+{
+    float v[K];
+    float tau = 0.f;                                   // squared distances are >= 0
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = fminf(best[k], other[(K - 1 - k) * stride]);
+        tau = fmaxf(tau, v[k]);
+    }
+    need = K;
+#pragma unroll
+    for (int k = 0; k < K; k++) need -= (v[k] < tau) ? 1 : 0;
+    return tau;
+}
+
 // Heaviest-first order of the (chunk, slot) work items of the launch below.  An item's time grows with the vertices in the 3x3x3
 // cell box of its segments' cells (pass 1) and with its number of queries (pass 2): at C3 126 of the 2217 workgroups with work
 // scan 450+ candidates and run twice as long as the median, and a tenth of them used to start at 75 us of a 158 us launch (the
@@ -504,10 +548,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 for (int k = 0; k < K; k++) merge[wave - 2][k][lane] = best[k];
             }
             __syncthreads();
-            if (wave < 2) {
-#pragma unroll 2
-                for (int k = 0; k < K; k++) chain_insert<K>(best, merge[wave][k][lane]);
-            }
+            if (wave < 2) merge_sorted<K>(best, &merge[wave][0][lane], WAVE);
             __syncthreads();
             if (wave == 1) {
 #pragma unroll
@@ -515,12 +556,8 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
             }
             __syncthreads();
             if (wave == 0) {
-#pragma unroll 2
-                for (int k = 0; k < K; k++) chain_insert<K>(best, merge[0][k][lane]);
-                const float tau = best[K - 1];
-                int need = K;                                         // how many candidates AT tau the query takes
-#pragma unroll
-                for (int k = 0; k < K; k++) need -= (best[k] < tau) ? 1 : 0;
+                int need;                                             // how many candidates AT tau the query takes
+                const float tau = merge_sorted_kth<K>(best, &merge[0][0][lane], WAVE, need);
                 tau_s[lane] = tau;
                 need_s[lane] = need;
                 // vertices not visited yet lie beyond an open face of the box: the distance to the nearest one bounds them
