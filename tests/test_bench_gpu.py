@@ -49,7 +49,7 @@ def test_bench_forced_dist_path_runs_rccl():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["mode"] == "plan" and d["config"]["collectives"].startswith("rccl")
+    assert d["n_gpus"] == 1 and d["config"]["mode"] == "plan-eager" and d["config"]["collectives"].startswith("rccl")
     assert d["value"] > 0
 
 
