@@ -99,6 +99,37 @@ if VARIANTS:
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4, fused=True)
     timed("avatar_stage_loss, binning_capacity and torch.optim.Adam(fused=True)", "fused")
 
+if VARIANTS:
+    # GaussianBatchRenderer.gt_forward: the frame at video resolution + the normal view and the back normal view at 1024 x 1024
+    import math
+    res = 1024
+    nf = 2 * math.atan(0.5 / 1.2)
+    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=pc)
+    opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4)
+    gt_batch = dict(gt_fovx=spec.fovx, gt_fovy=spec.fovy, gt_c2w=syn.make_c2w()[None], gt_normal_fovx=nf, gt_normal_fovy=nf, gt_normal_res=res,
+                    gt_normal_cx=torch.tensor([res / 2.0]), gt_normal_cy=torch.tensor([res / 2.0]), gt_cx=torch.tensor([W / 2.0]),
+                    gt_cy=torch.tensor([H / 2.0]), gt_width=W, gt_height=H, rand_bg_color=bg)
+
+    def gt_step(f):
+        opt.zero_grad(set_to_none=True)
+        o = renderer.gt_forward(dict(gt_batch, gt_index=f))
+        (o["comp_rgb"].mean() + o["comp_normal"].mean() + o["comp_mask"].mean() + o["comp_normal_mask"].mean()).backward()
+        opt.step()
+
+    from soar_amd.renderer import diff_gaussian as dg
+    for label, fused in (("one node, one warp each way", True), ("three composed forward calls", False)):
+        dg.FUSED_VIEW = fused
+        for f in range(F + 4):
+            gt_step(f)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(40):
+            gt_step(f)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        print(f"plugin path, gt_forward (3 views: 1080p + 2 x {res}^2) + mean losses + backward + Adam, {label}: {dt * 1e3:.2f} ms per step", flush=True)
+    dg.FUSED_VIEW = True
+
 if os.environ.get("SOAR_PROFILE_HOST") == "1" and VARIANTS:
     import cProfile, pstats
     pr = cProfile.Profile()

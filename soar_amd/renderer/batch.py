@@ -57,12 +57,18 @@ class GaussianBatchRenderer:
                        full_proj_transform=proj_n, camera_center=cam_p_n, prcppoint=half)
         acc: Dict[str, list] = {"viewspace_points": [], "visibility_filter": [], "radii": []}
         with torch.autocast("cuda", enabled=False):
-            pkg = self.forward(cam_rgb, batch["rand_bg_color"], gt=True, mode=mode, stage=stage, **batch)
+            views = [{"camera": cam_rgb, "bg_color": batch["rand_bg_color"], "render_front": True},
+                     {"camera": cam_n, "bg_color": self.background_tensor, "render_front": True},
+                     {"camera": cam_n, "bg_color": self.background_tensor, "render_front": False}]
+            if hasattr(self, "forward_views"):
+                # the three views show one pose: one warp each way, one autograd node (the reference calls forward three times)
+                pkg, pkg_n, pkg_b = self.forward_views(views, gt=True, mode=mode, stage=stage, **batch)
+            else:
+                pkg, pkg_n, pkg_b = (self.forward(v["camera"], v["bg_color"], gt=True, mode=mode, stage=stage,
+                                                  render_front=v["render_front"], **batch) for v in views)
             self._collect(acc, pkg, want=("render", "depth", "mask", "occ", "curv"))
-            pkg_n = self.forward(cam_n, self.background_tensor, gt=True, mode=mode, stage=stage, **batch)
             self._collect(acc, pkg_n, want=("normal", "pred_normal"))
             acc.setdefault("normal_mask", []).append(pkg_n["mask"])
-            pkg_b = self.forward(cam_n, self.background_tensor, gt=True, mode=mode, stage=stage, render_front=False, **batch)
             self._collect(acc, pkg_b, want=("normal", "pred_normal"))
             acc["normal_mask"].append(pkg_b["mask"])
         return self._finish(acc, {"render": "comp_rgb", "normal": "comp_normal", "pred_normal": "comp_pred_normal",

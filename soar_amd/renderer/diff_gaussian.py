@@ -27,7 +27,7 @@ from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rast
 from . import registry
 from .batch import GaussianBatchRenderer
 from .cameras import device_constant
-from .fused_view import render_view
+from .fused_view import render_view, render_views
 from .postops import depth2normal, normal2curv
 
 # SOAR_FUSED_VIEW=0: always take the composed path (separate autograd ops), e.g. to compare the two
@@ -131,6 +131,46 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
             "render": image, "normal": normal, "depth": depth, "pred_normal": pred_normal, "mask": opac, "occ": occ, "curv": curv,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
         }
+
+    def forward_views(self, views, gt=True, **kwargs):
+        """Several full-patch views of ONE pose -- `views` = [{"camera", "bg_color", "render_front"}], e.g. the three of
+        ``gt_forward`` -- as one autograd node: the surfels are warped once each way and the views' geometry stages are enqueued in
+        front of the first read-back.  Same per-view dicts as ``forward``; falls back to one ``forward`` call per view when the
+        one-node form does not apply (camera leaves, reference-style guidance, ``SOAR_FUSED_VIEW=0``)."""
+        pc = self.geometry
+        guide = pc.smpl_guidance
+        cams = [v["camera"] for v in views]
+        cam_leaf = any(getattr(t, "requires_grad", False) for c in cams
+                       for t in (c.world_view_transform, c.full_proj_transform, c.camera_center))
+        if not (FUSED_VIEW and not cam_leaf and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights")):
+            return [self.forward(v["camera"], v["bg_color"], gt=gt, render_front=v.get("render_front", True), **kwargs) for v in views]
+        points, rot = pc.get_xyz, pc.get_rotation
+        fields = pc.attribute_field(points.detach()) if not gt else pc.attribute_field(points.detach(), z=None)
+        offsets = fields["offsets"] if self.cfg.offset else None
+        axis_perm = None if gt else axis_permutation("+z,+x,+y", points.device)
+        idx, a_smpl = kwargs.get("gt_index"), kwargs.get("gt_a_smpl")
+        with torch.no_grad():
+            mats = guide.joint_mats(smpl_parms_in=a_smpl, idx=None if a_smpl is not None else idx, zero_out=not gt)
+            w = guide.blend_weights(points)
+        settings, carriers = [], []
+        for v in views:
+            cam, bg_color = v["camera"], v["bg_color"]
+            if gt and not self.training:
+                bg_color = torch.ones_like(bg_color)
+            carriers.append(torch.zeros((points.shape[0], 3), dtype=points.dtype, device=points.device, requires_grad=True))
+            settings.append(GaussianRasterizationSettings(
+                image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+                tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color, scale_modifier=kwargs.get("scaling_modifier", 1.0),
+                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                patch_bbox=cam.random_patch(float("inf"), float("inf")), prcppoint=cam.prcppoint, sh_degree=pc.active_sh_degree,
+                campos=cam.camera_center, prefiltered=False, render_front=False, sort_descending=False, debug=False,
+                config=pc.config))
+        outs = render_views(points, rot, pc.get_colors if self.cfg.use_explicit else fields["shs"],
+                            pc.get_scaling if self.cfg.use_explicit else fields["scales"], carriers, pc.get_occ, w, mats, offsets,
+                            axis_perm, settings, cams, [not v.get("render_front", True) for v in views],
+                            capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None)
+        return [{"render": o[0], "normal": o[1], "depth": o[2], "pred_normal": o[3], "mask": o[4], "occ": o[5], "curv": o[6],
+                 "viewspace_points": c, "visibility_filter": o[7] > 0, "radii": o[7]} for o, c in zip(outs, carriers)]
 
     def forward(self, viewpoint_camera, bg_color: torch.Tensor, patch_size: list = [float("inf"), float("inf")],
                 scaling_modifier=1.0, override_color=None, gt=False, render_front=True, stage=0, **kwargs):

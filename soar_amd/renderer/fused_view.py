@@ -8,7 +8,8 @@ autograd ops that is ~10 graph nodes and ~45 launches each way whose cost is the
 ``torch.autograd.Function``: warp -> rasterize (fused occlusion pass) -> ``soar_view_finish`` forward, and
 ``soar_view_finish_backward`` -> rasterizer backward -> warp backward on the way back.  Same kernels as the composed
 path except for the post-op glue, which ``soar_view_finish`` folds into the two stencil kernels
-(``tests/test_plugin_gpu.py::test_fused_view_matches_the_composed_path``).
+(``tests/test_plugin_gpu.py::test_fused_view_matches_the_composed_path``).  Several views of one pose (``gt_forward``'s three)
+share the warp and the node.
 """
 from __future__ import annotations
 
@@ -43,10 +44,16 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-class _RenderView(torch.autograd.Function):
-    # outputs: render, normal, depth, pred_normal, mask, occ, curv, radii
+class _RenderViews(torch.autograd.Function):
+    """n views of the SAME warped surfels (one pose: e.g. the three views of ``gt_forward``) as one node: one warp each way, the
+    geometry stages of all views in front of the first read-back.  Per view 8 outputs: render, normal, depth, pred_normal, mask,
+    occ, curv, radii.  specs[i] = (settings, (focal_k00, focal_k11), capacity or None, back)."""
+    N_OUT = 8
+    N_COMMON = 9          # saved tensors shared by the views
+    N_VIEW = 8            # saved tensors per view (+ 4 for a separately rasterized occlusion pass whose gradient is wanted)
+
     @staticmethod
-    def forward(ctx, xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal, capacity, back):
+    def forward(ctx, xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, *means2D):
         L = hip_lib.lib()
         dev = xyz.device
         x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
@@ -55,7 +62,8 @@ class _RenderView(torch.autograd.Function):
         P, J = x.shape[0], A.shape[0]
         if w.shape != (P, J):
             raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
-        H, W = int(rs.image_height), int(rs.image_width)
+        if len(means2D) != len(specs):
+            raise ValueError("one screen-space gradient carrier per view")
         xyz_p, rot_p = torch.empty_like(x), torch.empty_like(q)
         with torch.cuda.device(dev):
             check(L.soar_lbs_warp_forward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(off), ptr(T), P, J, ptr(xyz_p), ptr(rot_p), None,
@@ -64,79 +72,127 @@ class _RenderView(torch.autograd.Function):
         scales3[..., -1] = -1e10
         cols = _f32(colors)
         ones = _ones_column(P, dev)
-        geometry = lambda colours, front, descending: _NativeOps._geometry_stage(
-            rs.bg, xyz_p, colours, ones, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
-            rs.patch_bbox, rs.tanfovx, rs.tanfovy, H, W, None, rs.sh_degree, rs.campos, rs.prefiltered, front, descending, rs.debug,
-            rs.config)
-        occ_grad = bool(ctx.needs_input_grad[5])             # the occlusion parameter is trained
-        st_occ = None
-        if not back:
-            # main pass front-to-back: the occlusion pass (:193-211, :281-291) is a subsequence of it, blended in the same launch
-            # (its gradient w.r.t. the occlusion values, when they are trained: soar_rast_occ_backward, one more walk of the lists)
-            st = geometry(cols, False, False)
-            R = _NativeOps._render_stage(st, occ, capacity=capacity)
-            if capacity is not None:
-                rasterizer._last_batch = [(st["geom"], P, 0, dev)]        # what rasterizer.check_binning() reads
-            occ_img = st["occ"]
-        else:
-            # render_front=False: main pass sorted back-to-front (:173-191), the occlusion pass is a rasterization of its own, as
-            # in the reference (:193-211, :281-291)
-            st = geometry(cols, False, True)
-            occ3 = _f32(occ).reshape(P, 1).repeat(1, 3)
-            st_occ = geometry(occ3, True, False)                      # both geometry stages in front of the read-backs
-            R = _NativeOps._render_stage(st, None)
-            R_occ = _NativeOps._render_stage(st_occ, None)
-            occ_img = st_occ["out"][0]
-        color, normal, depth, opac = st["out"]
+        occ_grad = bool(ctx.needs_input_grad[4])                    # the occlusion parameter is trained
+        occ3 = _f32(occ).reshape(P, 1).repeat(1, 3) if any(sp[3] for sp in specs) else None
         f = dict(dtype=torch.float32, device=dev)
-        normal_out, curv, pred = torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((3, H, W), **f)
-        prcp = st["ctx"].keep[3]
-        with torch.cuda.device(dev):
-            check(L.soar_view_finish(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), focal[0], focal[1], ptr(normal_out),
-                                     ptr(curv), ptr(pred), _stream(dev)), "soar_view_finish")
-        ctx.rs, ctx.focal, ctx.R, ctx.J = rs, focal, R, J
-        ctx.scale_shape = tuple(scale_src.shape)
-        ctx.off_grad = offsets is not None and offsets.requires_grad
         empty = torch.empty((0,), **f)
-        ctx.occ_shape = None
-        occ_state = ()
-        if occ_grad:
-            ctx.occ_shape, ctx.back = tuple(occ.shape), back
-            if back:
-                ctx.R_occ = R_occ
-                occ_state = (occ3, st_occ["radii"], st_occ["geom"], st_occ["binning"], st_occ["img"])
-        ctx.save_for_backward(x, q, w, A, T if T is not None else empty, cols, scales3, xyz_p, rot_p, st["radii"], st["geom"],
-                              st["binning"], st["img"], normal, depth, opac, prcp, *occ_state)
-        if ctx.occ_shape is None:
-            ctx.mark_non_differentiable(st["radii"], occ_img)
-        else:
-            ctx.mark_non_differentiable(st["radii"])
+
+        def geometry(rs, colours, front, descending):
+            return _NativeOps._geometry_stage(
+                rs.bg, xyz_p, colours, ones, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
+                rs.patch_bbox, rs.tanfovx, rs.tanfovy, int(rs.image_height), int(rs.image_width), None, rs.sh_degree, rs.campos,
+                rs.prefiltered, front, descending, rs.debug, rs.config)
+
+        # every geometry stage in front of the first read-back of an instance count
+        states = []
+        for rs, _focal, _cap, back in specs:
+            if not back:
+                # main pass front-to-back: the occlusion pass (:193-211, :281-291) is a subsequence of it, blended in the same
+                # launch (its gradient w.r.t. the occlusion values, when they are trained: soar_rast_occ_backward)
+                states.append((geometry(rs, cols, False, False), None))
+            else:
+                # render_front=False: main pass sorted back-to-front (:173-191), the occlusion pass is a rasterization of its own
+                states.append((geometry(rs, cols, False, True), geometry(rs, occ3, True, False)))
+        outs, saved, layout, nondiff = [], [x, q, w, A, T if T is not None else empty, cols, scales3, xyz_p, rot_p], [], []
+        last_batch = []
+        for (rs, focal, cap, back), (st, st_occ) in zip(specs, states):
+            H, W = int(rs.image_height), int(rs.image_width)
+            if not back:
+                R = _NativeOps._render_stage(st, occ, capacity=cap)
+                if cap is not None:
+                    last_batch.append((st["geom"], P, 0, dev))
+                occ_img, R_occ = st["occ"], None
+            else:
+                R = _NativeOps._render_stage(st, None)
+                R_occ = _NativeOps._render_stage(st_occ, None)
+                occ_img = st_occ["out"][0]
+            color, normal, depth, opac = st["out"]
+            normal_out, curv, pred = torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((3, H, W), **f)
+            prcp = st["ctx"].keep[3]
+            with torch.cuda.device(dev):
+                check(L.soar_view_finish(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), focal[0], focal[1], ptr(normal_out),
+                                         ptr(curv), ptr(pred), _stream(dev)), "soar_view_finish")
+            outs += [color, normal_out, depth, pred, opac, occ_img, curv, st["radii"]]
+            first = len(saved)
+            saved += [st["radii"], st["geom"], st["binning"], st["img"], normal, depth, opac, prcp]
+            own_occ_pass = back and occ_grad
+            if own_occ_pass:
+                saved += [st_occ["radii"], st_occ["geom"], st_occ["binning"], st_occ["img"]]
+            layout.append((first, R, R_occ if own_occ_pass else None))
+            nondiff.append(st["radii"])
+            if not occ_grad:
+                nondiff.append(occ_img)
+        if last_batch:
+            rasterizer._last_batch = last_batch                      # what rasterizer.check_binning() reads
+        if occ_grad and occ3 is not None:
+            saved.append(occ3)
+        ctx.specs, ctx.layout, ctx.J = specs, layout, J
+        ctx.scale_shape = tuple(scale_src.shape)
+        ctx.occ_shape = tuple(occ.shape) if occ_grad else None
+        ctx.off_grad = offsets is not None and offsets.requires_grad
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)
-        return color, normal_out, depth, pred, opac, occ_img, curv, st["radii"]
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_color, g_normal_out, g_depth, g_pred, g_opac, g_occ_img, g_curv, _g_radii):
+    def backward(ctx, *gouts):
         L = hip_lib.lib()
-        (x, q, w, A, T, cols, scales3, xyz_p, rot_p, radii, geom, binning, img, normal, depth, opac, prcp) = ctx.saved_tensors[:17]
-        rs, dev = ctx.rs, x.device
-        H, W = int(rs.image_height), int(rs.image_width)
+        saved = ctx.saved_tensors
+        x, q, w, A, T, cols, scales3, xyz_p, rot_p = saved[:_RenderViews.N_COMMON]
+        dev = x.device
         P = x.shape[0]
         f = dict(dtype=torch.float32, device=dev)
-        g_xyz = g_rot = g_colors = g_scale = g_means2D = g_off = None
-        if any(g is not None for g in (g_color, g_normal_out, g_depth, g_pred, g_opac, g_curv)):        # else: only the occlusion image was used
-            g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
-            opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
-            gn, gc, gp, gd = opt(g_normal_out), opt(g_curv), opt(g_pred), opt(g_depth)
-            with torch.cuda.device(dev):
-                check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), ctx.focal[0], ctx.focal[1],
-                                                  ptr(gn), ptr(gc), ptr(gp), ptr(gd), ptr(g_nd), _stream(dev)), "soar_view_finish_backward")
-            g_color = g_color if g_color is not None else torch.zeros((3, H, W), **f)
-            g_opac = g_opac if g_opac is not None else torch.zeros((1, H, W), **f)
-            (g_means2D, g_colors, _g_opacity, g_means3D, _g_cov, _g_sh, g_scales3, g_rot_p, _gv, _gpj, _gcam) = \
-                _NativeOps.rasterize_gaussians_backward(
-                    rs.bg, xyz_p, radii, cols, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
-                    rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_nd[:3], g_nd[3:], g_opac, None, rs.sh_degree, rs.campos, geom,
-                    ctx.R, binning, img, rs.debug, rs.config)
+        add = lambda acc, g: g if acc is None else acc.add_(g)
+        g_means3D = g_rot_p = g_colors = g_scales3 = g_occ = None
+        g_means2D = []
+        NO = _RenderViews.N_OUT
+        for v, ((rs, focal, _cap, back), (first, R, R_occ)) in enumerate(zip(ctx.specs, ctx.layout)):
+            g_color, g_normal_out, g_depth, g_pred, g_opac, g_occ_img, g_curv, _g_radii = gouts[v * NO:(v + 1) * NO]
+            radii, geom, binning, img, normal, depth, opac, prcp = saved[first:first + 8]
+            H, W = int(rs.image_height), int(rs.image_width)
+            g2d = None
+            if any(g is not None for g in (g_color, g_normal_out, g_depth, g_pred, g_opac, g_curv)):    # else: at most the occlusion image was used
+                g_nd = torch.empty((4, H, W), **f)                  # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
+                opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
+                gn, gc, gp, gd = opt(g_normal_out), opt(g_curv), opt(g_pred), opt(g_depth)
+                with torch.cuda.device(dev):
+                    check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(opac), ptr(prcp), focal[0], focal[1],
+                                                      ptr(gn), ptr(gc), ptr(gp), ptr(gd), ptr(g_nd), _stream(dev)),
+                          "soar_view_finish_backward")
+                g_color = g_color if g_color is not None else torch.zeros((3, H, W), **f)
+                g_opac = g_opac if g_opac is not None else torch.zeros((1, H, W), **f)
+                (g2d, gc_v, _g_opacity, gm_v, _g_cov, _g_sh, gs_v, gr_v, _gv, _gpj, _gcam) = \
+                    _NativeOps.rasterize_gaussians_backward(
+                        rs.bg, xyz_p, radii, cols, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix,
+                        rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_color, g_nd[:3], g_nd[3:], g_opac, None, rs.sh_degree,
+                        rs.campos, geom, R, binning, img, rs.debug, rs.config)
+                g_means3D, g_rot_p, g_colors, g_scales3 = add(g_means3D, gm_v), add(g_rot_p, gr_v), add(g_colors, gc_v), add(g_scales3, gs_v)
+            g_means2D.append(g2d)
+            if ctx.occ_shape is not None and g_occ_img is not None:
+                if not back:
+                    # the occlusion image came out of the main pass's blend: one more walk of its lists for dL/docc
+                    from ..rasterizer import _Ctx
+                    c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, False, rs.debug, rs.bg,
+                             rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
+                    g_flat = torch.empty((P,), **f)
+                    go = _dev_f32(g_occ_img, dev, "gradient of the occlusion image")
+                    with torch.cuda.device(dev):
+                        check(L.soar_rast_occ_backward(C.byref(c.params), ptr(geom), ptr(binning), ptr(img), int(R), ptr(go),
+                                                       ptr(g_flat), _stream(dev)), "soar_rast_occ_backward")
+                    g_occ = add(g_occ, g_flat.reshape(ctx.occ_shape))
+                else:
+                    # that occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient
+                    radii_o, geom_o, binning_o, img_o = saved[first + 8:first + 12]
+                    occ3 = saved[-1]
+                    z3, z1 = torch.zeros((3, H, W), **f), torch.zeros((1, H, W), **f)
+                    g_occ3 = _NativeOps.rasterize_gaussians_backward(
+                        rs.bg, xyz_p, radii_o, occ3, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix,
+                        rs.prcppoint, rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_occ_img, z3, z1, z1, None, rs.sh_degree, rs.campos,
+                        geom_o, R_occ, binning_o, img_o, rs.debug, rs.config)[1]
+                    g_occ = add(g_occ, g_occ3.sum(1, keepdim=True).reshape(ctx.occ_shape))
+        g_xyz = g_rot = g_scale = g_off = None
+        if g_means3D is not None:
             g_xyz, g_rot = torch.empty_like(x), torch.empty_like(q)
             with torch.cuda.device(dev):
                 check(L.soar_lbs_warp_backward(ptr(x), ptr(q), ptr(w), ptr(A), ptr(T) if T.numel() else None, P, ctx.J, ptr(g_means3D),
@@ -149,31 +205,13 @@ class _RenderView(torch.autograd.Function):
                 g3 = g_scales3.clone()
                 g3[..., -1] = 0
                 g_scale = g3.reshape(P, 3, k).sum(1)
-            g_off = None
             if ctx.off_grad:
                 g_off = g_means3D if T.numel() == 0 else g_means3D @ T.t()       # p'' = (p' + offsets) T
-        g_occ = None
-        if ctx.occ_shape is not None and g_occ_img is not None and not ctx.back:
-            # the occlusion image came out of the main pass's blend: one more walk of its lists for dL/docc
-            from ..rasterizer import _Ctx
-            c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, False, rs.debug, rs.bg,
-                     rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
-            g_flat = torch.empty((P,), **f)
-            go = _dev_f32(g_occ_img, dev, "gradient of the occlusion image")
-            with torch.cuda.device(dev):
-                check(L.soar_rast_occ_backward(C.byref(c.params), ptr(geom), ptr(binning), ptr(img), int(ctx.R), ptr(go), ptr(g_flat),
-                                               _stream(dev)), "soar_rast_occ_backward")
-            g_occ = g_flat.reshape(ctx.occ_shape)
-        elif ctx.occ_shape is not None and g_occ_img is not None:
-            # the occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient
-            occ3, radii_o, geom_o, binning_o, img_o = ctx.saved_tensors[17:]
-            z3, z1 = torch.zeros((3, H, W), **f), torch.zeros((1, H, W), **f)
-            g_occ3 = _NativeOps.rasterize_gaussians_backward(
-                rs.bg, xyz_p, radii_o, occ3, scales3, rot_p, rs.scale_modifier, None, rs.viewmatrix, rs.projmatrix, rs.prcppoint,
-                rs.patch_bbox, rs.tanfovx, rs.tanfovy, g_occ_img, z3, z1, z1, None, rs.sh_degree, rs.campos, geom_o, ctx.R_occ,
-                binning_o, img_o, rs.debug, rs.config)[1]
-            g_occ = g_occ3.sum(1, keepdim=True).reshape(ctx.occ_shape)
-        return g_xyz, g_rot, g_colors, g_scale, g_means2D, g_occ, None, None, g_off, None, None, None, None, None
+        return (g_xyz, g_rot, g_colors, g_scale, g_occ, None, None, g_off, None, None, *g_means2D)
+
+
+def _focal(camera):
+    return (float(fov2focal(float(camera.FoVy), camera.image_height)), float(fov2focal(float(camera.FoVx), camera.image_width)))
 
 
 def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets: Optional[torch.Tensor], axis_perm, rs,
@@ -182,6 +220,17 @@ def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, 
     capacity: the sync-free form of ``rasterizer.rasterize_views`` (binning buffer sized by this bound, nothing read back;
     ``rasterizer.check_binning()`` afterwards).  back: the ``render_front=False`` form (main pass sorted back-to-front, occlusion
     pass rasterized separately; always with the read-back)."""
-    focal = (float(fov2focal(float(camera.FoVy), camera.image_height)), float(fov2focal(float(camera.FoVx), camera.image_width)))
-    return _RenderView.apply(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets, axis_perm, rs, focal,
-                             int(capacity) if capacity and not back else None, bool(back))
+    spec = (rs, _focal(camera), int(capacity) if capacity and not back else None, bool(back))
+    return _RenderViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, [spec], means2D)
+
+
+def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_mats, offsets, axis_perm, settings_list, cameras,
+                 backs, capacity: Optional[int] = None):
+    """Several views of one pose (``GaussianBatchRenderer.gt_forward``: the video frame at video resolution, the normal view and
+    the back normal view): the surfels are warped once each way and the geometry stages of all views are enqueued in front of the
+    first read-back.  -> list of the per-view 8-tuples of ``render_view``."""
+    specs = [(rs, _focal(cam), int(capacity) if capacity and not back else None, bool(back))
+             for rs, cam, back in zip(settings_list, cameras, backs)]
+    outs = _RenderViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, *means2D_list)
+    n = _RenderViews.N_OUT
+    return [tuple(outs[i * n:(i + 1) * n]) for i in range(len(specs))]
