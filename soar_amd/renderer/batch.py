@@ -84,19 +84,26 @@ class GaussianBatchRenderer:
                                          relative_radius=True, fovy_range=[30, 45], zoom_range=[1.0, 1.0])
         batch["head_c2ws"] = []
         acc: Dict[str, list] = {"viewspace_points": [], "visibility_filter": [], "radii": []}
+        cams = []
         for i in range(bs):
-            batch["batch_idx"] = i
-            batch["head_c2w"] = T_ocam[i % T_ocam.shape[0]]
-            batch["head_fovy"] = fovy_deg[i % fovy_deg.shape[0]]
             fovy = batch["fovy"][i]
             w2c, proj, cam_p = get_cam_info_gaussian_cxcy(c2w=batch["c2w"][i], fovx=fovy, fovy=fovy, znear=0.1, zfar=100,
                                                           device=dev)
-            cam = Camera(FoVx=fovy, FoVy=fovy, image_width=batch["width"], image_height=batch["height"],
-                         world_view_transform=w2c, full_proj_transform=proj, camera_center=cam_p,
-                         prcppoint=device_constant((0.5, 0.5), dev))
-            with torch.autocast("cuda", enabled=False):
-                pkg = self.forward(cam, torch.zeros_like(self.background_tensor) * 0.5, mode=mode, head_flag=head_flag,
-                                   stage=stage, **batch)
+            cams.append(Camera(FoVx=fovy, FoVy=fovy, image_width=batch["width"], image_height=batch["height"],
+                               world_view_transform=w2c, full_proj_transform=proj, camera_center=cam_p,
+                               prcppoint=device_constant((0.5, 0.5), dev)))
+        batch["batch_idx"] = bs - 1                     # what the per-view loop of the reference leaves in the batch dict
+        batch["head_c2w"] = T_ocam[(bs - 1) % T_ocam.shape[0]]
+        batch["head_fovy"] = fovy_deg[(bs - 1) % fovy_deg.shape[0]]
+        with torch.autocast("cuda", enabled=False):
+            if hasattr(self, "forward_views"):
+                # the SDS views of a step show one pose (zeroed root, one gt_index): one warp each way, one autograd node
+                views = [{"camera": c, "bg_color": torch.zeros_like(self.background_tensor) * 0.5, "render_front": True} for c in cams]
+                pkgs = self.forward_views(views, gt=False, mode=mode, head_flag=head_flag, stage=stage, **batch)
+            else:
+                pkgs = [self.forward(c, torch.zeros_like(self.background_tensor) * 0.5, mode=mode, head_flag=head_flag, stage=stage,
+                                     **batch) for c in cams]
+        for pkg in pkgs:
             self._collect(acc, pkg)
         renders = torch.stack(acc["render"], dim=0)
         masks = torch.stack(acc["mask"], dim=0)

@@ -362,6 +362,36 @@ def test_gt_forward_renders_the_three_views_of_a_video_frame(world):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
 
 
+def test_batch_forward_renders_the_sds_views_as_one_node(world):
+    """GaussianBatchRenderer.batch_forward: the bs SDS views of a step (zeroed root, "+z,+x,+y" permutation) through
+    DiffGaussian.forward_views against one forward call per view: same stacked outputs, same gradients."""
+    from soar_amd.renderer import diff_gaussian as dg
+    w = world
+    bs = 3
+    c2w = torch.stack([syn.make_c2w(2.5, 0.1 * i, 0.7 * i, target=(0.0, 0.0, 0.0)) for i in range(bs)])
+    batch = dict(c2w=c2w, fovy=torch.full((bs,), 0.8), width=W, height=H, rays_d=torch.zeros(bs, H, W, 3, device=DEV), gt_index=2)
+    w.renderer.background = lambda dirs: torch.full(dirs.shape, 0.3, device=DEV)
+    leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color)
+    res = []
+    for fused in (True, False):
+        dg.FUSED_VIEW = fused
+        try:
+            out = w.renderer.batch_forward(dict(batch))
+        finally:
+            dg.FUSED_VIEW = True
+        assert out["comp_rgb"].shape == (bs, H, W, 3) and out["comp_normal"].shape == (bs, H, W, 3) and len(out["radii"]) == bs
+        (out["comp_rgb"].square().mean() + out["comp_normal"].mean() + out["comp_depth"].mean()).backward()
+        res.append(({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, [t.grad.clone() for t in leaves]))
+        for t in leaves:
+            t.grad = None
+    (fo, fg), (co, cg) = res
+    for k in fo:
+        assert torch.equal(fo[k], co[k]), k
+    assert (fo["comp_mask"] > 0.5).float().mean() > 0.01
+    for a, b in zip(fg, cg):
+        assert b.abs().max() > 0 and (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+
+
 def test_reference_style_guidance_gives_same_frame(world):
     """A guidance object exposing only the reference call (root, mat[1,P,4,4], scale) (smpl.py:552-615) goes through
     the per-point-matrix form of the warp kernel and must give the same images as the fused fast path."""
