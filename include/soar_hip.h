@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+/* ABI history.  1: round 1.  2: the KNN query's sort scratch is caller-owned (soar_lbs_knn_query_bytes).  3 (round 2): soar_frame_loss
+ * takes SOAR_FRAME_LOSS_SCRATCH_FLOATS floats of scratch, the background colour and the normalize_depth switch; new entry points
+ * soar_lbs_warp_forward_batch / soar_lbs_warp_backward_sum, soar_view_finish[_backward], soar_rast_occ_backward;
+ * soar_sum_frames_when_last (introduced and withdrawn within round 2) is gone. */
 #define SOAR_HIP_ABI_VERSION 3
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
