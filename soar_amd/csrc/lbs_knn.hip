@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(1024) item_order_kernel(const uint32_t *__rest
 }
 
 template <bool WITH_IDX, bool LOG = false>
-__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+// five wavefronts per SIMD (96 VGPRs, 16 bytes of scratch per lane) against four at 110: 139 -> 132 us
+__global__ void __launch_bounds__(KNN_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(5, 8)))
 knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__restrict__ meta,
                 const uint2 *__restrict__ cell_range, const float4 *__restrict__ sorted_verts,
                 const uint32_t *__restrict__ q_keys, const uint32_t *__restrict__ q_ids,
