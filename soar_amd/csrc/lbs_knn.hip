@@ -636,7 +636,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 // blend: lanes = joints
                 float accj = 0.f, norm = 0.f;
                 const int jl = min(lane, KNN_JMAX - 1);
-#pragma unroll 6
+#pragma unroll 15
                 for (int k = 0; k < cnt; k++) {
                     const float wk = lw[k];
                     accj = __builtin_fmaf(wk, rows_padded[(size_t)lpos[k] * KNN_JMAX + jl], accj);
