@@ -391,11 +391,24 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_frames_kernel(Warp
     if (p < a.P && k >= 1 && k - 1 < fs.n_extra) {                // wavefronts 1, 2: the extra blocks of these points
         const int e = k - 1, w = fs.width[e];
         const size_t count = (size_t)a.P * w;
-        for (int c = 0; c < w; c++) {
-            const size_t at = (size_t)p * w + c;
-            float s = fs.src[e][at];
-            for (int f = 1; f < n; f++) s += fs.src[e][(size_t)f * count + at];
-            fs.dst[e][at] = s;
+        const float *src = fs.src[e] + (size_t)p * w;
+        float *dst = fs.dst[e] + (size_t)p * w;
+        // every load of the (up to) 4 x 4 values in flight before the first add; the sums still run in frame order
+        for (int c0 = 0; c0 < w; c0 += 4) {
+            float v[4][WARP_NF];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int f = 0; f < WARP_NF; f++) v[c][f] = (c0 + c < w && f < n) ? src[(size_t)f * count + c0 + c] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (c0 + c >= w) break;
+                float s = v[c][0];
+#pragma unroll
+                for (int f = 1; f < WARP_NF; f++) s = f < n ? s + v[c][f] : s;
+                for (int f = WARP_NF; f < n; f++) s += src[(size_t)f * count + c0 + c];
+                dst[c0 + c] = s;
+            }
         }
     }
 }
