@@ -209,13 +209,12 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
             float rx0 = (float)bx0, ry0 = (float)by0, rex = 3.f, rey = 3.f;
             {
                 const unsigned long long am = __ballot(alive + alive_o != 0.f);           // 4 lanes per pixel, pixel = lane >> 2
-                uint32_t cols = 0, rows = 0;                                               // active columns / rows of the block
-#pragma unroll
-                for (int pp = 0; pp < 16; pp++) {
-                    const uint32_t on = (uint32_t)((am >> (4 * pp)) & 1ull);
-                    cols |= on << (pp & 3);
-                    rows |= on << (pp >> 2);
-                }
+                // active columns / rows of the block: pixel pp owns the nibble 4 pp of the ballot, a row of pixels 16 bits
+                const uint32_t lo = (uint32_t)am, hi = (uint32_t)(am >> 32);
+                const uint32_t rows = ((lo & 0xFFFFu) ? 1u : 0u) | ((lo >> 16) ? 2u : 0u) | ((hi & 0xFFFFu) ? 4u : 0u) | ((hi >> 16) ? 8u : 0u);
+                uint32_t fold = lo | hi;
+                fold |= fold >> 16;                                                        // nibble c = column c of any row
+                const uint32_t cols = (fold & 1u) | ((fold >> 3) & 2u) | ((fold >> 6) & 4u) | ((fold >> 9) & 8u);
                 if (cols) {
                     const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), r0 = __builtin_ctz(rows), r1 = 31 - __builtin_clz(rows);
                     rx0 = (float)(bx0 + c0); ry0 = (float)(by0 + r0); rex = (float)(c1 - c0); rey = (float)(r1 - r0);
@@ -513,13 +512,11 @@ __device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int ra
             float rx0 = (float)bx0, ry0 = (float)by0, rex = 3.f, rey = 3.f;             // bounding box of the pixels still walking
             {
                 const unsigned long long am = __ballot(alive_o != 0.f);
-                uint32_t cols = 0, rows = 0;
-#pragma unroll
-                for (int pp = 0; pp < 16; pp++) {
-                    const uint32_t on = (uint32_t)((am >> (4 * pp)) & 1ull);
-                    cols |= on << (pp & 3);
-                    rows |= on << (pp >> 2);
-                }
+                const uint32_t lo = (uint32_t)am, hi = (uint32_t)(am >> 32);
+                const uint32_t rows = ((lo & 0xFFFFu) ? 1u : 0u) | ((lo >> 16) ? 2u : 0u) | ((hi & 0xFFFFu) ? 4u : 0u) | ((hi >> 16) ? 8u : 0u);
+                uint32_t fold = lo | hi;
+                fold |= fold >> 16;                                                        // nibble c = column c of any row
+                const uint32_t cols = (fold & 1u) | ((fold >> 3) & 2u) | ((fold >> 6) & 4u) | ((fold >> 9) & 8u);
                 if (cols) {
                     const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), q0 = __builtin_ctz(rows), q1 = 31 - __builtin_clz(rows);
                     rx0 = (float)(bx0 + c0); ry0 = (float)(by0 + q0); rex = (float)(c1 - c0); rey = (float)(q1 - q0);
