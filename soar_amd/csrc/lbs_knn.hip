@@ -352,16 +352,20 @@ __device__ __forceinline__ void chain_insert(float (&best)[K], float d)
 // reversed (both padded to 32 with +inf) is a bitonic sequence that holds the 32 smallest; five compare-exchange stages sort it
 // (80 min/max pairs instead of the 900 median steps of K chain insertions).  `other`: the second list, element k at other[k * stride].
 template <int K>
+struct PaddedList {                                  // best[0 .. K-1] followed by two more values: 32 slots without a second array
+    float (&b)[K];
+    float &x, &y;
+    __device__ __forceinline__ float &operator[](int i) { return i < K ? b[i] : (i == K ? x : y); }
+};
+template <int K>
 __device__ __forceinline__ void merge_sorted(float (&best)[K], const float *other, int stride)
 {
-    static_assert(K <= 32 && K >= 16, "padded to 32");
-    float m[32];
+    static_assert(K == 30, "two padding slots");
+    // m[k] = min(best_padded[k], other_padded[31 - k]) in place: slots 30, 31 meet other[1], other[0]; slots 0, 1 meet the padding
+    float x = other[1 * stride], y = other[0];
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const float a = k < K ? best[k] : 3.0e38f;
-        const float b = (31 - k) < K ? other[(31 - k) * stride] : 3.0e38f;
-        m[k] = fminf(a, b);
-    }
+    for (int k = 2; k < K; k++) best[k] = fminf(best[k], other[(31 - k) * stride]);
+    PaddedList<K> m{best, x, y};
 #pragma unroll
     for (int j = 16; j >= 1; j >>= 1)
 #pragma unroll
@@ -370,8 +374,6 @@ __device__ __forceinline__ void merge_sorted(float (&best)[K], const float *othe
                 const float lo = fminf(m[i], m[i + j]), hi = fmaxf(m[i], m[i + j]);
                 m[i] = lo; m[i + j] = hi;
             }
-#pragma unroll
-    for (int k = 0; k < K; k++) best[k] = m[k];
 }
 // The same union when only its K-th smallest value and the number of elements strictly below it are wanted (the last merge):
 // no sort at all.  Returns tau; need = how many elements AT tau belong to the K.
