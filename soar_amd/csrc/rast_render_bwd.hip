@@ -171,7 +171,6 @@ __global__ void selftest_wave_reduce_kernel(float *out)
     out[64 + lane] = (float)pixel_reduce16_slot(lane);
 }
 
-constexpr int BWD_GRID_RANKS = 2048;   // tiles one pass of the grid covers
 
 template <bool WIDE>
 __device__ __forceinline__ void backward_quad(const BwdArgs &a, const int rank, const int quad)
@@ -380,7 +379,7 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.dL_dcolor = dL_dcolor; a.dL_dnormal = dL_dnormal; a.dL_ddepth = dL_ddepth; a.dL_dopac = dL_dopac;
     a.acc = acc; a.acc64 = acc64;
     StageTimer timer(ST_RENDER_BWD, stream);
-    static const int grid_ranks = getenv("SOAR_BLEND_GRID_RANKS") ? atoi(getenv("SOAR_BLEND_GRID_RANKS")) / 8 * 8 : BWD_GRID_RANKS;   // development switch
+    const int grid_ranks = blend_grid_ranks(a.ntiles);
     const dim3 grid(4 * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
         if (blend) hipLaunchKernelGGL(render_backward_slots_kernel<true>, grid, dim3(256), 0, stream, a);

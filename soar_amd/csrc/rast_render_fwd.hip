@@ -22,7 +22,7 @@
 //  * scalar instructions are kept out of the loops: one SIMD of gfx950 issues a scalar instruction only every ~4 cycles
 //    whatever the number of resident wavefronts (tests/tools/issue_model).  Liveness of a pixel is a 0 / 1 number folded
 //    into alpha, not a predicate (a per-lane bool that lives across the loop is a 64-bit scalar mask merged at every join);
-//  * a fixed grid of 4 x 2048 workgroups walks the longest-list-first tile order of tile_order_block (soar_common.h) with
+//  * a small grid of 4 x blend_grid_ranks() workgroups (1024 ranks at 1080p, 4096 at 4K) walks the longest-list-first tile order of tile_order_block (soar_common.h) with
 //    a rank stride, ranks dealt round-robin to the XCDs with the four quads of a tile on one XCD: the long tiles start
 //    first, everywhere, and the ~29 000 workgroups of tiles without work (a slot, two loads and ~100 instructions each) are
 //    never launched.  The
@@ -41,7 +41,6 @@ namespace {
 #define SOAR_FWD_CHUNK 256
 #endif
 constexpr int CHUNK = SOAR_FWD_CHUNK;   // list entries staged per workgroup iteration (one per thread)
-constexpr int FWD_GRID_RANKS = 2048; // tiles one pass of the grid covers (see render_forward_kernel)
 
 struct FwdArgs {
     int W, H, gx, gy, ntiles;
@@ -626,7 +625,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.bg_tiles = img.bg_tiles; a.bg_state = img.bg_state; a.keep_background = (prm.debug & 4) ? 1 : 0;
     a.wave_log = nullptr;
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
-    static const int grid_ranks = getenv("SOAR_BLEND_GRID_RANKS") ? atoi(getenv("SOAR_BLEND_GRID_RANKS")) / 8 * 8 : FWD_GRID_RANKS;   // development switch
+    const int grid_ranks = blend_grid_ranks(a.ntiles);
     const int Tpad = (a.ntiles + 7) / 8 * 8;
     const int nblocks = 4 * (log_path ? Tpad : min(Tpad, grid_ranks));
     StageTimer timer(ST_RENDER_FWD, stream);
@@ -663,7 +662,7 @@ int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBu
     a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.front = g.front;
     a.g_occ = dL_dout_occ; a.g_values = dL_docc;
     const int Tpad = (a.ntiles + 7) / 8 * 8;
-    const int nblocks = 4 * min(Tpad, FWD_GRID_RANKS);
+    const int nblocks = 4 * min(Tpad, blend_grid_ranks(a.ntiles));
     SOAR_HIP_OK(hipMemsetAsync(dL_docc, 0, sizeof(float) * (size_t)prm.P, stream));
     StageTimer timer(ST_RENDER_BWD, stream);
     hipLaunchKernelGGL(occ_backward_kernel, dim3(nblocks), dim3(256), 0, stream, a);
