@@ -70,6 +70,23 @@ typedef struct SoarRastParams {
     const float *campos_dev;     /* [3]  */
 } SoarRastParams;
 
+/* ---- the same stage of several frames in ONE launch (no reference counterpart) ----
+ * Every kernel of the rasterizer's frame chain (geometry, binning, blends, frame loss, backward) takes its frame's argument block
+ * by blockIdx.y.  Between soar_batch_begin(n) and soar_batch_end() the caller walks ONE entry point at a time over the n frames
+ * of a step -- soar_batch_frame(f) in front of each call, f = 0 .. n-1 in order -- and the library launches every stage once,
+ * with gridDim.y = n, when the last frame's call arrives:
+ *     soar_batch_begin(4);
+ *     for (f = 0; f < 4; f++) { soar_batch_frame(f); soar_rast_forward_geometry(prm[f], ..., stream); }
+ *     for (f = 0; f < 4; f++) { soar_batch_frame(f); soar_rast_forward_render_occ(prm[f], ..., capacity, ..., stream); }
+ *     ...
+ *     soar_batch_end();
+ * Requirements: the frames agree in everything that shapes a launch (P, M, W, H, sort order, capacity, buffer alignment, which
+ * optional pointers are NULL); sync-free forms only (no num_rendered read-back inside a batch); one stream; per thread (the
+ * state is thread-local).  n <= 8.  The calls of the frames 0 .. n-2 only record their argument blocks and return 0. */
+int soar_batch_begin(int32_t n_frames);
+int soar_batch_frame(int32_t frame);
+int soar_batch_end(void);
+
 /* ---- scratch sizing: replaces required<GeometryState/ImageState/BinningState>()
  *      (DGR/cuda_rasterizer/rasterizer_impl.h:77-84, rasterizer_impl.cu:134-184) ---- */
 int soar_rast_geometry_bytes(int32_t P, int32_t M, size_t *bytes);

@@ -36,10 +36,18 @@ int post_launch(const char *what, hipStream_t stream, int debug)
     return 1;
 }
 
+BatchCtx &batch_ctx()
+{
+    static thread_local BatchCtx ctx;
+    return ctx;
+}
+
 namespace {
 struct ZeroArgs { uint32_t *ptr[4]; size_t words[4]; size_t first_block[5]; };
-__global__ void __launch_bounds__(256) zero_ranges_kernel(ZeroArgs z)
+__global__ void __launch_bounds__(256) zero_ranges_kernel(Batch<ZeroArgs> b)
 {
+    const ZeroArgs &z = b.v[blockIdx.y];
+    if (blockIdx.x >= z.first_block[4]) return;
     int r = 0;
     while (r < 3 && blockIdx.x >= z.first_block[r + 1]) r++;
     const size_t w0 = ((size_t)blockIdx.x - z.first_block[r]) * 1024 + threadIdx.x * 4;
@@ -65,7 +73,7 @@ int launch_zero_ranges(const ZeroRange *ranges, int count, hipStream_t stream)
     }
     z.first_block[4] = blocks;
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z);
+    SOAR_LAUNCH_BATCHED(zero_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z);
     return post_launch("zero_ranges", stream, 0);
 }
 
@@ -251,6 +259,27 @@ int soar_prof_timestamp(unsigned long long *ring_dev, int64_t capacity, int64_t 
     if (!ring_dev || capacity <= 0) { set_error("soar_prof_timestamp: bad arguments"); return 1; }
     hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), ring_dev,
                        (unsigned long long)capacity, (unsigned long long)tag);
+    return 0;
+}
+
+int soar_batch_begin(int32_t n_frames)
+{
+    if (n_frames < 1 || n_frames > soar::MAX_BATCH) { soar::set_error("soar_batch_begin: 1 <= n_frames <= %d", soar::MAX_BATCH); return 1; }
+    if (soar::batch_ctx().n) { soar::set_error("soar_batch_begin: a batch is already open on this thread"); return 1; }
+    soar::batch_ctx().n = n_frames;
+    soar::batch_ctx().f = 0;
+    return 0;
+}
+int soar_batch_frame(int32_t frame)
+{
+    if (!soar::batch_ctx().n || frame < 0 || frame >= soar::batch_ctx().n) { soar::set_error("soar_batch_frame: no such frame in the open batch"); return 1; }
+    soar::batch_ctx().f = frame;
+    return 0;
+}
+int soar_batch_end(void)
+{
+    soar::batch_ctx().n = 0;
+    soar::batch_ctx().f = 0;
     return 0;
 }
 

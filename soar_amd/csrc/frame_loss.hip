@@ -50,8 +50,9 @@ __device__ __forceinline__ bool any_contrib(const uint4 *p, int i) { const uint4
 __device__ __forceinline__ bool any_contrib(const uint32_t *p, int i) { return p[i] != 0u; }
 
 template <int V>
-__global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
+__global__ void __launch_bounds__(256) frame_loss_kernel(Batch<LossArgs> batch)
 {
+    LossArgs a = batch.v[blockIdx.y];                 // (a copy: the pooled form points it at its frame's target planes)
     typedef typename Vec<V>::type T;
     const int nv = a.n / V;
     if (a.set_index) {           // frame data resident in HBM: pick this frame's planes (colour 3, mask 1, normal 3)
@@ -106,9 +107,19 @@ __global__ void __launch_bounds__(256) frame_loss_kernel(LossArgs a)
 
 // loss = wc*S[0]/(3n) + wm*S[1]/n + wn*S[2]/(3n) + wd*S[3]/n,  S = the workgroups' partial sums added in a fixed order (thread t
 // takes workgroups t, t + 256, ...; then a fixed tree): no atomics, the value does not depend on who finished first
-__global__ void __launch_bounds__(256) frame_loss_finish_kernel(const float *sums, int blocks, int n, float wc, float wm, float wn, float wd,
-                                                                float *loss)
+struct LossFinishArgs {
+    const float *sums;
+    int blocks, n;
+    float wc, wm, wn, wd;
+    float *loss;
+};
+__global__ void __launch_bounds__(256) frame_loss_finish_kernel(Batch<LossFinishArgs> batch)
 {
+    const LossFinishArgs &fa = batch.v[blockIdx.y];
+    const float *sums = fa.sums;
+    const int blocks = fa.blocks, n = fa.n;
+    const float wc = fa.wc, wm = fa.wm, wn = fa.wn, wd = fa.wd;
+    float *loss = fa.loss;
     __shared__ float4 red[256];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = threadIdx.x; b < blocks; b += 256) {
@@ -201,10 +212,10 @@ static int frame_loss_launch(int32_t W, int32_t H, const float *color, const flo
                                           (uintptr_t)target_mask | (uintptr_t)target_normal | (uintptr_t)dL_dcolor | (uintptr_t)dL_dnormal |
                                           (uintptr_t)dL_ddepth | (uintptr_t)dL_dopac) & 15) == 0;
     const int blocks = min(SOAR_FRAME_LOSS_SCRATCH_FLOATS / 4, max(1, (a.n / (vec4 ? 4 : 1) + 255) / 256));
-    if (vec4) hipLaunchKernelGGL(frame_loss_kernel<4>, dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(frame_loss_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, sums4, blocks, a.n, w_color, w_mask, w_normal, w_depth,
-                       loss_out);
+    if (vec4) SOAR_LAUNCH_BATCHED(frame_loss_kernel<4>, dim3(blocks), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED(frame_loss_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
+    const soar::LossFinishArgs fa = {sums4, blocks, a.n, w_color, w_mask, w_normal, w_depth, loss_out};
+    SOAR_LAUNCH_BATCHED(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
     SOAR_LAUNCH_OK("frame_loss", stream, 0);
     return 0;
 }

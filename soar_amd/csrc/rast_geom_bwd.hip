@@ -61,8 +61,9 @@ __device__ __forceinline__ void wave_atomic_add(float *dst, float v)
     if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
 }
 
-__global__ void __launch_bounds__(256) geometry_backward_kernel(GeomBwdArgs a)
+__global__ void __launch_bounds__(256) geometry_backward_kernel(Batch<GeomBwdArgs> batch)
 {
+    const GeomBwdArgs &a = batch.v[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx < a.P;
     const bool active = in_range && a.radii[idx] > 0;    // backward.cu:178, :465
@@ -371,7 +372,7 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
         if (launch_zero_ranges(zr, 3, stream)) return 1;
     }
     StageTimer timer(ST_GEOM_BWD, stream);
-    hipLaunchKernelGGL(geometry_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED(geometry_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("geometry_backward", stream, prm.debug);
     return 0;
 }

@@ -121,8 +121,9 @@ struct PreArgs {
     int32_t *radii;
 };
 
-__global__ void __launch_bounds__(256) preprocess_kernel(PreArgs a)
+__global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
 {
+    const PreArgs &a = batch.v[blockIdx.y];
     // lanes past the end redo the last Gaussian (identical stores) so that whole wavefronts reach the reduction below
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = idx_raw < a.P;
@@ -368,7 +369,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
     const int threads = 256;
     const int blocks = (prm.P + threads - 1) / threads;
     StageTimer timer(ST_PREPROCESS, stream);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+    SOAR_LAUNCH_BATCHED(preprocess_kernel, dim3(blocks), dim3(threads), 0, stream, a);
     SOAR_LAUNCH_OK("preprocess", stream, prm.debug);
     return 0;
 }

@@ -341,8 +341,9 @@ __device__ __forceinline__ void backward_quad(const BwdArgs &a, const int rank, 
 #define SOAR_BWD_OCC
 #endif
 template <bool WIDE>
-__global__ void __launch_bounds__(256) SOAR_BWD_OCC render_backward_slots_kernel(BwdArgs a)
+__global__ void __launch_bounds__(256) SOAR_BWD_OCC render_backward_slots_kernel(Batch<BwdArgs> batch)
 {
+    const BwdArgs &a = batch.v[blockIdx.y];
     const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
@@ -382,11 +383,11 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     const int grid_ranks = blend_grid_ranks(a.ntiles);
     const dim3 grid(4 * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
-        if (blend) hipLaunchKernelGGL(render_backward_slots_kernel<true>, grid, dim3(256), 0, stream, a);
+        if (blend) SOAR_LAUNCH_BATCHED(render_backward_slots_kernel<true>, grid, dim3(256), 0, stream, a);
         const size_t n = (size_t)prm.P * ACC_STRIDE;
         hipLaunchKernelGGL(narrow_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, acc64, acc);
     } else {
-        hipLaunchKernelGGL(render_backward_slots_kernel<false>, grid, dim3(256), 0, stream, a);
+        SOAR_LAUNCH_BATCHED(render_backward_slots_kernel<false>, grid, dim3(256), 0, stream, a);
     }
     SOAR_LAUNCH_OK("render_backward", stream, prm.debug & 1);
     return 0;

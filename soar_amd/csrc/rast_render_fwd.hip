@@ -398,8 +398,9 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
 #define SOAR_FWD_WPE 6
 #endif
 template <bool LOG, bool OCC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_FWD_WPE, 8))) render_forward_kernel(FwdArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_FWD_WPE, 8))) render_forward_kernel(Batch<FwdArgs> batch)
 {
+    const FwdArgs &a = batch.v[blockIdx.y];
     const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
@@ -635,8 +636,8 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
         const size_t nbytes = sizeof(unsigned long long) * 16 * (size_t)nblocks;
         SOAR_HIP_OK(hipMalloc(&a.wave_log, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(a.wave_log, 0, nbytes, stream));
-        if (out_occ) hipLaunchKernelGGL((render_forward_kernel<true, true>), dim3(nblocks), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((render_forward_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, a);
+        if (out_occ) SOAR_LAUNCH_BATCHED((render_forward_kernel<true, true>), dim3(nblocks), dim3(256), 0, stream, a);
+        else SOAR_LAUNCH_BATCHED((render_forward_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, a);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, a.wave_log, nbytes, hipMemcpyDeviceToHost));
@@ -646,8 +647,8 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
         (void)hipFree(a.wave_log);
         return 0;
     }
-    if (out_occ) hipLaunchKernelGGL((render_forward_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((render_forward_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, a);
+    if (out_occ) SOAR_LAUNCH_BATCHED((render_forward_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((render_forward_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("render_forward", stream, prm.debug);
     return 0;
 }

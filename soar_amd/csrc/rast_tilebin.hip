@@ -47,8 +47,17 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float
     return (uint32_t)min(B - 1, (int)((float)(key - kmin) * scale));
 }
 
-__global__ void __launch_bounds__(256)
-bucket_count_kernel(int P, int B, const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ blk_stats, int nblk,
+struct BucketCountArgs {
+    int P;
+    int B;
+    const uint32_t *depth_key;
+    const uint32_t *blk_stats;
+    int nblk;
+    uint32_t *header;
+    uint32_t *bucket_cnt;
+    uint32_t *slot;
+};
+__device__ __forceinline__ void bucket_count_kernel_body(int P, int B, const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ blk_stats, int nblk,
                     uint32_t *__restrict__ header, uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ slot)
 {
     // every workgroup folds the per-block statistics preprocess left behind (max of: key, ~key, x1, y1, ~x0, ~y0)
@@ -82,9 +91,24 @@ bucket_count_kernel(int P, int B, const uint32_t *__restrict__ depth_key, const 
     const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
     slot[i] = atomicAdd(&bucket_cnt[bucket_of(key, kmin, scale, B)], 1u);
 }
+__global__ void __launch_bounds__(256) bucket_count_kernel(Batch<BucketCountArgs> batch)
+{
+    const BucketCountArgs &a = batch.v[blockIdx.y];
+    bucket_count_kernel_body(a.P, a.B, a.depth_key, a.blk_stats, a.nblk, a.header, a.bucket_cnt, a.slot);
+}
 
-__global__ void __launch_bounds__(1024)
-bucket_scatter_kernel(int P, int B, const uint32_t *__restrict__ depth_key, uint32_t *__restrict__ header,
+
+struct BucketScatterArgs {
+    int P;
+    int B;
+    const uint32_t *depth_key;
+    uint32_t *header;
+    const uint32_t *bucket_cnt;
+    uint32_t *bucket_base;
+    const uint32_t *slot;
+    uint64_t *pairs;
+};
+__device__ __forceinline__ void bucket_scatter_kernel_body(int P, int B, const uint32_t *__restrict__ depth_key, uint32_t *__restrict__ header,
                       const uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ bucket_base,
                       const uint32_t *__restrict__ slot, uint64_t *__restrict__ pairs)
 {
@@ -136,6 +160,12 @@ bucket_scatter_kernel(int P, int B, const uint32_t *__restrict__ depth_key, uint
         pairs[base[bucket_of(key, kmin, scale, B)] + slot[i]] = ((uint64_t)key << 32) | (uint32_t)i;
     }
 }
+__global__ void __launch_bounds__(1024) bucket_scatter_kernel(Batch<BucketScatterArgs> batch)
+{
+    const BucketScatterArgs &a = batch.v[blockIdx.y];
+    bucket_scatter_kernel_body(a.P, a.B, a.depth_key, a.header, a.bucket_cnt, a.bucket_base, a.slot, a.pairs);
+}
+
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask)
 {
@@ -177,8 +207,9 @@ __device__ __forceinline__ void emit_sorted(const BucketSortArgs &a, uint32_t po
 }
 
 // workgroup = 4 wavefronts = 4 consecutive buckets
-__global__ void __launch_bounds__(256) bucket_sort_kernel(BucketSortArgs a)
+__global__ void __launch_bounds__(256) bucket_sort_kernel(Batch<BucketSortArgs> batch)
 {
+    const BucketSortArgs &a = batch.v[blockIdx.y];
     __shared__ uint64_t lds[BKT_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // phase 1: every wavefront sorts its own bucket if it fits one value per lane
@@ -275,8 +306,9 @@ __device__ __forceinline__ void band_wave_counts(int nb, int b0, int b1, int lan
     if (lane < nb) wcnt[wave][lane] = mine;
 }
 
-__global__ void __launch_bounds__(BAND_THREADS) band_count_kernel(BandArgs a)
+__global__ void __launch_bounds__(BAND_THREADS) band_count_kernel(Batch<BandArgs> batch)
 {
+    const BandArgs &a = batch.v[blockIdx.y];
     __shared__ uint32_t wcnt[BAND_WAVES][BAND_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nvis = (int)a.header[H_NVIS];
@@ -293,8 +325,9 @@ __global__ void __launch_bounds__(BAND_THREADS) band_count_kernel(BandArgs a)
     }
 }
 
-__global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(BandArgs a)
+__global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs> batch)
 {
+    const BandArgs &a = batch.v[blockIdx.y];
     __shared__ uint32_t wcnt[BAND_WAVES][BAND_MAX];
     __shared__ uint32_t part[BAND_THREADS];
     __shared__ uint32_t base[BAND_MAX];         // where this chunk's entries of every band go
@@ -397,8 +430,16 @@ __device__ __forceinline__ int band_of_block(int block, int gx, int band_rows)
     return ((block / nsx) * BIN_SUPER) / band_rows;
 }
 
-__global__ void __launch_bounds__(BIN_THREADS)
-bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+struct BinCountArgs {
+    const uint32_t *header;
+    int gx;
+    int gy;
+    int band_rows;
+    const uint32_t *band_info;
+    const uint2 *band_rect;
+    uint32_t *tile_count;
+};
+__device__ __forceinline__ void bin_count_kernel_body(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, uint32_t *__restrict__ tile_count)
 {
     __shared__ int diff[BIN_SUPER + 1][BIN_SUPER + 1];
@@ -449,12 +490,25 @@ bin_count_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_r
         if (tx < st.tx1 && ty < st.ty1) tile_count[ty * gx + tx] = (uint32_t)diff[tid >> 2][tid & 3];
     }
 }
+__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(Batch<BinCountArgs> batch)
+{
+    const BinCountArgs &a = batch.v[blockIdx.y];
+    bin_count_kernel_body(a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.tile_count);
+}
+
 
 // One workgroup: exclusive scan of the tile counts in tile order = ranges (untouched tiles keep (0,0) like
 // identifyTileRanges, rasterizer_impl.cu:287-295).
 // `capacity` = instances the caller's binning buffer holds: when the lists would not fit, every range is left empty
 // (nothing is written or rendered) and header[H_OVERFLOW] reports the number that was needed.
-__global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
+struct TileScanArgs {
+    int T;
+    const uint32_t *tile_count;
+    uint2 *ranges;
+    uint32_t capacity;
+    uint32_t *header;
+};
+__device__ __forceinline__ void tile_scan_kernel_body(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
                                                          uint32_t capacity, uint32_t *__restrict__ header)
 {
     __shared__ uint32_t part[16];
@@ -514,6 +568,12 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t *
         }
     }
 }
+__global__ void __launch_bounds__(1024) tile_scan_kernel(Batch<TileScanArgs> batch)
+{
+    const TileScanArgs &a = batch.v[blockIdx.y];
+    tile_scan_kernel_body(a.T, a.tile_count, a.ranges, a.capacity, a.header);
+}
+
 
 // 16-bit mask of the tiles of the super-tile a rectangle covers (bit 4*y + x)
 __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
@@ -529,8 +589,25 @@ __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
 // the tiles they cover.  A flush hands the buffered survivors out in slabs of 64 to the wavefronts; per slab and tile
 // a ballot gives the number of entries, a scan over the slabs gives every slab its place in each tile's list, and
 // the ids are appended with ballot-prefix compaction: every list comes out in depth order, without atomics or sorts.
-__global__ void __launch_bounds__(BIN_THREADS)
-bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+struct BinTilesArgs {
+    const uint32_t *header;
+    int gx;
+    int gy;
+    int band_rows;
+    const uint32_t *band_info;
+    const uint2 *band_rect;
+    const uint32_t *band_id;
+    const uint2 *ranges;
+    uint32_t *point_list;
+    int nblocks_tiles;
+    const uint32_t *tile_count;
+    uint32_t *tile_order;
+    const float *bg;
+    int normalize_depth;
+    uint32_t *bg_state;
+    unsigned long long *dbg;
+};
+__device__ __forceinline__ void bin_tiles_kernel_body(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
                  uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
                  uint32_t *__restrict__ tile_order, const float *__restrict__ bg, int normalize_depth,
@@ -669,6 +746,12 @@ bin_tiles_kernel(const uint32_t *__restrict__ header, int gx, int gy, int band_r
         w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits; w[3] = (unsigned long long)P;
     }
 }
+__global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesArgs> batch)
+{
+    const BinTilesArgs &a = batch.v[blockIdx.y];
+    bin_tiles_kernel_body(a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg);
+}
+
 
 }  // namespace
 
@@ -685,10 +768,10 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
     const int B = bucket_count_for(prm.P);
     const int nblk = (prm.P + 255) / 256;               // = preprocess grid: one statistics row per block
     StageTimer timer(ST_SORT, stream);
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(256), 0, stream, prm.P, B, g.depth_key, g.blk_stats, nblk, g.header,
-                       g.bucket_cnt, g.sort_slot);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(min(64, (prm.P + 1023) / 1024)), dim3(1024), 0, stream, prm.P, B, g.depth_key,
-                       g.header, g.bucket_cnt, g.bucket_base, g.sort_slot, g.sort_pairs);
+    const BucketCountArgs ca = {prm.P, B, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_cnt, g.sort_slot};
+    SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nblk), dim3(256), 0, stream, ca);
+    const BucketScatterArgs sa = {prm.P, B, g.depth_key, g.header, g.bucket_cnt, g.bucket_base, g.sort_slot, g.sort_pairs};
+    SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3(min(64, (prm.P + 1023) / 1024)), dim3(1024), 0, stream, sa);
     SOAR_LAUNCH_OK("depth_buckets", stream, prm.debug);
     return 0;
 }
@@ -703,7 +786,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         a.B = bucket_count_for(prm.P);
         a.bucket_base = g.bucket_base; a.pairs = g.sort_pairs; a.rect = g.rect; a.ids_sorted = g.ids_sorted;
         a.rect_sorted = g.rect_sorted;
-        hipLaunchKernelGGL(bucket_sort_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+        SOAR_LAUNCH_BATCHED(bucket_sort_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
     }
     SOAR_LAUNCH_OK("bucket_sort", stream, prm.debug);
     // band lists: the band arrays live in the key / value scratch of the binning buffer (only the descending path and the key
@@ -719,11 +802,12 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
     ba.band_rect = reinterpret_cast<uint2 *>(b.keys_unsorted); ba.band_id = b.vals_unsorted;
     {
         StageTimer timer(ST_RANGES, stream);
-        hipLaunchKernelGGL(band_count_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
-        hipLaunchKernelGGL(band_place_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
-        hipLaunchKernelGGL(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
-                           ba.band_rect, img.tile_count);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, gx * gy, img.tile_count, img.ranges, ba.capacity, g.header);
+        SOAR_LAUNCH_BATCHED(band_count_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
+        SOAR_LAUNCH_BATCHED(band_place_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
+        const BinCountArgs bc = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, img.tile_count};
+        SOAR_LAUNCH_BATCHED(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bc);
+        const TileScanArgs ts = {gx * gy, img.tile_count, img.ranges, ba.capacity, g.header};
+        SOAR_LAUNCH_BATCHED(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
     }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
     {
@@ -735,8 +819,9 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             const size_t nw = (size_t)(nsx * nsy + 1) * 4;
             SOAR_HIP_OK(hipMalloc(&dbg, 8 * nw));
             SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * nw, stream));
-            hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
-                               ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg);
+            const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
+                                     img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg};
+            SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
             SOAR_HIP_OK(hipStreamSynchronize(stream));
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
             SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
@@ -752,8 +837,9 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             free(h);
             return 0;
         }
-        hipLaunchKernelGGL(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, g.header, gx, gy, band_rows, g.band_info,
-                           ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy, img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg);
+        const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
+                                 img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg};
+        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
     }
     SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);
     return 0;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -28,6 +29,36 @@ int post_launch(const char *what, hipStream_t stream, int debug);
 #define SOAR_LAUNCH_OK(what, stream, debug)                                       \
     do {                                                                          \
         if (::soar::post_launch((what), (stream), (debug))) return 1;             \
+    } while (0)
+
+// ---- the same stage of several frames in ONE launch ------------------------------------------------------------------------
+// Every kernel of the rasterizer's frame chain takes Batch<Args> and picks its frame's argument block by blockIdx.y.  A plain
+// call launches with one frame.  Between soar_batch_begin(n) and soar_batch_end() the caller walks the SAME entry point over
+// the n frames (soar_batch_frame(f) in front of each call): the launch sites keep the argument blocks of the frames 0 .. n-2
+// and launch once, with gridDim.y = n, when frame n-1 hands in its own -- stage by stage, in the order of the calls.  Four
+// frame chains on four streams cost a fork and a join per step (~90 us at C3) and depend on how the hardware queues are
+// arbitrated once two chains saturate the GPU (C5); one stream with four frames per launch does neither.
+constexpr int MAX_BATCH = 8;
+template <typename A>
+struct Batch {
+    A v[MAX_BATCH];
+};
+struct BatchCtx {
+    int n = 0, f = 0;             // n == 0: no batch open
+};
+BatchCtx &batch_ctx();
+#define SOAR_LAUNCH_BATCHED(kernel, grid, block, lds, stream, args)                                   \
+    do {                                                                                                \
+        using SoarArgsT_ = std::decay_t<decltype(args)>;                                                \
+        static thread_local ::soar::Batch<SoarArgsT_> soar_pending_;                                    \
+        const ::soar::BatchCtx &soar_c_ = ::soar::batch_ctx();                                          \
+        const int soar_f_ = soar_c_.n ? soar_c_.f : 0, soar_n_ = soar_c_.n ? soar_c_.n : 1;             \
+        soar_pending_.v[soar_f_] = (args);                                                              \
+        if (soar_f_ == soar_n_ - 1) {                                                                   \
+            dim3 soar_g_ = (grid);                                                                      \
+            soar_g_.y = (unsigned)soar_n_;                                                              \
+            hipLaunchKernelGGL(kernel, soar_g_, block, lds, stream, soar_pending_);                     \
+        }                                                                                               \
     } while (0)
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg) ----

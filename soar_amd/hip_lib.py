@@ -53,6 +53,9 @@ SIGNATURES = {
                            + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_backward_scaled": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 5
                                   + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
+    "soar_batch_begin": (C.c_int, [C.c_int32]),
+    "soar_batch_frame": (C.c_int, [C.c_int32]),
+    "soar_batch_end": (C.c_int, []),
     "soar_rast_occ_backward": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "soar_rast_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_rast_export_state": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, C.c_int64] + [_vp] * 17 + [_vp]),
