@@ -489,6 +489,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
                                f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
                                f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}", "mode": mode,
+                   "frame_chains": (("one stream, every stage launched once for all frames" if plan.batched else "one stream per frame")
+                                    if plan is not None and plan.graphs is None else "one stream per frame"),
                    "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")
                    if use_dist else "none",
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),

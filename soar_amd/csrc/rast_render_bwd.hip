@@ -343,8 +343,10 @@ __device__ __forceinline__ void backward_quad(const BwdArgs &a, const int rank, 
 template <bool WIDE>
 __global__ void __launch_bounds__(256) SOAR_BWD_OCC render_backward_slots_kernel(Batch<BwdArgs> batch)
 {
-    const BwdArgs &a = batch.v[blockIdx.y];
-    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    int frame, bx;
+    batch_interleave(frame, bx);
+    const BwdArgs &a = batch.v[frame];
+    const int xcd = bx & 7, kth = bx >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];

@@ -400,8 +400,10 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
 template <bool LOG, bool OCC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_FWD_WPE, 8))) render_forward_kernel(Batch<FwdArgs> batch)
 {
-    const FwdArgs &a = batch.v[blockIdx.y];
-    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    int frame, bx;
+    batch_interleave(frame, bx);
+    const FwdArgs &a = batch.v[frame];
+    const int xcd = bx & 7, kth = bx >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const int stride = (int)(gridDim.x >> 2);                // ranks per pass of the grid (a multiple of 8)
     const int Tpad = (a.ntiles + 7) / 8 * 8;
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_F
     // device: tile_order_block compared them one launch ago)
     const bool keep = a.keep_background && a.bg_state[4] == 0u;
     if (!LOG)
-        for (int rank = n_work + (int)blockIdx.x; rank < a.ntiles; rank += (int)gridDim.x) {
+        for (int rank = n_work + bx; rank < a.ntiles; rank += (int)gridDim.x) {
             const int tile = (int)a.tile_order[rank];
             const uint32_t holds_background = __hip_atomic_load(a.bg_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_barrier();                                   // every wavefront has read the flag before the first one may set it below

@@ -43,6 +43,16 @@ template <typename A>
 struct Batch {
     A v[MAX_BATCH];
 };
+// Blend kernels: the frames of a batched launch interleave in groups of 8 workgroups (one per XCD: the dispatcher deals
+// consecutive workgroups to the XCDs in turn) instead of one frame's whole grid after the other -- both orders walk every frame's
+// tiles longest list first, but only the interleaved one STARTS every frame's longest lists first.  frame / bx replace
+// blockIdx.y / blockIdx.x; bx & 7 is still the XCD the workgroup runs on.  gridDim.x must be a multiple of 8.
+__device__ __forceinline__ void batch_interleave(int &frame, int &bx)
+{
+    const unsigned n = gridDim.y, l = blockIdx.y * gridDim.x + blockIdx.x;       // place in the dispatch order
+    frame = (int)((l >> 3) % n);
+    bx = (int)(((l >> 3) / n) * 8u + (l & 7u));
+}
 struct BatchCtx {
     int n = 0, f = 0;             // n == 0: no batch open
 };

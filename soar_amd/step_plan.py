@@ -39,7 +39,7 @@ from .rasterizer import _Ctx
 
 class FrameStepPlan:
     def __init__(self, seq, n_frames: int, targets: Dict[str, torch.Tensor], bg: torch.Tensor, capacity: int, flat,
-                 loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True):
+                 loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True, batched: Optional[bool] = None):
         """seq: AvatarSequence; targets: {"color","mask","normal"} image targets shared by the frames, or a resident pool
         [n_sets,7,H,W] of per-frame targets (``synthetic.make_loss_target_pool``; frame f uses set f mod n_sets); capacity: bound
         of the (tile, Gaussian) instances of one frame (checked on the device, see ``check()``); flat: FlatGradBuffer of
@@ -118,6 +118,15 @@ class FrameStepPlan:
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n)]
         if os.environ.get("SOAR_PLAN_MAIN_FRAME", "0") == "1":
             self.streams[0] = None
+        # Eager form only.  batched: ONE stream, every stage of the chain launched once for all frames (soar_batch_*: the kernels
+        # take their frame from blockIdx.y) -- no fork / join per step and a quarter of the launches, but every stage ends in a
+        # barrier over all frames.  Not batched: the frames' chains on streams of their own, whose small latency-bound kernels
+        # fill the tails of the other chains' blends.  Measured (bench.py, frames/s batched against streams): 540p 6500 / 5400,
+        # 1080p 3450 / 3380, 4K 845 / 905 -- the default follows the image size; SOAR_PLAN_BATCHED=0 / 1 or the argument force it.
+        if batched is None:
+            env = os.environ.get("SOAR_PLAN_BATCHED")
+            batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 1920 * 1080)
+        self.batched = bool(batched) and self.n <= 8
         self.graphs = None
         if use_graphs:
             if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
@@ -176,22 +185,21 @@ class FrameStepPlan:
         check(L.soar_lbs_warp_forward_batch(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
                                             self.P, J, ptr(self.xyz_p_all), ptr(self.rot_p_all), stream), "warp_forward_batch")
 
-    def _frame(self, i: int, stream: int) -> None:
-        """forward and backward of frame i: a straight line of launches on one stream"""
-        L, s, v, P, W, H = self.L, self.seq, self.views[i], self.P, self.W, self.H
-        prm = C.byref(self.ctx.params)
-        J = int(self.blend_weights.shape[1])
-        mats = self.mats[i]
-        xyz, rot = s.xyz.detach(), s.rot.detach()
-        self._stamp(2 + 2 * i, stream)
-        self._stage_stamp(i, 0, stream)
-        check(L.soar_rast_forward_geometry(prm, ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
-                                           ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream), "geometry")
-        self._stage_stamp(i, 1, stream)
-        check(L.soar_rast_forward_render_occ(prm, ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
-                                             ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
+    # ---- the frame chain, stage by stage -----------------------------------------------------------------------------------
+    def _f_geometry(self, i: int, stream: int) -> None:
+        L, s, v = self.L, self.seq, self.views[i]
+        check(L.soar_rast_forward_geometry(C.byref(self.ctx.params), ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones),
+                                           ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream),
+              "geometry")
+
+    def _f_render(self, i: int, stream: int) -> None:
+        L, s, v = self.L, self.seq, self.views[i]
+        check(L.soar_rast_forward_render_occ(C.byref(self.ctx.params), ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
+                                             self.capacity, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
                                              ptr(v["occ"]), stream), "render")
-        self._stage_stamp(i, 2, stream)
+
+    def _f_loss(self, i: int, stream: int) -> None:
+        L, v, W, H = self.L, self.views[i], self.W, self.H
         wc, wm, wn, wd = self.weights
         if self.pool is not None:
             check(L.soar_frame_loss_pooled(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
@@ -205,15 +213,42 @@ class FrameStepPlan:
                                     wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
                                     ptr(v["gO"]), ptr(v["img"]), self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
                   "frame_loss")
-        self._stage_stamp(i, 3, stream)
-        check(L.soar_rast_backward(prm, ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()), ptr(s.scales.detach()),
-                                   ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
-                                   ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
+
+    def _f_backward(self, i: int, stream: int) -> None:
+        L, s, v = self.L, self.seq, self.views[i]
+        check(L.soar_rast_backward(C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
+                                   ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
+                                   self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
                                    ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]), ptr(v["g_cov3D"]), None,
                                    ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
                                    ptr(v["work"]), v["work"].numel(), stream), "backward")
+
+    def _frame(self, i: int, stream: int) -> None:
+        """forward and backward of frame i: a straight line of launches on one stream"""
+        self._stamp(2 + 2 * i, stream)
+        for k, stage in enumerate((self._f_geometry, self._f_render, self._f_loss, self._f_backward)):
+            self._stage_stamp(i, k, stream)
+            stage(i, stream)
         self._stage_stamp(i, 4, stream)
         self._stamp(3 + 2 * i, stream)
+
+    def _frames_batched(self, stream: int) -> None:
+        """All frames on ONE stream, every stage of the chain as one launch for all of them (soar_batch_begin / _frame / _end:
+        the kernels take their frame from blockIdx.y): no fork and join per step, a quarter of the launches, and nothing depends
+        on how the hardware arbitrates four queues."""
+        L, n = self.L, self.n
+        for i in range(n):
+            self._stamp(2 + 2 * i, stream)
+        check(L.soar_batch_begin(n), "batch_begin")
+        try:
+            for stage in (self._f_geometry, self._f_render, self._f_loss, self._f_backward):
+                for i in range(n):
+                    check(L.soar_batch_frame(i), "batch_frame")
+                    stage(i, stream)
+        finally:
+            L.soar_batch_end()
+        for i in range(n):
+            self._stamp(3 + 2 * i, stream)
 
     def _epilogue(self, stream: int) -> None:
         """Behind the join, on the caller's stream, ONE launch: the backward warps of all frames, added in frame order, straight
@@ -271,7 +306,10 @@ class FrameStepPlan:
             self._prologue(main.cuda_stream, self.steps % self.RESORT_EVERY == 0)
             self.flat.wait_all()
             self._warp_all(main.cuda_stream)
-            self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
+            if self.batched:
+                self._frames_batched(main.cuda_stream)
+            else:
+                self._fan_out(main, lambda i, s: self._frame(i, s.cuda_stream))
             self._epilogue(main.cuda_stream)
         self.steps += 1
         # every later forward blend of a chain writes the same image buffer and output planes again, with the same background:

@@ -606,6 +606,35 @@ def test_step_plan_matches_autograd(use_graphs, pooled):
         assert _rel(flat.flat.cpu().numpy(), want.cpu().numpy()) < 1e-4
 
 
+def test_step_plan_batched_launches_equal_the_per_frame_chains():
+    """FrameStepPlan(batched=True): one stream, every stage of the chain as one launch for all frames (soar_batch_begin / _frame /
+    _end, frame = blockIdx.y) against the frames' chains on streams of their own: same images bit for bit, same losses, gradients
+    to float-atomic order -- over several steps with moving frames (the kept background of empty tiles included)."""
+    import bench
+    from soar_amd import rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+    seq, pool, _ = bench.build_sequence("tiny", DEV)
+    flats = [FlatGradBuffer(seq.leaves()) for _ in range(2)]
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    bench.run_step(seq, pool, flats[0], [0, 1, 2, 3], bg)
+    cap = 2 * rasterizer.last_num_rendered
+    plans = [FrameStepPlan(seq, 4, pool, bg, cap, flats[k], use_graphs=False, batched=(k == 0)) for k in range(2)]
+    assert plans[0].batched and not plans[1].batched
+    for frames in ([0, 1, 2, 3], [9, 2, 30, 17], [3, 2, 1, 0], [3, 2, 1, 0]):
+        losses = []
+        for plan in plans:
+            losses.append(plan.run(frames).clone())
+            torch.cuda.synchronize()
+            assert all(o == 0 for _, o in plan.check())
+        assert torch.equal(losses[0], losses[1])
+        for va, vb in zip(plans[0].views, plans[1].views):
+            for name in ("color", "normal", "depth", "opac", "occ", "radii"):
+                assert torch.equal(va[name], vb[name]), (frames, name)
+        a, b = flats[0].flat, flats[1].flat
+        assert b.abs().max() > 0 and (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
 def test_step_plan_keeps_background_of_empty_tiles_only():
     """From its second step on the plan asks the forward blend not to rewrite tiles that stay empty (SoarRastParams.debug bit 2:
     85 % of the output bytes of a 1080p frame).  With the allocator's free blocks full of junk, and frames whose silhouettes
