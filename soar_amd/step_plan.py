@@ -125,7 +125,10 @@ class FrameStepPlan:
         # 1080p 3450 / 3380, 4K 845 / 905 -- the default follows the image size; SOAR_PLAN_BATCHED=0 / 1 or the argument force it.
         if batched is None:
             env = os.environ.get("SOAR_PLAN_BATCHED")
-            batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 1920 * 1080)
+            # (next to a live process group the streams form is ~1 % ahead: the all-reduce the next step waits for hides behind
+            # the fork; alone the batched form is ~2 % ahead)
+            alone = not (hasattr(flat, "_collectives_on") and flat._collectives_on())
+            batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 1920 * 1080 and alone)
         self.batched = bool(batched) and self.n <= 8
         self.graphs = None
         if use_graphs:
