@@ -1,0 +1,18 @@
+"""Mean duration of the batched launches (gridDim.y = frames per step) of one bench run, from a rocprofv3 kernel trace:
+   rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py ... ; python scripts/batched_trace.py DIR [frames]"""
+import collections, csv, glob, sys
+rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+d = collections.defaultdict(list)
+for r in rows:
+    gy = int(r.get("Grid_Size_Y", "1") or 1) // max(int(r.get("Workgroup_Size_Y", "1") or 1), 1)
+    if gy == n:
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000)
+tot = 0.0
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]) / len(kv[1])):
+    m = sum(v) / len(v)
+    per_step = 2 if "zero_ranges" in k else 1
+    tot += m * per_step
+    name = k.split("::")[-1].split("(")[0]
+    print(f"{m:8.1f} us x{len(v):3d}  {name}")
+print(f"sum over one step: {tot:.0f} us")
