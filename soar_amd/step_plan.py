@@ -15,6 +15,10 @@ out once:
   the chains an epilogue of one launch (soar_lbs_warp_backward_sum: the warp backward of all frames, their sum in frame
   order and the sums of the frames' scale / colour gradients, written straight into the flat gradient buffer).
 
+Eager form (``use_graphs=False``, bench.py's default): the same launches issued from the host (0.45 ms of a 1.2 ms step).  Up
+to 1080p it runs the frames' chains as ONE chain on the caller's stream, every stage launched once for all frames
+(``batched``, ``soar_batch_begin / _frame / _end``): no fork and join, a quarter of the launches.
+
 Per step the host replays 2 + n_frames graphs (one more while a gradient reduction is pending between the KNN and the warp) instead of enqueueing ~105 launches through autograd, and the frames'
 chains overlap by ordinary stream semantics (a single captured graph with four branches was measured to be released
 one branch at a time by the graph executor).  The kernels and their results are those of the autograd path
