@@ -69,6 +69,21 @@ def test_bad_arguments_fail_loudly_without_touching_the_gpu(lib):
     assert lib.soar_lbs_warp_forward(None, None, None, None, None, None, 5, 100, None, None, None, None) != 0
 
 
+def test_batch_control_calls_check_their_arguments(lib):
+    """soar_batch_begin / _frame / _end (the same stage of several frames in one launch): host-side state only."""
+    from soar_amd import hip_lib
+    assert lib.soar_batch_begin(0) != 0 and lib.soar_batch_begin(9) != 0
+    assert "n_frames" in hip_lib.last_error()
+    assert lib.soar_batch_frame(0) != 0                       # no batch open
+    assert lib.soar_batch_begin(4) == 0
+    try:
+        assert lib.soar_batch_begin(2) != 0 and "already open" in hip_lib.last_error()
+        assert lib.soar_batch_frame(3) == 0 and lib.soar_batch_frame(4) != 0 and lib.soar_batch_frame(-1) != 0
+    finally:
+        assert lib.soar_batch_end() == 0
+    assert lib.soar_batch_begin(8) == 0 and lib.soar_batch_end() == 0
+
+
 def test_python_api_rejects_cpu_tensors_instead_of_falling_back():
     from soar_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from soar_amd import lbs
