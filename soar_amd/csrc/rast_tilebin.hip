@@ -439,14 +439,14 @@ struct BinCountArgs {
     const uint2 *band_rect;
     uint32_t *tile_count;
 };
-__device__ __forceinline__ void bin_count_kernel_body(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+__device__ __forceinline__ void bin_count_kernel_body(const int bx, const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, uint32_t *__restrict__ tile_count)
 {
     __shared__ int diff[BIN_SUPER + 1][BIN_SUPER + 1];
     const int tid = threadIdx.x;
-    const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
+    const SuperTile st = super_tile_of(bx, gx, gy);
     const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
-    const int band = band_of_block(blockIdx.x, gx, band_rows);
+    const int band = band_of_block(bx, gx, band_rows);
     const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles, depth order
     const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
     const bool inside = P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0;
@@ -492,8 +492,10 @@ __device__ __forceinline__ void bin_count_kernel_body(const uint32_t *__restrict
 }
 __global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(Batch<BinCountArgs> batch)
 {
-    const BinCountArgs &a = batch.v[blockIdx.y];
-    bin_count_kernel_body(a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.tile_count);
+    int frame, bx;
+    batch_interleave1(frame, bx);
+    const BinCountArgs &a = batch.v[frame];
+    bin_count_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.tile_count);
 }
 
 
@@ -607,7 +609,7 @@ struct BinTilesArgs {
     uint32_t *bg_state;
     unsigned long long *dbg;
 };
-__device__ __forceinline__ void bin_tiles_kernel_body(const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
+__device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
                  uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
                  uint32_t *__restrict__ tile_order, const float *__restrict__ bg, int normalize_depth,
@@ -616,7 +618,7 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const uint32_t *__restrict
     const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
     unsigned long long dbg_flush = 0;
     int dbg_nflush = 0, dbg_hits = 0;
-    if ((int)blockIdx.x == nblocks_tiles) {
+    if (bx == nblocks_tiles) {
         // the extra workgroup: longest-list-first order of the tiles for the blend launches (needs the counts only)
         const int T = gx * gy;
         tile_order_block(T, (T + 7) / 8 * 8, tile_count, ranges, tile_order, bg, normalize_depth, bg_state);
@@ -627,12 +629,12 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const uint32_t *__restrict
     __shared__ uint32_t tile_cursor[NT];
     __shared__ uint32_t wave_cnt[2][BIN_WAVES];
     __shared__ int any_s;
-    const int band = band_of_block(blockIdx.x, gx, band_rows);
+    const int band = band_of_block(bx, gx, band_rows);
     const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles / ids, depth order
     const uint32_t *__restrict__ ids_sorted = band_id + band_info[band];
     const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const SuperTile st = super_tile_of(blockIdx.x, gx, gy);
+    const SuperTile st = super_tile_of(bx, gx, gy);
 
     if (tid == 0) any_s = 0;
     lds_barrier();
@@ -742,14 +744,16 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const uint32_t *__restrict
     }
     flush();
     if (dbg && tid == 0) {
-        unsigned long long *w = dbg + (size_t)blockIdx.x * 4;
+        unsigned long long *w = dbg + (size_t)bx * 4;
         w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits; w[3] = (unsigned long long)P;
     }
 }
 __global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesArgs> batch)
 {
-    const BinTilesArgs &a = batch.v[blockIdx.y];
-    bin_tiles_kernel_body(a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg);
+    int frame, bx;
+    batch_interleave1(frame, bx);
+    const BinTilesArgs &a = batch.v[frame];
+    bin_tiles_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg);
 }
 
 

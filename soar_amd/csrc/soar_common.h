@@ -53,6 +53,13 @@ __device__ __forceinline__ void batch_interleave(int &frame, int &bx)
     frame = (int)((l >> 3) % n);
     bx = (int)(((l >> 3) / n) * 8u + (l & 7u));
 }
+// the same for kernels whose grid has no XCD structure: the frames alternate workgroup by workgroup
+__device__ __forceinline__ void batch_interleave1(int &frame, int &bx)
+{
+    const unsigned n = gridDim.y, l = blockIdx.y * gridDim.x + blockIdx.x;
+    frame = (int)(l % n);
+    bx = (int)(l / n);
+}
 struct BatchCtx {
     int n = 0, f = 0;             // n == 0: no batch open
 };
