@@ -239,22 +239,23 @@ class FrameStepPlan:
         self._stage_stamp(i, 4, stream)
         self._stamp(3 + 2 * i, stream)
 
-    def _frames_batched(self, stream: int) -> None:
-        """All frames on ONE stream, every stage of the chain as one launch for all of them (soar_batch_begin / _frame / _end:
-        the kernels take their frame from blockIdx.y): no fork and join per step, a quarter of the launches, and nothing depends
-        on how the hardware arbitrates four queues."""
-        L, n = self.L, self.n
-        for i in range(n):
+    def _frames_batched(self, stream: int, frames: Optional[Sequence[int]] = None) -> None:
+        """The given frames (default: all) on ONE stream, every stage of the chain as one launch for all of them (soar_batch_begin /
+        _frame / _end: the kernels take their frame from blockIdx.y): no fork and join per step, a quarter of the launches, and
+        nothing depends on how the hardware arbitrates four queues."""
+        L = self.L
+        frames = list(range(self.n)) if frames is None else list(frames)
+        for i in frames:
             self._stamp(2 + 2 * i, stream)
-        check(L.soar_batch_begin(n), "batch_begin")
+        check(L.soar_batch_begin(len(frames)), "batch_begin")
         try:
             for stage in (self._f_geometry, self._f_render, self._f_loss, self._f_backward):
-                for i in range(n):
-                    check(L.soar_batch_frame(i), "batch_frame")
+                for k, i in enumerate(frames):
+                    check(L.soar_batch_frame(k), "batch_frame")
                     stage(i, stream)
         finally:
             L.soar_batch_end()
-        for i in range(n):
+        for i in frames:
             self._stamp(3 + 2 * i, stream)
 
     def _epilogue(self, stream: int) -> None:
