@@ -110,6 +110,8 @@ void prof_drain()
 StageTimer::StageTimer(int stage, hipStream_t s) : slot(-1), stream(s)
 {
     if (!g_prof_on) return;
+    // inside a batch only the last frame's call launches: the earlier ones have nothing to time
+    if (batch_ctx().n && batch_ctx().f != batch_ctx().n - 1) return;
     {
         std::lock_guard<std::mutex> lock(g_prof_mutex);
         if (!g_slots_init) {
