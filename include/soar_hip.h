@@ -441,6 +441,11 @@ int soar_prof_timestamp(unsigned long long *ring_dev, int64_t capacity, int64_t 
  * q(lane) that total belongs to. */
 int soar_selftest_wave_reduce(float *out128_dev, void *stream);
 
+/* ---- device self-test of the 64-lane scan of affine maps of the backward blend's entry-lane form (rast_render_bwd.hip):
+ * m64_dev / b64_dev [64] = the map P -> m P + b of every lane; out192_dev [192]: [0..63] m and [64..127] b of the composition of
+ * the maps of the lanes 0..i (lane 0's applied first), [128..191] b of lane i - 1 (lane 0: -7). */
+int soar_selftest_affine_scan(const float *m64_dev, const float *b64_dev, float *out192_dev, void *stream);
+
 /* ---- device self-test of the blend kernels' exp: out_dev[i] = the kernels' exp(x[i]), expf_dev[i] = the device math
  * library's expf(x[i]) (what the reference's `exp(power)` becomes when built for this GPU); equal bit for bit on [-87, 0]. */
 int soar_selftest_exp(const float *x_dev, int32_t n, float *out_dev, float *expf_dev, void *stream);

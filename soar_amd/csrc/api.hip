@@ -93,7 +93,7 @@ long long g_stage_n[ST_COUNT];
 // Gaussians (bucket_count / _scatter / _sort; the rocPRIM key sort in the descending path)
 const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "tile_lists", "depth_order", "tile_ranges", "render_forward",
                                        "render_backward", "geometry_backward", "lbs_knn_weights", "lbs_warp_forward",
-                                       "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops"};
+                                       "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops", "block_masks"};
 void prof_drain()
 {
     for (int i = 0; i < g_slot_used; i++) {
@@ -197,6 +197,9 @@ int carve_binning(void *base, int64_t R, BinBuf *out)
     char *tmp;
     take(p, tmp, out->sort_temp_bytes);
     out->sort_temp = tmp;
+    take(p, out->tile_xy, n);
+    out->mask_plane = n / 64 + 2;
+    take(p, out->block_masks, 16 * out->mask_plane);
     out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
     return 0;
 }
@@ -456,6 +459,7 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
         if (launch_scan(*prm, g, stream)) return 1;                // key emission needs the prefix sum of tiles_touched
         if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
     }
+    if (num_rendered > 0 && launch_block_masks(*prm, g, b, num_rendered, stream)) return 1;
     if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
 }

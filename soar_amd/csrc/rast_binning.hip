@@ -85,11 +85,12 @@ emit_keys_kernel(int P, const uint2 *__restrict__ rect, const uint32_t *__restri
 }
 
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(int64_t L, const uint64_t *__restrict__ keys, uint2 *__restrict__ ranges)
+tile_ranges_kernel(int64_t L, const uint64_t *__restrict__ keys, uint2 *__restrict__ ranges, uint32_t *__restrict__ tile_xy, uint32_t gx)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
     const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    tile_xy[idx] = ((cur / gx) << 16) | (cur % gx);          // the tile of every list position (block masks)
     if (idx == 0) {
         ranges[cur].x = 0;
     } else {
@@ -151,7 +152,7 @@ int launch_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &i
     {
     StageTimer timer(ST_RANGES, stream);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, b.keys_sorted,
-                       img.ranges);
+                       img.ranges, b.tile_xy, (uint32_t)gx);
     }
     SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
     return launch_tile_order(prm, img, stream);

@@ -1,0 +1,150 @@
+// rast_blockmask.hip -- which entries of a tile's list can touch which 4x4-pixel block of the tile.
+//
+// Part of the replacement of renderCUDA forward / backward (DGR/cuda_rasterizer/forward.cu:390-692, backward.cu:529-858): both walk,
+// per 16x16 tile, the tile's whole list for every pixel and skip an entry per pixel when alpha < 1/255 (forward.cu:545,
+// backward.cu:680).  The blend kernels here work per 4x4 block with one wavefront and only want the entries that can pass that test
+// somewhere in the block.  Rounds 1-2 made each blend kernel find them itself (a conservative test of all the tile's entries per
+// wavefront, the same test twice per frame, behind workgroup barriers); this pass does it once, ahead of both, and leaves one bit
+// per (block, entry): soar_common.h "block masks" has the layout.  Dropping an entry whose bit is clear changes no result -- every
+// pixel of the block would have skipped it (splat_may_touch_rect, soar_common.h).
+//
+// One wavefront per 128 consecutive list positions (lists of all tiles, back to back; two groups of 64, so that a wavefront has two
+// independent gathers in flight), lane = entry: the entry's tile comes from BinBuf::tile_xy (written with the lists), the 24 bytes
+// of its record that the test needs from one gather; lane b stores the word of block b.  Flat over the list positions: no
+// dependence on how the lists' lengths are distributed, two round trips to memory per wavefront.
+//
+// The test is splat_may_touch_rect (soar_common.h) for the 16 blocks of the entry's tile at once: the minimum of the falloff form
+// q(d) = A dx^2 + 2 B dx dy + C dy^2 over a block's rectangle of pixel centres lies, when the splat's centre is outside, on the
+// rectangle's nearest vertical or horizontal edge -- and the 16 blocks share 4 + 4 such edges.  Per column (row) of blocks: the
+// distance n to its nearest edge line, the unconstrained minimiser along that line (-B n / C), and the two coefficients of q along
+// it; per block: clamp the minimiser to the block's extent (v_med3), two fused multiply-adds per edge, v_min3 with the "centre
+// inside" candidate.  ~11 vector instructions per block instead of ~25.
+#include "soar_common.h"
+
+namespace soar {
+
+namespace {
+
+struct BlockMaskArgs {
+    const uint32_t *header;          // GeomBuf::header (H_TOTAL: instances found by the tile binning), or NULL: `total` is exact
+    uint32_t total;
+    uint32_t P;
+    const uint32_t *tile_xy;
+    const uint32_t *point_list;
+    const GaussRec *rec;
+    uint64_t *masks;                 // BinBuf::block_masks
+    size_t plane;
+};
+
+constexpr float BM_BIG = 1.0e30f;
+
+// edge data of one column (or row) of blocks: h = centre - first pixel centre of the column, extent 3
+struct EdgeLine {
+    float lo, hi;        // centre - last / first pixel centre: the interval of d over the column
+    float t;             // unconstrained minimiser of q along the nearest edge line, in the OTHER coordinate
+    float k2, k1;        // q along that line = k2 + s (k1 + K s), K = the other diagonal coefficient; k2 = BIG when the centre is inside
+    float inside;        // 0 when the centre's coordinate lies inside the column, BIG otherwise
+};
+__device__ __forceinline__ EdgeLine edge_line(float h, float D, float B, float rcp_other)
+{
+    // D: this coordinate's diagonal coefficient (A for columns), rcp_other: 1 / the other one (1 / C for columns)
+    EdgeLine e;
+    e.hi = h; e.lo = h - 3.f;
+    const float n = h - __builtin_amdgcn_fmed3f(h, 0.f, 3.f);        // distance to the nearest edge line, 0 inside
+    const float Bn = B * n;
+    e.t = -Bn * rcp_other;
+    e.k1 = Bn + Bn;
+    const bool in = n == 0.f;
+    e.k2 = in ? BM_BIG : D * n * n;
+    e.inside = in ? 0.f : BM_BIG;
+    return e;
+}
+
+// the 16 words of one group of 64 list positions: bit = the entry may reach alpha >= 1/255 in the block
+__device__ __forceinline__ void block_words(const int lane, bool valid, float x, float y, float A, float B, float C, float thr, float tx0,
+                                            float ty0, uint32_t &w_lo, uint32_t &w_hi)
+{
+    // invisible <=> pd && qmin * 0.9999 - 1e-3 > thr (splat_may_touch_rect); not positive definite or NaN: visible
+    const bool pd = (A > 0.f) && (C > 0.f) && (A * C - B * B > 0.f);
+    float limit = (thr + 1.0e-3f) * (1.0f / 0.9999f);
+    limit = pd ? limit : 3.0e38f;
+    limit = valid ? limit : -3.0e38f;                                 // no entry: never visible
+    const float rcpA = __builtin_amdgcn_rcpf(A), rcpC = __builtin_amdgcn_rcpf(C);
+    EdgeLine col[4], row[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        col[k] = edge_line(x - (tx0 + (float)(4 * k)), A, B, rcpC);
+        row[k] = edge_line(y - (ty0 + (float)(4 * k)), C, B, rcpA);
+    }
+    w_lo = 0u; w_hi = 0u;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        const int c = (b & 1) + ((b >> 2) & 1) * 2, r = ((b >> 1) & 1) + (b >> 3) * 2;       // block = quad * 4 + wave
+        const float s1 = __builtin_amdgcn_fmed3f(col[c].t, row[r].lo, row[r].hi);          // along the vertical edge: dy
+        const float q1 = __builtin_fmaf(__builtin_fmaf(C, s1, col[c].k1), s1, col[c].k2);
+        const float s2 = __builtin_amdgcn_fmed3f(row[r].t, col[c].lo, col[c].hi);          // along the horizontal edge: dx
+        const float q2 = __builtin_fmaf(__builtin_fmaf(A, s2, row[r].k1), s2, row[r].k2);
+        const float q0 = fmaxf(col[c].inside, row[r].inside);                              // 0: the centre lies in the block
+        const float qmin = fminf(fminf(q1, q2), q0);   // (the compiler fuses the pair into v_min3_f32)
+        const unsigned long long m = __ballot(!(qmin > limit));
+        const bool mine = lane == b;
+        w_lo = mine ? (uint32_t)m : w_lo;
+        w_hi = mine ? (uint32_t)(m >> 32) : w_hi;
+    }
+}
+
+__global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> batch)
+{
+    int frame, bx;
+    batch_interleave1(frame, bx);
+    const BlockMaskArgs &a = batch.v[frame];
+    const int lane = threadIdx.x & 63;
+    const uint32_t g0 = ((uint32_t)bx * 4u + (threadIdx.x >> 6)) * 2u;
+    if ((uint64_t)g0 * 64u >= a.total) return;
+    // Everything is asked for before the number of instances is known (one round trip less): positions behind it hold stale ids,
+    // clamped into the record array, and their bits are masked away
+    float x[2], y[2], A[2], B[2], C[2], thr[2], tx0[2], ty0[2];
+    uint32_t pos[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        pos[u] = min((g0 + (uint32_t)u) * 64u + (uint32_t)lane, a.total - 1u);
+        const uint32_t id = min(a.point_list[pos[u]], a.P - 1u), xy = a.tile_xy[pos[u]];
+        const float4 q0 = a.rec[id].q0;
+        x[u] = q0.x; y[u] = q0.y; A[u] = q0.z; B[u] = q0.w;
+        C[u] = a.rec[id].q1.x;
+        thr[u] = a.rec[id].q3.w;
+        tx0[u] = (float)((xy & 0xFFFFu) * TILE); ty0[u] = (float)((xy >> 16) * TILE);
+    }
+    // (an overflow of the caller's binning buffer leaves every tile range empty and the lists unwritten)
+    if (a.header && (a.header[H_OVERFLOW] | a.header[H_BAND_OVERFLOW]) != 0u) return;
+    const uint32_t total = a.header ? min(a.header[H_TOTAL], a.total) : a.total;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t g = g0 + (uint32_t)u;
+        if ((uint64_t)g * 64u >= total) break;
+        uint32_t w_lo, w_hi;
+        block_words(lane, g * 64u + (uint32_t)lane < total, x[u], y[u], A[u], B[u], C[u], thr[u], tx0[u], ty0[u], w_lo, w_hi);
+        if (lane < 16) a.masks[(size_t)lane * a.plane + g] = (uint64_t)w_lo | ((uint64_t)w_hi << 32);
+    }
+}
+
+}  // namespace
+
+// `R`: the instances the lists hold -- exact on the key-sort path, the capacity of the caller's binning buffer on the tile-binning
+// path (the real number is then read on the device; nothing is written when it overflowed: every range is empty)
+int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, int64_t R, hipStream_t stream)
+{
+    BlockMaskArgs a;
+    a.header = prm.sort_descending ? nullptr : g.header;
+    a.total = (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R);
+    a.P = (uint32_t)prm.P;
+    a.tile_xy = b.tile_xy; a.point_list = b.vals_sorted; a.rec = g.rec;
+    a.masks = b.block_masks; a.plane = b.mask_plane;
+    StageTimer timer(ST_BLOCK_MASKS, stream);
+    const unsigned nblocks = (unsigned)((R + 511) / 512);
+    SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_OK("block_masks", stream, prm.debug);
+    return 0;
+}
+
+}  // namespace soar

@@ -608,12 +608,13 @@ struct BinTilesArgs {
     int normalize_depth;
     uint32_t *bg_state;
     unsigned long long *dbg;
+    uint32_t *tile_xy;       // BinBuf::tile_xy
 };
 __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
                  const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
                  uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
                  uint32_t *__restrict__ tile_order, const float *__restrict__ bg, int normalize_depth,
-                 uint32_t *__restrict__ bg_state, unsigned long long *__restrict__ dbg)
+                 uint32_t *__restrict__ bg_state, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ tile_xy)
 {
     const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
     unsigned long long dbg_flush = 0;
@@ -654,6 +655,7 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const uint32
     static_assert(BIN_WAVES == NT, "one wavefront per tile of the super-tile");
     int nbuf = 0;
     uint32_t cursor = tile_cursor[wave];          // next free position of this wavefront's tile list
+    const uint32_t my_xy = ((uint32_t)(st.ty0 + (wave >> 2)) << 16) | (uint32_t)(st.tx0 + (wave & 3));   // ... and whose list it is (block masks)
     auto flush = [&]() {
         const unsigned long long f0 = dbg ? wall_clock64() : 0ull;
         dbg_nflush++; dbg_hits += nbuf;
@@ -672,7 +674,11 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const uint32
             for (int u = 0; u < FU; u++) {
                 const bool h = (m[u] >> wave) & 1u;
                 const unsigned long long bal = __ballot(h);
-                if (h) point_list[cursor + (uint32_t)prefix_in_mask(bal)] = id[u];
+                if (h) {
+                    const uint32_t at = cursor + (uint32_t)prefix_in_mask(bal);
+                    point_list[at] = id[u];
+                    tile_xy[at] = my_xy;
+                }
                 cursor += (uint32_t)__builtin_popcountll(bal);
             }
         }
@@ -753,7 +759,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesAr
     int frame, bx;
     batch_interleave1(frame, bx);
     const BinTilesArgs &a = batch.v[frame];
-    bin_tiles_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg);
+    bin_tiles_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg, a.tile_xy);
 }
 
 
@@ -824,7 +830,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             SOAR_HIP_OK(hipMalloc(&dbg, 8 * nw));
             SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * nw, stream));
             const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
-                                     img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg};
+                                     img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg, b.tile_xy};
             SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
             SOAR_HIP_OK(hipStreamSynchronize(stream));
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
@@ -842,7 +848,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             return 0;
         }
         const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
-                                 img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg};
+                                 img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg, b.tile_xy};
         SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
     }
     SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);

@@ -81,7 +81,7 @@ BatchCtx &batch_ctx();
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg) ----
 enum Stage {
     ST_PREPROCESS = 0, ST_SCAN, ST_EMIT_KEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_GEOM_BWD,
-    ST_LBS_KNN, ST_LBS_WARP_FWD, ST_LBS_WARP_BWD, ST_DIST2, ST_FRAME_LOSS, ST_POSTOPS, ST_COUNT
+    ST_LBS_KNN, ST_LBS_WARP_FWD, ST_LBS_WARP_BWD, ST_DIST2, ST_FRAME_LOSS, ST_POSTOPS, ST_BLOCK_MASKS, ST_COUNT
 };
 struct StageTimer {   // records start/stop events around a stage when profiling is enabled
     StageTimer(int stage, hipStream_t stream);
@@ -161,6 +161,10 @@ struct BinBuf {
     uint32_t *vals_sorted;   // [R]  (point_list)
     void *sort_temp;
     size_t sort_temp_bytes;
+    uint32_t *tile_xy;       // [R] tile of every list position, (ty << 16 | tx): written with the lists (bin_tiles / tile_ranges)
+    uint64_t *block_masks;   // [16][mask_plane]: plane b, word g = which of the list positions 64 g .. 64 g + 63 may touch block b of
+                             // THEIR tile (rast_blockmask.hip)
+    size_t mask_plane;       // R / 64 + 2
     size_t total_bytes;
 };
 int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out);
@@ -381,6 +385,14 @@ inline int blend_grid_ranks(int ntiles)
     const int r = (ntiles / 8 + 7) / 8 * 8;
     return r < 1024 ? 1024 : (r > 4096 ? 4096 : r);
 }
+// ---- block masks (rast_blockmask.hip) ---------------------------------------------------------------------------------------
+// The blend kernels work on 4x4-pixel blocks (16 per tile, block = quad * 4 + wave: x0 = 16 tx + 8 (quad & 1) + 4 (wave & 1),
+// y0 = 16 ty + 8 (quad >> 1) + 4 (wave >> 1)).  One pass over the tile lists decides, once for the forward and the backward blend,
+// which entries can reach alpha >= 1/255 anywhere in which block of their tile (splat_may_touch_rect: conservative, so dropping
+// the others changes no result): one bit per (block, list position), BinBuf::block_masks[block][position >> 6] bit position & 63.
+// A word may hold positions of two or more tiles (lists follow each other without padding): a reader masks it to its own range.
+int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, int64_t R, hipStream_t stream);
+
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
                           float *out_color, float *out_normal, float *out_depth, float *out_opac,
                           const float *occ_values, float *out_occ, hipStream_t stream);

@@ -100,6 +100,7 @@ SIGNATURES = {
                                          C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "soar_selftest_exp": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "soar_selftest_wave_reduce": (C.c_int, [_vp, _vp]),
+    "soar_selftest_affine_scan": (C.c_int, [_vp, _vp, _vp, _vp]),
     "soar_prof_enable": (C.c_int, [C.c_int]),
     "soar_prof_reset": (C.c_int, []),
     "soar_prof_stage_count": (C.c_int, []),

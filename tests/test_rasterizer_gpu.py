@@ -259,6 +259,30 @@ def test_wave_transpose_reduce_selftest():
     np.testing.assert_allclose(out[:64], expect[lane & 3, q_of], rtol=1e-6)
 
 
+def test_affine_scan_of_the_entry_lane_backward():
+    """The 64-lane scan of affine maps behind the backward blend's two recurrences (rast_render_bwd.hip affine_scan): lane i ends
+    with the composition of the maps of the lanes 0..i, lane 0's applied first; wave_shr:1 hands lane i the value of lane i - 1."""
+    from soar_amd import hip_lib
+    g = torch.Generator().manual_seed(3)
+    m = (0.01 + 0.99 * torch.rand(64, generator=g)).double()
+    b = torch.randn(64, generator=g).double()
+    out = torch.zeros(192, device=_dev())
+    m_dev, b_dev = m.float().to(_dev()), b.float().to(_dev())
+    hip_lib.check(hip_lib.lib().soar_selftest_affine_scan(m_dev.data_ptr(), b_dev.data_ptr(), out.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "selftest_affine_scan")
+    out = out.cpu().double().numpy()
+    M, B = np.zeros(64), np.zeros(64)
+    cm, cb = 1.0, 0.0
+    m, b = m_dev.cpu().double(), b_dev.cpu().double()
+    for i in range(64):                       # map i applied after the maps 0..i-1
+        cm, cb = float(m[i]) * cm, float(m[i]) * cb + float(b[i])
+        M[i], B[i] = cm, cb
+    np.testing.assert_allclose(out[:64], M, rtol=2e-5, atol=1e-30)
+    np.testing.assert_allclose(out[64:128], B, rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(out[129:192], out[64:127])
+    assert out[128] == -7.0
+
+
 def test_blend_exp_is_the_device_expf_bit_for_bit():
     """The blends' exp (soar_common.h exp_nonpositive) == expf of the device math library on the range the blend uses: the
     alphas, transmittance products and skip / stop decisions are then those of the reference's kernels built for this GPU."""
