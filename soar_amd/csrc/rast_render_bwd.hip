@@ -438,6 +438,38 @@ __device__ __forceinline__ void affine_scan(float &m, float &b)
         "s_nop 1"
         : "+v"(b), "+v"(m));
 }
+// The same scan with the wait states between its dependent DPP steps filled by six products the pair terms need anyway (and the
+// reciprocal of 1 - alpha) instead of s_nop: a scalar instruction between vector ones costs a wavefront far more than its slot
+// (tests/tools/issue_model: ~10 cycles per alternation, whatever the number of resident wavefronts).
+struct PairProducts { float dxdx, dxdy, dydy, gA, gC, r_om; };
+__device__ __forceinline__ PairProducts affine_scan_with_products(float &m, float &b, float dx, float dy, float A, float B, float C)
+{
+    PairProducts o;
+    asm volatile(
+        "v_mul_f32 %2, %8, %8\n\t"                                                    // dx dx
+        "v_mul_f32 %3, %8, %9\n\t"                                                    // dx dy
+        "v_rcp_f32 %7, %1\n\t"                                                        // 1 / (1 - alpha): m still is this lane's factor
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %4, %9, %9\n\t"                                                    // dy dy
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %5, %10, %8\n\t"                                                   // A dx
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %6, %12, %9\n\t"                                                   // C dy
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32 %5, %11, %9\n\t"                                                  // + B dy
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_fmac_f32 %6, %11, %8\n\t"                                                  // + B dx
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om)
+        : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    return o;
+}
 // device self-test of affine_scan (soar_selftest_affine_scan): out[lane] = {m, b} of the scan of known maps
 __global__ void selftest_affine_scan_kernel(const float *m_in, const float *b_in, float *out)
 {
@@ -779,7 +811,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     load_pixel_at_once(a, px, py, inside, c, st);
     float vT = st.T, vP = 0.f;                   // lane p: transmittance behind / blend of everything behind . upstream gradient, pixel p
     const uint32_t vLast = c.last;
-    const uint32_t deepest = wave_max_u32(vLast);
+    const uint32_t deepest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vLast));
     if (deepest == 0u) return;
     set_wave_priority_by_length(deepest);
     if (lane < 16) {
@@ -911,7 +943,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #pragma unroll
         for (int q = 0; q < 13; q++) acc[q] = 0.f;
         float sdD = 0.f;
-        bool any_live = false;
+        float any_live = 0.f;                    // > 0: some pair of this lane's entry was live
         const float oh = -0.5f * eop;
         while (act) {
             const int p = __builtin_ctz(act);
@@ -923,18 +955,21 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             const float power = falloff_power(eA, eB, eC, dx, dy);
             const float Gx = exp_nonpositive(power);
             const float alpha = fminf(0.99f, eop * Gx);
-            const bool live = (epos < last_p) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);      // :653-680
-            const float a_eff = live ? alpha : 0.f;
+            // the skip rules (:653-680) as three selects on the number, not one predicate: combining the comparisons first costs
+            // scalar mask instructions
+            float a_eff = (power > 0.0f) ? 0.f : alpha;
+            a_eff = (alpha < 1.0f / 255.0f) ? 0.f : a_eff;
+            a_eff = (epos < last_p) ? a_eff : 0.f;
+            const bool live = a_eff != 0.f;
             const float G = live ? Gx : 0.f;
-            const float om = 1.f - a_eff;
             const float d_cur = edepth - (dx * epa + dy * epb);
             const float u = er * c0.z + eg * c0.w + eb * c1.x + enx * c1.y + eny * c1.z + enz * c1.w + d_cur * c2.y;
-            float m = om, b = a_eff * u;
-            affine_scan(m, b);
+            float m = 1.f - a_eff, b = a_eff * u;
+            const PairProducts pp = affine_scan_with_products(m, b, dx, dy, eA, eB, eC);
             const float P_front = __builtin_fmaf(m, P_in, b);
             const float T_mine = T_in * __builtin_amdgcn_rcpf(m);
             const float P_mine = dpp_or<DPP_WAVE_SHR1, 0xf>(P_in, P_front);
-            const float r_om = __builtin_amdgcn_rcpf(om);
+            const float r_om = pp.r_om;
             const float wgt = a_eff * T_mine;                                            // dchannel_dcolor
             acc[6] = __builtin_fmaf(wgt, c0.z, acc[6]); acc[7] = __builtin_fmaf(wgt, c0.w, acc[7]);      // :711
             acc[8] = __builtin_fmaf(wgt, c1.x, acc[8]);
@@ -943,14 +978,14 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             acc[12] = __builtin_fmaf(wgt, c2.y, acc[12]);                                 // :782
             const float dL_dalpha = __builtin_fmaf(u - P_mine, T_mine, c2.z * r_om);
             const float dL_ddist = dL_dalpha * (oh * G);                                 // :823; 0 for a dead pair (G = 0)
-            acc[0] = __builtin_fmaf(dL_ddist, eA * dx + eB * dy, acc[0]);               // :828 (x 2 ddelx_dx at the end)
-            acc[1] = __builtin_fmaf(dL_ddist, eC * dy + eB * dx, acc[1]);               // :829
-            acc[2] = __builtin_fmaf(dL_ddist, dx * dx, acc[2]);                          // :831-835
-            acc[3] = __builtin_fmaf(dL_ddist, dx * dy, acc[3]);
-            acc[4] = __builtin_fmaf(dL_ddist, dy * dy, acc[4]);
+            acc[0] = __builtin_fmaf(dL_ddist, pp.gA, acc[0]);                            // :828 (x 2 ddelx_dx at the end)
+            acc[1] = __builtin_fmaf(dL_ddist, pp.gC, acc[1]);                            // :829
+            acc[2] = __builtin_fmaf(dL_ddist, pp.dxdx, acc[2]);                          // :831-835
+            acc[3] = __builtin_fmaf(dL_ddist, pp.dxdy, acc[3]);
+            acc[4] = __builtin_fmaf(dL_ddist, pp.dydy, acc[4]);
             acc[5] = __builtin_fmaf(G, dL_dalpha, acc[5]);                               // :854
             sdD += live ? c2.x : 0.f;                                                    // :839-840: - dL_dpixD plane_(a, b)
-            any_live = any_live || live;
+            any_live = fmaxf(any_live, a_eff);
             float T_out = lane_value(T_mine, 63), P_out = lane_value(P_front, 63);
             asm volatile("" : "+s"(T_out), "+s"(P_out));
             const bool mine = lane == p;
@@ -963,7 +998,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         acc[9] *= 10.f; acc[10] *= 10.f; acc[11] *= 10.f;
 #pragma unroll
         for (int q = 0; q < 13; q++) xpose[lane * 13 + q] = acc[q];
-        xgid[lane] = any_live ? egid : 0xFFFFFFFFu;
+        xgid[lane] = any_live != 0.f ? egid : 0xFFFFFFFFu;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

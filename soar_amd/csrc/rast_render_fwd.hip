@@ -290,6 +290,22 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                         some_stop = true;
                     }
                     const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
+#ifdef SOAR_EXP_PAD_VALU
+                    {   // timing experiment: extra independent vector instructions (results never used for real)
+                        float pz = w;
+#pragma unroll
+                        for (int k = 0; k < SOAR_EXP_PAD_VALU; k++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(pz) : "v"(dx), "v"(dy));
+                        if (pz == 123456.f) C0 += 1.f;
+                    }
+#endif
+#ifdef SOAR_EXP_PAD_SALU
+                    {
+                        int sz = it;
+#pragma unroll
+                        for (int k = 0; k < SOAR_EXP_PAD_SALU; k++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sz));
+                        if (sz == -12345) C0 += 1.f;
+                    }
+#endif
                     const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
                     D = __builtin_fmaf(depth, w, D);
                     C0 = __builtin_fmaf(q2.y, w, C0);
