@@ -57,9 +57,11 @@ STAGE_KERNELS = {
     "tile_ranges": ["bin_count_kernel", "tile_scan_kernel", "band_count_kernel", "band_place_kernel"],
     "tile_lists": ["bin_tiles_kernel", "(its last workgroup builds the tile order)"],
     "render_forward": ["render_forward_kernel"],
-    "render_backward": ["render_backward_slots_kernel", "zero_ranges_kernel"],
+    "render_backward": ["render_backward_blocks_kernel", "zero_ranges_kernel"],
+    "block_masks": ["block_mask_kernel"],
     "geometry_backward": ["geometry_backward_kernel"],
-    "lbs_knn_weights": ["knn_cell_kernel", "query_cells_ordered_kernel", "item_cost_kernel + item_order_kernel (with every re-sort)"],
+    "lbs_knn_weights": ["knn_refresh_kernel", "knn_cell_kernel + query sort + item order (the full search, every 64th step)"],
+    "optimizer": ["adam_update_kernel", "adam_tick_kernel"],
     "lbs_warp_forward": ["warp_forward_kernel"],
     "lbs_warp_backward": ["warp_backward_kernel"],
     "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel"],
@@ -96,6 +98,9 @@ def algorithmic_bytes(P, R, W, H, R_occ=None):
         "lbs_warp_forward": 276 * P, "lbs_warp_backward": 304 * P,
         "lbs_knn_weights": 232 * P + 232 * 10475,
         "frame_loss": 92 * pix,
+        # (not SURVEY rows) block masks: list ids + tile of every instance read, 24 bytes of its record gathered, 2 bytes of masks
+        # written; Adam: parameter, gradient and both moments read, parameter and moments written, 15 floats per Gaussian
+        "block_masks": 34 * R, "optimizer": 28 * 15 * P,
     }
 
 
@@ -376,12 +381,20 @@ def main():
         try:
             from soar_amd.step_plan import FrameStepPlan
             plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat, use_graphs=(mode == "plan"))
+            from soar_amd.optim import FusedAdam
+            # The reference's optimizer (Adam, eps 1e-15) with its learning rates carried over to this sequence's leaves, which are
+            # the ACTIVATED values (the reference keeps log-scales and logit-colours): 5e-3 on a log-scale is 0.5 % of a ~0.01
+            # scale, 1e-2 on a logit ~2.5e-3 on the colour; positions and rotations as in the reference
+            adam = FusedAdam(flat, lr={"xyz": 1.6e-5, "rot": 1e-3, "scales": 5e-5, "colors": 2.5e-3})
 
             def stepper(frames):
-                # plan.run waits for the xyz bucket of the previous step's all-reduce before the KNN prologue and for the
-                # other bucket before the frames; this step's buckets are issued behind its epilogue (frame_dp.FlatGradBuffer)
+                # a whole training step: gradients of the step's frames (plan.run), their sum over the ranks (two asynchronous
+                # buckets; the stream waits, the host does not), Adam on every leaf.  The positions move every step, so the next
+                # step's KNN blend weights are recomputed from new positions (certified neighbour sets or a seeded search)
                 plan.run(frames)
-                return flat.all_reduce_buckets()
+                flat.all_reduce_buckets()
+                flat.wait_all()
+                adam.step()
         except Exception as e:
             fallback = "graph" if (mode == "plan" and world == 1) else "async"
             print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode {fallback}", file=sys.stderr)
@@ -430,7 +443,7 @@ def main():
         L.soar_prof_reset()
         L.soar_prof_enable(1)
         for s in range(args.steps):
-            plan.run(frames_of(args.warmup + s))
+            stepper(frames_of(args.warmup + s))
         torch.cuda.synchronize()
         L.soar_prof_enable(0)
         for k, v in stats_timed.items():
@@ -517,6 +530,12 @@ def main():
                                     if plan is not None and plan.graphs is None else "one stream per frame"),
                    "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")
                    if use_dist else "none",
+                   "optimizer": ("Adam (eps 1e-15), one launch over all leaves, the reference's learning rates on the activated leaves "
+                                 "(xyz 1.6e-5, rotation 1e-3, scale 5e-5 = 0.5 %, colour 2.5e-3): inside the timed step"
+                                 if plan is not None else "none (gradients only)"),
+                   "knn": (f"neighbour sets kept on the device: {int(plan.knn.searched.item())} of {plan.steps * P} query refreshes "
+                           f"needed the seeded search, the others were certified; full search every {plan.RESORT_EVERY} steps"
+                           if plan is not None else "full grid search per step"),
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,

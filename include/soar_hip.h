@@ -33,7 +33,7 @@ extern "C" {
  * takes SOAR_FRAME_LOSS_SCRATCH_FLOATS floats of scratch, the background colour and the normalize_depth switch; new entry points
  * soar_lbs_warp_forward_batch / soar_lbs_warp_backward_sum, soar_view_finish[_backward], soar_rast_occ_backward;
  * soar_sum_frames_when_last (introduced and withdrawn within round 2) is gone. */
-#define SOAR_HIP_ABI_VERSION 3
+#define SOAR_HIP_ABI_VERSION 4
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
@@ -248,6 +248,23 @@ int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *
                                float *weights_out, int32_t *knn_idx_out,
                                void *query_workspace, size_t query_workspace_bytes, void *stream);
 
+/* ---- neighbour sets that follow the queries (round 3).  The canonical vertices are constants (TS/utils/smpl.py:508-511) and a
+ * query moves by an optimizer step between two calls of query_weights_smpl (:618-637): its K = 30 nearest vertices are almost always
+ * the same.  soar_lbs_knn_query_state = soar_lbs_knn_query_ordered that also stores, per query, its neighbour set (state_buffer:
+ * soar_lbs_knn_state_bytes(P), caller-owned, 256-byte aligned).  soar_lbs_knn_refresh then recomputes the blend weights of moved
+ * queries: a query whose displacement since its set was found stays below half the gap between its K-th and (K+1)-th neighbour
+ * distance keeps its set (certified: the full search would return the same one) and only recomputes the K distances, the weights
+ * and the blend of the skinning rows; any other query is searched exactly, seeded by its old set, and gets a new set and gap.
+ * Either way the weights are those of soar_lbs_knn_query_ordered at the same positions, bit for bit.  `order` (nullable): the
+ * query order of the last sort, for locality only.  searched_counter_dev (nullable): device uint32 that the number of queries that
+ * needed the search is added to.  The state is tied to (grid, P): after densification start again with soar_lbs_knn_query_state. */
+int soar_lbs_knn_state_bytes(int32_t P, size_t *bytes);
+int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P,
+                             uint32_t *order, int32_t resort, float *weights_out, void *state_buffer, void *query_workspace,
+                             size_t query_workspace_bytes, void *stream);
+int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t J, const float *xyz, int32_t P, const uint32_t *order,
+                         void *state_buffer, float *weights_out, uint32_t *searched_counter_dev, void *stream);
+
 /* soar_lbs_warp_forward: blend + apply, i.e. SMPL_Guidance.__call__ line TS/utils/smpl.py:613
  *   (pt_mats = einsum("bnj,bjxy->bnxy", w, cano2live)) fused with DiffGaussian.forward's warp
  *   (TS/renderer/diff_gaussian_rasterizer.py:103-114 / :138-149):
@@ -430,6 +447,22 @@ int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_dev, float 
 int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
                             const int32_t *frame_ids_dev, const float *table_dev, float *mats_out_dev,
                             int32_t *set_index_out_dev, void *stream);
+
+/* ---- the optimizer step (round 3).  torch.optim.Adam(eps=1e-15) over the parameter groups of the Gaussian model
+ * (TS/geometry/surfel_base.py:596-681 training_setup, TS/system/gaussian_surfel_mvdream.py:471-472 optimizer.step()) as ONE launch
+ * over a table of up to 8 rows, a row = one leaf {parameter, gradient, first moment, second moment, number of floats, learning
+ * rate}.  No weight decay, no amsgrad.  state_dev: 16 bytes of zero-initialised device memory owned by the caller = {int32 step,
+ * float 1 - beta1^step, float sqrt(1 - beta2^step), pad}; every call advances the step on the device (graph-capturable). */
+typedef struct SoarAdamRow {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t count;
+    float lr;
+    int32_t pad_;
+} SoarAdamRow;
+int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev, void *stream);
 
 /* soar_prof_timestamp: one-thread kernel that appends {tag, device wall clock (100 MHz ticks)} to a ring in device memory when
  * `stream` gets there: ring[0] counts the stamps, stamp n lies at ring[1 + 2 (n mod capacity)].  Timelines of launch chains

@@ -93,7 +93,7 @@ long long g_stage_n[ST_COUNT];
 // Gaussians (bucket_count / _scatter / _sort; the rocPRIM key sort in the descending path)
 const char *g_stage_names[ST_COUNT] = {"preprocess", "scan", "tile_lists", "depth_order", "tile_ranges", "render_forward",
                                        "render_backward", "geometry_backward", "lbs_knn_weights", "lbs_warp_forward",
-                                       "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops", "block_masks"};
+                                       "lbs_warp_backward", "dist2_knn3", "frame_loss", "postops", "block_masks", "optimizer"};
 void prof_drain()
 {
     for (int i = 0; i < g_slot_used; i++) {

@@ -282,6 +282,7 @@ constexpr int KNN_RMAX = 3;              // beyond this box radius the search fa
 constexpr int KNN_ROWS = (2 * KNN_RMAX + 1) * (2 * KNN_RMAX + 1);
 
 constexpr int KNN_WAVES = 4;             // wavefronts per workgroup: they split the candidates (pass 1) and the queries (pass 2)
+constexpr int KNN_STATE_STRIDE = 32;     // neighbour state: 32 words per query (K = 30 positions in the vertex grid's order + 2 spare)
 
 // First wavefront of the workgroup: list the contiguous sorted-vertex ranges covered by the box of radius r around
 // (cx,cy,cz) (the cells of one grid row are adjacent keys) as prefix offsets; info[0] = number of candidates,
@@ -476,6 +477,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 const uint32_t *__restrict__ q_keys, const uint32_t *__restrict__ q_ids,
                 const float *__restrict__ rows_padded, int J, float *__restrict__ weights_out,
                 int32_t *__restrict__ knn_idx_out, const uint32_t *__restrict__ item_order,
+                uint32_t *__restrict__ state_nbr, float4 *__restrict__ state_ref,
                 unsigned long long *__restrict__ wave_log = nullptr)
 {
     constexpr int K = KNN_K;
@@ -635,9 +637,12 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 if (lane < cnt) lw[lane] = 1.0f / fminf(fmaxf(sqrtf(lw[lane]), 0.0001f), 1.0f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // blend: lanes = joints
-                float accj = 0.f, norm = 0.f;
+                // blend: lanes = joints.  ONE chain of fused multiply-adds over the neighbours in vertex-grid order, whatever the
+                // number of candidate chunks the box needed: the result is a function of the query and its neighbour set alone
+                // (soar_lbs_knn_refresh below reproduces it from a stored set, bit for bit)
                 const int jl = min(lane, KNN_JMAX - 1);
+                float accj = (base == 0 || lane >= J) ? 0.f : weights_out[(size_t)pl * J + lane];
+                float norm = base == 0 ? 0.f : __shfl(norm_lane, l);
 #pragma unroll 15
                 for (int k = 0; k < cnt; k++) {
                     const float wk = lw[k];
@@ -646,11 +651,16 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 }
                 if (WITH_IDX && lane < cnt && taken0 + lane < K)
                     knn_idx_out[(size_t)pl * K + taken0 + lane] = (int)__float_as_uint(sorted_verts[lpos[lane]].w);
-                if (lane == l) { norm_lane += norm; cnt_lane += cnt; need_left = uneed; }
+                if (state_nbr) {
+                    // neighbour state for soar_lbs_knn_refresh: the set (positions in the vertex grid's order, ascending), the
+                    // position it was found at, and a margin of 0 -- the first refresh measures the gap to the 31st neighbour
+                    if (lane < cnt && taken0 + lane < K) state_nbr[(size_t)pl * KNN_STATE_STRIDE + taken0 + lane] = lpos[lane];
+                    if (lane == 0) state_ref[pl] = make_float4(ux, uy, uz, 0.f);
+                }
+                if (lane == l) { norm_lane = norm; cnt_lane += cnt; need_left = uneed; }
                 if (lane < J) {
                     float *out = weights_out + (size_t)pl * J + lane;
-                    if (single) *out = accj / norm;
-                    else *out = (base == 0) ? accj : *out + accj;
+                    *out = single ? accj / norm : accj;
                 }
             }
         }
@@ -669,6 +679,191 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
         unsigned long long *w = wave_log + ((size_t)blockIdx.x * KNN_WAVES + wave) * 8;
         w[0] = t_start; w[1] = wall_clock64(); w[2] = n_pairs; w[3] = n_cand; w[4] = n_blend;
     }
+}
+
+
+// ---- neighbour sets that follow the queries ------------------------------------------------------------------------------------
+// The canonical vertices never move (TS/utils/smpl.py:508-511) and a query moves by an optimizer step: the K nearest vertices of
+// almost every query are those of the step before.  The state of a query = its K neighbours (positions in the vertex grid's order),
+// the position x_ref they were found at and h = half the gap between its K-th and (K+1)-th distance there, minus rounding slack.
+// For every vertex |d(x, v) - d(x_ref, v)| <= |x - x_ref|, so while |x - x_ref| < h the K stored vertices are still strictly closer
+// than every other one: the set the full search would return, certified without searching.  Then only the K distances, the
+// inverse-distance weights and the blend of the K skinning rows are recomputed -- the same expressions in the same (vertex-grid)
+// order as knn_cell_kernel's, so the weights are the full search's bit for bit.
+// A query that fails the certificate is searched exactly, seeded by its old set: every new neighbour lies within the largest
+// new distance to an old one (there are K vertices that close), so only the grid cells that ball touches are scanned (lanes =
+// candidates, ~10 rows of a few vertices); the candidates inside the ball are ranked by (distance, grid position) -- the full
+// search's tie rule -- the best K become the new set, the next one (or the ball's radius) the new gap.
+constexpr int RF_CAP = 192;              // candidates the seeded search holds between two selections (K + a chunk of 64 always fit)
+
+__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+knn_refresh_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restrict__ meta, const uint2 *__restrict__ cell_range,
+                   const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded, int J,
+                   const uint32_t *__restrict__ order, uint32_t *__restrict__ state_nbr, float4 *__restrict__ state_ref,
+                   float *__restrict__ weights_out, uint32_t *__restrict__ counters)
+{
+    constexpr int K = KNN_K;
+    __shared__ uint32_t c_pos[KNN_WAVES][RF_CAP];
+    __shared__ float c_d[KNN_WAVES][RF_CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *cp = c_pos[wave];
+    float *cd = c_d[wave];
+    const GridMeta m = *meta;
+    uint32_t n_searched = 0;
+    const int jl = min(lane, KNN_JMAX - 1);
+    for (int q = (int)blockIdx.x * KNN_WAVES + wave; q < P; q += (int)gridDim.x * KNN_WAVES) {
+        const int p = order ? (int)order[q] : q;
+        const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
+        const float4 ref = state_ref[p];
+        uint32_t pos = lane < K ? state_nbr[(size_t)p * KNN_STATE_STRIDE + lane] : 0u;
+        float d2 = lane < K ? dist2_exact(x, y, z, sorted_verts[pos]) : 0.f;
+        const float mx = x - ref.x, my = y - ref.y, mz = z - ref.z;
+        const float moved = sqrtf((mx * mx + my * my) + mz * mz) * 1.0001f + 1.0e-12f;
+        if (!(ref.w > 0.f && moved < ref.w)) {                       // wave-uniform
+            n_searched++;
+            // ---- exact search seeded by the old set: everything within the largest new distance to an old neighbour
+            float tau_ub = d2;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tau_ub = fmaxf(tau_ub, __shfl_xor(tau_ub, off));
+            // ... and a fifteenth further: what the search proves about the vertices it does NOT return is "at least the ball's
+            // radius away" -- with the bare radius the new gap would always be measured as zero.  (On a surface the K-th and
+            // (K+1)-th distances differ by ~1/60 of the K-th on average.)
+            const float ball = sqrtf(tau_ub) * (1.0f + 1.0f / 15.0f);
+            const float ball2 = ball * ball;
+            const float rho = ball * 1.0001f + 1.0e-7f;
+            const int cx0 = cell_coord(x - rho, m.minx, m.inv_h, m.nx), cx1 = cell_coord(x + rho, m.minx, m.inv_h, m.nx);
+            const int cy0 = cell_coord(y - rho, m.miny, m.inv_h, m.ny), cy1 = cell_coord(y + rho, m.miny, m.inv_h, m.ny);
+            const int cz0 = cell_coord(z - rho, m.minz, m.inv_h, m.nz), cz1 = cell_coord(z + rho, m.minz, m.inv_h, m.nz);
+            const int ny_b = cy1 - cy0 + 1, n_rows = ny_b * (cz1 - cz0 + 1);
+            int n_in = 0;                                             // candidates held in (cp, cd), ascending grid position
+            float next_d2 = 3.0e38f;                                  // smallest distance of a candidate that was dropped
+            // keep the K best of the n_in held candidates (ties in list = grid order), remember the best one dropped
+            auto select_k = [&]() {
+                uint32_t e_pos[RF_CAP / WAVE];
+                float e_d[RF_CAP / WAVE];
+                int rank[RF_CAP / WAVE];
+#pragma unroll
+                for (int u = 0; u < RF_CAP / WAVE; u++) {
+                    const int i = u * WAVE + lane;
+                    e_pos[u] = i < n_in ? cp[i] : 0u;
+                    e_d[u] = i < n_in ? cd[i] : 3.0e38f;
+                    rank[u] = 0;
+                }
+                for (int j = 0; j < n_in; j++) {
+                    const float dj = cd[j];                           // (wave-uniform address)
+#pragma unroll
+                    for (int u = 0; u < RF_CAP / WAVE; u++)
+                        rank[u] += (dj < e_d[u] || (dj == e_d[u] && j < u * WAVE + lane)) ? 1 : 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int kept = 0;
+#pragma unroll
+                for (int u = 0; u < RF_CAP / WAVE; u++) {
+                    const bool have = u * WAVE + lane < n_in;
+                    const bool keep = have && rank[u] < K;
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int at = kept + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                        cp[at] = e_pos[u];
+                        cd[at] = e_d[u];
+                    }
+                    kept += (int)__builtin_popcountll(km);
+                    float dropped = (have && !keep) ? e_d[u] : 3.0e38f;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) dropped = fminf(dropped, __shfl_xor(dropped, off));
+                    next_d2 = fminf(next_d2, dropped);
+                }
+                n_in = kept;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
+            float tau_cur = ball2;                                    // candidates above it are not collected
+            for (int r0 = 0; r0 < n_rows; r0 += WAVE) {
+                // lane = one (gz, gy) row of the box: the cells of a grid row are adjacent keys = one range of grid positions
+                uint32_t rs = 0u, re = 0u;
+                if (r0 + lane < n_rows) {
+                    const int gz = cz0 + (r0 + lane) / ny_b, gy = cy0 + (r0 + lane) % ny_b;
+                    const int base = (gz * GRID_MAX + gy) * GRID_MAX;
+                    bool any = false;
+                    for (int gx = cx0; gx <= cx1; gx++) {
+                        const uint2 rg = cell_range[base + gx];
+                        if (rg.y > rg.x) {
+                            if (!any) rs = rg.x;
+                            re = rg.y;
+                            any = true;
+                        }
+                    }
+                }
+                const int rows_here = min(WAVE, n_rows - r0);
+                for (int r = 0; r < rows_here; r++) {
+                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, r), e0 = (uint32_t)__builtin_amdgcn_readlane((int)re, r);
+                    for (uint32_t t0 = s0; t0 < e0; t0 += WAVE) {
+                        const uint32_t t = t0 + (uint32_t)lane;
+                        const float d = t < e0 ? dist2_exact(x, y, z, sorted_verts[t]) : 3.0e38f;
+                        const bool in = d <= tau_cur;
+                        // outside the ball but inside the box: a lower bound of the (K+1)-th distance all the same
+                        float out_d = (t < e0 && !in) ? d : 3.0e38f;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) out_d = fminf(out_d, __shfl_xor(out_d, off));
+                        next_d2 = fminf(next_d2, out_d);
+                        const unsigned long long im = __ballot(in);
+                        if (im == 0ull) continue;
+                        if (n_in + (int)__builtin_popcountll(im) > RF_CAP) {
+                            select_k();                               // K stay (K + 64 <= RF_CAP): nothing above their largest
+                            float worst = lane < K ? cd[lane] : 0.f;  // distance can be among the K best any more
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+                            tau_cur = worst;
+                        }
+                        const bool in2 = d <= tau_cur;
+                        const unsigned long long im2 = __ballot(in2);
+                        if (in2) {
+                            const int at = n_in + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im2, 0u));
+                            cp[at] = t;
+                            cd[at] = d;
+                        }
+                        float out2 = (in && !in2) ? d : 3.0e38f;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) out2 = fminf(out2, __shfl_xor(out2, off));
+                        next_d2 = fminf(next_d2, out2);
+                        n_in += (int)__builtin_popcountll(im2);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            select_k();                                               // n_in == K now (at least K vertices lie inside the ball)
+            pos = lane < K ? cp[lane] : 0u;
+            d2 = lane < K ? cd[lane] : 0.f;
+            float kth = d2;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) kth = fmaxf(kth, __shfl_xor(kth, off));
+            // every vertex that is not in the set is at least this far: the best dropped candidate, or the ball's radius
+            const float next_d = sqrtf(fminf(next_d2, ball2));
+            const float half_gap = 0.5f * (next_d - sqrtf(kth)) - 4.0e-6f * next_d - 1.0e-12f;
+            if (lane < K) state_nbr[(size_t)p * KNN_STATE_STRIDE + lane] = pos;
+            if (lane == 0) state_ref[p] = make_float4(x, y, z, half_gap);
+        }
+        // ---- weights from the set: ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634), rows blended in grid order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < K) {
+            cp[lane] = pos;
+            cd[lane] = 1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float accj = 0.f, norm = 0.f;
+#pragma unroll 15
+        for (int k = 0; k < K; k++) {
+            const float wk = cd[k];
+            accj = __builtin_fmaf(wk, rows_padded[(size_t)cp[k] * KNN_JMAX + jl], accj);
+            norm += wk;
+        }
+        if (lane < J) weights_out[(size_t)p * J + lane] = accj / norm;
+    }
+    if (counters && lane == 0 && n_searched) atomicAdd(counters, n_searched);
 }
 
 }  // namespace
@@ -760,11 +955,27 @@ int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
     return 0;
 }
 
+// neighbour state of soar_lbs_knn_refresh: [P][KNN_STATE_STRIDE] grid positions, then [P] {x_ref, y_ref, z_ref, half gap}
+struct KnnState { uint32_t *nbr; float4 *ref; size_t total; };
+int carve_knn_state(void *base, int32_t P, KnnState *out)
+{
+    char *b = static_cast<char *>(base);
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t o_ref = align_up(sizeof(uint32_t) * KNN_STATE_STRIDE * n);
+    out->nbr = reinterpret_cast<uint32_t *>(b);
+    out->ref = reinterpret_cast<float4 *>(b + o_ref);
+    out->total = o_ref + align_up(sizeof(float4) * n);
+    return 0;
+}
+
 int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P, int32_t K,
               float *weights_out, int32_t *knn_idx_out, uint32_t *order, int resort, void *query_ws, size_t query_ws_bytes,
-              hipStream_t stream)
+              hipStream_t stream, const KnnState *state = nullptr)
 {
     const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
+    uint32_t *st_nbr = state ? state->nbr : nullptr;
+    float4 *st_ref = state ? state->ref : nullptr;
+    if (!fast && state) { set_error("soar_lbs_knn: the neighbour state needs K = %d and J <= %d", KNN_K, KNN_JMAX); return 1; }
     if (!fast) {
         hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P, V,
                            g.meta, g.cell_range, g.sorted_verts, vert_weights, J, K, weights_out, knn_idx_out);
@@ -804,7 +1015,7 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
         SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
         hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, log_dev);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref, log_dev);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
@@ -816,10 +1027,10 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
     }
     if (knn_idx_out)
         hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref);
     else
         hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref);
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
     return 0;
 }
@@ -899,6 +1110,54 @@ extern "C" int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, co
     StageTimer timer(ST_LBS_KNN, stream);
     return knn_query(g, V, vert_weights, J, xyz, P, K, weights_out, knn_idx_out, order, resort, query_workspace,
                      query_workspace_bytes, stream);
+}
+
+extern "C" int soar_lbs_knn_state_bytes(int32_t P, size_t *bytes)
+{
+    if (P < 0 || !bytes) { set_error("soar_lbs_knn_state_bytes: bad arguments"); return 1; }
+    KnnState st;
+    carve_knn_state(nullptr, P, &st);
+    *bytes = st.total;
+    return 0;
+}
+
+extern "C" int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz,
+                                        int32_t P, uint32_t *order, int32_t resort, float *weights_out, void *state_buffer,
+                                        void *query_workspace, size_t query_workspace_bytes, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_knn_sizes(P, V, J, KNN_K)) return 1;
+    if (P == 0) return 0;
+    if (!grid_buffer || !xyz || !vert_weights || !weights_out || !order || !state_buffer) { set_error("soar_lbs_knn_query_state: NULL pointer"); return 1; }
+    if (check_ws("soar_lbs_knn_query_state", query_workspace, query_workspace_bytes) || check_ws("soar_lbs_knn_query_state", state_buffer, 0)) return 1;
+    KnnGrid g;
+    if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
+    KnnState st;
+    carve_knn_state(state_buffer, P, &st);
+    StageTimer timer(ST_LBS_KNN, stream);
+    return knn_query(g, V, vert_weights, J, xyz, P, KNN_K, weights_out, nullptr, order, resort, query_workspace, query_workspace_bytes,
+                     stream, &st);
+}
+
+extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t J, const float *xyz, int32_t P, const uint32_t *order,
+                                    void *state_buffer, float *weights_out, uint32_t *searched_counter_dev, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_knn_sizes(P, V, J, KNN_K)) return 1;
+    if (J > KNN_JMAX) { set_error("soar_lbs_knn_refresh: J <= %d", KNN_JMAX); return 1; }
+    if (P == 0) return 0;
+    if (!grid_buffer || !xyz || !weights_out || !state_buffer) { set_error("soar_lbs_knn_refresh: NULL pointer"); return 1; }
+    if (check_ws("soar_lbs_knn_refresh", state_buffer, 0)) return 1;
+    KnnGrid g;
+    if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
+    KnnState st;
+    carve_knn_state(state_buffer, P, &st);
+    StageTimer timer(ST_LBS_KNN, stream);
+    const int nblocks = min((P + KNN_WAVES - 1) / KNN_WAVES, 8192);
+    hipLaunchKernelGGL(knn_refresh_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.meta, g.cell_range,
+                       g.sorted_verts, g.rows, J, order, st.nbr, st.ref, weights_out, searched_counter_dev);
+    SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
+    return 0;
 }
 
 extern "C" int soar_lbs_knn_weights_bytes(int32_t P, int32_t V, size_t *bytes)

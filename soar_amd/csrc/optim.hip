@@ -1,0 +1,100 @@
+// optim.hip -- the optimizer step of the per-frame training path: Adam on the per-Gaussian leaves, one launch for all of them.
+//
+// The reference ends every training step with torch.optim.Adam(eps=1e-15).step() over the parameter groups of the Gaussian model
+// (TS/geometry/surfel_base.py:596-681 training_setup: one group per leaf with its own learning rate;
+// TS/system/gaussian_surfel_mvdream.py:471-472 optimizer.step()).  Between two steps the positions move by ~lr: the KNN blend
+// weights of the next step are recomputed from the new positions (lbs_knn.hip).  torch's optimizer costs one multi-tensor
+// launch chain and ~100 us of host time per step; here the update of all leaves is one kernel over a table of rows
+// {parameter, gradient, first / second moment, count, learning rate}, with the step counter and its bias corrections kept on
+// the device so that the launch can sit in a captured graph.
+//
+// Arithmetic = torch.optim.Adam (no weight decay, no amsgrad, maximize = False):
+//   m = m + (g - m) (1 - beta1);  v = beta2 v + (1 - beta2) g g;
+//   p = p - (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+#include "soar_common.h"
+
+#include <cmath>
+
+namespace soar {
+
+namespace {
+
+constexpr int ADAM_MAX_ROWS = 8;
+struct AdamTable {
+    SoarAdamRow row[ADAM_MAX_ROWS];
+    int64_t first_block[ADAM_MAX_ROWS + 1];      // blocks of 1024 elements, row after row
+    int n;
+};
+struct AdamState {           // 16 bytes of device memory owned by the caller
+    int32_t step;
+    float bias_correction1, bias_correction2_sqrt;
+    int32_t pad;
+};
+
+__global__ void adam_tick_kernel(AdamState *st, double beta1, double beta2)
+{
+    const int t = st->step + 1;
+    st->step = t;
+    st->bias_correction1 = (float)(1.0 - pow(beta1, (double)t));
+    st->bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
+
+__global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const AdamState *__restrict__ st, float beta1, float beta2, float eps)
+{
+    int r = 0;
+    while (r + 1 < tab.n && (int64_t)blockIdx.x >= tab.first_block[r + 1]) r++;
+    const SoarAdamRow row = tab.row[r];
+    const int64_t i0 = ((int64_t)blockIdx.x - tab.first_block[r]) * 1024 + threadIdx.x * 4;
+    const float step_size = row.lr / st->bias_correction1, bc2s = st->bias_correction2_sqrt;
+    const float one_minus_b1 = 1.f - beta1, one_minus_b2 = 1.f - beta2;
+    for (int k = 0; k < 4; k++) {
+#pragma clang fp contract(off)
+        const int64_t i = i0 + k;
+        if (i >= row.count) break;
+        const float g = row.grad[i];
+        float m = row.exp_avg[i], v = row.exp_avg_sq[i];
+        m = m + (g - m) * one_minus_b1;
+        v = beta2 * v + one_minus_b2 * g * g;
+        const float denom = sqrtf(v) / bc2s + eps;
+        row.param[i] = row.param[i] - step_size * (m / denom);
+        row.exp_avg[i] = m;
+        row.exp_avg_sq[i] = v;
+    }
+}
+
+}  // namespace
+
+}  // namespace soar
+
+using namespace soar;
+
+extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
+                              void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_rows < 0 || n_rows > ADAM_MAX_ROWS || (n_rows && !rows_host) || !state_dev) {
+        set_error("soar_adam_step: 0 <= n_rows <= %d, rows and the 16-byte device state must be given", ADAM_MAX_ROWS);
+        return 1;
+    }
+    AdamTable tab;
+    tab.n = n_rows;
+    int64_t blocks = 0;
+    for (int r = 0; r < n_rows; r++) {
+        const SoarAdamRow &w = rows_host[r];
+        if (w.count < 0 || (w.count && (!w.param || !w.grad || !w.exp_avg || !w.exp_avg_sq))) {
+            set_error("soar_adam_step: row %d has a NULL pointer or a negative count", r);
+            return 1;
+        }
+        tab.row[r] = w;
+        tab.first_block[r] = blocks;
+        blocks += (w.count + 1023) / 1024;
+    }
+    for (int r = n_rows; r <= ADAM_MAX_ROWS; r++) tab.first_block[r] = blocks;
+    AdamState *st = static_cast<AdamState *>(state_dev);
+    StageTimer timer(ST_OPTIMIZER, stream);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, (double)beta1, (double)beta2);
+    if (blocks > 0)
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, beta1, beta2, eps);
+    SOAR_LAUNCH_OK("adam_step", stream, 0);
+    return 0;
+}

@@ -986,6 +986,22 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             acc[5] = __builtin_fmaf(G, dL_dalpha, acc[5]);                               // :854
             sdD += live ? c2.x : 0.f;                                                    // :839-840: - dL_dpixD plane_(a, b)
             any_live = fmaxf(any_live, a_eff);
+#ifdef SOAR_EXP_PAD_VALU
+            {   // timing experiment: extra vector instructions (results never used for real)
+                float pz = wgt;
+#pragma unroll
+                for (int k = 0; k < SOAR_EXP_PAD_VALU; k++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(pz) : "v"(dx), "v"(dy));
+                if (pz == 123456.f) sdD += 1.f;
+            }
+#endif
+#ifdef SOAR_EXP_PAD_SALU
+            {
+                int sz = p;
+#pragma unroll
+                for (int k = 0; k < SOAR_EXP_PAD_SALU; k++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sz));
+                if (sz == -12345) sdD += 1.f;
+            }
+#endif
             float T_out = lane_value(T_mine, 63), P_out = lane_value(P_front, 63);
             asm volatile("" : "+s"(T_out), "+s"(P_out));
             const bool mine = lane == p;

@@ -81,7 +81,7 @@ BatchCtx &batch_ctx();
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg) ----
 enum Stage {
     ST_PREPROCESS = 0, ST_SCAN, ST_EMIT_KEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_GEOM_BWD,
-    ST_LBS_KNN, ST_LBS_WARP_FWD, ST_LBS_WARP_BWD, ST_DIST2, ST_FRAME_LOSS, ST_POSTOPS, ST_BLOCK_MASKS, ST_COUNT
+    ST_LBS_KNN, ST_LBS_WARP_FWD, ST_LBS_WARP_BWD, ST_DIST2, ST_FRAME_LOSS, ST_POSTOPS, ST_BLOCK_MASKS, ST_OPTIMIZER, ST_COUNT
 };
 struct StageTimer {   // records start/stop events around a stage when profiling is enabled
     StageTimer(int stage, hipStream_t stream);

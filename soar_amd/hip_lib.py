@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libsoar_hip.so")
 
 FRAME_LOSS_SCRATCH_FLOATS = 4 * 2048   # SOAR_FRAME_LOSS_SCRATCH_FLOATS: the scratch argument of soar_frame_loss[_pooled]
-ABI_VERSION = 3          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
+ABI_VERSION = 4          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 
@@ -33,6 +33,12 @@ class SoarRastParams(C.Structure):
 class SoarDensifyRow(C.Structure):
     """Mirror of ``struct SoarDensifyRow`` (include/soar_hip.h)."""
     _fields_ = [("src", _vp), ("dst", _vp), ("width", C.c_int32), ("mode", C.c_int32)]
+
+
+class SoarAdamRow(C.Structure):
+    """Mirror of ``struct SoarAdamRow`` (include/soar_hip.h)."""
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("count", C.c_int64), ("lr", C.c_float),
+                ("pad_", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/soar_hip.h declares
@@ -67,6 +73,9 @@ SIGNATURES = {
     "soar_lbs_knn_query": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "soar_lbs_knn_query_ordered": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp,
                                              _vp, C.c_size_t, _vp]),
+    "soar_lbs_knn_state_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "soar_lbs_knn_query_state": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "soar_lbs_knn_refresh": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_lbs_warp_forward": (C.c_int, [_vp] * 6 + [C.c_int32, C.c_int32] + [_vp] * 4),
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_lbs_warp_forward_batch": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 3),
@@ -109,6 +118,7 @@ SIGNATURES = {
     "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
+    "soar_adam_step": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

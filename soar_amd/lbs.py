@@ -94,6 +94,58 @@ class KnnGrid:
         return (out, idx) if return_idx else out
 
 
+class KnnFollower:
+    """Blend weights of queries that move a little between calls (the optimizer's steps on the canonical positions):
+    ``soar_lbs_knn_query_state`` once, then ``soar_lbs_knn_refresh`` -- a query keeps its neighbour set while its displacement
+    stays below half the gap to its 31st neighbour (certified on the device) and is searched again, seeded by the old set,
+    otherwise.  The weights are those of ``KnnGrid.query`` at the same positions, bit for bit (TS/utils/smpl.py:618-637).
+    Tied to the number of queries: build a new follower after densification."""
+
+    RESORT_EVERY = 64     # refreshes between two sorts of the query order (locality of the skinning-row reads only)
+
+    def __init__(self, grid: "KnnGrid", P: int):
+        import ctypes as C
+        self.grid, self.P = grid, int(P)
+        dev = grid.verts.device
+        n = C.c_size_t(0)
+        check(hip_lib.lib().soar_lbs_knn_state_bytes(self.P, C.byref(n)), "soar_lbs_knn_state_bytes")
+        self.state = torch.empty(int(n.value), dtype=torch.uint8, device=dev)
+        self.order = torch.empty((self.P,), dtype=torch.int32, device=dev)
+        self.ws = grid.query_workspace(self.P)
+        self.searched = torch.zeros((1,), dtype=torch.int32, device=dev)       # queries that needed the seeded search, summed
+        self.calls = 0
+
+    def full(self, xyz: torch.Tensor, out: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        """The full search (stores the neighbour sets and a fresh query order)."""
+        g = self.grid
+        stream = _stream(xyz.device) if stream is None else stream
+        check(hip_lib.lib().soar_lbs_knn_query_state(ptr(g.buffer), g.V, ptr(g.weights), g.J, ptr(xyz), self.P, ptr(self.order), 1,
+                                                     ptr(out), ptr(self.state), ptr(self.ws), self.ws.numel(), stream),
+              "soar_lbs_knn_query_state")
+        self.calls = 1
+        return out
+
+    def refresh(self, xyz: torch.Tensor, out: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        g = self.grid
+        stream = _stream(xyz.device) if stream is None else stream
+        if self.calls == 0 or self.calls % self.RESORT_EVERY == 0:
+            return self.full(xyz, out, stream)
+        check(hip_lib.lib().soar_lbs_knn_refresh(ptr(g.buffer), g.V, g.J, ptr(xyz), self.P, ptr(self.order), ptr(self.state), ptr(out),
+                                                 ptr(self.searched), stream), "soar_lbs_knn_refresh")
+        self.calls += 1
+        return out
+
+    def __call__(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _need_hip(xyz, "xyz")
+        x = _f32(xyz)
+        if int(x.shape[0]) != self.P:
+            raise ValueError(f"KnnFollower was built for {self.P} queries, got {int(x.shape[0])}")
+        if out is None:
+            out = torch.empty((self.P, self.grid.J), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            return self.refresh(x, out)
+
+
 def knn_blend_weights(xyz: torch.Tensor, verts: torch.Tensor, vert_weights: torch.Tensor, K: int = KNN_K,
                       return_idx: bool = False):
     """xyz [P,3], verts [V,3], vert_weights [V,J] -> weights [P,J] (detached), optionally the K-NN indices [P,K]."""

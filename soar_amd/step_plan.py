@@ -105,8 +105,15 @@ class FrameStepPlan:
         self.g_scales = torch.empty((self.n, P, 3), **f)
         self.g_colors = torch.empty((self.n, P, 3), **f)
         self.losses = torch.empty((self.n,), **f)
-        self.knn_order = torch.empty((P,), dtype=torch.int32, device=dev)     # query order of the KNN, refreshed every few steps
-        self.knn_ws = seq.knn_grid.query_workspace(P)        # query scratch owned by THIS plan (its graphs hold the pointer)
+        # blend weights of positions that move by an optimizer step: neighbour sets kept on the device, certified or searched again
+        # (lbs.KnnFollower; its buffers are owned by THIS plan: its graphs hold the pointers)
+        from . import lbs as _lbs
+        self.knn = _lbs.KnnFollower(seq.knn_grid, P)
+        # the slices of the flat gradient buffer this plan never writes (opacity: the plugin renders with ones; occ: no occlusion
+        # loss here) must not carry anything from an earlier autograd step into the reductions / the optimizer
+        for name in ("opacity", "occ"):
+            if name in flat.views:
+                flat.views[name].zero_()
         self.steps = 0
         # SOAR_PLAN_TIMESTAMPS=1 (diagnostic): {tag, device wall clock} stamps at the start / end of the prologue (tags 0, 1), of
         # frame chain i (2 + 2 i, 3 + 2 i) and of the epilogue (2 n + 2, 2 n + 3), appended to a ring on every replay
@@ -158,7 +165,7 @@ class FrameStepPlan:
                                "pointers)")
 
     # ---- the three pieces -------------------------------------------------------------------------------------------
-    RESORT_EVERY = 8      # steps between two sorts of the KNN query order (lbs.KnnGrid.RESORT_EVERY)
+    RESORT_EVERY = 64     # steps between two full KNN searches (which also re-sort the query order; lbs.KnnFollower.RESORT_EVERY)
 
     def _stamp(self, k: int, stream: int) -> None:
         if self.stamps is not None:
@@ -177,10 +184,11 @@ class FrameStepPlan:
                                         ptr(self.frame_sel), stream), "gather_step_inputs")
         # (the flat gradient buffer is not zeroed here: the epilogue overwrites every registered slice, and the previous
         # step's second all-reduce bucket may still be reading it)
-        check(L.soar_lbs_knn_query_ordered(ptr(s.knn_grid.buffer), s.knn_grid.V, ptr(s.knn_grid.weights), s.knn_grid.J,
-                                           ptr(s.xyz.detach()), self.P, 30, ptr(self.knn_order), int(resort),
-                                           ptr(self.blend_weights), None, ptr(self.knn_ws), self.knn_ws.numel(), stream),
-              "knn_query")
+        if resort:
+            self.knn.full(s.xyz.detach(), self.blend_weights, stream)
+        else:
+            self.knn.calls = 1                   # (the plan decides when the full search runs, not the follower)
+            self.knn.refresh(s.xyz.detach(), self.blend_weights, stream)
         self._stamp(1, stream)
 
     def _warp_all(self, stream: int) -> None:

@@ -200,6 +200,49 @@ def test_knn_query_order_reuse_is_exact():
         torch.testing.assert_close(w_got[same], w_ref[same], rtol=1e-5, atol=1e-7)
 
 
+def test_knn_follower_is_the_full_search_bit_for_bit_under_motion():
+    """lbs.KnnFollower (neighbour sets kept between optimizer steps, exactness certificate = displacement below half the gap to
+    the 31st neighbour, seeded exact search otherwise) == KnnGrid.query at the same positions, bit for bit, over steps of
+    different sizes: small ones (most queries certified), large ones (all searched again) and none at all."""
+    from soar_amd import lbs
+    bm = syn.make_body_model(0)
+    v, w = bm.v_template.to(DEV), bm.lbs_weights.to(DEV)
+    grid = lbs.KnnGrid(v, w)
+    x = syn.make_surfels(6000, 4).xyz.to(DEV)
+    fol = lbs.KnnFollower(grid, x.shape[0])
+    g = torch.Generator().manual_seed(11)
+    searched_before = 0
+    fractions = []
+    for step, sigma in enumerate([0.0, 1e-5, 1e-5, 1e-5, 3e-3, 1e-5, 1e-5, 0.0, 5e-2, 1e-4, 1e-4]):
+        x = x + sigma * torch.randn(x.shape, generator=g).to(DEV)
+        got = fol(x).clone()
+        want = grid.query(x)
+        assert torch.equal(got, want), (step, sigma, float((got - want).abs().max()))
+        n = int(fol.searched.item())
+        fractions.append((n - searched_before) / x.shape[0])
+        searched_before = n
+    # step 0 is the full search; step 1 measures every gap (all searched); then small steps are mostly certified, large ones not
+    assert fractions[1] == 1.0 and fractions[2] < 0.3 and fractions[3] < 0.4 and fractions[4] > 0.9 and fractions[7] < 0.01, fractions
+
+
+def test_knn_follower_with_ties_and_dense_clusters():
+    """Duplicated vertices (exact distance ties at the K-th place, thousands of candidates in one cell): the follower still equals
+    the full search bit for bit -- ties are never certified and the seeded search applies the full search's tie rule (grid order)."""
+    from soar_amd import lbs
+    g = torch.Generator().manual_seed(31)
+    base = torch.randn(2500, 3, generator=g) * 0.004
+    far = torch.randn(300, 3, generator=g) * torch.tensor([0.3, 0.9, 0.2])
+    verts = torch.cat([base, base.clone(), far]).to(DEV)
+    w = torch.rand(verts.shape[0], 55, generator=g)
+    w = (w / w.sum(1, keepdim=True)).to(DEV)
+    grid = lbs.KnnGrid(verts, w)
+    x = (base[torch.randint(0, 2500, (2000,), generator=g)] + 0.001 * torch.randn(2000, 3, generator=g)).to(DEV)
+    fol = lbs.KnnFollower(grid, x.shape[0])
+    for sigma in (0.0, 1e-5, 1e-5, 2e-4, 1e-2):
+        x = x + sigma * torch.randn(x.shape, generator=g).to(DEV)
+        assert torch.equal(fol(x), grid.query(x)), sigma
+
+
 def test_smplx_joint_chain_kernel_matches_reference_lbs_goldens():
     """soar_smplx_joint_mats (Rodrigues + 55-joint chain + transl + right product, all frames in one launch) == the
     reference's lbs() transforms A (tests/golden/smplx_joint_transforms.npz, generated by the reference's own smplx code)
