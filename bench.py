@@ -233,12 +233,40 @@ def cpu_baseline(workload, parts, n_frames=8, seed=0):
                       f"(oracle/rasterizer_oracle.c, OpenMP {threads} threads); {dt:.1f} s wall"}
 
 
+def visible_gpu_count():
+    """GPUs this job can use, found WITHOUT any torch.cuda / HIP call in this process (the parent of the ranks must never
+    initialise the GPU: its children are fresh processes, but a parent that touched HIP may not exec or fork safely on this
+    stack): GPU nodes of the KFD topology in sysfs (a node with SIMDs is a GPU, CPUs have none), cut down by the visible-devices
+    environment the HIP runtime honours.  Without readable sysfs the count comes from a throw-away child process."""
+    import glob
+    import subprocess
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    count = None
+    if nodes:
+        count = 0
+        for f in nodes:
+            try:
+                props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+                count += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                count = None
+                break
+    if count is None:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+        count = int(r.stdout.strip() or 0) if r.returncode == 0 else 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            count = min(count, len([t for t in v.split(",") if t.strip() != ""]))
+    return count
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without torch.distributed.run: start N ranks of this script (fresh processes, one per GPU,
     rendezvous on 127.0.0.1) from a parent that has not initialised the GPU, print rank 0's JSON line, return the exit code."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()              # counts devices without initialising the HIP runtime
+    have = visible_gpu_count()                    # sysfs / environment only: no HIP call in this process
     if have < n:
         print(f"[bench] --gpus {n} but only {have} GPU(s) visible: not running (a line with n_gpus != --gpus would be wrong)",
               file=sys.stderr)
@@ -528,6 +556,8 @@ def main():
                                f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}", "mode": mode,
                    "frame_chains": (("one stream, every stage launched once for all frames" if plan.batched else "one stream per frame")
                                     if plan is not None and plan.graphs is None else "one stream per frame"),
+                   "plan_form": (("batched" if plan.batched else "streams") + (", graphs" if plan.graphs is not None else ", eager")
+                                 if plan is not None else None),
                    "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")
                    if use_dist else "none",
                    "optimizer": ("Adam (eps 1e-15), one launch over all leaves, the reference's learning rates on the activated leaves "

@@ -123,6 +123,12 @@ int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_
 int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
                              void *stream);
 
+/* `prefiltered` (GaussianRasterizationSettings.prefiltered): the caller promises that no Gaussian is culled.  The reference prints
+ * "Point is filtered although prefiltered is set. This shouldn't happen!" from the kernel and traps (auxiliary.h:163-167, 195-199),
+ * which takes the context down; here the culled Gaussians are counted on the device.  In debug mode (SoarRastParams.debug bit 0)
+ * soar_rast_forward_geometry reads the count and fails with that message; otherwise this call reads it (one stream sync). */
+int soar_rast_prefilter_violations(const void *geom_buffer, int32_t P, int32_t M, int64_t *violations_host, void *stream);
+
 /* stage 2: duplicateWithKeys (:66-99) + radix sort on bits [0,32+bit) (:266-285) + identifyTileRanges
  *   (:104-124,287-295) + per-tile blend (forward.cu:390-692).
  *   out_color [3,H,W], out_normal [3,H,W], out_depth [1,H,W], out_opac [1,H,W]. */
@@ -254,9 +260,11 @@ int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *
  * soar_lbs_knn_state_bytes(P), caller-owned, 256-byte aligned).  soar_lbs_knn_refresh then recomputes the blend weights of moved
  * queries: a query whose displacement since its set was found stays below half the gap between its K-th and (K+1)-th neighbour
  * distance keeps its set (certified: the full search would return the same one) and only recomputes the K distances, the weights
- * and the blend of the skinning rows; any other query is searched exactly, seeded by its old set, and gets a new set and gap.
- * Either way the weights are those of soar_lbs_knn_query_ordered at the same positions, bit for bit.  `order` (nullable): the
- * query order of the last sort, for locality only.  searched_counter_dev (nullable): device uint32 that the number of queries that
+ * and the blend of the skinning rows; the state holds the 32 nearest vertices and a second gap behind the 32nd, so that a query
+ * whose first gap is smaller than a step re-ranks its 32 instead of searching; a query that fails both certificates is searched
+ * exactly, seeded by its old set, and gets a new set and new gaps.
+ * Either way the weights are those of soar_lbs_knn_query_ordered at the same positions, bit for bit.  `order`: the
+ * query order soar_lbs_knn_query_state stored -- the state is kept in that order.  searched_counter_dev (nullable): device uint32 that the number of queries that
  * needed the search is added to.  The state is tied to (grid, P): after densification start again with soar_lbs_knn_query_state. */
 int soar_lbs_knn_state_bytes(int32_t P, size_t *bytes);
 int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P,

@@ -358,6 +358,18 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     }
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
+    if (prm->prefiltered && (prm->debug & 1)) {
+        // debug mode is synchronous (CHECK_CUDA semantics): report what the reference's kernel would have trapped on
+        // (auxiliary.h:163-167, 195-199)
+        uint32_t bad = 0;
+        SOAR_HIP_OK(hipMemcpyAsync(&bad, g.header + H_PREFILTER_VIOLATIONS, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SOAR_HIP_OK(hipStreamSynchronize(stream));
+        if (bad) {
+            set_error("Point is filtered although prefiltered is set. This shouldn't happen! (%u Gaussians culled by the frustum / "
+                      "back-face tests)", bad);
+            return 1;
+        }
+    }
     if (!prm->sort_descending && launch_depth_buckets(*prm, g, stream)) return 1;
     // asynchronous form: R (and the prefix sum of tiles_touched it comes from) is produced by soar_rast_num_rendered() if
     // the caller asks for it; the sync-free form never needs it
@@ -410,6 +422,22 @@ int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int6
     SOAR_HIP_OK(hipStreamSynchronize(stream));
     *instances_host = (int64_t)w[0];
     *overflow_host = (int64_t)w[1];
+    return 0;
+}
+
+int soar_rast_prefilter_violations(const void *geom_buffer, int32_t P, int32_t M, int64_t *violations_host, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!violations_host || P < 0) { set_error("soar_rast_prefilter_violations: bad arguments"); return 1; }
+    *violations_host = 0;
+    if (P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    GeomBuf g;
+    carve_geom(const_cast<void *>(geom_buffer), P, M, &g);
+    uint32_t bad = 0;
+    SOAR_HIP_OK(hipMemcpyAsync(&bad, g.header + H_PREFILTER_VIOLATIONS, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SOAR_HIP_OK(hipStreamSynchronize(stream));
+    *violations_host = (int64_t)bad;
     return 0;
 }
 

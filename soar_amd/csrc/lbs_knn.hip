@@ -282,7 +282,14 @@ constexpr int KNN_RMAX = 3;              // beyond this box radius the search fa
 constexpr int KNN_ROWS = (2 * KNN_RMAX + 1) * (2 * KNN_RMAX + 1);
 
 constexpr int KNN_WAVES = 4;             // wavefronts per workgroup: they split the candidates (pass 1) and the queries (pass 2)
-constexpr int KNN_STATE_STRIDE = 32;     // neighbour state: 32 words per query (K = 30 positions in the vertex grid's order + 2 spare)
+constexpr int KNN_STATE_STRIDE = 32;     // neighbour state: the 32 nearest vertices of a query (positions in the vertex grid's order)
+// per-query state of soar_lbs_knn_refresh (layout: carve_knn_state)
+struct KnnStatePtrs {        // (every array in the queries' sorted order: entry q belongs to query order[q])
+    uint32_t *nbr;           // [P][32] the 32 nearest vertices, ascending grid position
+    float4 *ref30, *ref32;   // [P] {position the 30-subset / the 32-set was determined at, half the gap behind it (0: unknown)}
+    uint32_t *in30;          // [P] which of the 32 are the K = 30 nearest
+    uint32_t *work;          // [2 + 2 P] {entries, wavefronts done, {query, bits of its search radius squared} ...}
+};
 
 // First wavefront of the workgroup: list the contiguous sorted-vertex ranges covered by the box of radius r around
 // (cx,cy,cz) (the cells of one grid row are adjacent keys) as prefix offsets; info[0] = number of candidates,
@@ -477,7 +484,7 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 const uint32_t *__restrict__ q_keys, const uint32_t *__restrict__ q_ids,
                 const float *__restrict__ rows_padded, int J, float *__restrict__ weights_out,
                 int32_t *__restrict__ knn_idx_out, const uint32_t *__restrict__ item_order,
-                uint32_t *__restrict__ state_nbr, float4 *__restrict__ state_ref,
+                KnnStatePtrs state,
                 unsigned long long *__restrict__ wave_log = nullptr)
 {
     constexpr int K = KNN_K;
@@ -651,11 +658,18 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
                 }
                 if (WITH_IDX && lane < cnt && taken0 + lane < K)
                     knn_idx_out[(size_t)pl * K + taken0 + lane] = (int)__float_as_uint(sorted_verts[lpos[lane]].w);
-                if (state_nbr) {
-                    // neighbour state for soar_lbs_knn_refresh: the set (positions in the vertex grid's order, ascending), the
-                    // position it was found at, and a margin of 0 -- the first refresh measures the gap to the 31st neighbour
-                    if (lane < cnt && taken0 + lane < K) state_nbr[(size_t)pl * KNN_STATE_STRIDE + taken0 + lane] = lpos[lane];
-                    if (lane == 0) state_ref[pl] = make_float4(ux, uy, uz, 0.f);
+                if (state.nbr) {
+                    // neighbour state for soar_lbs_knn_refresh: the K nearest (positions in the vertex grid's order, ascending; the two
+                    // spare slots repeat the last one) and gaps of 0 -- the first refresh searches, seeded by these, and measures them
+                    // (the state is kept in the queries' SORTED order, like q_ids: the refresh walks it front to back)
+                    const size_t ql = (size_t)chunk * WAVE + l;
+                    if (lane < cnt && taken0 + lane < K) state.nbr[ql * KNN_STATE_STRIDE + taken0 + lane] = lpos[lane];
+                    if (lane < 2 && cnt > 0 && taken0 + cnt >= K) state.nbr[ql * KNN_STATE_STRIDE + K + lane] = lpos[cnt - 1];
+                    if (lane == 0) {
+                        state.ref30[ql] = make_float4(ux, uy, uz, 0.f);
+                        state.ref32[ql] = make_float4(ux, uy, uz, 0.f);
+                        state.in30[ql] = 0x3FFFFFFFu;
+                    }
                 }
                 if (lane == l) { norm_lane = norm; cnt_lane += cnt; need_left = uneed; }
                 if (lane < J) {
@@ -683,62 +697,178 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
 
 
 // ---- neighbour sets that follow the queries ------------------------------------------------------------------------------------
-// The canonical vertices never move (TS/utils/smpl.py:508-511) and a query moves by an optimizer step: the K nearest vertices of
-// almost every query are those of the step before.  The state of a query = its K neighbours (positions in the vertex grid's order),
-// the position x_ref they were found at and h = half the gap between its K-th and (K+1)-th distance there, minus rounding slack.
-// For every vertex |d(x, v) - d(x_ref, v)| <= |x - x_ref|, so while |x - x_ref| < h the K stored vertices are still strictly closer
-// than every other one: the set the full search would return, certified without searching.  Then only the K distances, the
-// inverse-distance weights and the blend of the K skinning rows are recomputed -- the same expressions in the same (vertex-grid)
-// order as knn_cell_kernel's, so the weights are the full search's bit for bit.
-// A query that fails the certificate is searched exactly, seeded by its old set: every new neighbour lies within the largest
-// new distance to an old one (there are K vertices that close), so only the grid cells that ball touches are scanned (lanes =
-// candidates, ~10 rows of a few vertices); the candidates inside the ball are ranked by (distance, grid position) -- the full
-// search's tie rule -- the best K become the new set, the next one (or the ball's radius) the new gap.
-constexpr int RF_CAP = 192;              // candidates the seeded search holds between two selections (K + a chunk of 64 always fit)
+// The canonical vertices never move (TS/utils/smpl.py:508-511) and a query moves by an optimizer step: the K = 30 nearest vertices
+// of almost every query are those of the step before.  For every vertex |d(x, v) - d(x_ref, v)| <= |x - x_ref|: while a query has
+// moved less than half the gap between its 30th and 31st distance at x_ref (minus rounding slack), its 30 stored vertices are still
+// strictly closer than every other one -- the set the full search would return, certified without searching.  About one query in
+// fifteen has a gap smaller than an optimizer step and would fail that every time; so the state holds the 32 nearest vertices and
+// a second gap, behind the 32nd: while THAT certificate holds, the 30 nearest are among the stored 32 and are found by ranking 32
+// distances in registers.  Only a query that fails both (under 1 % of them per step at the reference's learning rate) is searched
+// again, exactly, seeded by its old set: every vertex it can want lies within the largest new distance to an old neighbour, so only
+// the grid cells that ball touches are scanned.
+// Whatever the tier, the K distances, the inverse-distance weights and the blend of the K skinning rows are then recomputed with the
+// expressions and in the (vertex-grid) order of knn_cell_kernel: the weights are the full search's bit for bit.
+constexpr int KNN_KEEP = KNN_STATE_STRIDE;   // neighbours kept per query
+constexpr int RF_CAP = 192;              // candidates the seeded search holds between two selections (KNN_KEEP + a chunk of 64 fit)
 
-__global__ void __launch_bounds__(KNN_WAVES *WAVE)
-knn_refresh_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restrict__ meta, const uint2 *__restrict__ cell_range,
-                   const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded, int J,
-                   const uint32_t *__restrict__ order, uint32_t *__restrict__ state_nbr, float4 *__restrict__ state_ref,
-                   float *__restrict__ weights_out, uint32_t *__restrict__ counters)
+__device__ __forceinline__ float half_gap(float near_d2, float far_d2)
 {
-    constexpr int K = KNN_K;
+    const float far = sqrtf(far_d2);
+    return 0.5f * (far - sqrtf(near_d2)) - 4.0e-6f * far - 1.0e-12f;          // rounding of the distances, generously
+}
+
+// lanes 0..31 hold (pos ascending, d2) of the 32 stored vertices: the mask of the K nearest among them ((distance, grid position)
+// order: the full search's tie rule) and half the gap behind the K-th
+__device__ __forceinline__ uint32_t rank_32(float d2, int lane, float &h30)
+{
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < KNN_KEEP; j++) {
+        const float dj = __shfl(d2, j);
+        rank += (dj < d2 || (dj == d2 && j < lane)) ? 1 : 0;
+    }
+    const bool mine = lane < KNN_KEEP;
+    const bool in = mine && rank < KNN_K;
+    float d_in = in ? d2 : 0.f, d_out = (mine && !in) ? d2 : 3.0e38f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        d_in = fmaxf(d_in, __shfl_xor(d_in, off));
+        d_out = fminf(d_out, __shfl_xor(d_out, off));
+    }
+    h30 = half_gap(d_in, d_out);
+    return (uint32_t)__ballot(in);
+}
+
+// the blend of the K in-set neighbours, ascending grid position (lanes = joints); cp / cw: 32 words of LDS of this wavefront
+__device__ __forceinline__ void blend_rows(uint32_t mask, uint32_t pos, float d2, int lane, uint32_t *cp, float *cw,
+                                           const float *__restrict__ rows_padded, int J, float *__restrict__ out_row)
+{
+    if (lane < KNN_KEEP && ((mask >> lane) & 1u)) {
+        const int at = __builtin_popcount(mask & ((1u << lane) - 1u));
+        cp[at] = pos;
+        cw[at] = 1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f);       // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int jl = min(lane, KNN_JMAX - 1);
+    float accj = 0.f, norm = 0.f;
+#pragma unroll 15
+    for (int k = 0; k < KNN_K; k++) {
+        const float wk = cw[k];
+        accj = __builtin_fmaf(wk, rows_padded[(size_t)cp[k] * KNN_JMAX + jl], accj);
+        norm += wk;
+    }
+    if (lane < J) out_row[lane] = accj / norm;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// tiers 1 and 2: one wavefront per query, consecutive queries of the (cell-sorted) order per wavefront -- queries of one cell share
+// most neighbours, so the skinning rows mostly come from the CU's L1.  A query is a chain of dependent reads (its id -> its position;
+// its neighbour list -> their coordinates -> their skinning rows) around very little arithmetic: the wavefront keeps three queries in
+// flight, one per level of the chain.
+__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded,
+                  int J, const uint32_t *__restrict__ order, KnnStatePtrs st, float *__restrict__ weights_out)
+{
+    __shared__ uint32_t c_pos[KNN_WAVES][KNN_KEEP];
+    __shared__ float c_w[KNN_WAVES][KNN_KEEP];
+    // (wave-uniform index: what is the same for all lanes -- id, position, reference points, mask -- travels through scalar loads;
+    // as vector loads of one address the kernel measured 65 us against 57)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int per_wave = (P + (int)gridDim.x * KNN_WAVES - 1) / ((int)gridDim.x * KNN_WAVES);
+    const int q_begin = ((int)blockIdx.x * KNN_WAVES + wave) * per_wave, q_end = min(P, q_begin + per_wave);
+    // level 1 (two queries ahead): id, neighbour list, reference points, mask; level 2 (one ahead): position, neighbour coordinates
+    int p2 = 0, p1 = 0;
+    uint32_t nbr2 = 0u, nbr1 = 0u, mask2 = 0u, mask1 = 0u;
+    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2, a1 = a2, b1 = a2, v1 = a2;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    auto level1 = [&](int q) {
+        p2 = order ? (int)order[q] : q;
+        nbr2 = st.nbr[(size_t)q * KNN_STATE_STRIDE + (lane & (KNN_KEEP - 1))];
+        a2 = st.ref30[q]; b2 = st.ref32[q]; mask2 = st.in30[q];
+    };
+    auto level2 = [&]() {                                            // of the query level 1 last fetched
+        p1 = p2; nbr1 = nbr2; a1 = a2; b1 = b2; mask1 = mask2;
+        x1 = xyz[3 * p1]; y1 = xyz[3 * p1 + 1]; z1 = xyz[3 * p1 + 2];
+        v1 = sorted_verts[nbr1];
+    };
+    if (q_begin < q_end) { level1(q_begin); level2(); }
+    if (q_begin + 1 < q_end) level1(q_begin + 1);
+    for (int q = q_begin; q < q_end; q++) {
+        const int p = p1;
+        const float x = x1, y = y1, z = z1;
+        const float4 ra = a1, rb = b1;
+        const uint32_t pos = nbr1;
+        uint32_t mask = mask1;
+        const float d2 = dist2_exact(x, y, z, v1);                   // (lanes 32..63 repeat lanes 0..31)
+        if (q + 1 < q_end) level2();
+        if (q + 2 < q_end) level1(q + 2);
+        const float ax = x - ra.x, ay = y - ra.y, az = z - ra.z, bx = x - rb.x, by = y - rb.y, bz = z - rb.z;
+        const float moved_a = sqrtf((ax * ax + ay * ay) + az * az) * 1.0001f + 1.0e-12f;
+        const float moved_b = sqrtf((bx * bx + by * by) + bz * bz) * 1.0001f + 1.0e-12f;
+        if (!(ra.w > 0.f && moved_a < ra.w)) {                        // (wave-uniform)
+            if (!(rb.w > 0.f && moved_b < rb.w)) {
+                // neither certificate holds: the seeded search (knn_search_kernel) takes the query
+                // (with the largest new distance to a stored neighbour: the radius of its search)
+                float far = d2;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
+                if (lane == 0) {
+                    const uint32_t at = atomicAdd(st.work, 1u);
+                    st.work[2u + 2u * at] = (uint32_t)q;
+                    st.work[3u + 2u * at] = __float_as_uint(far);
+                }
+                continue;
+            }
+            // the 32 stored vertices still are the 32 nearest: the K nearest among them, and the gap behind the K-th, from here
+            float h30;
+            mask = rank_32(d2, lane, h30);
+            if (lane == 0) { st.ref30[q] = make_float4(x, y, z, h30); st.in30[q] = mask; }
+        }
+        blend_rows(mask, pos, d2, lane, c_pos[wave], c_w[wave], rows_padded, J, weights_out + (size_t)p * J);
+    }
+}
+
+// tier 3: one wavefront per query of the work list
+__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+knn_search_kernel(const float *__restrict__ xyz, const GridMeta *__restrict__ meta, const uint2 *__restrict__ cell_range,
+                  const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded, int J, const uint32_t *__restrict__ order,
+                  KnnStatePtrs st, float *__restrict__ weights_out, uint32_t *__restrict__ counters)
+{
+    constexpr int KEEP = KNN_KEEP;
     __shared__ uint32_t c_pos[KNN_WAVES][RF_CAP];
     __shared__ float c_d[KNN_WAVES][RF_CAP];
+    __shared__ uint32_t row_first[KNN_WAVES][WAVE], row_end[KNN_WAVES][WAVE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *cp = c_pos[wave];
     float *cd = c_d[wave];
     const GridMeta m = *meta;
-    uint32_t n_searched = 0;
-    const int jl = min(lane, KNN_JMAX - 1);
-    for (int q = (int)blockIdx.x * KNN_WAVES + wave; q < P; q += (int)gridDim.x * KNN_WAVES) {
-        const int p = order ? (int)order[q] : q;
+    const uint32_t n_work = st.work[0];
+    for (uint32_t w = blockIdx.x * KNN_WAVES + wave; w < n_work; w += gridDim.x * KNN_WAVES) {
+        const size_t q = st.work[2u + 2u * w];
+        // everything within the largest new distance to an old neighbour (there are at least K vertices that close) ...
+        const float tau_ub = __uint_as_float(st.work[3u + 2u * w]);
+        const int p = order ? (int)order[q] : (int)q;
         const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
-        const float4 ref = state_ref[p];
-        uint32_t pos = lane < K ? state_nbr[(size_t)p * KNN_STATE_STRIDE + lane] : 0u;
-        float d2 = lane < K ? dist2_exact(x, y, z, sorted_verts[pos]) : 0.f;
-        const float mx = x - ref.x, my = y - ref.y, mz = z - ref.z;
-        const float moved = sqrtf((mx * mx + my * my) + mz * mz) * 1.0001f + 1.0e-12f;
-        if (!(ref.w > 0.f && moved < ref.w)) {                       // wave-uniform
-            n_searched++;
-            // ---- exact search seeded by the old set: everything within the largest new distance to an old neighbour
-            float tau_ub = d2;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) tau_ub = fmaxf(tau_ub, __shfl_xor(tau_ub, off));
-            // ... and a fifteenth further: what the search proves about the vertices it does NOT return is "at least the ball's
-            // radius away" -- with the bare radius the new gap would always be measured as zero.  (On a surface the K-th and
-            // (K+1)-th distances differ by ~1/60 of the K-th on average.)
-            const float ball = sqrtf(tau_ub) * (1.0f + 1.0f / 15.0f);
-            const float ball2 = ball * ball;
+        int n_in = 0;                                                 // candidates held in (cp, cd), ascending grid position
+        float next_d2 = 3.0e38f, ball2 = 0.f;
+        // ... and a fifteenth further: what the search proves about the vertices it does NOT return is "at least the ball's radius
+        // away" -- with the bare radius the gap behind the set would always be measured as zero (on a surface the K-th and
+        // (K+1)-th distances differ by ~1/60 of the K-th on average).  Enlarged again should the ball hold fewer than KEEP vertices
+        // (the state of a fresh full search only knows K of them)
+        for (float grow = 1.0f + 1.0f / 15.0f;; grow *= 1.3f) {
+            const float ball = sqrtf(tau_ub) * grow + 1.0e-6f;
+            ball2 = ball * ball;
             const float rho = ball * 1.0001f + 1.0e-7f;
             const int cx0 = cell_coord(x - rho, m.minx, m.inv_h, m.nx), cx1 = cell_coord(x + rho, m.minx, m.inv_h, m.nx);
             const int cy0 = cell_coord(y - rho, m.miny, m.inv_h, m.ny), cy1 = cell_coord(y + rho, m.miny, m.inv_h, m.ny);
             const int cz0 = cell_coord(z - rho, m.minz, m.inv_h, m.nz), cz1 = cell_coord(z + rho, m.minz, m.inv_h, m.nz);
             const int ny_b = cy1 - cy0 + 1, n_rows = ny_b * (cz1 - cz0 + 1);
-            int n_in = 0;                                             // candidates held in (cp, cd), ascending grid position
-            float next_d2 = 3.0e38f;                                  // smallest distance of a candidate that was dropped
-            // keep the K best of the n_in held candidates (ties in list = grid order), remember the best one dropped
-            auto select_k = [&]() {
+            n_in = 0;
+            next_d2 = 3.0e38f;
+            // keep the KEEP best of the n_in held candidates (ties in list = grid order), remember the best one dropped
+            auto select_keep = [&]() {
                 uint32_t e_pos[RF_CAP / WAVE];
                 float e_d[RF_CAP / WAVE];
                 int rank[RF_CAP / WAVE];
@@ -761,7 +891,7 @@ knn_refresh_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restr
 #pragma unroll
                 for (int u = 0; u < RF_CAP / WAVE; u++) {
                     const bool have = u * WAVE + lane < n_in;
-                    const bool keep = have && rank[u] < K;
+                    const bool keep = have && rank[u] < KEEP;
                     const unsigned long long km = __ballot(keep);
                     if (keep) {
                         const int at = kept + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
@@ -795,75 +925,95 @@ knn_refresh_kernel(const float *__restrict__ xyz, int P, const GridMeta *__restr
                         }
                     }
                 }
-                const int rows_here = min(WAVE, n_rows - r0);
-                for (int r = 0; r < rows_here; r++) {
-                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, r), e0 = (uint32_t)__builtin_amdgcn_readlane((int)re, r);
-                    for (uint32_t t0 = s0; t0 < e0; t0 += WAVE) {
-                        const uint32_t t = t0 + (uint32_t)lane;
-                        const float d = t < e0 ? dist2_exact(x, y, z, sorted_verts[t]) : 3.0e38f;
-                        const bool in = d <= tau_cur;
-                        // outside the ball but inside the box: a lower bound of the (K+1)-th distance all the same
-                        float out_d = (t < e0 && !in) ? d : 3.0e38f;
+                // the rows' candidates as one list (ascending grid position): lanes = candidates, 64 at a time
+                uint32_t incl = re - rs;
 #pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) out_d = fminf(out_d, __shfl_xor(out_d, off));
-                        next_d2 = fminf(next_d2, out_d);
-                        const unsigned long long im = __ballot(in);
-                        if (im == 0ull) continue;
-                        if (n_in + (int)__builtin_popcountll(im) > RF_CAP) {
-                            select_k();                               // K stay (K + 64 <= RF_CAP): nothing above their largest
-                            float worst = lane < K ? cd[lane] : 0.f;  // distance can be among the K best any more
-#pragma unroll
-                            for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
-                            tau_cur = worst;
-                        }
-                        const bool in2 = d <= tau_cur;
-                        const unsigned long long im2 = __ballot(in2);
-                        if (in2) {
-                            const int at = n_in + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im2, 0u));
-                            cp[at] = t;
-                            cd[at] = d;
-                        }
-                        float out2 = (in && !in2) ? d : 3.0e38f;
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) out2 = fminf(out2, __shfl_xor(out2, off));
-                        next_d2 = fminf(next_d2, out2);
-                        n_in += (int)__builtin_popcountll(im2);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += up;
                 }
-            }
-            select_k();                                               // n_in == K now (at least K vertices lie inside the ball)
-            pos = lane < K ? cp[lane] : 0u;
-            d2 = lane < K ? cd[lane] : 0.f;
-            float kth = d2;
+                const int n_cand = (int)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+                row_first[wave][lane] = rs;
+                row_end[wave][lane] = incl;                           // candidates of the rows 0 .. lane
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int rows_here = min(WAVE, n_rows - r0);
+                constexpr int TRIPS = 4;                              // candidate gathers in flight together
+                for (int g00 = 0; g00 < n_cand; g00 += TRIPS * WAVE) {
+                uint32_t tt[TRIPS];
+                float4 vv[TRIPS];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) kth = fmaxf(kth, __shfl_xor(kth, off));
-            // every vertex that is not in the set is at least this far: the best dropped candidate, or the ball's radius
-            const float next_d = sqrtf(fminf(next_d2, ball2));
-            const float half_gap = 0.5f * (next_d - sqrtf(kth)) - 4.0e-6f * next_d - 1.0e-12f;
-            if (lane < K) state_nbr[(size_t)p * KNN_STATE_STRIDE + lane] = pos;
-            if (lane == 0) state_ref[p] = make_float4(x, y, z, half_gap);
+                for (int u = 0; u < TRIPS; u++) {
+                    const int g = g00 + u * WAVE + lane;
+                    int row = 0;
+                    while (row + 1 < rows_here && row_end[wave][row] <= (uint32_t)g) row++;
+                    tt[u] = row_first[wave][row] + ((uint32_t)g - (row ? row_end[wave][row - 1] : 0u));
+                    vv[u] = sorted_verts[g < n_cand ? tt[u] : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < TRIPS; u++) {
+                    const int g0 = g00 + u * WAVE;
+                    if (g0 >= n_cand) break;
+                    const int g = g0 + lane;
+                    const uint32_t t = tt[u];
+                    const bool have = g < n_cand;
+                    const float d = have ? dist2_exact(x, y, z, vv[u]) : 3.0e38f;
+                    const bool in = d <= tau_cur;
+                    // outside the ball but inside the box: a lower bound of the distances behind the set all the same
+                    float out_d = (have && !in) ? d : 3.0e38f;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) out_d = fminf(out_d, __shfl_xor(out_d, off));
+                    next_d2 = fminf(next_d2, out_d);
+                    const unsigned long long im = __ballot(in);
+                    if (im == 0ull) continue;
+                    if (n_in + (int)__builtin_popcountll(im) > RF_CAP) {
+                        select_keep();                                // KEEP stay (KEEP + 64 <= RF_CAP): nothing above their largest
+                        float worst = lane < KEEP ? cd[lane] : 0.f;   // distance can be among the KEEP best any more
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+                        tau_cur = worst;
+                    }
+                    const bool in2 = d <= tau_cur;
+                    const unsigned long long im2 = __ballot(in2);
+                    if (in2) {
+                        const int at = n_in + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im2, 0u));
+                        cp[at] = t;
+                        cd[at] = d;
+                    }
+                    float out2 = (in && !in2) ? d : 3.0e38f;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) out2 = fminf(out2, __shfl_xor(out2, off));
+                    next_d2 = fminf(next_d2, out2);
+                    n_in += (int)__builtin_popcountll(im2);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // row_first / row_end are rewritten by the next 64 rows
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (n_in >= KEEP) { select_keep(); break; }               // n_in == KEEP now
         }
-        // ---- weights from the set: ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634), rows blended in grid order
+        const uint32_t pos = lane < KEEP ? cp[lane] : 0u;
+        const float d2 = lane < KEEP ? cd[lane] : 3.0e38f;
+        float far = lane < KEEP ? d2 : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
+        // every vertex that is not among the KEEP is at least this far: the best dropped candidate, or the ball's radius
+        const float h32 = half_gap(far, fminf(next_d2, ball2));
+        float h30;
+        const uint32_t mask = rank_32(lane < KEEP ? d2 : 3.0e38f, lane, h30);
+        if (lane < KEEP) st.nbr[q * KNN_STATE_STRIDE + lane] = pos;
+        if (lane == 0) {
+            st.ref30[q] = make_float4(x, y, z, h30);
+            st.ref32[q] = make_float4(x, y, z, h32);
+            st.in30[q] = mask;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < K) {
-            cp[lane] = pos;
-            cd[lane] = 1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float accj = 0.f, norm = 0.f;
-#pragma unroll 15
-        for (int k = 0; k < K; k++) {
-            const float wk = cd[k];
-            accj = __builtin_fmaf(wk, rows_padded[(size_t)cp[k] * KNN_JMAX + jl], accj);
-            norm += wk;
-        }
-        if (lane < J) weights_out[(size_t)p * J + lane] = accj / norm;
+        blend_rows(mask, pos, d2, lane, cp, cd, rows_padded, J, weights_out + (size_t)p * J);
     }
-    if (counters && lane == 0 && n_searched) atomicAdd(counters, n_searched);
+    if (counters && blockIdx.x == 0 && threadIdx.x == 0 && n_work) atomicAdd(counters, n_work);
 }
 
 }  // namespace
@@ -955,16 +1105,20 @@ int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
     return 0;
 }
 
-// neighbour state of soar_lbs_knn_refresh: [P][KNN_STATE_STRIDE] grid positions, then [P] {x_ref, y_ref, z_ref, half gap}
-struct KnnState { uint32_t *nbr; float4 *ref; size_t total; };
+// neighbour state of soar_lbs_knn_refresh: [P][32] grid positions | [P] ref30 | [P] ref32 | [P] in30 | [2 + P] work list
+struct KnnState { KnnStatePtrs p; size_t total; };
 int carve_knn_state(void *base, int32_t P, KnnState *out)
 {
     char *b = static_cast<char *>(base);
     const size_t n = (size_t)(P > 0 ? P : 1);
-    const size_t o_ref = align_up(sizeof(uint32_t) * KNN_STATE_STRIDE * n);
-    out->nbr = reinterpret_cast<uint32_t *>(b);
-    out->ref = reinterpret_cast<float4 *>(b + o_ref);
-    out->total = o_ref + align_up(sizeof(float4) * n);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return b + o; };
+    out->p.nbr = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * KNN_STATE_STRIDE * n));
+    out->p.ref30 = reinterpret_cast<float4 *>(carve(sizeof(float4) * n));
+    out->p.ref32 = reinterpret_cast<float4 *>(carve(sizeof(float4) * n));
+    out->p.in30 = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * n));
+    out->p.work = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * (2 * n + 2)));
+    out->total = off;
     return 0;
 }
 
@@ -973,8 +1127,8 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
               hipStream_t stream, const KnnState *state = nullptr)
 {
     const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
-    uint32_t *st_nbr = state ? state->nbr : nullptr;
-    float4 *st_ref = state ? state->ref : nullptr;
+    KnnStatePtrs st_none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const KnnStatePtrs st = state ? state->p : st_none;
     if (!fast && state) { set_error("soar_lbs_knn: the neighbour state needs K = %d and J <= %d", KNN_K, KNN_JMAX); return 1; }
     if (!fast) {
         hipLaunchKernelGGL(knn_grid_kernel, dim3((P + KNN_THREADS - 1) / KNN_THREADS), dim3(KNN_THREADS), 0, stream, xyz, P, V,
@@ -1015,7 +1169,7 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
         SOAR_HIP_OK(hipMalloc(&log_dev, nbytes));
         SOAR_HIP_OK(hipMemsetAsync(log_dev, 0, nbytes, stream));
         hipLaunchKernelGGL((knn_cell_kernel<false, true>), grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref, log_dev);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st, log_dev);
         SOAR_HIP_OK(hipStreamSynchronize(stream));
         unsigned long long *host = (unsigned long long *)malloc(nbytes);
         SOAR_HIP_OK(hipMemcpy(host, log_dev, nbytes, hipMemcpyDeviceToHost));
@@ -1027,10 +1181,10 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
     }
     if (knn_idx_out)
         hipLaunchKernelGGL(knn_cell_kernel<true>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st);
     else
         hipLaunchKernelGGL(knn_cell_kernel<false>, grid, dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, V, g.meta, g.cell_range,
-                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st_nbr, st_ref);
+                           g.sorted_verts, qk1, qv1, g.rows, J, weights_out, knn_idx_out, chunk_order, st);
     SOAR_LAUNCH_OK("lbs_knn_weights", stream, 0);
     return 0;
 }
@@ -1132,9 +1286,11 @@ extern "C" int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, cons
     if (check_ws("soar_lbs_knn_query_state", query_workspace, query_workspace_bytes) || check_ws("soar_lbs_knn_query_state", state_buffer, 0)) return 1;
     KnnGrid g;
     if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
+    if (V <= KNN_KEEP) { set_error("soar_lbs_knn_query_state: the neighbour state keeps %d vertices per query, V = %d", KNN_KEEP, V); return 1; }
     KnnState st;
     carve_knn_state(state_buffer, P, &st);
     StageTimer timer(ST_LBS_KNN, stream);
+    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
     return knn_query(g, V, vert_weights, J, xyz, P, KNN_K, weights_out, nullptr, order, resort, query_workspace, query_workspace_bytes,
                      stream, &st);
 }
@@ -1146,7 +1302,7 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     if (check_knn_sizes(P, V, J, KNN_K)) return 1;
     if (J > KNN_JMAX) { set_error("soar_lbs_knn_refresh: J <= %d", KNN_JMAX); return 1; }
     if (P == 0) return 0;
-    if (!grid_buffer || !xyz || !weights_out || !state_buffer) { set_error("soar_lbs_knn_refresh: NULL pointer"); return 1; }
+    if (!grid_buffer || !xyz || !weights_out || !state_buffer || !order) { set_error("soar_lbs_knn_refresh: NULL pointer"); return 1; }
     if (check_ws("soar_lbs_knn_refresh", state_buffer, 0)) return 1;
     KnnGrid g;
     if (carve_knn_grid(const_cast<void *>(grid_buffer), V, &g, stream)) return 1;
@@ -1154,8 +1310,13 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     carve_knn_state(state_buffer, P, &st);
     StageTimer timer(ST_LBS_KNN, stream);
     const int nblocks = min((P + KNN_WAVES - 1) / KNN_WAVES, 8192);
-    hipLaunchKernelGGL(knn_refresh_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.meta, g.cell_range,
-                       g.sorted_verts, g.rows, J, order, st.nbr, st.ref, weights_out, searched_counter_dev);
+    // (the work list starts empty: a memset node -- letting the last wavefront of the search kernel reset it meant one atomic per
+    // wavefront on one address, 50 us for 2048 of them)
+    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(knn_follow_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, g.rows, J, order,
+                       st.p, weights_out);
+    hipLaunchKernelGGL(knn_search_kernel, dim3(512), dim3(KNN_WAVES * WAVE), 0, stream, xyz, g.meta, g.cell_range, g.sorted_verts,
+                       g.rows, J, order, st.p, weights_out, searched_counter_dev);
     SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
     return 0;
 }

@@ -119,6 +119,7 @@ struct PreArgs {
     uint32_t *depth_key_out;
     uint32_t *blk_stats;
     int32_t *radii;
+    uint32_t *header;        // GeomBuf::header (H_PREFILTER_VIOLATIONS)
 };
 
 __global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
@@ -164,6 +165,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
             pix_y >= y1 + h * expand)
             alive = false;
     }
+    // The reference prints and traps when a point is culled although the caller promised a prefiltered set (auxiliary.h:163-167,
+    // 195-199).  A trap takes the whole context down; here the violations are counted (one atomic per wavefront that has any) and
+    // reported as an error by the host: soar_rast_forward_geometry in debug mode, soar_rast_prefilter_violations on request
+    bool prefilter_violation = a.prefiltered && in_range && !alive;
 
     M3 R;
     if (alive) {
@@ -194,7 +199,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
         float dot = vx * nview[0] + vy * nview[1] + vz * nview[2];
         bool front = !((double)dot > -0.01);
         faces_camera = front;
-        if (a.render_front && !front) alive = false;
+        if (a.render_front && !front) {
+            alive = false;
+            prefilter_violation = prefilter_violation || (a.prefiltered && in_range);
+        }
 
         if (alive && a.pix_depth) {
             // local homography between the image plane and the surfel plane (auxiliary.h:291-388)
@@ -344,6 +352,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
     a.front_out[idx] = faces_camera ? 1.f : 0.f;
     a.radii[idx] = out_radius;
     a.tiles_touched[idx] = out_tiles;
+    if (a.prefiltered) {                                         // (uniform: SOAR never sets it)
+        const unsigned long long bad = __ballot(prefilter_violation);
+        if (bad != 0ull && (threadIdx.x & 63) == 0) atomicAdd(a.header + H_PREFILTER_VIOLATIONS, (uint32_t)__builtin_popcountll(bad));
+    }
 }
 
 }  // namespace
@@ -365,7 +377,7 @@ int launch_preprocess(const SoarRastParams &prm, const float *means3D, const flo
     a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
     a.view = prm.viewmatrix_dev; a.proj = prm.projmatrix_dev; a.prcp = prm.prcppoint_dev;
     a.bbox = prm.patchbbox_dev; a.campos = prm.campos_dev;
-    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.front_out = g.front; a.rect_out = g.rect; a.depth_key_out = g.depth_key; a.blk_stats = g.blk_stats; a.radii = radii;
+    a.rec = g.rec; a.cov3D = g.cov3D; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.front_out = g.front; a.rect_out = g.rect; a.depth_key_out = g.depth_key; a.blk_stats = g.blk_stats; a.radii = radii; a.header = g.header;
     const int threads = 256;
     const int blocks = (prm.P + threads - 1) / threads;
     StageTimer timer(ST_PREPROCESS, stream);

@@ -139,6 +139,7 @@ constexpr int H_NOT_Y0 = 7;
 constexpr int H_TOTAL = 8;      // instances (sum of the tile counts) found by the tile binning
 constexpr int H_OVERFLOW = 9;   // 0, or H_TOTAL when it exceeded the capacity of the caller's binning buffer
 constexpr int H_BAND_OVERFLOW = 10;   // 0, or the entries the band lists needed when they exceeded that capacity
+constexpr int H_PREFILTER_VIOLATIONS = 11;   // Gaussians culled although SoarRastParams.prefiltered was set (auxiliary.h:163-167, 195-199)
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
     uint2 *ranges;           // [T]

@@ -101,7 +101,7 @@ class KnnFollower:
     otherwise.  The weights are those of ``KnnGrid.query`` at the same positions, bit for bit (TS/utils/smpl.py:618-637).
     Tied to the number of queries: build a new follower after densification."""
 
-    RESORT_EVERY = 64     # refreshes between two sorts of the query order (locality of the skinning-row reads only)
+    RESORT_EVERY = 1024   # refreshes between two full searches (they re-sort the query order: locality of the skinning-row reads only)
 
     def __init__(self, grid: "KnnGrid", P: int):
         import ctypes as C

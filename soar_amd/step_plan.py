@@ -70,6 +70,7 @@ class FrameStepPlan:
         # mats / frame_sel follow on the device (soar_gather_step_inputs, first launch of the prologue)
         self.frame_ids = torch.zeros((self.n,), dtype=torch.int32, device=dev)
         self._ids_pinned = torch.zeros((64, self.n), dtype=torch.int32).pin_memory()
+        self._ids_copied = [None] * 64            # event behind the copy out of each slot: a slot is rewritten only once its copy ran
         self.mats = torch.empty((self.n, 55, 4, 4), **f)                 # static input: joint transforms of the step's frames
         self.blend_weights = torch.empty((P, seq.lbs_weights.shape[1]), **f)
         self.ones = torch.ones((P, 1), **f)
@@ -165,7 +166,7 @@ class FrameStepPlan:
                                "pointers)")
 
     # ---- the three pieces -------------------------------------------------------------------------------------------
-    RESORT_EVERY = 64     # steps between two full KNN searches (which also re-sort the query order; lbs.KnnFollower.RESORT_EVERY)
+    RESORT_EVERY = 1024   # steps between two full KNN searches (which also re-sort the query order; lbs.KnnFollower.RESORT_EVERY)
 
     def _stamp(self, k: int, stream: int) -> None:
         if self.stamps is not None:
@@ -368,10 +369,18 @@ class FrameStepPlan:
         dev = self.device
         # the step's only host -> device traffic: n frame ids, through a ring of pinned slots (the host runs steps ahead of the
         # device; a slot is reused 64 steps later)
-        slot = self._ids_pinned[self.steps % self._ids_pinned.shape[0]]
+        k_slot = self.steps % self._ids_pinned.shape[0]
+        slot = self._ids_pinned[k_slot]
+        if self._ids_copied[k_slot] is not None:
+            # the host may run more than 64 steps ahead of the device (nothing else in a step synchronises): the copy that read
+            # this slot 64 steps ago must have executed before the slot is rewritten
+            self._ids_copied[k_slot].synchronize()
         for k, f in enumerate(frames):
             slot[k] = int(f) % self.seq.num_frames
         self.frame_ids.copy_(slot, non_blocking=True)
+        ev = self._ids_copied[k_slot] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._ids_copied[k_slot] = ev
         if self.graphs is None:
             self._run_eager()
             return self.losses

@@ -320,6 +320,28 @@ def test_all_culled():
         assert (hip[k] == 0).all()
 
 
+def test_prefiltered_promise_is_checked():
+    """`prefiltered=True` with a Gaussian the frustum test culls: the reference prints "Point is filtered although prefiltered is
+    set" and traps (auxiliary.h:163-167); here debug mode raises with that message, and without debug the call goes through (the
+    reference's non-debug failures are unchecked too) while the device count is there for whoever asks."""
+    from soar_amd.rasterizer import GaussianRasterizer
+    scene = S.person_scene(P=300, seed=3)
+    scene.means3D[:7] += np.array([0, 0, 50.0], np.float32)               # seven points far behind the camera
+    dev = _dev()
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+    args = (t(scene.means3D), t(scene.means3D) * 0, t(scene.opacities))
+    kw = dict(colors_precomp=t(scene.colors), scales=t(scene.scales), rotations=t(scene.rotations))
+    st = S.torch_settings(scene, dev)
+    ok = GaussianRasterizer(st)(*args, **kw)
+    got = GaussianRasterizer(st._replace(prefiltered=True))(*args, **kw)                   # unchecked, same images
+    assert torch.equal(ok[0], got[0])
+    with pytest.raises(Exception, match="Point is filtered although prefiltered is set"):
+        GaussianRasterizer(st._replace(prefiltered=True, debug=True))(*args, **kw)
+    fine = S.person_scene(P=300, seed=3)                                    # nothing culled: the promise holds
+    GaussianRasterizer(S.torch_settings(fine, dev)._replace(prefiltered=True, debug=True))(
+        t(fine.means3D), t(fine.means3D) * 0, t(fine.opacities), colors_precomp=t(fine.colors), scales=t(fine.scales), rotations=t(fine.rotations))
+
+
 def test_autograd_module_matches_C_interface():
     """GaussianRasterizer (autograd path) returns the same images and input gradients as the raw _C calls."""
     from soar_amd.rasterizer import GaussianRasterizer
