@@ -15,6 +15,6 @@ cmd = [B.HIPCC] + B.COMMON_FLAGS + B.EXTRA_FLAGS.get(unit, []) + flags + ["-c", 
 subprocess.check_call(cmd)
 objs = [obj if s == unit else os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES]
 lib = os.path.join(out_dir, name + ".so")
-subprocess.check_call([B.HIPCC, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
+subprocess.check_call([B.HIPCC, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
 os.remove(obj)
 print(lib)

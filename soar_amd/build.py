@@ -83,7 +83,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs = list(ex.map(lambda s: _compile_one(s, verbose), SOURCES))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

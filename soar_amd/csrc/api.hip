@@ -4,6 +4,8 @@
 
 #include <mutex>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -107,8 +109,36 @@ void prof_drain()
 }
 }  // namespace
 
+// roctx ranges around the stages (the reference has no tracing at all): with SOAR_ROCTX=1 in the environment every
+// stage's launches sit inside a range named like the stage timers ("preprocess", "render_forward", ...), which
+// `rocprofv3 --marker-trace --kernel-trace` shows beside the kernels.  The library is loaded on demand: nothing links against it.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *on = getenv("SOAR_ROCTX");
+        if (!on || on[0] == '0') return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+const Roctx &roctx()
+{
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+
 StageTimer::StageTimer(int stage, hipStream_t s) : slot(-1), stream(s)
 {
+    marked = roctx().push != nullptr;
+    if (marked) (void)roctx().push(g_stage_names[stage]);
     if (!g_prof_on) return;
     // inside a batch only the last frame's call launches: the earlier ones have nothing to time
     if (batch_ctx().n && batch_ctx().f != batch_ctx().n - 1) return;
@@ -127,6 +157,7 @@ StageTimer::StageTimer(int stage, hipStream_t s) : slot(-1), stream(s)
 StageTimer::~StageTimer()
 {
     if (slot >= 0) (void)hipEventRecord(g_slots[slot].b, stream);
+    if (marked) (void)roctx().pop();
 }
 
 // ---- scratch carving (bump allocation, 256-byte aligned; same idea as obtain(), rasterizer_impl.h:22-28) ----

@@ -88,6 +88,7 @@ struct StageTimer {   // records start/stop events around a stage when profiling
     ~StageTimer();
     int slot;
     hipStream_t stream;
+    bool marked;             // a roctx range is open (SOAR_ROCTX=1)
 };
 
 inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }

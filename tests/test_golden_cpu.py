@@ -65,3 +65,28 @@ def test_camera_helper_matches_reference():
     cx, cy, W, H = [float(v) for v in g["cam_cxcy"]]
     wv, fp, cc = syn.camera_from_c2w(c2w, fx, fy, 0.1, 100, cxcy=(cx, cy), img_wh=(W, H))
     np.testing.assert_allclose(fp.numpy(), g["cam_fullproj_cxcy"], atol=1e-5)
+
+
+def test_torch_cpu_rasterizer_matches_the_c_oracle():
+    """oracle/torch_rasterizer.py (the pure-PyTorch CPU baseline bench.py times) against the plain-C oracle on a small scene:
+    images within 1e-4 and the colour gradient within 1e-3 of the oracle's backward.  (Only that one: autograd differentiates the
+    forward as written, while the reference's hand-written backward is not its exact derivative -- x10 normal gain, raw per-pixel
+    depth term, no quaternion normalisation Jacobian: SURVEY Appendix A #22, #25, #27.  The file is a timing baseline.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scenes as S
+    from oracle import torch_rasterizer as tr
+    scene = S.person_scene(P=400, seed=5)
+    fw, bw = S.run_oracle(scene, S.upstream_grads(scene))
+    st = S.torch_settings(scene, torch.device("cpu"))
+    leaf = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).clone().requires_grad_(True)
+    means, scl, rot, cols = leaf(scene.means3D), leaf(scene.scales), leaf(scene.rotations), leaf(scene.colors)
+    color, normal, depth, opac, stats = tr.rasterize(st, means, torch.as_tensor(scene.opacities), cols, scl, rot)
+    assert stats["num_rendered"] == fw.num_rendered
+    for got, want in ((color, fw.out_color), (normal, fw.out_normal), (depth, fw.out_depth), (opac, fw.out_opac)):
+        assert np.abs(got.detach().numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0)
+    g = [torch.as_tensor(x) for x in S.upstream_grads(scene)]
+    ((color * g[0]).sum() + (normal * g[1]).sum() + (depth * g[2]).sum() + (opac * g[3]).sum()).backward()
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert rel(cols.grad.numpy(), bw.dL_dcolors) < 1e-3
+    assert np.isfinite(means.grad.numpy()).all() and np.isfinite(rot.grad.numpy()).all() and np.isfinite(scl.grad.numpy()).all()
