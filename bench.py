@@ -360,6 +360,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-step", type=int, default=4)
+    ap.add_argument("--loss", default="synthetic", choices=["synthetic", "avatar"],
+                    help="synthetic (default): one fused L1-type loss kernel per frame on render/normal/depth/mask (the metric is the "
+                         "renderer's fwd+bwd; the loss only has to produce the four image gradients); avatar: the reference's avatar "
+                         "stage on the video frame -- 0.8 masked L1 + 0.2 (1 - SSIM), mask L1, cosine normal loss through the "
+                         "renderer's post-ops, loss_occ through the occlusion image's backward "
+                         "(TS/system/gaussian_surfel_mvdream.py:305-338, 412-417) -- a second line, same units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--mode", default=None, choices=["plan", "plan-eager", "graph", "async", "sync"],
@@ -421,7 +427,13 @@ def main():
 
     seq, targets, parts = build_sequence(args.workload, device)
     P, W, H, F = WORKLOADS[args.workload]
-    flat = FlatGradBuffer(seq.leaves())
+    if args.loss == "avatar":
+        if args.mode not in ("plan", "plan-eager"):
+            raise SystemExit("--loss avatar is a form of the step plan: --mode plan or plan-eager")
+        seq.occ.requires_grad_(True)                             # loss_occ trains the per-surfel occlusion values
+        flat = FlatGradBuffer(dict(seq.leaves(), occ=seq.occ))
+    else:
+        flat = FlatGradBuffer(seq.leaves())
     bg = torch.tensor([0.2, 0.5, 0.7], device=device)
     fps_per_rank = args.frames_per_step
 
@@ -452,12 +464,15 @@ def main():
     if mode in ("plan", "plan-eager"):
         try:
             from soar_amd.step_plan import FrameStepPlan
-            plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat, use_graphs=(mode == "plan"))
+            plan = FrameStepPlan(seq, len(frames_of(0)), targets, bg, capacity, flat, use_graphs=(mode == "plan"), loss=args.loss)
             from soar_amd.optim import FusedAdam
             # The reference's optimizer (Adam, eps 1e-15) with its learning rates carried over to this sequence's leaves, which are
             # the ACTIVATED values (the reference keeps log-scales and logit-colours): 5e-3 on a log-scale is 0.5 % of a ~0.01
             # scale, 1e-2 on a logit ~2.5e-3 on the colour; positions and rotations as in the reference
-            adam = FusedAdam(flat, lr={"xyz": 1.6e-5, "rot": 1e-3, "scales": 5e-5, "colors": 2.5e-3})
+            lrs = {"xyz": 1.6e-5, "rot": 1e-3, "scales": 5e-5, "colors": 2.5e-3}
+            if args.loss == "avatar":
+                lrs["occ"] = 1e-2
+            adam = FusedAdam(flat, lr=lrs)
 
             def stepper(frames):
                 # a whole training step: gradients of the step's frames (plan.run), their sum over the ranks (two asynchronous
@@ -600,6 +615,9 @@ def main():
                                f"occlusion rasterize fwd", "parallelism": f"frame-dp{world}", "mode": mode,
                    "frame_chains": (("one stream, every stage launched once for all frames" if plan.batched else "one stream per frame")
                                     if plan is not None and plan.graphs is None else "one stream per frame"),
+                   "loss": ("synthetic: one fused loss kernel per frame on render/normal/depth/mask" if args.loss == "synthetic" else
+                            "avatar: 0.8 masked L1 + 0.2 (1 - SSIM), mask L1, cosine normal loss through the post-ops, loss_occ "
+                            "through the occlusion image's backward; Adam also on the occlusion values"),
                    "plan_form": (("batched" if plan.batched else "streams") + (", graphs" if plan.graphs is not None else ", eager")
                                  if plan is not None else None),
                    "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")

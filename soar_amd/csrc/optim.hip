@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const A
         const float g = row.grad[i];
         float m = row.exp_avg[i], v = row.exp_avg_sq[i];
         m = m + (g - m) * one_minus_b1;
-        v = beta2 * v + one_minus_b2 * g * g;
+        v = beta2 * v + one_minus_b2 * (g * g);        // (torch squares first: a gradient beyond 1.8e19 makes v infinite and the value stops moving -- kept)
         const float denom = sqrtf(v) / bc2s + eps;
         row.param[i] = row.param[i] - step_size * (m / denom);
         row.exp_avg[i] = m;

@@ -43,11 +43,25 @@ from .rasterizer import _Ctx
 
 class FrameStepPlan:
     def __init__(self, seq, n_frames: int, targets: Dict[str, torch.Tensor], bg: torch.Tensor, capacity: int, flat,
-                 loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True, batched: Optional[bool] = None):
+                 loss_weights: Sequence[float] = (1.0, 1.0, 0.1, 0.01), use_graphs: bool = True, batched: Optional[bool] = None,
+                 loss: str = "synthetic", lambdas: Optional[Dict[str, float]] = None):
         """seq: AvatarSequence; targets: {"color","mask","normal"} image targets shared by the frames, or a resident pool
         [n_sets,7,H,W] of per-frame targets (``synthetic.make_loss_target_pool``; frame f uses set f mod n_sets); capacity: bound
         of the (tile, Gaussian) instances of one frame (checked on the device, see ``check()``); flat: FlatGradBuffer of
-        ``seq.leaves()`` that receives the summed gradients."""
+        ``seq.leaves()`` that receives the summed gradients.
+
+        loss = "synthetic": the dense four-term loss of SURVEY 8(d) (one fused kernel per frame).  loss = "avatar": the image-loss
+        block of the reference's training step on the video frame (TS/system/gaussian_surfel_mvdream.py:305-338, 412-417), through
+        the renderer's post-ops: lambda_recon (0.8 masked L1 + 0.2 (1 - SSIM)) + lambda_mask mean|mask - gt_mask| + lambda_normal
+        0.2 cos_loss(normal, gt_normal) + lambda_occ mean(1 - occ[mask]) -- the kernels of ``losses.avatar_stage_loss`` and of the
+        plugin's fused view (``renderer/fused_view.py``), the occlusion term back through ``soar_rast_occ_backward`` into the
+        flat buffer's ``occ`` slice (needs a target pool and the eager form; ``lambdas``: recon / mask / normal / occ, default 1,
+        1, 1, 0.1)."""
+        if loss not in ("synthetic", "avatar"):
+            raise ValueError(f"loss must be 'synthetic' or 'avatar', got {loss!r}")
+        self.loss_kind = loss
+        if loss == "avatar" and (use_graphs or not torch.is_tensor(targets)):
+            raise ValueError("loss='avatar' needs a resident target pool and use_graphs=False")
         L = hip_lib.lib()
         self.L, self.seq, self.flat, self.n = L, seq, flat, int(n_frames)
         dev = seq.device
@@ -114,7 +128,9 @@ class FrameStepPlan:
         # loss here) must not carry anything from an earlier autograd step into the reductions / the optimizer
         for name in ("opacity", "occ"):
             if name in flat.views:
-                flat.views[name].zero_()
+                flat.views[name].zero_()                                 # (loss="avatar" writes the occ slice every step)
+        if loss == "avatar":
+            self._setup_avatar(lambdas)
         self.steps = 0
         # SOAR_PLAN_TIMESTAMPS=1 (diagnostic): {tag, device wall clock} stamps at the start / end of the prologue (tags 0, 1), of
         # frame chain i (2 + 2 i, 3 + 2 i) and of the epilogue (2 n + 2, 2 n + 3), appended to a ring on every replay
@@ -148,6 +164,85 @@ class FrameStepPlan:
                 raise RuntimeError("FrameStepPlan(use_graphs=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment "
                                    "before the HIP runtime starts (see the module docstring); use use_graphs=False otherwise")
             self._capture()
+
+    # ---- the reference's image losses (loss="avatar") ---------------------------------------------------------------------
+    def _setup_avatar(self, lambdas):
+        from .losses import _AvatarStageLoss as S
+        L, dev, H, W, P = self.L, self.device, self.H, self.W, self.P
+        f = dict(dtype=torch.float32, device=dev)
+        lam = dict(recon=1.0, mask=1.0, normal=1.0, occ=0.1)
+        lam.update(lambdas or {})
+        self.lam = lam
+        pool = self.pool
+        n_sets = int(pool.shape[0])
+        # what the data module's collate hands the system (TS/data/uncond_multiview.py:340-681), per target set, resident:
+        # gt_rgb, gt_mask, gt_normal views of the pool; the selections gt_mask > 1e-5 (:305) and > 0 (:413); gt_rgb blended over the
+        # render's background (:307-309)
+        m = pool[:, 3:4]
+        self.av = dict(rgb=pool[:, 0:3], mask=m, normal=pool[:, 4:7],
+                       sel=(m > 1e-5).reshape(n_sets, H, W).contiguous().view(torch.uint8),
+                       sel_occ=(m > 0).reshape(n_sets, H, W).contiguous().view(torch.uint8),
+                       blended=(pool[:, 0:3] * m + self.bg.reshape(1, 3, 1, 1) * (1 - m)).contiguous())
+        k = C.c_size_t(0)
+        check(L.soar_image_loss_scratch_floats(C.byref(k)), "soar_image_loss_scratch_floats")
+        n_loss = int(k.value)
+        check(L.soar_ssim_scratch_floats(3, H, W, C.byref(k)), "soar_ssim_scratch_floats")
+        coef = [0.0] * S.N
+        coef[S.L1], coef[S.SSIM], coef[S.ONE] = 0.8 * lam["recon"], -0.2 * lam["recon"], 0.2 * lam["recon"]
+        coef[S.L1M], coef[S.COS] = lam["mask"], 0.2 * lam["normal"]
+        self.av_coef = torch.tensor(coef, **f)                         # loss = terms . coef; also the upstream factor of every term
+        self.av_occ_up = torch.tensor([lam["occ"]], **f)
+        self.av_ones3 = torch.ones((3, H, W), **f)
+        self.av_focal = (H / (2.0 * self.seq.camera.tanfovy), W / (2.0 * self.seq.camera.tanfovx))     # fov2focal(FoVy, H), (FoVx, W)
+        self.g_occ_all = torch.empty((self.n, P), **f)
+        for v in self.views:
+            g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
+            v.update(normal_out=torch.empty((3, H, W), **f), curv=torch.empty((1, H, W), **f), pred=torch.empty((3, H, W), **f),
+                     g_ssim=torch.empty((3, H, W), **f), g_n=torch.empty((3, H, W), **f), g_nd=g_nd, g_occ_img=torch.empty((3, H, W), **f),
+                     terms=torch.zeros((S.N,), **f), occ_terms=torch.zeros((2,), **f),
+                     av_scratch=torch.empty((max(n_loss, int(k.value)),), **f))
+            v["terms"][S.ONE] = 1.0
+            v["gN"], v["gD"] = g_nd[:3], g_nd[3:]                       # what the rasterizer backward reads
+
+    def _f_avatar_loss(self, i: int, frame: int, stream: int) -> None:
+        """post-ops -> the four image-loss kernels and the occlusion term -> their backwards -> post-ops backward: everything
+        between the blend and the rasterizer backward of one frame (plain launches: outside a batch)"""
+        from .losses import _AvatarStageLoss as S
+        L, v, W, H, a = self.L, self.views[i], self.W, self.H, self.av
+        k = frame % int(self.pool.shape[0])
+        prcp = self.ctx.keep[3]
+        at = lambda t, j: t.data_ptr() + 4 * j
+        sc = ptr(v["av_scratch"])
+        check(L.soar_view_finish(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(prcp), self.av_focal[0], self.av_focal[1],
+                                 ptr(v["normal_out"]), ptr(v["curv"]), ptr(v["pred"]), stream), "soar_view_finish")
+        t = v["terms"]
+        check(L.soar_masked_l1(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), sc, stream), "soar_masked_l1")
+        check(L.soar_ssim(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), stream), "soar_ssim")
+        check(L.soar_masked_l1(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), sc, stream), "soar_masked_l1")
+        check(L.soar_cos_loss(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS), sc, stream),
+              "soar_cos_loss")
+        check(L.soar_masked_l1(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]), sc, stream),
+              "soar_masked_l1")
+        up = self.av_coef
+        check(L.soar_masked_l1_backward(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), at(up, S.L1),
+                                        ptr(v["gC"]), stream), "soar_masked_l1_backward")
+        check(L.soar_masked_l1_backward(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), at(up, S.L1M), ptr(v["gO"]),
+                                        stream), "soar_masked_l1_backward")
+        check(L.soar_cos_loss_backward(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS),
+                                       at(up, S.COS), ptr(v["g_n"]), stream), "soar_cos_loss_backward")
+        check(L.soar_masked_l1_backward(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]),
+                                        ptr(self.av_occ_up), ptr(v["g_occ_img"]), stream), "soar_masked_l1_backward")
+        v["gC"].addcmul_(v["g_ssim"], up[S.SSIM])
+        check(L.soar_view_finish_backward(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(prcp), self.av_focal[0],
+                                          self.av_focal[1], ptr(v["g_n"]), None, None, None, ptr(v["g_nd"]), stream),
+              "soar_view_finish_backward")
+        # the frame's loss value (device side): terms . coef + lambda_occ mean(1 - occ[mask])
+        torch.add(torch.dot(t, up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
+
+    def _f_occ_backward(self, i: int, stream: int) -> None:
+        v = self.views[i]
+        check(self.L.soar_rast_occ_backward(C.byref(self.ctx.params), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
+                                            ptr(v["g_occ_img"]), ptr(self.g_occ_all[i]), stream), "soar_rast_occ_backward")
 
     def _leaf_signature(self):
         s = self.seq
@@ -242,6 +337,14 @@ class FrameStepPlan:
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
         self._stamp(2 + 2 * i, stream)
+        if self.loss_kind == "avatar":
+            self._f_geometry(i, stream)
+            self._f_render(i, stream)
+            self._f_avatar_loss(i, self._frames_now[i], stream)
+            self._f_backward(i, stream)
+            self._f_occ_backward(i, stream)
+            self._stamp(3 + 2 * i, stream)
+            return
         for k, stage in enumerate((self._f_geometry, self._f_render, self._f_loss, self._f_backward)):
             self._stage_stamp(i, k, stream)
             stage(i, stream)
@@ -256,14 +359,25 @@ class FrameStepPlan:
         frames = list(range(self.n)) if frames is None else list(frames)
         for i in frames:
             self._stamp(2 + 2 * i, stream)
-        check(L.soar_batch_begin(len(frames)), "batch_begin")
-        try:
-            for stage in (self._f_geometry, self._f_render, self._f_loss, self._f_backward):
-                for k, i in enumerate(frames):
-                    check(L.soar_batch_frame(k), "batch_frame")
-                    stage(i, stream)
-        finally:
-            L.soar_batch_end()
+        def batch(stages):
+            check(L.soar_batch_begin(len(frames)), "batch_begin")
+            try:
+                for stage in stages:
+                    for k, i in enumerate(frames):
+                        check(L.soar_batch_frame(k), "batch_frame")
+                        stage(i, stream)
+            finally:
+                L.soar_batch_end()
+        if self.loss_kind == "avatar":
+            # the loss block's kernels take one frame per launch: between two batches
+            batch((self._f_geometry, self._f_render))
+            for i in frames:
+                self._f_avatar_loss(i, self._frames_now[i], stream)
+            batch((self._f_backward,))
+            for i in frames:
+                self._f_occ_backward(i, stream)
+        else:
+            batch((self._f_geometry, self._f_render, self._f_loss, self._f_backward))
         for i in frames:
             self._stamp(3 + 2 * i, stream)
 
@@ -280,6 +394,8 @@ class FrameStepPlan:
         check(L.soar_lbs_warp_backward_sum(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
                                            self.P, J, ptr(self.g_means3D_all), ptr(self.g_rot_p_all), ptr(fv["xyz"]), ptr(fv["rot"]),
                                            2, src, dst, width, stream), "warp_backward_sum")
+        if self.loss_kind == "avatar" and "occ" in fv:
+            check(L.soar_sum_frames(self.n, self.P, ptr(self.g_occ_all), ptr(fv["occ"]), stream), "sum_frames")
         self._stamp(2 * self.n + 3, stream)
 
     # ---- graphs -------------------------------------------------------------------------------------------------------
@@ -367,6 +483,7 @@ class FrameStepPlan:
             raise ValueError(f"the plan was built for {self.n} frames per step, got {len(frames)}")
         self._check_fresh()
         dev = self.device
+        self._frames_now = [int(f) % self.seq.num_frames for f in frames]
         # the step's only host -> device traffic: n frame ids, through a ring of pinned slots (the host runs steps ahead of the
         # device; a slot is reused 64 steps later)
         k_slot = self.steps % self._ids_pinned.shape[0]

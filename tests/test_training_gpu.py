@@ -113,3 +113,130 @@ def test_step_plan_trains_with_adam(use_graphs):
     plan.check()
     assert losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
     assert seq.colors.grad is not None and seq.colors.grad.data_ptr() == flat.views["colors"].data_ptr()
+
+
+_AV = dict(P=3000, W=160, H=128, frames=[0, 1, 2, 3],
+           lr={"xyz": 1.6e-5, "rot": 1e-3, "scales": 5e-5, "colors": 2.5e-3, "occ": 1e-2},
+           lam=dict(recon=1.0, mask=1.0, normal=1.0, occ=0.1))
+
+
+def _avatar_scene():
+    P, W, H = _AV["P"], _AV["W"], _AV["H"]
+    body, poses, cam = syn.make_body_model(0, V=2048), syn.make_pose_sequence(4, 0), syn.make_camera(W, H)
+    seq = AvatarSequence(syn.make_surfels(P, 0), body, poses, cam, DEV)
+    seq.occ.requires_grad_(True)
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    pool = syn.make_loss_target_pool(H, W, 4, 1, DEV)
+    return seq, dict(seq.leaves(), occ=seq.occ), cam, bg, pool
+
+
+def _avatar_plan_steps(steps):
+    """`steps` training steps of FrameStepPlan(loss="avatar") + optim.FusedAdam: per-step losses, first-step gradients, per-step leaves."""
+    from soar_amd import optim, rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+    seq, leaves, cam, bg, pool = _avatar_scene()
+    flat = FlatGradBuffer(leaves)
+    with torch.no_grad():
+        seq.render_frames(_AV["frames"], bg, with_occ=True)
+    plan = FrameStepPlan(seq, 4, pool, bg, 3 * rasterizer.last_num_rendered, flat, use_graphs=False, loss="avatar", lambdas=_AV["lam"])
+    adam = optim.FusedAdam(flat, lr=_AV["lr"])
+    losses_, grads, snaps = [], None, []
+    for _ in range(steps):
+        losses_.append(plan.run(_AV["frames"]).clone())
+        if grads is None:
+            grads = {n: flat.views[n].clone() for n in _AV["lr"]}
+        adam.step()
+        snaps.append({n: leaves[n].detach().clone() for n in _AV["lr"]})
+    plan.check()
+    return losses_, grads, snaps
+
+
+def _avatar_composed_steps(steps):
+    """The same steps composed from the autograd pieces of the plugin path: lbs_warp, GaussianRasterizer twice, the post-op functions
+    (TS/renderer/diff_gaussian_rasterizer.py:292-303), losses.avatar_stage_loss + loss_occ, torch.optim.Adam."""
+    from collections import namedtuple
+    import math
+    from soar_amd import lbs, losses
+    from soar_amd.rasterizer import GaussianRasterizer
+    from soar_amd.renderer.postops import depth2normal, normal2curv
+    seq, leaves, cam, bg, pool = _avatar_scene()
+    lr, lam, H, W = _AV["lr"], _AV["lam"], _AV["H"], _AV["W"]
+    opt = torch.optim.Adam([{"params": [leaves[n]], "lr": lr[n]} for n in lr], lr=0.0, eps=1e-15)
+    Cam = namedtuple("Cam", "FoVx FoVy image_height image_width prcppoint")
+    camera = Cam(2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy), H, W, seq.prcp)
+    flip = torch.tensor([1.0, -1.0, -1.0], device=DEV)[:, None, None]
+    losses_, grads, snaps = [], None, []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        seq.refresh_blend_weights()
+        per_frame = []
+        for f in _AV["frames"]:
+            xyz_p, rot_p = lbs.lbs_warp(seq.xyz, seq.rot, seq.blend_weights, seq.cano2live[f])
+            ones = torch.ones_like(seq.opacity)
+            tap = torch.zeros_like(xyz_p, requires_grad=True)
+            render, normal, depth, opac, _ = GaussianRasterizer(seq.settings(bg, False, False))(
+                means3D=xyz_p, means2D=tap, opacities=ones, colors_precomp=seq.colors, scales=seq.scales, rotations=rot_p)
+            occ_img = GaussianRasterizer(seq.settings(bg, True, False))(
+                means3D=xyz_p.detach(), means2D=tap.detach(), opacities=ones, colors_precomp=seq.occ.repeat(1, 3),
+                scales=seq.scales.detach(), rotations=rot_p.detach())[0]
+            mask = opac > 1e-5
+            n = torch.where(mask.repeat(3, 1, 1), normal, normal.detach()) * flip
+            curv = normal2curv(n, opac.detach() > 1e-5)
+            n = (n + 1) / 2
+            pred = (depth2normal(depth, opac.detach() > 1e-5, camera) * flip + 1) / 2
+            out = {"render": render, "normal": n, "depth": depth, "pred_normal": pred, "mask": opac, "occ": occ_img, "curv": curv}
+            k = f % pool.shape[0]
+            gt_rgb, gt_mask, gt_normal = pool[k, 0:3], pool[k, 3:4], pool[k, 4:7]
+            blended = gt_rgb * gt_mask + bg[:, None, None] * (1 - gt_mask)
+            loss = losses.avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, gt_mask[0] > 1e-5, gt_rgb_blended=blended,
+                                            lambda_recon=lam["recon"], lambda_mask=lam["mask"], lambda_normal=lam["normal"])
+            loss = loss + lam["occ"] * (1 - occ_img.permute(1, 2, 0)[gt_mask[0] > 0]).mean()
+            per_frame.append(loss)
+        sum(per_frame).backward()
+        if grads is None:
+            grads = {n: leaves[n].grad.clone() for n in lr}
+        opt.step()
+        losses_.append(torch.stack([l.detach() for l in per_frame]))
+        snaps.append({n: leaves[n].detach().clone() for n in lr})
+    return losses_, grads, snaps
+
+
+def test_step_plan_avatar_loss_with_fused_adam_equals_the_composed_training_steps():
+    """FrameStepPlan(loss="avatar") + optim.FusedAdam -- the reference's image losses on the video frame (0.8 masked L1 + 0.2 (1 -
+    SSIM), mask L1, cosine normal loss through the renderer's post-ops, loss_occ through the occlusion image;
+    TS/system/gaussian_surfel_mvdream.py:305-338, 412-417) and its optimizer step (:471-472) as explicit launches -- against the
+    same 20 training steps composed from the autograd pieces of the plugin path: the same gradients (1e-5 of the largest) on the
+    first step, the same losses along the 20 steps, the occlusion values trained."""
+    losses_a, grads_a, snaps_a = _avatar_plan_steps(20)
+    losses_b, grads_b, snaps_b = _avatar_composed_steps(20)
+    for n in _AV["lr"]:
+        assert float((grads_a[n] - grads_b[n]).abs().max()) <= 1e-5 * float(grads_b[n].abs().max()), n
+    for step, (la, lb) in enumerate(zip(losses_a, losses_b)):
+        torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-6, msg=lambda m: f"step {step}: {m}")
+    for n in _AV["lr"]:
+        a, b = snaps_a[-1][n], snaps_b[-1][n]
+        finite = b.abs() < 1e9                                             # (scales carry the surfel marker z = -1e10)
+        assert float((a[finite] - b[finite]).abs().max()) <= 1e-5 * max(float(b[finite].abs().max()), 1.0), n
+        assert float((snaps_a[-1][n] - snaps_a[0][n])[finite].abs().max()) > 5 * _AV["lr"][n], n      # ... and every leaf trained
+    assert float(losses_a[-1].sum()) < float(losses_a[0].sum())
+
+
+def test_adam_keeps_torchs_overflow_behaviour():
+    """A gradient beyond ~1.8e19 (the rotation gradient of a surfel does reach that: the marker scale z = -1e10 is a factor of it)
+    squares to infinity in torch.optim.Adam -- the second moment is infinite from then on and the value never moves again.  The fused
+    Adam squares first too; it used to scale first, moved those values by lr per step, and 20 steps later nothing agreed."""
+    from soar_amd import optim
+    from soar_amd.frame_dp import FlatGradBuffer
+    p = torch.nn.Parameter(torch.tensor([[1.0, 2.0, 3.0, 4.0]], device=DEV))
+    q = torch.nn.Parameter(p.detach().clone())
+    g = torch.tensor([[5.0e19, -3.0e19, 1.0e19, 1e-3]], device=DEV)
+    flat = FlatGradBuffer({"rot": p})
+    adam, ref = optim.FusedAdam(flat, lr={"rot": 1e-2}), torch.optim.Adam([q], lr=1e-2, eps=1e-15)
+    for _ in range(3):
+        flat.views["rot"].copy_(g)
+        q.grad = g.clone()
+        adam.step(); ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach()[0, :2], torch.tensor([1.0, 2.0], device=DEV))
+    torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=0)
