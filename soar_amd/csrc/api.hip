@@ -518,7 +518,7 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
         if (launch_scan(*prm, g, stream)) return 1;                // key emission needs the prefix sum of tiles_touched
         if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
     }
-    if (num_rendered > 0 && launch_block_masks(*prm, g, b, num_rendered, stream)) return 1;
+    if (num_rendered > 0 && launch_block_masks(*prm, g, b, img, num_rendered, stream)) return 1;
     if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
 }
@@ -657,6 +657,36 @@ __global__ void export_records_kernel(int P, const GaussRec *rec, float *means2D
     if (depth_plane) { depth_plane[2 * i] = r.q1.w; depth_plane[2 * i + 1] = r.q2.x; }
     if (rgb) { rgb[3 * i] = r.q2.y; rgb[3 * i + 1] = r.q2.z; rgb[3 * i + 2] = r.q2.w; }
 }
+// The tile binning lays the tiles' lists out in the order its workgroups reserved room (rast_tilebin.hip); the reference's
+// binningState.point_list has them in tile order (rasterizer_impl.cu:266-295).  The export re-packs: ranges in tile order ...
+__global__ void __launch_bounds__(1024) export_pack_ranges_kernel(int T, const uint2 *__restrict__ ranges, uint2 *__restrict__ packed)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x, per = (T + 1023) / 1024, t0 = tid * per, t1 = min(T, t0 + per);
+    uint32_t s = 0;
+    for (int t = t0; t < t1; t++) s += ranges[t].y - ranges[t].x;
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 1024; k++) { const uint32_t c = part[k]; part[k] = run; run += c; }
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (int t = t0; t < t1; t++) {
+        const uint32_t c = ranges[t].y - ranges[t].x;
+        packed[t] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
+        run += c;
+    }
+}
+// ... and every tile's list copied to its place
+__global__ void __launch_bounds__(64) export_pack_lists_kernel(const uint2 *__restrict__ ranges, const uint2 *__restrict__ packed,
+                                                               const uint32_t *__restrict__ list, uint32_t *__restrict__ out)
+{
+    const uint2 from = ranges[blockIdx.x], to = packed[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < from.y - from.x; k += 64) out[to.x + k] = list[from.x + k];
+}
+
 }  // namespace
 }  // namespace soar
 
@@ -697,11 +727,25 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
     if (binning_buffer && num_rendered > 0) {
         carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
         const size_t R = (size_t)num_rendered;
-        COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
+        if (!prm->sort_descending && image_buffer && (point_list || ranges)) {
+            uint2 *packed = nullptr;
+            SOAR_HIP_OK(hipMalloc(&packed, tiles * sizeof(uint2)));
+            hipLaunchKernelGGL(soar::export_pack_ranges_kernel, dim3(1), dim3(1024), 0, stream, (int)tiles, img.ranges, packed);
+            if (point_list)
+                hipLaunchKernelGGL(soar::export_pack_lists_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, img.ranges, packed, b.vals_sorted,
+                                   point_list);
+            if (ranges) SOAR_HIP_OK(hipMemcpyAsync(ranges, packed, tiles * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+            SOAR_HIP_OK(hipStreamSynchronize(stream));
+            SOAR_HIP_OK(hipFree(packed));
+        } else {
+            COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
+        }
         if (!prm->sort_descending && image_buffer && (keys_unsorted || vals_unsorted || keys_sorted)) {
             // the ascending path never materialises the 64-bit keys: produce them for inspection with the key sort
             // (point_list and ranges above were copied out first; the key sort rewrites them with its own result)
             if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
+            // ... the lists now lie in tile order: the block masks (one bit per list position) follow
+            if (launch_block_masks(*prm, g, b, img, num_rendered, stream)) return 1;
         }
         COPY(keys_unsorted, b.keys_unsorted, R * sizeof(uint64_t));
         COPY(vals_unsorted, b.vals_unsorted, R * sizeof(uint32_t));

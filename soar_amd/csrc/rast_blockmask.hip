@@ -34,9 +34,24 @@ struct BlockMaskArgs {
     const GaussRec *rec;
     uint64_t *masks;                 // BinBuf::block_masks
     size_t plane;
+    // the tile order of the blend kernels, built by one more workgroup of this launch on the tile-binning path (the launch that
+    // writes the lists also finds their lengths: the order can only be built behind it); tile_order == NULL: built elsewhere
+    int T;
+    const uint32_t *tile_count;
+    uint2 *ranges;
+    uint32_t *tile_order;
+    const float *bg;
+    int normalize_depth;
+    uint32_t *bg_state;
 };
+constexpr unsigned BM_EXTRA = 8;     // workgroups at the front of every grid row that make no masks (one XCD round: the rest of the row
+                                     // keeps its place on the XCDs); those of row 0 build the tile orders, one frame each
 
 constexpr float BM_BIG = 1.0e30f;
+#ifndef SOAR_BM_GROUPS
+#define SOAR_BM_GROUPS 2
+#endif
+constexpr int BM_GROUPS = SOAR_BM_GROUPS;      // groups of 64 list positions per wavefront: their gathers are in flight together
 
 // edge data of one column (or row) of blocks: h = centre - first pixel centre of the column, extent 3
 struct EdgeLine {
@@ -95,31 +110,53 @@ __device__ __forceinline__ void block_words(const int lane, bool valid, float x,
 
 __global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> batch)
 {
-    int frame, bx;
-    batch_interleave1(frame, bx);
+    // Which part of which frame's lists this workgroup takes follows from the XCD it runs on (the dispatcher deals consecutive
+    // workgroups to the 8 XCDs in turn): every XCD walks ONE contiguous part of ONE frame's list positions, front to back.  List
+    // positions are sorted by tile, so the workgroups an XCD runs at any moment gather the records of a few neighbouring tiles and
+    // its L2 (4 MB) serves most of the gathers; dealt round-robin, every XCD would gather from every frame's whole record array
+    // (4 x 6.4 MB at C3), out of the memory-side cache.
+    const unsigned n = gridDim.y;
+    static_assert(BM_EXTRA >= (unsigned)MAX_BATCH, "one extra workgroup per frame");
+    if (blockIdx.x < BM_EXTRA) {
+        if (blockIdx.y == 0 && blockIdx.x < n) {
+            const BlockMaskArgs &o = batch.v[blockIdx.x];
+            if (o.tile_order) {
+                const bool overflow = (o.header[H_OVERFLOW] | o.header[H_BAND_OVERFLOW]) != 0u;
+                tile_order_block(o.T, (o.T + 7) / 8 * 8, o.tile_count, o.ranges, o.tile_order, o.bg, o.normalize_depth, o.bg_state,
+                                 overflow ? o.ranges : nullptr);
+            }
+        }
+        return;
+    }
+    const unsigned l = blockIdx.y * (gridDim.x - BM_EXTRA) + (blockIdx.x - BM_EXTRA);
+    const unsigned xcd = l & 7u, k = l >> 3;
+    const bool parted = (8u % n) == 0u;
+    const unsigned frame = parted ? xcd % n : l % n, parts = parted ? 8u / n : 1u, part = parted ? xcd / n : 0u;
     const BlockMaskArgs &a = batch.v[frame];
     const int lane = threadIdx.x & 63;
-    const uint32_t g0 = ((uint32_t)bx * 4u + (threadIdx.x >> 6)) * 2u;
-    if ((uint64_t)g0 * 64u >= a.total) return;
-    // Everything is asked for before the number of instances is known (one round trip less): positions behind it hold stale ids,
-    // clamped into the record array, and their bits are masked away
-    float x[2], y[2], A[2], B[2], C[2], thr[2], tx0[2], ty0[2];
-    uint32_t pos[2];
+    // (an overflow of the caller's binning buffer leaves every tile range empty and the lists unwritten)
+    if (a.header && (a.header[H_OVERFLOW] | a.header[H_BAND_OVERFLOW]) != 0u) return;
+    const uint32_t total = a.header ? min(a.header[H_TOTAL], a.total) : a.total;
+    constexpr uint32_t PER_WG = 256u * (uint32_t)BM_GROUPS;
+    const uint32_t nb = (total + PER_WG - 1u) / PER_WG, per = (nb + parts - 1u) / parts;
+    const uint32_t kk = parted ? k : l / n;
+    if (kk >= per) return;
+    const uint32_t bx = part * per + kk;
+    const uint32_t g0 = (bx * 4u + (threadIdx.x >> 6)) * (uint32_t)BM_GROUPS;
+    if ((uint64_t)g0 * 64u >= total) return;
+    float x[BM_GROUPS], y[BM_GROUPS], A[BM_GROUPS], B[BM_GROUPS], C[BM_GROUPS], thr[BM_GROUPS], tx0[BM_GROUPS], ty0[BM_GROUPS];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        pos[u] = min((g0 + (uint32_t)u) * 64u + (uint32_t)lane, a.total - 1u);
-        const uint32_t id = min(a.point_list[pos[u]], a.P - 1u), xy = a.tile_xy[pos[u]];
+    for (int u = 0; u < BM_GROUPS; u++) {
+        const uint32_t pos = min((g0 + (uint32_t)u) * 64u + (uint32_t)lane, total - 1u);
+        const uint32_t id = min(a.point_list[pos], a.P - 1u), xy = a.tile_xy[pos];
         const float4 q0 = a.rec[id].q0;
         x[u] = q0.x; y[u] = q0.y; A[u] = q0.z; B[u] = q0.w;
         C[u] = a.rec[id].q1.x;
         thr[u] = a.rec[id].q3.w;
         tx0[u] = (float)((xy & 0xFFFFu) * TILE); ty0[u] = (float)((xy >> 16) * TILE);
     }
-    // (an overflow of the caller's binning buffer leaves every tile range empty and the lists unwritten)
-    if (a.header && (a.header[H_OVERFLOW] | a.header[H_BAND_OVERFLOW]) != 0u) return;
-    const uint32_t total = a.header ? min(a.header[H_TOTAL], a.total) : a.total;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < BM_GROUPS; u++) {
         const uint32_t g = g0 + (uint32_t)u;
         if ((uint64_t)g * 64u >= total) break;
         uint32_t w_lo, w_hi;
@@ -132,7 +169,7 @@ __global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> ba
 
 // `R`: the instances the lists hold -- exact on the key-sort path, the capacity of the caller's binning buffer on the tile-binning
 // path (the real number is then read on the device; nothing is written when it overflowed: every range is empty)
-int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, int64_t R, hipStream_t stream)
+int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream)
 {
     BlockMaskArgs a;
     a.header = prm.sort_descending ? nullptr : g.header;
@@ -140,9 +177,13 @@ int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, i
     a.P = (uint32_t)prm.P;
     a.tile_xy = b.tile_xy; a.point_list = b.vals_sorted; a.rec = g.rec;
     a.masks = b.block_masks; a.plane = b.mask_plane;
+    a.T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
+    a.tile_count = img.tile_count; a.ranges = img.ranges;
+    a.tile_order = prm.sort_descending ? nullptr : img.tile_order;       // (the key-sort path builds its own: rast_binning.hip)
+    a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
+    const unsigned nblocks = ((unsigned)((R + 256 * BM_GROUPS - 1) / (256 * BM_GROUPS)) + 7u) / 8u * 8u;      // (whole rounds of the 8 XCDs)
     StageTimer timer(ST_BLOCK_MASKS, stream);
-    const unsigned nblocks = (unsigned)((R + 511) / 512);
-    SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(BM_EXTRA + nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("block_masks", stream, prm.debug);
     return 0;
 }

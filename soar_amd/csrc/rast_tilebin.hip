@@ -376,7 +376,11 @@ __global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs
             const uint32_t st = a.band_info[tid], en = a.band_info[BAND_MAX + tid];
             a.band_info[BAND_MAX + tid] = fits ? en - st : 0u;
         }
-        if (tid == 0) a.header[H_BAND_OVERFLOW] = fits ? 0u : total;
+        if (tid == 0) {
+            a.header[H_BAND_OVERFLOW] = fits ? 0u : total;
+            a.header[H_TOTAL] = 0u;                         // bin_tiles adds up the instances ...
+            a.header[H_OVERFLOW] = fits ? 0u : total;       // ... and raises this when the lists do not fit either
+        }
     }
     if (!fits) return;
     // place: wavefront w's entries of band b follow those of the wavefronts before it
@@ -397,9 +401,10 @@ __global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs
 constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile: one tile per wavefront
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_WAVES = BIN_THREADS / WAVE;
-constexpr int BIN_UNROLL = 8;           // rectangles per thread and trip (independent loads in flight)
+constexpr int BIN_UNROLL = 4;           // rectangles per thread and trip (independent loads in flight)
 constexpr int BIN_CHUNK = BIN_THREADS * BIN_UNROLL;
-constexpr int BIN_CAP = BIN_CHUNK;      // survivors buffered between two flushes: a whole trip's hits always fit (64 KB of LDS)
+constexpr int BIN_CAP = BIN_CHUNK;      // survivors buffered per ROW of tiles between two flushes: a whole trip's hits always fit
+                                        // (4 rows x 4096 entries x 4 bytes = 64 KB of LDS)
 
 struct SuperTile {
     int tx0, ty0, tx1, ty1;
@@ -420,162 +425,12 @@ __device__ __forceinline__ bool rect_hits(uint2 rc, const SuperTile &s)
     return x0 < s.tx1 && x1 > s.tx0 && y0 < s.ty1 && y1 > s.ty0;       // empty rectangles are never stored in the sorted list
 }
 
-// Pass A: instances per tile.  One workgroup per 4x4 tiles walks the depth-ordered rectangles and adds every rectangle
-// that touches its tiles to a 5x5 difference grid in LDS (4 LDS atomics per hit); the grid's 2-D prefix sum is the
-// number of instances of each of its 16 tiles.  Workgroups outside the bounding box of all rectangles leave at once.
 // band of a super-tile: its row of super-tiles, or several rows per band on very tall images
 __device__ __forceinline__ int band_of_block(int block, int gx, int band_rows)
 {
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER;
     return ((block / nsx) * BIN_SUPER) / band_rows;
 }
-
-struct BinCountArgs {
-    const uint32_t *header;
-    int gx;
-    int gy;
-    int band_rows;
-    const uint32_t *band_info;
-    const uint2 *band_rect;
-    uint32_t *tile_count;
-};
-__device__ __forceinline__ void bin_count_kernel_body(const int bx, const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
-                 const uint2 *__restrict__ band_rect, uint32_t *__restrict__ tile_count)
-{
-    __shared__ int diff[BIN_SUPER + 1][BIN_SUPER + 1];
-    const int tid = threadIdx.x;
-    const SuperTile st = super_tile_of(bx, gx, gy);
-    const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
-    const int band = band_of_block(bx, gx, band_rows);
-    const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles, depth order
-    const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
-    const bool inside = P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0;
-    if (tid < (BIN_SUPER + 1) * (BIN_SUPER + 1)) (&diff[0][0])[tid] = 0;
-    lds_barrier();
-    if (inside) {
-        uint2 rc[BIN_UNROLL];
-#pragma unroll
-        for (int j = 0; j < BIN_UNROLL; j++) rc[j] = j * BIN_THREADS + tid < P ? rect_sorted[j * BIN_THREADS + tid] : make_uint2(0u, 0u);
-        for (int base = 0; base < P; base += BIN_CHUNK) {
-            uint2 nx[BIN_UNROLL];                              // next trip's rectangles are in flight while this one is counted
-#pragma unroll
-            for (int j = 0; j < BIN_UNROLL; j++) {
-                const int k = base + BIN_CHUNK + j * BIN_THREADS + tid;
-                nx[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int j = 0; j < BIN_UNROLL; j++) {
-                if (rect_hits(rc[j], st)) {
-                    const int x0 = max((int)(rc[j].x & 0xFFFFu), st.tx0) - st.tx0, x1 = min((int)(rc[j].x >> 16), st.tx1) - st.tx0;
-                    const int y0 = max((int)(rc[j].y & 0xFFFFu), st.ty0) - st.ty0, y1 = min((int)(rc[j].y >> 16), st.ty1) - st.ty0;
-                    atomicAdd(&diff[y0][x0], 1);
-                    atomicAdd(&diff[y0][x1], -1);
-                    atomicAdd(&diff[y1][x0], -1);
-                    atomicAdd(&diff[y1][x1], 1);
-                }
-                rc[j] = nx[j];
-            }
-        }
-    }
-    lds_barrier();
-    if (tid == 0) {
-        for (int y = 0; y < BIN_SUPER; y++)
-            for (int x = 1; x < BIN_SUPER; x++) diff[y][x] += diff[y][x - 1];
-        for (int x = 0; x < BIN_SUPER; x++)
-            for (int y = 1; y < BIN_SUPER; y++) diff[y][x] += diff[y - 1][x];
-    }
-    lds_barrier();
-    if (tid < BIN_SUPER * BIN_SUPER) {
-        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + (tid >> 2);
-        if (tx < st.tx1 && ty < st.ty1) tile_count[ty * gx + tx] = (uint32_t)diff[tid >> 2][tid & 3];
-    }
-}
-__global__ void __launch_bounds__(BIN_THREADS) bin_count_kernel(Batch<BinCountArgs> batch)
-{
-    int frame, bx;
-    batch_interleave1(frame, bx);
-    const BinCountArgs &a = batch.v[frame];
-    bin_count_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.tile_count);
-}
-
-
-// One workgroup: exclusive scan of the tile counts in tile order = ranges (untouched tiles keep (0,0) like
-// identifyTileRanges, rasterizer_impl.cu:287-295).
-// `capacity` = instances the caller's binning buffer holds: when the lists would not fit, every range is left empty
-// (nothing is written or rendered) and header[H_OVERFLOW] reports the number that was needed.
-struct TileScanArgs {
-    int T;
-    const uint32_t *tile_count;
-    uint2 *ranges;
-    uint32_t capacity;
-    uint32_t *header;
-};
-__device__ __forceinline__ void tile_scan_kernel_body(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
-                                                         uint32_t capacity, uint32_t *__restrict__ header)
-{
-    __shared__ uint32_t part[16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // every thread owns `per` consecutive tiles (a multiple of 4: 16-byte loads, several in flight -- one load per trip made this
-    // one-workgroup kernel a chain of load latencies: 51 us for the 32 400 tiles of a 4K frame); the counts stay in registers
-    // between the two passes when they fit (per <= 32: images up to 4K)
-    const int per = ((T + 1023) / 1024 + 3) / 4 * 4;
-    const int t0 = tid * per, t1 = min(T, t0 + per);
-    constexpr int KEEP = 32;
-    uint32_t cnt[KEEP];
-    const bool keep = per <= KEEP && (T & 3) == 0;           // (whole uint4 groups: t1 - t0 is a multiple of 4 as well)
-    uint32_t s = 0;
-    if (keep) {
-#pragma unroll
-        for (int k = 0; k < KEEP; k += 4) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k < per && t0 + k < t1) v = *reinterpret_cast<const uint4 *>(tile_count + t0 + k);
-            cnt[k] = v.x; cnt[k + 1] = v.y; cnt[k + 2] = v.z; cnt[k + 3] = v.w;
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-    } else {
-        for (int t = t0; t < t1; t++) s += tile_count[t];
-    }
-    uint32_t incl = s;                         // wavefront scan by shuffles, then the 16 wavefront totals
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up;
-    }
-    if (lane == WAVE - 1) part[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { wbase += w < wave ? part[w] : 0u; total += part[w]; }
-    const uint32_t band_over = header[H_BAND_OVERFLOW];
-    const bool fits = total <= capacity && band_over == 0u;
-    if (tid == 0) { header[H_TOTAL] = total; header[H_OVERFLOW] = fits ? 0u : max(total, band_over); }
-    uint32_t run = wbase + incl - s;
-    if (keep) {
-#pragma unroll
-        for (int k = 0; k < KEEP; k += 2) {
-            if (k < per && t0 + k < t1) {                     // two ranges = one 16-byte store
-                const uint32_t c0 = cnt[k], c1 = cnt[k + 1];
-                const uint2 r0 = (c0 && fits) ? make_uint2(run, run + c0) : make_uint2(0u, 0u);
-                run += c0;
-                const uint2 r1 = (c1 && fits) ? make_uint2(run, run + c1) : make_uint2(0u, 0u);
-                run += c1;
-                *reinterpret_cast<uint4 *>(ranges + t0 + k) = make_uint4(r0.x, r0.y, r1.x, r1.y);
-            }
-        }
-    } else {
-        for (int t = t0; t < t1; t++) {
-            const uint32_t c = tile_count[t];
-            ranges[t] = (c && fits) ? make_uint2(run, run + c) : make_uint2(0u, 0u);
-            run += c;
-        }
-    }
-}
-__global__ void __launch_bounds__(1024) tile_scan_kernel(Batch<TileScanArgs> batch)
-{
-    const TileScanArgs &a = batch.v[blockIdx.y];
-    tile_scan_kernel_body(a.T, a.tile_count, a.ranges, a.capacity, a.header);
-}
-
 
 // 16-bit mask of the tiles of the super-tile a rectangle covers (bit 4*y + x)
 __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
@@ -587,170 +442,243 @@ __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
     return row * spread;                       // row < 16: no carries between the nibbles
 }
 
-// Pass B: the lists.  Same walk; the rectangles that touch the 4x4 tiles are kept (in order) in LDS with the mask of
-// the tiles they cover.  A flush hands the buffered survivors out in slabs of 64 to the wavefronts; per slab and tile
-// a ballot gives the number of entries, a scan over the slabs gives every slab its place in each tile's list, and
-// the ids are appended with ballot-prefix compaction: every list comes out in depth order, without atomics or sorts.
+// The lists.  One workgroup per 4x4 tiles walks its band's depth-ordered rectangles; those that touch the 16 tiles are kept (in order)
+// in LDS with the mask of the tiles they cover.  Wavefront t owns tile t: it counts the kept entries that cover its tile, the
+// workgroup reserves room for its 16 lists behind whatever has been reserved so far (ONE atomic add on header[H_TOTAL] per
+// workgroup: the lists of a tile are contiguous and in depth order, the tiles of a frame lie in the order the workgroups got there --
+// `ranges` says where; nothing downstream assumes tile order), and every wavefront appends its tile's entries by ballot-prefix
+// compaction at its own cursor: no per-tile sort, no atomics on the lists.  Rounds 1-2 had a counting launch, a one-workgroup scan of
+// the tile counts and this launch: two walks of every band list and a serial kernel between them, 100 us per 4-frame step at C3.
+// A super-tile with more kept entries than the LDS buffer holds (8192) counts buffer by buffer and walks its band a second time.
+// When the lists do not fit the caller's buffer (`capacity`) the workgroup writes no list; header[H_OVERFLOW] ends up as the number
+// of instances needed, and the workgroup that builds the tile order one launch later (block_mask_kernel) empties every range.
 struct BinTilesArgs {
-    const uint32_t *header;
+    uint32_t *header;
     int gx;
     int gy;
     int band_rows;
     const uint32_t *band_info;
     const uint2 *band_rect;
     const uint32_t *band_id;
-    const uint2 *ranges;
+    uint2 *ranges;
     uint32_t *point_list;
-    int nblocks_tiles;
-    const uint32_t *tile_count;
-    uint32_t *tile_order;
-    const float *bg;
-    int normalize_depth;
-    uint32_t *bg_state;
+    uint32_t *tile_count;
+    uint32_t capacity;
     unsigned long long *dbg;
     uint32_t *tile_xy;       // BinBuf::tile_xy
 };
-__device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const uint32_t *__restrict__ header, int gx, int gy, int band_rows, const uint32_t *__restrict__ band_info,
-                 const uint2 *__restrict__ band_rect, const uint32_t *__restrict__ band_id, const uint2 *__restrict__ ranges,
-                 uint32_t *__restrict__ point_list, int nblocks_tiles, const uint32_t *__restrict__ tile_count,
-                 uint32_t *__restrict__ tile_order, const float *__restrict__ bg, int normalize_depth,
-                 uint32_t *__restrict__ bg_state, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ tile_xy)
+__device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTilesArgs &a)
 {
-    const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
+    const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
     unsigned long long dbg_flush = 0;
     int dbg_nflush = 0, dbg_hits = 0;
-    if (bx == nblocks_tiles) {
-        // the extra workgroup: longest-list-first order of the tiles for the blend launches (needs the counts only)
-        const int T = gx * gy;
-        tile_order_block(T, (T + 7) / 8 * 8, tile_count, ranges, tile_order, bg, normalize_depth, bg_state);
+    constexpr int NT = BIN_SUPER * BIN_SUPER;
+    static_assert(BIN_WAVES == NT && BIN_SUPER == 4, "one wavefront per tile of the 4x4 super-tile");
+    // The kept entries are buffered per ROW of tiles (an entry that spans rows is kept once per row): id << 4 | the columns of the
+    // row it covers.  A wavefront then only walks its own row's buffer -- a third of the entries of a dense super-tile, where a
+    // splat covers one or two tiles: the walks of the buffers are what the slowest workgroups of this launch spend their time on.
+    __shared__ uint32_t surv[BIN_SUPER][BIN_CAP];
+    __shared__ uint32_t tile_cnt[NT], tile_base[NT];
+    __shared__ uint32_t wave_cnt[2][BIN_WAVES * BIN_SUPER];
+    __shared__ int fits_s;
+    const uint32_t *__restrict__ header = a.header;
+    const int gx = a.gx, gy = a.gy;
+    const int band = band_of_block(bx, gx, a.band_rows);
+    const uint2 *__restrict__ rect_sorted = a.band_rect + a.band_info[band];      // this band's rectangles / ids, depth order
+    const uint32_t *__restrict__ ids_sorted = a.band_id + a.band_info[band];
+    const int P = header[H_NVIS] ? (int)a.band_info[BAND_MAX + band] : 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int my_row = wave >> 2, my_col = wave & 3;
+    const SuperTile st = super_tile_of(bx, gx, gy);
+    const int my_tx = st.tx0 + my_col, my_ty = st.ty0 + my_row;
+    const bool my_tile = my_tx < st.tx1 && my_ty < st.ty1;
+    uint32_t *__restrict__ point_list = a.point_list;
+    uint32_t *__restrict__ tile_xy = a.tile_xy;
+
+    // super-tiles outside the bounding box of all rectangles leave at once
+    const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
+    if (!(P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0)) {
+        if (lane == 0 && my_tile) { a.tile_count[my_ty * gx + my_tx] = 0u; a.ranges[my_ty * gx + my_tx] = make_uint2(0u, 0u); }
         return;
     }
-    constexpr int NT = BIN_SUPER * BIN_SUPER;
-    __shared__ uint32_t surv_mask[BIN_CAP], surv_id[BIN_CAP];
-    __shared__ uint32_t tile_cursor[NT];
-    __shared__ uint32_t wave_cnt[2][BIN_WAVES];
-    __shared__ int any_s;
-    const int band = band_of_block(bx, gx, band_rows);
-    const uint2 *__restrict__ rect_sorted = band_rect + band_info[band];      // this band's rectangles / ids, depth order
-    const uint32_t *__restrict__ ids_sorted = band_id + band_info[band];
-    const int P = header[H_NVIS] ? (int)band_info[BAND_MAX + band] : 0;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const SuperTile st = super_tile_of(bx, gx, gy);
 
-    if (tid == 0) any_s = 0;
-    lds_barrier();
-    if (tid < NT) {
-        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + (tid >> 2);
-        uint2 rg = make_uint2(0u, 0u);
-        if (tx < st.tx1 && ty < st.ty1) rg = ranges[ty * gx + tx];
-        tile_cursor[tid] = rg.x;
-        if (rg.y != rg.x) any_s = 1;
-    }
-    lds_barrier();
-    if (!any_s) return;                           // no Gaussian touches these 16 tiles
-
-    // Flush: wavefront t owns tile t of the super-tile (16 wavefronts, 16 tiles) and walks the buffered survivors slab by
-    // slab; the entries that cover its tile are appended to the tile's list by ballot-prefix compaction at the wavefront's own
-    // running cursor -- one pass, no counting phase, no barrier between slabs; lists stay in depth order.
-    static_assert(BIN_WAVES == NT, "one wavefront per tile of the super-tile");
-    int nbuf = 0;
-    uint32_t cursor = tile_cursor[wave];          // next free position of this wavefront's tile list
-    const uint32_t my_xy = ((uint32_t)(st.ty0 + (wave >> 2)) << 16) | (uint32_t)(st.tx0 + (wave & 3));   // ... and whose list it is (block masks)
-    auto flush = [&]() {
-        const unsigned long long f0 = dbg ? wall_clock64() : 0ull;
-        dbg_nflush++; dbg_hits += nbuf;
+    int nbuf[BIN_SUPER] = {0, 0, 0, 0};           // entries buffered per row (the same in every wavefront)
+    uint32_t cnt = 0;                             // entries of this wavefront's tile
+    uint32_t cursor = 0;                          // next free position of this wavefront's tile list
+    const uint32_t my_xy = ((uint32_t)my_ty << 16) | (uint32_t)my_tx;           // whose list it is (block masks)
+    constexpr int FU = 8;                         // slabs per round: their LDS reads are in flight together
+    auto my_nbuf = [&]() { return my_row == 0 ? nbuf[0] : my_row == 1 ? nbuf[1] : my_row == 2 ? nbuf[2] : nbuf[3]; };
+    // the buffered entries that cover this wavefront's tile: counted ...
+    auto count_buffer = [&]() {
         lds_barrier();                                // the survivors of the last trip are in LDS
-        const int nslab = (nbuf + WAVE - 1) / WAVE;
-        constexpr int FU = 8;                          // slabs per round: their LDS reads are in flight together
+        const int n = my_nbuf(), nslab = (n + WAVE - 1) / WAVE;
         for (int sl = 0; sl < nslab; sl += FU) {
-            uint32_t m[FU], id[FU];
+            uint32_t m[FU];
 #pragma unroll
             for (int u = 0; u < FU; u++) {
                 const int e = (sl + u) * WAVE + lane;
-                m[u] = e < nbuf ? surv_mask[e] : 0u;
-                id[u] = surv_id[min(e, BIN_CAP - 1)];
+                m[u] = e < n ? surv[my_row][e] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < FU; u++) cnt += (uint32_t)__builtin_popcountll(__ballot((m[u] >> my_col) & 1u));
+        }
+    };
+    // ... and appended to the tile's list, slab by slab, at the wavefront's own running cursor -- one pass, no barrier between slabs;
+    // lists stay in depth order
+    auto flush = [&]() {
+        const unsigned long long f0 = a.dbg ? wall_clock64() : 0ull;
+        dbg_nflush++; dbg_hits += nbuf[0] + nbuf[1] + nbuf[2] + nbuf[3];
+        lds_barrier();
+        const int n = my_nbuf(), nslab = (n + WAVE - 1) / WAVE;
+        for (int sl = 0; sl < nslab; sl += FU) {
+            uint32_t m[FU];
+#pragma unroll
+            for (int u = 0; u < FU; u++) {
+                const int e = (sl + u) * WAVE + lane;
+                m[u] = e < n ? surv[my_row][e] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < FU; u++) {
-                const bool h = (m[u] >> wave) & 1u;
+                const bool h = (m[u] >> my_col) & 1u;
                 const unsigned long long bal = __ballot(h);
                 if (h) {
                     const uint32_t at = cursor + (uint32_t)prefix_in_mask(bal);
-                    point_list[at] = id[u];
+                    point_list[at] = m[u] >> 4;
                     tile_xy[at] = my_xy;
                 }
                 cursor += (uint32_t)__builtin_popcountll(bal);
             }
         }
-        lds_barrier();                                // the buffer may be overwritten
-        nbuf = 0;
-        if (dbg) dbg_flush += wall_clock64() - f0;
+        if (a.dbg) dbg_flush += wall_clock64() - f0;
     };
 
-    // wavefront w scans the contiguous slice [base + w*512, base + (w+1)*512) of every trip: survivors stay in depth
-    // order when the wavefronts append one after the other.  The next trip's loads are issued before this one is used.
-    uint2 rc[BIN_UNROLL];
-    uint32_t id[BIN_UNROLL];
-    {
-        const int k0 = wave * (WAVE * BIN_UNROLL) + lane;
-#pragma unroll
-        for (int j = 0; j < BIN_UNROLL; j++) {
-            const int k = k0 + j * WAVE;
-            rc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
-            id[j] = k < P ? ids_sorted[k] : 0u;
-        }
-    }
-    auto append = [&](uint32_t at, const unsigned long long (&hits)[BIN_UNROLL]) {
-#pragma unroll
-        for (int j = 0; j < BIN_UNROLL; j++) {
-            if ((hits[j] >> lane) & 1ull) {
-                const uint32_t pos = at + (uint32_t)prefix_in_mask(hits[j]);
-                surv_mask[pos] = cover_mask(rc[j], st);
-                surv_id[pos] = id[j];
-            }
-            at += (uint32_t)__builtin_popcountll(hits[j]);
-        }
-    };
-    int parity = 0;
-    for (int base = 0; base < P; base += BIN_CHUNK, parity ^= 1) {
-        uint2 nrc[BIN_UNROLL];
-        uint32_t nid[BIN_UNROLL];
+    // The walk: wavefront w scans the contiguous slice [base + w*256, base + (w+1)*256) of every trip: survivors stay in depth
+    // order when the wavefronts append one after the other.  The next trip's loads are issued before this one is used.  `drain`
+    // empties the buffers when the next trip's survivors would not fit.
+    auto walk = [&](auto &&drain) {
+        uint2 rc[BIN_UNROLL];
+        uint32_t id[BIN_UNROLL];
         {
-            const int k0 = base + BIN_CHUNK + wave * (WAVE * BIN_UNROLL) + lane;
+            const int k0 = wave * (WAVE * BIN_UNROLL) + lane;
 #pragma unroll
             for (int j = 0; j < BIN_UNROLL; j++) {
                 const int k = k0 + j * WAVE;
-                nrc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
-                nid[j] = k < P ? ids_sorted[k] : 0u;
+                rc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
+                id[j] = k < P ? ids_sorted[k] : 0u;
             }
         }
-        unsigned long long hits[BIN_UNROLL];
-        uint32_t mine = 0;
+        int parity = 0;
+        for (int base = 0; base < P; base += BIN_CHUNK, parity ^= 1) {
+            uint2 nrc[BIN_UNROLL];
+            uint32_t nid[BIN_UNROLL];
+            {
+                const int k0 = base + BIN_CHUNK + wave * (WAVE * BIN_UNROLL) + lane;
 #pragma unroll
-        for (int j = 0; j < BIN_UNROLL; j++) {
-            hits[j] = __ballot(rect_hits(rc[j], st));
-            mine += (uint32_t)__builtin_popcountll(hits[j]);
+                for (int j = 0; j < BIN_UNROLL; j++) {
+                    const int k = k0 + j * WAVE;
+                    nrc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
+                    nid[j] = k < P ? ids_sorted[k] : 0u;
+                }
+            }
+            // rows / columns of the super-tile a rectangle covers (0 when it misses the super-tile)
+            uint32_t rows[BIN_UNROLL], cols[BIN_UNROLL];
+            unsigned long long hits[BIN_UNROLL][BIN_SUPER];
+            uint32_t mine[BIN_SUPER] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < BIN_UNROLL; j++) {
+                const bool hit = rect_hits(rc[j], st);
+                const int x0 = max((int)(rc[j].x & 0xFFFFu), st.tx0) - st.tx0, x1 = min((int)(rc[j].x >> 16), st.tx1) - st.tx0;
+                const int y0 = max((int)(rc[j].y & 0xFFFFu), st.ty0) - st.ty0, y1 = min((int)(rc[j].y >> 16), st.ty1) - st.ty0;
+                rows[j] = hit ? ((1u << y1) - (1u << y0)) : 0u;
+                cols[j] = (1u << x1) - (1u << x0);
+#pragma unroll
+                for (int r = 0; r < BIN_SUPER; r++) {
+                    hits[j][r] = __ballot((rows[j] >> r) & 1u);
+                    mine[r] += (uint32_t)__builtin_popcountll(hits[j][r]);
+                }
+            }
+            if (lane < BIN_SUPER) wave_cnt[parity][wave * BIN_SUPER + lane] = lane == 0 ? mine[0] : lane == 1 ? mine[1] : lane == 2 ? mine[2] : mine[3];
+            lds_barrier();
+            // lane (w, r) holds wavefront w's count of row r: sums over the wavefronts before this one / over all of them
+            uint32_t before, all;
+            {
+                const uint32_t c = wave_cnt[parity][lane];
+                before = (lane >> 2) < wave ? c : 0u;
+                all = c;
+#pragma unroll
+                for (int d = 4; d < WAVE; d <<= 1) {
+                    before += (uint32_t)__shfl_xor((int)before, d);
+                    all += (uint32_t)__shfl_xor((int)all, d);
+                }
+            }
+            uint32_t off[BIN_SUPER], total[BIN_SUPER];
+            bool any = false, room = true;
+#pragma unroll
+            for (int r = 0; r < BIN_SUPER; r++) {
+                off[r] = (uint32_t)__builtin_amdgcn_readlane((int)before, r);
+                total[r] = (uint32_t)__builtin_amdgcn_readlane((int)all, r);
+                any = any || total[r] != 0u;
+                room = room && nbuf[r] + (int)total[r] <= BIN_CAP;
+            }
+            if (any) {
+                if (!room) drain();                                  // total <= BIN_CHUNK = BIN_CAP: after a drain a trip always fits
+#pragma unroll
+                for (int r = 0; r < BIN_SUPER; r++) {
+                    uint32_t at = (uint32_t)nbuf[r] + off[r];
+#pragma unroll
+                    for (int j = 0; j < BIN_UNROLL; j++) {
+                        if ((hits[j][r] >> lane) & 1ull) surv[r][at + (uint32_t)prefix_in_mask(hits[j][r])] = (id[j] << 4) | cols[j];
+                        at += (uint32_t)__builtin_popcountll(hits[j][r]);
+                    }
+                    nbuf[r] += (int)total[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BIN_UNROLL; j++) { rc[j] = nrc[j]; id[j] = nid[j]; }
         }
-        if (lane == 0) wave_cnt[parity][wave] = mine;
+    };
+    auto clear = [&]() {
         lds_barrier();
-        uint32_t off = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < BIN_WAVES; w++) {
-            const uint32_t c = wave_cnt[parity][w];
-            off += w < wave ? c : 0u;
-            total += c;
-        }
-        if (total != 0u) {
-            if (nbuf + (int)total > BIN_CAP) flush();          // total <= BIN_CHUNK = BIN_CAP: after a flush a trip always fits
-            append((uint32_t)nbuf + off, hits);
-            nbuf += (int)total;
+        for (int r = 0; r < BIN_SUPER; r++) nbuf[r] = 0;
+    };
+
+    bool several = false;                         // more survivors than the buffers hold: counted buffer by buffer, walked twice
+    walk([&]() { count_buffer(); clear(); several = true; });
+    count_buffer();                               // (the last buffers stay where they are)
+    if (lane == 0) tile_cnt[wave] = cnt;
+    lds_barrier();
+    if (tid == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) { tile_base[t] = sum; sum += tile_cnt[t]; }
+        uint32_t start = 0;
+        bool fits = true;
+        if (sum) {
+            start = atomicAdd(&a.header[H_TOTAL], sum);
+            fits = (uint64_t)start + sum <= (uint64_t)a.capacity;
+            if (!fits) atomicMax(&a.header[H_OVERFLOW], start + sum);     // the last one to get here leaves the number needed
         }
 #pragma unroll
-        for (int j = 0; j < BIN_UNROLL; j++) { rc[j] = nrc[j]; id[j] = nid[j]; }
+        for (int t = 0; t < NT; t++) tile_base[t] += start;
+        fits_s = fits ? 1 : 0;
     }
-    flush();
-    if (dbg && tid == 0) {
-        unsigned long long *w = dbg + (size_t)bx * 4;
+    lds_barrier();
+    const bool fits = fits_s != 0;
+    cursor = tile_base[wave];
+    if (lane == 0 && my_tile) {
+        a.tile_count[my_ty * gx + my_tx] = cnt;
+        a.ranges[my_ty * gx + my_tx] = (cnt && fits) ? make_uint2(cursor, cursor + cnt) : make_uint2(0u, 0u);
+    }
+    if (fits) {
+        if (several) {
+            clear();
+            walk([&]() { flush(); clear(); });
+        }
+        flush();
+    }
+    if (a.dbg && tid == 0) {
+        unsigned long long *w = a.dbg + (size_t)bx * 4;
         w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits; w[3] = (unsigned long long)P;
     }
 }
@@ -758,8 +686,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesAr
 {
     int frame, bx;
     batch_interleave1(frame, bx);
-    const BinTilesArgs &a = batch.v[frame];
-    bin_tiles_kernel_body(bx, a.header, a.gx, a.gy, a.band_rows, a.band_info, a.band_rect, a.band_id, a.ranges, a.point_list, a.nblocks_tiles, a.tile_count, a.tile_order, a.bg, a.normalize_depth, a.bg_state, a.dbg, a.tile_xy);
+    bin_tiles_kernel_body(bx, batch.v[frame]);
 }
 
 
@@ -788,6 +715,7 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
 
 int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t capacity, hipStream_t stream)
 {
+    if (prm.P >= (1 << 28)) { set_error("tile binning packs a Gaussian's index into 28 bits: P = %d is too large", prm.P); return 1; }
     const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, nsy = (gy + BIN_SUPER - 1) / BIN_SUPER;
     {
@@ -814,30 +742,28 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         StageTimer timer(ST_RANGES, stream);
         SOAR_LAUNCH_BATCHED(band_count_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
         SOAR_LAUNCH_BATCHED(band_place_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
-        const BinCountArgs bc = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, img.tile_count};
-        SOAR_LAUNCH_BATCHED(bin_count_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bc);
-        const TileScanArgs ts = {gx * gy, img.tile_count, img.ranges, ba.capacity, g.header};
-        SOAR_LAUNCH_BATCHED(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
     }
-    SOAR_LAUNCH_OK("tile_ranges", stream, prm.debug);
+    SOAR_LAUNCH_OK("band_lists", stream, prm.debug);
     {
         StageTimer timer(ST_EMIT_KEYS, stream);
         unsigned long long *dbg = nullptr;
         static int dbg_left = getenv("SOAR_BIN_LOG") ? 1 : 0;          // diagnostic: per-workgroup timings of ONE launch
-        if (dbg_left > 0 && prm.W >= 1920) {
+        const bool log_now = dbg_left > 0 && prm.W >= 1920 && !batch_ctx().n;
+        if (log_now) {
             dbg_left = 0;
-            const size_t nw = (size_t)(nsx * nsy + 1) * 4;
-            SOAR_HIP_OK(hipMalloc(&dbg, 8 * nw));
-            SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * nw, stream));
-            const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
-                                     img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg, b.tile_xy};
-            SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
+            SOAR_HIP_OK(hipMalloc(&dbg, 8 * (size_t)(nsx * nsy) * 4));
+            SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * (size_t)(nsx * nsy) * 4, stream));
+        }
+        const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted,
+                                 img.tile_count, ba.capacity, dbg, b.tile_xy};
+        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bt);
+        if (log_now) {
+            const size_t nw = (size_t)(nsx * nsy) * 4;
             SOAR_HIP_OK(hipStreamSynchronize(stream));
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
             SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
             (void)hipFree(dbg);
-            // the five slowest workgroups
-            for (int rep = 0; rep < 5; rep++) {
+            for (int rep = 0; rep < 5; rep++) {             // the five slowest workgroups
                 int best = -1;
                 for (int i = 0; i < nsx * nsy; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
                 fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, %.1f us in %llu flushes, %llu survivors of %llu band entries\n", best,
@@ -845,11 +771,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
                 h[best * 4] = 0;
             }
             free(h);
-            return 0;
         }
-        const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted, nsx * nsy,
-                                 img.tile_count, img.tile_order, prm.bg_dev, prm.cfg_normalize_depth, img.bg_state, dbg, b.tile_xy};
-        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy + 1), dim3(BIN_THREADS), 0, stream, bt);
     }
     SOAR_LAUNCH_OK("bin_tiles", stream, prm.debug);
     return 0;

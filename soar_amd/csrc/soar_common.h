@@ -300,28 +300,32 @@ __device__ __forceinline__ uint32_t class_slot(uint32_t *counter, int cls, bool 
     return base + (uint32_t)rank;
 }
 
-// One 1024-thread workgroup: `order` = tile ids, longest list first.  Lengths from the tile counts when given (tile binning:
-// the ranges are written by a kernel this one may run beside), else from the ranges (descending / key-sort path).
+// One workgroup (any size): `order` = tile ids, longest list first.  Lengths from the tile counts when given (tile binning), else
+// from the ranges (descending / key-sort path).  `empty_ranges` != NULL: the lists did not fit the caller's buffer -- every tile
+// counts as empty and every range is emptied (nothing is rendered; whichever lists were written before the overflow are dropped).
 static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const uint32_t *tile_count, const uint2 *ranges, uint32_t *order,
-                                                        const float *bg, int normalize_depth, uint32_t *bg_state)
+                                                        const float *bg, int normalize_depth, uint32_t *bg_state,
+                                                        uint2 *empty_ranges = nullptr)
 {
     __shared__ uint32_t count[16], cursor[16];
-    const int tid = threadIdx.x;
-    auto len_of = [&](int t) -> uint32_t { return tile_count ? tile_count[t] : ranges[t].y - ranges[t].x; };
+    const int tid = threadIdx.x, NTH = (int)blockDim.x;
+    auto len_of = [&](int t) -> uint32_t { return empty_ranges ? 0u : tile_count ? tile_count[t] : ranges[t].y - ranges[t].x; };
     if (tid < 16) count[tid] = 0u;
     __syncthreads();
+    if (empty_ranges)
+        for (int t = tid; t < T; t += NTH) empty_ranges[t] = make_uint2(0u, 0u);
     // eight lengths per thread in flight per trip (one load per trip would make both passes a chain of load latencies)
-    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
+    for (int t0 = 0; t0 < T; t0 += 8 * NTH) {
         uint32_t len[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
+            const int t = t0 + k * NTH + tid;
             len[k] = t < T ? len_of(t) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int cls = 15 - min(15, 32 - __clz((int)len[k]));   // class 0: >= 16384 entries ... class 15: empty
-            (void)class_slot(count, cls, t0 + k * 1024 + tid < T);
+            (void)class_slot(count, cls, t0 + k * NTH + tid < T);
         }
     }
     __syncthreads();
@@ -330,22 +334,22 @@ static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const u
         for (int k = 0; k < 16; k++) { cursor[k] = acc; acc += count[k]; }
     }
     __syncthreads();
-    for (int t0 = 0; t0 < T; t0 += 8 * 1024) {
+    for (int t0 = 0; t0 < T; t0 += 8 * NTH) {
         uint32_t len[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
+            const int t = t0 + k * NTH + tid;
             len[k] = t < T ? len_of(t) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int t = t0 + k * 1024 + tid;
+            const int t = t0 + k * NTH + tid;
             const int cls = 15 - min(15, 32 - __clz((int)len[k]));
             const uint32_t at = class_slot(cursor, cls, t < T);
             if (t < T) order[at] = (uint32_t)t;
         }
     }
-    for (int t = T + tid; t < Tpad; t += 1024) order[t] = 0xFFFFFFFFu;
+    for (int t = T + tid; t < Tpad; t += NTH) order[t] = 0xFFFFFFFFu;
     if (tid == 0) order[Tpad] = (uint32_t)T - count[15];                 // tiles with a non-empty list (class 15 = empty)
     // is the background of this frame the one the flagged tiles (ImageBuf::bg_tiles) were filled with?  Decided here, one
     // launch before the forward blend reads it, so that no workgroup of the blend sees the state change under it
@@ -393,7 +397,7 @@ inline int blend_grid_ranks(int ntiles)
 // which entries can reach alpha >= 1/255 anywhere in which block of their tile (splat_may_touch_rect: conservative, so dropping
 // the others changes no result): one bit per (block, list position), BinBuf::block_masks[block][position >> 6] bit position & 63.
 // A word may hold positions of two or more tiles (lists follow each other without padding): a reader masks it to its own range.
-int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, int64_t R, hipStream_t stream);
+int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream);
 
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
                           float *out_color, float *out_normal, float *out_depth, float *out_opac,

@@ -189,6 +189,9 @@ FORWARD_SCENES = [
     lambda: S.person_scene(config=(1, 1, 1, 0), seed=8, opacity=None, distance=1.2),
     lambda: S.person_scene(P=20000, config=(1, 1, 1, 0), seed=9, name="dense_person_P20000"),
     lambda: S.person_scene(P=20000, config=(1, 1, 1, 0), seed=10, sort_descending=True, distance=1.5, name="dense_close_desc"),
+    # a whole person inside two or three 64x64-pixel super-tiles: more kept entries per row of tiles than the tile binning buffers in
+    # LDS (4096), so the workgroups count buffer by buffer and walk their band twice (rast_tilebin.hip)
+    lambda: S.person_scene(P=40000, config=(1, 1, 1, 0), seed=13, distance=5.0, name="far_dense_person_P40000"),
     lambda: S.blob_scene(),
     lambda: S.blob_scene(use_sh=True, sh_degree=3, seed=2),
     lambda: S.blob_scene(use_sh=True, sh_degree=1, seed=3),
