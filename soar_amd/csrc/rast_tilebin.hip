@@ -3,8 +3,10 @@
 // Produces exactly what duplicateWithKeys + cub::DeviceRadixSort::SortPairs + identifyTileRanges produce for the
 // ascending sort (DGR/cuda_rasterizer/rasterizer_impl.cu:66-124, 266-295): for every tile the list of Gaussians whose
 // rectangle covers it, ordered by view depth, ties by Gaussian index (a stable sort of keys emitted in index order),
-// laid out tile after tile (`point_list`), plus `ranges`.  The reference sorts R = sum(tiles_touched) 64-bit keys
-// (7.6e5 at 100k Gaussians / 1080p); the library sort that does this here is ~20 launch-bound kernels, 180 us.
+// plus `ranges`.  (The reference lays the lists out tile after tile; here every tile's list is contiguous and `ranges` says where,
+// but the tiles follow each other in the order their workgroups reserved room -- soar_rast_export_state re-packs for inspection.)
+// The reference sorts R = sum(tiles_touched) 64-bit keys (7.6e5 at 100k Gaussians / 1080p); the library sort that does this here
+// is ~20 launch-bound kernels, 180 us.
 //
 // Same result from the structure of the problem instead:
 //   1. bucket_count / bucket_scatter / bucket_sort: depth order of the P (not R) Gaussians -- monotone buckets of the key
@@ -12,12 +14,13 @@
 //   2. band_count / band_place: the depth-ordered rectangles are split -- stably, by ballot-prefix compaction, no atomics --
 //      into one list per BAND of tile rows (a band = the rows of one super-tile row, or a few of them on very tall images).
 //      A super-tile only has to look at its own band's list (~1/10 of the Gaussians at 1080p) instead of all of them.
-//   3. bin_count: one workgroup per super-tile (4x4 tiles) walks its band list and counts the instances of its 16 tiles on a
-//      5x5 difference grid in LDS; tile_scan: exclusive scan of the tile counts = `ranges` (+ capacity check).
-//   4. bin_tiles: same walk; the rectangles that touch the super-tile are kept (in order) with the mask of the tiles they
-//      cover and appended to each covered tile's list with ballot-prefix compaction: every list comes out in depth order
-//      with no per-tile sort and no atomics.  One extra workgroup of the same launch builds the longest-list-first tile
-//      order of the blend kernels (it only needs the tile counts).
+//   3. bin_tiles: one workgroup per super-tile (4x4 tiles) walks its band list twice.  First pass: the sizes of its 16 lists, in
+//      byte-wide counters in registers; then ONE atomic add reserves room for the 16 lists (ranges, capacity check).  Second pass:
+//      the rectangles that touch the super-tile are kept (in order, per row of tiles) and appended to each covered tile's list with
+//      ballot-prefix compaction: every list comes out in depth order with no per-tile sort and no atomics on the lists.
+//      (Rounds 1-2: a counting launch on an LDS difference grid, a one-workgroup scan of the tile counts, then the placing launch.)
+//   The longest-list-first tile order of the blend kernels needs every tile's count: one workgroup of the NEXT launch builds it
+//   (block_mask_kernel, rast_blockmask.hip).
 // The descending sort (back views) keeps the library path (rast_binning.hip).
 #include "soar_common.h"
 
@@ -508,23 +511,8 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
     const uint32_t my_xy = ((uint32_t)my_ty << 16) | (uint32_t)my_tx;           // whose list it is (block masks)
     constexpr int FU = 8;                         // slabs per round: their LDS reads are in flight together
     auto my_nbuf = [&]() { return my_row == 0 ? nbuf[0] : my_row == 1 ? nbuf[1] : my_row == 2 ? nbuf[2] : nbuf[3]; };
-    // the buffered entries that cover this wavefront's tile: counted ...
-    auto count_buffer = [&]() {
-        lds_barrier();                                // the survivors of the last trip are in LDS
-        const int n = my_nbuf(), nslab = (n + WAVE - 1) / WAVE;
-        for (int sl = 0; sl < nslab; sl += FU) {
-            uint32_t m[FU];
-#pragma unroll
-            for (int u = 0; u < FU; u++) {
-                const int e = (sl + u) * WAVE + lane;
-                m[u] = e < n ? surv[my_row][e] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < FU; u++) cnt += (uint32_t)__builtin_popcountll(__ballot((m[u] >> my_col) & 1u));
-        }
-    };
-    // ... and appended to the tile's list, slab by slab, at the wavefront's own running cursor -- one pass, no barrier between slabs;
-    // lists stay in depth order
+    // The buffered entries that cover this wavefront's tile are appended to the tile's list, slab by slab, at the wavefront's own
+    // running cursor -- one pass, no barrier between slabs; lists stay in depth order
     auto flush = [&]() {
         const unsigned long long f0 = a.dbg ? wall_clock64() : 0ull;
         dbg_nflush++; dbg_hits += nbuf[0] + nbuf[1] + nbuf[2] + nbuf[3];
@@ -556,15 +544,17 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
     // order when the wavefronts append one after the other.  The next trip's loads are issued before this one is used.  `drain`
     // empties the buffers when the next trip's survivors would not fit.
     auto walk = [&](auto &&drain) {
+        // (loads behind the end of the list are clamped, not skipped: a load under a branch makes the compiler wait for ALL loads
+        // in flight at the next use of any of them -- s_waitcnt vmcnt(1) right behind the prefetch -- and the prefetch hides nothing)
         uint2 rc[BIN_UNROLL];
         uint32_t id[BIN_UNROLL];
         {
             const int k0 = wave * (WAVE * BIN_UNROLL) + lane;
 #pragma unroll
             for (int j = 0; j < BIN_UNROLL; j++) {
-                const int k = k0 + j * WAVE;
-                rc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
-                id[j] = k < P ? ids_sorted[k] : 0u;
+                const int k = min(k0 + j * WAVE, P - 1);
+                rc[j] = rect_sorted[k];
+                id[j] = ids_sorted[k];
             }
         }
         int parity = 0;
@@ -575,9 +565,9 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
                 const int k0 = base + BIN_CHUNK + wave * (WAVE * BIN_UNROLL) + lane;
 #pragma unroll
                 for (int j = 0; j < BIN_UNROLL; j++) {
-                    const int k = k0 + j * WAVE;
-                    nrc[j] = k < P ? rect_sorted[k] : make_uint2(0u, 0u);
-                    nid[j] = k < P ? ids_sorted[k] : 0u;
+                    const int k = min(k0 + j * WAVE, P - 1);
+                    nrc[j] = rect_sorted[k];
+                    nid[j] = ids_sorted[k];
                 }
             }
             // rows / columns of the super-tile a rectangle covers (0 when it misses the super-tile)
@@ -586,7 +576,7 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
             uint32_t mine[BIN_SUPER] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < BIN_UNROLL; j++) {
-                const bool hit = rect_hits(rc[j], st);
+                const bool hit = base + wave * (WAVE * BIN_UNROLL) + j * WAVE + lane < P && rect_hits(rc[j], st);
                 const int x0 = max((int)(rc[j].x & 0xFFFFu), st.tx0) - st.tx0, x1 = min((int)(rc[j].x >> 16), st.tx1) - st.tx0;
                 const int y0 = max((int)(rc[j].y & 0xFFFFu), st.ty0) - st.ty0, y1 = min((int)(rc[j].y >> 16), st.ty1) - st.ty0;
                 rows[j] = hit ? ((1u << y1) - (1u << y0)) : 0u;
@@ -643,10 +633,56 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
         for (int r = 0; r < BIN_SUPER; r++) nbuf[r] = 0;
     };
 
-    bool several = false;                         // more survivors than the buffers hold: counted buffer by buffer, walked twice
-    walk([&]() { count_buffer(); clear(); several = true; });
-    count_buffer();                               // (the last buffers stay where they are)
-    if (lane == 0) tile_cnt[wave] = cnt;
+    // Pass 1, the sizes of the 16 lists: every wavefront walks its share of the band with 16 byte-wide counters per lane (the cover
+    // mask of a rectangle spread over four registers, one add each) -- no LDS, no ballots, no barriers; the counters are folded
+    // (wavefront sum, then 16 LDS atomics per wavefront) before a byte could overflow and at the end.
+    if (tid < NT) tile_cnt[tid] = 0u;
+    lds_barrier();
+    {
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};
+        auto fold = [&]() {
+            uint32_t part[8];
+#pragma unroll
+            for (int d = 0; d < 4; d++) { part[2 * d] = acc[d] & 0x00FF00FFu; part[2 * d + 1] = (acc[d] >> 8) & 0x00FF00FFu; acc[d] = 0u; }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) part[q] += (uint32_t)__shfl_xor((int)part[q], d);
+            // part[2d] = tiles 4d (low half) and 4d+2 (high half), part[2d+1] = tiles 4d+1 and 4d+3
+            if (lane < NT) {
+                const int d = lane >> 2, k = lane & 3;
+                const uint32_t w = (k & 1) ? (d == 0 ? part[1] : d == 1 ? part[3] : d == 2 ? part[5] : part[7])
+                                           : (d == 0 ? part[0] : d == 1 ? part[2] : d == 2 ? part[4] : part[6]);
+                const uint32_t c = (k & 2) ? w >> 16 : w & 0xFFFFu;
+                if (c) atomicAdd(&tile_cnt[lane], c);
+            }
+        };
+        constexpr int CU_ = 8;                    // rectangles per lane and trip of this pass
+        constexpr int CCHUNK = BIN_THREADS * CU_;
+        int since = 0;
+        uint2 rc[CU_];
+#pragma unroll
+        for (int j = 0; j < CU_; j++) rc[j] = rect_sorted[min(wave * (WAVE * CU_) + j * WAVE + lane, P - 1)];
+        for (int base = 0; base < P; base += CCHUNK) {
+            uint2 nrc[CU_];
+#pragma unroll
+            for (int j = 0; j < CU_; j++) nrc[j] = rect_sorted[min(base + CCHUNK + wave * (WAVE * CU_) + j * WAVE + lane, P - 1)];
+#pragma unroll
+            for (int j = 0; j < CU_; j++) {
+                const bool hit = base + wave * (WAVE * CU_) + j * WAVE + lane < P && rect_hits(rc[j], st);
+                const uint32_t m = hit ? cover_mask(rc[j], st) : 0u;
+#pragma unroll
+                for (int d = 0; d < 4; d++) acc[d] += (((m >> (4 * d)) & 15u) * 0x00204081u) & 0x01010101u;
+                rc[j] = nrc[j];
+            }
+            since += CU_;
+            if (since > 255 - CU_) { fold(); since = 0; }
+        }
+        fold();
+    }
+    lds_barrier();
+    cnt = tile_cnt[wave];
+    const unsigned long long dbg_t1 = a.dbg ? wall_clock64() : 0ull;
     lds_barrier();
     if (tid == 0) {
         uint32_t sum = 0;
@@ -661,25 +697,24 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) tile_base[t] += start;
-        fits_s = fits ? 1 : 0;
+        fits_s = (fits ? 1 : 0) | (sum ? 2 : 0);
     }
     lds_barrier();
-    const bool fits = fits_s != 0;
+    const bool fits = (fits_s & 1) != 0, cnt_total_nonzero = (fits_s & 2) != 0;
     cursor = tile_base[wave];
     if (lane == 0 && my_tile) {
         a.tile_count[my_ty * gx + my_tx] = cnt;
         a.ranges[my_ty * gx + my_tx] = (cnt && fits) ? make_uint2(cursor, cursor + cnt) : make_uint2(0u, 0u);
     }
-    if (fits) {
-        if (several) {
-            clear();
-            walk([&]() { flush(); clear(); });
-        }
+    if (fits && cnt_total_nonzero) {
+        // Pass 2: the walk that keeps the entries, flushing the buffers whenever the next trip's entries would not fit
+        walk([&]() { flush(); clear(); });
         flush();
     }
     if (a.dbg && tid == 0) {
         unsigned long long *w = a.dbg + (size_t)bx * 4;
-        w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits; w[3] = (unsigned long long)P;
+        w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits;
+        w[3] = ((dbg_t1 - dbg_t0) << 32) | (unsigned long long)P;
     }
 }
 __global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesArgs> batch)
@@ -766,8 +801,9 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             for (int rep = 0; rep < 5; rep++) {             // the five slowest workgroups
                 int best = -1;
                 for (int i = 0; i < nsx * nsy; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
-                fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, %.1f us in %llu flushes, %llu survivors of %llu band entries\n", best,
-                        h[best * 4] / 100.0, h[best * 4 + 1] / 100.0, h[best * 4 + 2] >> 32, h[best * 4 + 2] & 0xFFFFFFFFull, h[best * 4 + 3]);
+                fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, first walk %.1f us, %.1f us in %llu flushes, %llu kept entries of %llu band entries\n",
+                        best, h[best * 4] / 100.0, (h[best * 4 + 3] >> 32) / 100.0, h[best * 4 + 1] / 100.0, h[best * 4 + 2] >> 32,
+                        h[best * 4 + 2] & 0xFFFFFFFFull, h[best * 4 + 3] & 0xFFFFFFFFull);
                 h[best * 4] = 0;
             }
             free(h);
