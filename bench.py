@@ -54,32 +54,44 @@ STAGE_KERNELS = {
     "preprocess": ["preprocess_kernel", "zero_ranges_kernel"],
     "scan": ["rocprim inclusive_scan (synchronous form / key export only)"],
     "depth_order": ["bucket_sort_kernel", "bucket_count_kernel", "bucket_scatter_kernel"],
-    "tile_ranges": ["bin_count_kernel", "tile_scan_kernel", "band_count_kernel", "band_place_kernel"],
-    "tile_lists": ["bin_tiles_kernel", "(its last workgroup builds the tile order)"],
+    "tile_ranges": ["band_place_kernel", "band_count_kernel"],
+    "tile_lists": ["bin_tiles_kernel"],
     "render_forward": ["render_forward_kernel"],
     "render_backward": ["render_backward_blocks_kernel", "zero_ranges_kernel"],
-    "block_masks": ["block_mask_kernel"],
+    "block_masks": ["block_mask_kernel", "(one of its workgroups builds the tile order)"],
     "geometry_backward": ["geometry_backward_kernel"],
-    "lbs_knn_weights": ["knn_refresh_kernel", "knn_cell_kernel + query sort + item order (the full search, every 64th step)"],
+    "lbs_knn_weights": ["knn_follow_kernel", "knn_search_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
     "optimizer": ["adam_update_kernel", "adam_tick_kernel"],
     "lbs_warp_forward": ["warp_forward_kernel"],
     "lbs_warp_backward": ["warp_backward_kernel"],
     "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel"],
 }
+PMC_JSON = None               # --pmc-json: the counter summary to quote instead of the newest committed one
 
 
 def measured_traffic(stage):
-    """(HBM bytes per launch, source file) of the stage's main kernel from the newest COMMITTED PMC summary
-    (profiles/*_hbm_traffic.json; collected with scripts/profile_round.sh, FETCH_SIZE / WRITE_SIZE in separate rocprofv3
-    passes, gfx950 correction applied there).  Not measured in this run: the JSON line says where it comes from."""
+    """(HBM bytes per launch, source file) of the stage's main kernel from a PMC summary: --pmc-json, else the newest COMMITTED
+    one (profiles/*_hbm_traffic.json; collected with scripts/profile_round.sh, FETCH_SIZE / WRITE_SIZE in separate rocprofv3
+    passes, gfx950 correction applied there).  Not measured in this run: the JSON line says where it comes from.  A summary
+    taken from another build of the kernels (its `build_digest` is not this build's) or without the kernel is not quoted: the
+    reason comes back in place of the file name."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    from soar_amd import build
+    files = [PMC_JSON] if PMC_JSON else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
     if not files or stage not in STAGE_KERNELS:
         return None, None
+    path = files[-1]
+    rel = os.path.relpath(path, ROOT)
     try:
-        return json.load(open(files[-1]))["kernels"][STAGE_KERNELS[stage][0]]["traffic_bytes"], os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+        d = json.load(open(path))
+    except Exception as e:
+        return None, f"{rel}: unreadable ({type(e).__name__})"
+    if d.get("build_digest") != build.source_digest():
+        return None, f"{rel}: taken from build {d.get('build_digest')}, this one is {build.source_digest()} -- not quoted"
+    k = STAGE_KERNELS[stage][0]
+    if k not in d.get("kernels", {}):
+        return None, f"{rel}: no counters for {k}"
+    return d["kernels"][k]["traffic_bytes"], rel
 
 
 def algorithmic_bytes(P, R, W, H, R_occ=None):
@@ -368,6 +380,10 @@ def main():
                          "(TS/system/gaussian_surfel_mvdream.py:305-338, 412-417) -- a second line, same units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--pmc-json", default=None,
+                    help="rocprofv3 counter summary (scripts/make_traffic_json.py) whose FETCH_SIZE + WRITE_SIZE become roofline.traffic; "
+                         "default: the newest profiles/*_hbm_traffic.json.  Quoted only when its build_digest is this build's and it "
+                         "holds the dominant kernel")
     ap.add_argument("--mode", default=None, choices=["plan", "plan-eager", "graph", "async", "sync"],
                     help="plan-eager (default): explicit launch plan of the step (soar_amd/step_plan.py: the frames' forward+backward "
                          "chains on their own streams, no autograd in the loop), launches issued eagerly -- the host needs 0.45 ms "
@@ -378,6 +394,8 @@ def main():
                          "async: sync-free rasterizer through autograd, eager launches; sync: the reference's blocking "
                          "num_rendered read-back")
     args = ap.parse_args()
+    global PMC_JSON
+    PMC_JSON = args.pmc_json
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -595,15 +613,18 @@ def main():
                         "measured": how, "stage_total_ms": {k: round(v[0], 3) for k, v in stages.items()}, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": (f"not measured in this run: FETCH_SIZE + WRITE_SIZE per launch of "
-                                           f"{STAGE_KERNELS[dom][0]} from the committed rocprofv3 --pmc summary {traffic_src}")
-                        if traffic is not None else None,
+                                           f"{STAGE_KERNELS[dom][0]} from the rocprofv3 --pmc summary {traffic_src} (same build digest)")
+                        if traffic is not None else traffic_src,
                         "kernels_in_stage": STAGE_KERNELS.get(dom),
                         "avg_launch_us": round(1e3 * ms / n, 2), "launches": n,
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "whole_frame": {"algorithmic_bytes_per_frame": int(frame_bytes(P, R_main, R_occ, W, H)),
                                         "achieved_GBs": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9, 2),
                                         "frac": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9 / HBM_PEAK_GBS, 5)},
-                        "stage_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in stages.items()}}
+                        "stage_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in stages.items()},
+                        # a stage may be several timed scopes per step (depth_order: the bucket kernels of the geometry call and the
+                        # per-bucket sort of the render call): the totals per step add up to the step
+                        "stage_us_per_step": {k: round(1e3 * v[0] / args.steps, 2) for k, v in stages.items()}}
 
     result = {
         "metric": "fwd+bwd frames/sec @100k Gaussians, 1080p; achieved HBM GB/s vs roofline",
@@ -628,6 +649,7 @@ def main():
                    "knn": (f"neighbour sets kept on the device: {int(plan.knn.searched.item())} of {plan.steps * P} query refreshes "
                            f"needed the seeded search, the others were certified; full search every {plan.RESORT_EVERY} steps"
                            if plan is not None else "full grid search per step"),
+                   "build_digest": build.source_digest(),
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,

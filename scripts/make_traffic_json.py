@@ -1,6 +1,8 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh into profiles/<tag>_hbm_traffic.json.
 usage: python scripts/make_traffic_json.py gpurun_out/<tag> profiles/<tag>_hbm_traffic.json"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from soar_amd import build
 src, dst = sys.argv[1], sys.argv[2]
 
 
@@ -17,11 +19,13 @@ def agg(pattern, name):
 f = agg(src + "/pmc_fetch/*/*counter_collection.csv", "FETCH_SIZE")
 w = agg(src + "/pmc_write/*/*counter_collection.csv", "WRITE_SIZE")
 # kernels whose reads are dominated by 16-byte-per-lane loads (64-byte records / float4 rows): FETCH_SIZE x2 on gfx950
-wide = {"render_forward_kernel", "render_backward_slots_kernel", "geometry_backward_kernel", "frame_loss_kernel"}
+wide = {"render_forward_kernel", "render_backward_slots_kernel", "render_backward_blocks_kernel", "render_backward_entries_kernel",
+        "geometry_backward_kernel", "frame_loss_kernel", "block_mask_kernel"}
 out = {"_about": "per-launch HBM-side traffic of the soar kernels at C3 (bench.py --steps 2 --warmup 1), rocprofv3 --pmc FETCH_SIZE "
                  "and --pmc WRITE_SIZE in separate passes (scripts/profile_round.sh). Counters are in KB. fetch_bytes applies the "
                  "gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of the bytes of 16-byte-per-lane reads) to the "
                  "kernels whose reads are dominated by 16-byte loads; for the others the raw value is kept (uncalibrated width).",
+       "build_digest": build.source_digest(),      # the sources the profiled library was built from (bench.py checks it)
        "kernels": {}}
 for k in sorted(f):
     fv = sum(f[k]) / len(f[k]) * 1024

@@ -74,6 +74,15 @@ def _compile_one(src: str, verbose: bool) -> str:
     return obj
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources, the public header and the compile flags: what a profile of the library was taken from
+    (profiles/*_hbm_traffic.json carry it; bench.py refuses counters of another build)."""
+    paths = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    paths.append(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "soar_hip.h"))
+    flags = COMMON_FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items())]
+    return _digest(paths, flags)[:16]
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
