@@ -149,14 +149,12 @@ class FrameStepPlan:
         # Eager form only.  batched: ONE stream, every stage of the chain launched once for all frames (soar_batch_*: the kernels
         # take their frame from blockIdx.y) -- no fork / join per step and a quarter of the launches, but every stage ends in a
         # barrier over all frames.  Not batched: the frames' chains on streams of their own, whose small latency-bound kernels
-        # fill the tails of the other chains' blends.  Measured (bench.py, frames/s batched against streams): 540p 6500 / 5400,
-        # 1080p 3450 / 3380, 4K 845 / 905 -- the default follows the image size; SOAR_PLAN_BATCHED=0 / 1 or the argument force it.
+        # fill the tails of the other chains' blends.  Measured (bench.py, frames/s batched against streams; round 3): 1080p 3850 /
+        # 3500, 1080p next to a live RCCL communicator 3640 / 3410, 4K 858 / 871 -- the batched form is the default everywhere (the
+        # 1.5 % the streams form keeps at 4K do not pay for a second default); SOAR_PLAN_BATCHED=0 / 1 or the argument force one.
         if batched is None:
             env = os.environ.get("SOAR_PLAN_BATCHED")
-            # (next to a live process group the streams form is ~1 % ahead: the all-reduce the next step waits for hides behind
-            # the fork; alone the batched form is ~2 % ahead)
-            alone = not (hasattr(flat, "_collectives_on") and flat._collectives_on())
-            batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 1920 * 1080 and alone)
+            batched = (env != "0") if env in ("0", "1") else True
         self.batched = bool(batched) and self.n <= 8
         self.graphs = None
         if use_graphs:
