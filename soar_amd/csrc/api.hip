@@ -186,7 +186,7 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->sort_slot, n);
     take(p, out->sort_pairs, n);
     take(p, out->ids_sorted, n);
-    take(p, out->bucket_cnt, 8192);
+    take(p, out->bucket_mat, (8192 + 8) * ((n + 16383) / 16384));
     take(p, out->bucket_base, 8192 + 1);
     take(p, out->blk_stats, ((n + 255) / 256) * BLK_STATS);
     take(p, out->band_cnt, 64 * ((n + 1023) / 1024));
@@ -384,8 +384,8 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     carve_geom(geom_buffer, prm->P, prm->M, &g);
     // header (kmin / kmax / n_vis) and the depth-bucket counters start from zero
     {
-        const ZeroRange zr[2] = {{g.header, 64 * sizeof(uint32_t)}, {g.bucket_cnt, 8192 * sizeof(uint32_t)}};
-        if (launch_zero_ranges(zr, 2, stream)) return 1;
+        const ZeroRange zr[1] = {{g.header, 64 * sizeof(uint32_t)}};
+        if (launch_zero_ranges(zr, 1, stream)) return 1;
     }
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;

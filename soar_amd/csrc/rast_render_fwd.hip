@@ -613,9 +613,12 @@ __device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int ra
     }
 }
 
-__global__ void __launch_bounds__(256) occ_backward_kernel(OccGradArgs a)
+__global__ void __launch_bounds__(256) occ_backward_kernel(Batch<OccGradArgs> batch)
 {
-    const int xcd = blockIdx.x & 7, kth = blockIdx.x >> 3;
+    int frame, bx;
+    batch_interleave(frame, bx);
+    const OccGradArgs &a = batch.v[frame];
+    const int xcd = bx & 7, kth = bx >> 3;
     const int rank0 = (kth >> 2) * 8 + xcd, quad = kth & 3;
     const int stride = (int)(gridDim.x >> 2);
     const int Tpad = (a.ntiles + 7) / 8 * 8;
@@ -684,7 +687,7 @@ int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBu
     const int nblocks = 4 * min(Tpad, blend_grid_ranks(a.ntiles));
     SOAR_HIP_OK(hipMemsetAsync(dL_docc, 0, sizeof(float) * (size_t)prm.P, stream));
     StageTimer timer(ST_RENDER_BWD, stream);
-    hipLaunchKernelGGL(occ_backward_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED(occ_backward_kernel, dim3(nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("occ_backward", stream, prm.debug);
     return 0;
 }

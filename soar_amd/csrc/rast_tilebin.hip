@@ -50,6 +50,15 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float
     return (uint32_t)min(B - 1, (int)((float)(key - kmin) * scale));
 }
 
+// Places in the buckets without global atomics.  A workgroup takes BKT_CHUNK consecutive Gaussians and counts them into the B
+// bucket counters in LDS (32 KB): the value an LDS atomic returns is the Gaussian's place among the workgroup's members of its
+// bucket.  The counters go to row `w` of a [workgroups][B] matrix; the workgroup that finishes last turns the matrix into
+// where every workgroup's members of every bucket start (exclusive scan over the buckets of the column sums, then down the
+// columns), so that the scatter is one gather per Gaussian: pairs[start[w][bucket] + place].  (Rounds 1-2: one returning
+// global atomic per Gaussian on 8192 counters -- 31 us per 4-frame step at C3 -- and every workgroup of the scatter recomputing
+// the scan of the counters.)
+constexpr int BKT_CHUNK = 16384;         // Gaussians per counting workgroup
+constexpr int BKT_GROUPS = BKT_MAX / 1024; // groups of 1024 buckets: one scanning workgroup each
 struct BucketCountArgs {
     int P;
     int B;
@@ -57,116 +66,153 @@ struct BucketCountArgs {
     const uint32_t *blk_stats;
     int nblk;
     uint32_t *header;
-    uint32_t *bucket_cnt;
-    uint32_t *slot;
+    uint32_t *bucket_mat;    // [ceil(P / BKT_CHUNK)][B]: counts, then starts
+    uint32_t *bucket_base;   // [B + 1]: start of every bucket
+    uint32_t *slot;          // [P] place among the workgroup's members of the bucket
 };
-__device__ __forceinline__ void bucket_count_kernel_body(int P, int B, const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ blk_stats, int nblk,
-                    uint32_t *__restrict__ header, uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ slot)
+__global__ void __launch_bounds__(1024) bucket_count_kernel(Batch<BucketCountArgs> batch)
 {
+    const BucketCountArgs &a = batch.v[blockIdx.y];
+    __shared__ uint32_t cnt[BKT_MAX];
+    __shared__ uint32_t red[16][BLK_STATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = a.B;
+    for (int b = tid; b < B; b += 1024) cnt[b] = 0u;
     // every workgroup folds the per-block statistics preprocess left behind (max of: key, ~key, x1, y1, ~x0, ~y0)
-    __shared__ uint32_t red[4][BLK_STATS];
     {
         uint32_t v[BLK_STATS];
 #pragma unroll
         for (int k = 0; k < BLK_STATS; k++) v[k] = 0u;
-        for (int b = threadIdx.x; b < nblk; b += 256)
+        for (int b = tid; b < a.nblk; b += 1024)
 #pragma unroll
-            for (int k = 0; k < BLK_STATS; k++) v[k] = max(v[k], blk_stats[b * BLK_STATS + k]);
+            for (int k = 0; k < BLK_STATS; k++) v[k] = max(v[k], a.blk_stats[b * BLK_STATS + k]);
 #pragma unroll
         for (int k = 0; k < BLK_STATS; k++) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v[k] = max(v[k], (uint32_t)__shfl_xor((int)v[k], off));
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v[k];
+            if (lane == 0) red[wave][k] = v[k];
         }
         __syncthreads();
-        if (threadIdx.x < BLK_STATS) {
-            const uint32_t m = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
-            red[0][threadIdx.x] = m;
-            if (blockIdx.x == 0) header[H_KMAX + threadIdx.x] = m;      // H_KMAX, H_NOT_KMIN, H_X1, H_Y1, H_NOT_X0, H_NOT_Y0
+        if (tid < BLK_STATS) {
+            uint32_t m = 0u;
+#pragma unroll
+            for (int w = 0; w < 16; w++) m = max(m, red[w][tid]);
+            red[0][tid] = m;
+            if (blockIdx.x == 0) a.header[H_KMAX + tid] = m;      // H_KMAX, H_NOT_KMIN, H_X1, H_Y1, H_NOT_X0, H_NOT_Y0
         }
         __syncthreads();
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t key = depth_key[i];
-    if (key == 0xFFFFFFFFu) { slot[i] = 0xFFFFFFFFu; return; }
     const uint32_t kmin = ~red[0][1], kmax = red[0][0];
     const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
-    slot[i] = atomicAdd(&bucket_cnt[bucket_of(key, kmin, scale, B)], 1u);
-}
-__global__ void __launch_bounds__(256) bucket_count_kernel(Batch<BucketCountArgs> batch)
-{
-    const BucketCountArgs &a = batch.v[blockIdx.y];
-    bucket_count_kernel_body(a.P, a.B, a.depth_key, a.blk_stats, a.nblk, a.header, a.bucket_cnt, a.slot);
+    const int i0 = (int)blockIdx.x * BKT_CHUNK;
+    constexpr int PER = BKT_CHUNK / 1024;
+    uint32_t key[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = i0 + k * 1024 + tid;
+        key[k] = a.depth_key[min(i, a.P - 1)];
+        if (i >= a.P) key[k] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = i0 + k * 1024 + tid;
+        if (i < a.P) a.slot[i] = key[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&cnt[bucket_of(key[k], kmin, scale, B)], 1u);
+    }
+    __syncthreads();
+    uint32_t *row = a.bucket_mat + (size_t)blockIdx.x * B;
+    uint32_t *gtot = a.bucket_mat + (size_t)gridDim.x * B + (size_t)blockIdx.x * BKT_GROUPS;   // members per group of 1024 buckets
+    if (tid < BKT_GROUPS) red[0][tid] = 0u;       // (BKT_GROUPS <= BLK_STATS * 16: the statistics are not needed any more)
+    __syncthreads();
+    for (int b = tid, grp = 0; b - tid < B; b += 1024, grp++) {
+        uint32_t c = b < B ? cnt[b] : 0u;
+        if (b < B) row[b] = c;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+        if (lane == 0 && c) atomicAdd(&red[0][grp], c);
+    }
+    __syncthreads();
+    if (tid < BKT_GROUPS) gtot[tid] = red[0][tid];
 }
 
+// The [workgroups][B] counts become starts: one workgroup per 1024 consecutive buckets, one bucket per thread (consecutive threads
+// read consecutive cells of a row).  What lies before the group comes from the group totals the counting workgroups left behind.
+// (A launch of its own rather than "the last counting workgroup does it": handing data from one workgroup to another inside a
+// launch takes a device-scope release and a chain of acquire loads.)
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(Batch<BucketCountArgs> batch)
+{
+    const BucketCountArgs &a = batch.v[blockIdx.y];
+    __shared__ uint32_t part[16];
+    __shared__ uint32_t before_s, all_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = a.B, NW = (a.P + BKT_CHUNK - 1) / BKT_CHUNK;
+    const int grp = (int)blockIdx.x, b = grp * 1024 + tid;
+    if (grp * 1024 >= B) return;
+    if (tid == 0) { before_s = 0u; all_s = 0u; }
+    uint32_t s = 0;
+    if (b < B)
+        for (int w = 0; w < NW; w++) s += a.bucket_mat[(size_t)w * B + b];
+    __syncthreads();
+    {   // members of the groups before this one (and of all groups: the number of visible Gaussians)
+        const uint32_t *gtot = a.bucket_mat + (size_t)NW * B;
+        uint32_t before = 0, all = 0;
+        for (int k = tid; k < NW * BKT_GROUPS; k += 1024) {
+            const uint32_t c = gtot[k];
+            all += c;
+            before += (k % BKT_GROUPS) < grp ? c : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            before += (uint32_t)__shfl_xor((int)before, off);
+            all += (uint32_t)__shfl_xor((int)all, off);
+        }
+        if (lane == 0 && all) { atomicAdd(&before_s, before); atomicAdd(&all_s, all); }
+    }
+    uint32_t incl = s;                        // inclusive scan over the 1024 threads: wavefront shuffles, then the 16 wavefront totals
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == WAVE - 1) part[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) wbase += w < wave ? part[w] : 0u;
+    uint32_t run = before_s + wbase + incl - s;
+    if (b < B) {
+        a.bucket_base[b] = run;
+        for (int w0 = 0; w0 < NW; w0 += 8) {
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = w0 + u < NW ? a.bucket_mat[(size_t)(w0 + u) * B + b] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (w0 + u < NW) a.bucket_mat[(size_t)(w0 + u) * B + b] = run;
+                run += c[u];
+            }
+        }
+    }
+    if (grp == 0 && tid == 0) { a.bucket_base[B] = all_s; a.header[H_NVIS] = all_s; }
+}
 
 struct BucketScatterArgs {
     int P;
     int B;
     const uint32_t *depth_key;
-    uint32_t *header;
-    const uint32_t *bucket_cnt;
-    uint32_t *bucket_base;
+    const uint32_t *header;
+    const uint32_t *bucket_mat;
     const uint32_t *slot;
     uint64_t *pairs;
 };
-__device__ __forceinline__ void bucket_scatter_kernel_body(int P, int B, const uint32_t *__restrict__ depth_key, uint32_t *__restrict__ header,
-                      const uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ bucket_base,
-                      const uint32_t *__restrict__ slot, uint64_t *__restrict__ pairs)
-{
-    __shared__ uint32_t base[BKT_MAX];
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
-    // exclusive prefix of the bucket counts (every workgroup recomputes it: 32 KB from L2)
-    const int per = B / 1024 > 0 ? B / 1024 : 1;
-    uint32_t s = 0;
-    for (int k = 0; k < per; k++) {
-        const int b = tid * per + k;
-        if (b < B) s += bucket_cnt[b];
-    }
-    // inclusive scan over the 1024 threads: wavefront shuffles, then the 16 wavefront totals (two barriers instead of twenty)
-    uint32_t incl = s;
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == WAVE - 1) part[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) wbase += w < wave ? part[w] : 0u;
-        incl += wbase;
-        __syncthreads();
-        part[tid] = incl;                                   // (part[1023] = the total, read below)
-        __syncthreads();
-    }
-    uint32_t run = incl - s;
-    for (int k = 0; k < per; k++) {
-        const int b = tid * per + k;
-        if (b < B) {
-            base[b] = run;
-            if (blockIdx.x == 0) bucket_base[b] = run;
-            run += bucket_cnt[b];
-        }
-    }
-    if (blockIdx.x == 0 && tid == 1023) { bucket_base[B] = part[1023]; header[H_NVIS] = part[1023]; }
-    __syncthreads();
-    const uint32_t kmin = ~header[H_NOT_KMIN], kmax = header[H_KMAX];
-    const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
-    for (int i = blockIdx.x * 1024 + tid; i < P; i += gridDim.x * 1024) {
-        const uint32_t key = depth_key[i];
-        if (key == 0xFFFFFFFFu) continue;
-        pairs[base[bucket_of(key, kmin, scale, B)] + slot[i]] = ((uint64_t)key << 32) | (uint32_t)i;
-    }
-}
-__global__ void __launch_bounds__(1024) bucket_scatter_kernel(Batch<BucketScatterArgs> batch)
+__global__ void __launch_bounds__(256) bucket_scatter_kernel(Batch<BucketScatterArgs> batch)
 {
     const BucketScatterArgs &a = batch.v[blockIdx.y];
-    bucket_scatter_kernel_body(a.P, a.B, a.depth_key, a.header, a.bucket_cnt, a.bucket_base, a.slot, a.pairs);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const uint32_t key = a.depth_key[i], place = a.slot[i];
+    if (key == 0xFFFFFFFFu) return;
+    const uint32_t kmin = ~a.header[H_NOT_KMIN], kmax = a.header[H_KMAX];
+    const float scale = (float)a.B / ((float)(kmax - kmin) + 1.0f);
+    const uint32_t start = a.bucket_mat[(size_t)(i / BKT_CHUNK) * a.B + bucket_of(key, kmin, scale, a.B)];
+    a.pairs[start + place] = ((uint64_t)key << 32) | (uint32_t)i;
 }
 
 
@@ -734,16 +780,18 @@ static int bucket_count_for(int32_t P)
     return B;
 }
 
-// geometry stage: bucket counts and the scatter of the (key, index) pairs
+// geometry stage: places in the depth buckets and the scatter of the (key, index) pairs
 int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream)
 {
     const int B = bucket_count_for(prm.P);
     const int nblk = (prm.P + 255) / 256;               // = preprocess grid: one statistics row per block
+    const int nw = (prm.P + BKT_CHUNK - 1) / BKT_CHUNK;
     StageTimer timer(ST_SORT, stream);
-    const BucketCountArgs ca = {prm.P, B, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_cnt, g.sort_slot};
-    SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nblk), dim3(256), 0, stream, ca);
-    const BucketScatterArgs sa = {prm.P, B, g.depth_key, g.header, g.bucket_cnt, g.bucket_base, g.sort_slot, g.sort_pairs};
-    SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3(min(64, (prm.P + 1023) / 1024)), dim3(1024), 0, stream, sa);
+    const BucketCountArgs ca = {prm.P, B, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot};
+    SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nw), dim3(1024), 0, stream, ca);
+    SOAR_LAUNCH_BATCHED(bucket_scan_kernel, dim3((B + 1023) / 1024), dim3(1024), 0, stream, ca);
+    const BucketScatterArgs sa = {prm.P, B, g.depth_key, g.header, g.bucket_mat, g.sort_slot, g.sort_pairs};
+    SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, stream, sa);
     SOAR_LAUNCH_OK("depth_buckets", stream, prm.debug);
     return 0;
 }

@@ -120,7 +120,8 @@ struct GeomBuf {
     uint32_t *sort_slot;     // [P] slot of each visible Gaussian inside its depth bucket
     uint64_t *sort_pairs;    // [P] (depth key << 32 | index), bucket after bucket
     uint32_t *ids_sorted;    // [P] Gaussian ids in depth order (first header[H_NVIS] entries)
-    uint32_t *bucket_cnt;    // [8192] depth buckets
+    uint32_t *bucket_mat;    // [W = ceil(P / 16384)][B <= 8192] depth buckets: members per counting workgroup, then where they start;
+                             // behind it [W][8]: members per group of 1024 buckets
     uint32_t *bucket_base;   // [8192 + 1]
     uint32_t *blk_stats;     // [ceil(P/256)][BLK_STATS] per-block maxima written by preprocess
     uint32_t *band_cnt;      // [64][ceil(P/1024)] entries per (band of tile rows, chunk of the depth order) (rast_tilebin.hip)

@@ -371,9 +371,7 @@ class FrameStepPlan:
             batch((self._f_geometry, self._f_render))
             for i in frames:
                 self._f_avatar_loss(i, self._frames_now[i], stream)
-            batch((self._f_backward,))
-            for i in frames:
-                self._f_occ_backward(i, stream)
+            batch((self._f_backward, self._f_occ_backward))
         else:
             batch((self._f_geometry, self._f_render, self._f_loss, self._f_backward))
         for i in frames:
