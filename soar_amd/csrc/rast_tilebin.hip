@@ -255,21 +255,37 @@ __device__ __forceinline__ void emit_sorted(const BucketSortArgs &a, uint32_t po
     a.rect_sorted[pos] = rc;
 }
 
-// workgroup = 4 wavefronts = 4 consecutive buckets
+// workgroup = 4 wavefronts, wavefront = BKT_RUN consecutive buckets
+constexpr int BKT_RUN = 4;
 __global__ void __launch_bounds__(256) bucket_sort_kernel(Batch<BucketSortArgs> batch)
 {
     const BucketSortArgs &a = batch.v[blockIdx.y];
     __shared__ uint64_t lds[BKT_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // phase 1: every wavefront sorts its own bucket if it fits one value per lane
+    // phase 1: consecutive buckets are consecutive in `pairs` and ordered among each other (the bucket map is monotone): a run of
+    // buckets that fits one value per lane is sorted as ONE sequence -- with ~12 pairs per bucket most runs of four do.
+    // Otherwise bucket by bucket, whichever of them fit.
     {
-        const int b = blockIdx.x * 4 + wave;
-        if (b < a.B) {
-            const uint32_t lo = a.bucket_base[b], n = a.bucket_base[b + 1] - lo;
+        const int b0 = (blockIdx.x * 4 + wave) * BKT_RUN, b1 = min(a.B, b0 + BKT_RUN);
+        if (b0 < a.B) {
+            uint32_t edge[BKT_RUN + 1];
+#pragma unroll
+            for (int k = 0; k <= BKT_RUN; k++) edge[k] = a.bucket_base[min(b0 + k, b1)];
+            const uint32_t lo = edge[0], n = edge[BKT_RUN] - lo;
             if (n > 0u && n <= (uint32_t)WAVE) {
                 uint64_t v = lane < (int)n ? a.pairs[lo + lane] : ~0ull;
                 v = wave_sort64(v, lane);
                 if (lane < (int)n) emit_sorted(a, lo + lane, v);
+            } else if (n > 0u) {
+#pragma unroll
+                for (int k = 0; k < BKT_RUN; k++) {
+                    const uint32_t l = edge[k], m = edge[k + 1] - l;
+                    if (m > 0u && m <= (uint32_t)WAVE) {
+                        uint64_t v = lane < (int)m ? a.pairs[l + lane] : ~0ull;
+                        v = wave_sort64(v, lane);
+                        if (lane < (int)m) emit_sorted(a, l + lane, v);
+                    }
+                }
             }
         }
     }
@@ -277,10 +293,14 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(Batch<BucketSortArgs> 
     // (every comparator ascending, first step of a merge mirrored), which sorts any n when comparators whose upper end
     // is >= n are skipped -- in LDS, or in global memory for the (pathological: thousands of equal depths) buckets
     // beyond the LDS capacity
-    for (int w = 0; w < 4; w++) {
-        const int b = blockIdx.x * 4 + w;
+    // (the workgroup's bucket boundaries in one round trip, not one per trip of the loop)
+    __shared__ uint32_t edges[4 * BKT_RUN + 1];
+    if (tid <= 4 * BKT_RUN) edges[tid] = a.bucket_base[min((int)blockIdx.x * 4 * BKT_RUN + tid, a.B)];
+    __syncthreads();
+    for (int w = 0; w < 4 * BKT_RUN; w++) {
+        const int b = blockIdx.x * 4 * BKT_RUN + w;
         if (b >= a.B) break;
-        const uint32_t lo = a.bucket_base[b], n = a.bucket_base[b + 1] - lo;
+        const uint32_t lo = edges[w], n = edges[w + 1] - lo;
         if (n <= (uint32_t)WAVE) continue;
         uint32_t n2 = 1;
         while (n2 < n) n2 <<= 1;
@@ -807,7 +827,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         a.B = bucket_count_for(prm.P);
         a.bucket_base = g.bucket_base; a.pairs = g.sort_pairs; a.rect = g.rect; a.ids_sorted = g.ids_sorted;
         a.rect_sorted = g.rect_sorted;
-        SOAR_LAUNCH_BATCHED(bucket_sort_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+        SOAR_LAUNCH_BATCHED(bucket_sort_kernel, dim3((a.B + 4 * BKT_RUN - 1) / (4 * BKT_RUN)), dim3(256), 0, stream, a);
     }
     SOAR_LAUNCH_OK("bucket_sort", stream, prm.debug);
     // band lists: the band arrays live in the key / value scratch of the binning buffer (only the descending path and the key
