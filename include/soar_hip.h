@@ -123,6 +123,11 @@ int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_
 int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
                              void *stream);
 
+/* The same two words without blocking: copied into `status_pinned` (two uint32 of page-locked host memory: instances found, 0 or the
+ * number that did not fit) behind whatever `stream` already holds; the caller reads them once an event recorded behind this call has
+ * completed.  What a caller that sizes its binning buffers from earlier frames polls between frames. */
+int soar_rast_binning_status_async(const void *geom_buffer, int32_t P, int32_t M, uint32_t *status_pinned, void *stream);
+
 /* `prefiltered` (GaussianRasterizationSettings.prefiltered): the caller promises that no Gaussian is culled.  The reference prints
  * "Point is filtered although prefiltered is set. This shouldn't happen!" from the kernel and traps (auxiliary.h:163-167, 195-199),
  * which takes the context down; here the culled Gaussians are counted on the device.  In debug mode (SoarRastParams.debug bit 0)

@@ -78,6 +78,11 @@ for name, wl in VARIANTS:
     timed(name, wl)
 if VARIANTS:
     from soar_amd import rasterizer
+    # the default (Config.binning_capacity = -1) sizes the binning buffers from earlier frames; 0 = the reference's blocking read-back
+    # of the instance count in every forward call
+    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=pc)
+    timed("avatar_stage_loss, Config.binning_capacity = 0 (the reference's read-back per forward call)", "fused")
+    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=pc)
     capacity = 3 * rasterizer.last_num_rendered        # of the main pass of the last frame (the model moves under Adam: generous bound)
     # the occlusion parameter trained, as in the reference's configs: the occlusion pass is then a rasterization of its own with
     # a backward of its own (the fused blend gives the occlusion image without a gradient)
@@ -91,13 +96,10 @@ if VARIANTS:
     pc._occ.requires_grad_(False)
     pc._occ.grad = None
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4)
-    # opt-in, not in the reference: no read-back of the instance count per forward call (Config.binning_capacity)
-    renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": capacity},
-                                                          geometry=pc)
-    timed("avatar_stage_loss, Config.binning_capacity set (no host read-back per frame)", "fused")
-    print("   binning status (instances, overflow):", rasterizer.check_binning())
+    timed("avatar_stage_loss (default config again)", "fused")
+    print("   binning status (instances, overflow):", rasterizer.check_binning(), " learnt capacities:", rasterizer._auto_capacity)
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4, fused=True)
-    timed("avatar_stage_loss, binning_capacity and torch.optim.Adam(fused=True)", "fused")
+    timed("avatar_stage_loss, default config and torch.optim.Adam(fused=True)", "fused")
 
 if VARIANTS:
     # GaussianBatchRenderer.gt_forward: the frame at video resolution + the normal view and the back normal view at 1024 x 1024

@@ -456,6 +456,20 @@ int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int6
     return 0;
 }
 
+int soar_rast_binning_status_async(const void *geom_buffer, int32_t P, int32_t M, uint32_t *status_pinned, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!status_pinned || P < 0) { set_error("soar_rast_binning_status_async: bad arguments"); return 1; }
+    status_pinned[0] = 0u;
+    status_pinned[1] = 0u;
+    if (P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    GeomBuf g;
+    carve_geom(const_cast<void *>(geom_buffer), P, M, &g);
+    SOAR_HIP_OK(hipMemcpyAsync(status_pinned, g.header + H_TOTAL, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return 0;
+}
+
 int soar_rast_prefilter_violations(const void *geom_buffer, int32_t P, int32_t M, int64_t *violations_host, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

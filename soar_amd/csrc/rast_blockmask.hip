@@ -44,6 +44,7 @@ struct BlockMaskArgs {
     int normalize_depth;
     uint32_t *bg_state;
 };
+constexpr unsigned BM_MAX_WGS = 4096; // mask workgroups per frame (2 M list positions per round)
 constexpr unsigned BM_EXTRA = 8;     // workgroups at the front of every grid row that make no masks (one XCD round: the rest of the row
                                      // keeps its place on the XCDs); those of row 0 build the tile orders, one frame each
 
@@ -139,29 +140,32 @@ __global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> ba
     const uint32_t total = a.header ? min(a.header[H_TOTAL], a.total) : a.total;
     constexpr uint32_t PER_WG = 256u * (uint32_t)BM_GROUPS;
     const uint32_t nb = (total + PER_WG - 1u) / PER_WG, per = (nb + parts - 1u) / parts;
-    const uint32_t kk = parted ? k : l / n;
-    if (kk >= per) return;
-    const uint32_t bx = part * per + kk;
-    const uint32_t g0 = (bx * 4u + (threadIdx.x >> 6)) * (uint32_t)BM_GROUPS;
-    if ((uint64_t)g0 * 64u >= total) return;
-    float x[BM_GROUPS], y[BM_GROUPS], A[BM_GROUPS], B[BM_GROUPS], C[BM_GROUPS], thr[BM_GROUPS], tx0[BM_GROUPS], ty0[BM_GROUPS];
+    // (the grid is sized for at most BM_MAX_WGS workgroups per frame; longer lists -- a binning buffer sized with a wide margin holds
+    // far fewer instances than it could -- take further rounds)
+    const uint32_t wgs = (gridDim.x - BM_EXTRA) * n, round = parted ? wgs / 8u : wgs / n;
+    for (uint32_t kk = parted ? k : l / n; kk < per; kk += round) {
+        const uint32_t bx = part * per + kk;
+        const uint32_t g0 = (bx * 4u + (threadIdx.x >> 6)) * (uint32_t)BM_GROUPS;
+        if ((uint64_t)g0 * 64u >= total) return;
+        float x[BM_GROUPS], y[BM_GROUPS], A[BM_GROUPS], B[BM_GROUPS], C[BM_GROUPS], thr[BM_GROUPS], tx0[BM_GROUPS], ty0[BM_GROUPS];
 #pragma unroll
-    for (int u = 0; u < BM_GROUPS; u++) {
-        const uint32_t pos = min((g0 + (uint32_t)u) * 64u + (uint32_t)lane, total - 1u);
-        const uint32_t id = min(a.point_list[pos], a.P - 1u), xy = a.tile_xy[pos];
-        const float4 q0 = a.rec[id].q0;
-        x[u] = q0.x; y[u] = q0.y; A[u] = q0.z; B[u] = q0.w;
-        C[u] = a.rec[id].q1.x;
-        thr[u] = a.rec[id].q3.w;
-        tx0[u] = (float)((xy & 0xFFFFu) * TILE); ty0[u] = (float)((xy >> 16) * TILE);
-    }
+        for (int u = 0; u < BM_GROUPS; u++) {
+            const uint32_t pos = min((g0 + (uint32_t)u) * 64u + (uint32_t)lane, total - 1u);
+            const uint32_t id = min(a.point_list[pos], a.P - 1u), xy = a.tile_xy[pos];
+            const float4 q0 = a.rec[id].q0;
+            x[u] = q0.x; y[u] = q0.y; A[u] = q0.z; B[u] = q0.w;
+            C[u] = a.rec[id].q1.x;
+            thr[u] = a.rec[id].q3.w;
+            tx0[u] = (float)((xy & 0xFFFFu) * TILE); ty0[u] = (float)((xy >> 16) * TILE);
+        }
 #pragma unroll
-    for (int u = 0; u < BM_GROUPS; u++) {
-        const uint32_t g = g0 + (uint32_t)u;
-        if ((uint64_t)g * 64u >= total) break;
-        uint32_t w_lo, w_hi;
-        block_words(lane, g * 64u + (uint32_t)lane < total, x[u], y[u], A[u], B[u], C[u], thr[u], tx0[u], ty0[u], w_lo, w_hi);
-        if (lane < 16) a.masks[(size_t)lane * a.plane + g] = (uint64_t)w_lo | ((uint64_t)w_hi << 32);
+        for (int u = 0; u < BM_GROUPS; u++) {
+            const uint32_t g = g0 + (uint32_t)u;
+            if ((uint64_t)g * 64u >= total) break;
+            uint32_t w_lo, w_hi;
+            block_words(lane, g * 64u + (uint32_t)lane < total, x[u], y[u], A[u], B[u], C[u], thr[u], tx0[u], ty0[u], w_lo, w_hi);
+            if (lane < 16) a.masks[(size_t)lane * a.plane + g] = (uint64_t)w_lo | ((uint64_t)w_hi << 32);
+        }
     }
 }
 
@@ -181,7 +185,7 @@ int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, I
     a.tile_count = img.tile_count; a.ranges = img.ranges;
     a.tile_order = prm.sort_descending ? nullptr : img.tile_order;       // (the key-sort path builds its own: rast_binning.hip)
     a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
-    const unsigned nblocks = ((unsigned)((R + 256 * BM_GROUPS - 1) / (256 * BM_GROUPS)) + 7u) / 8u * 8u;      // (whole rounds of the 8 XCDs)
+    const unsigned nblocks = min(((unsigned)((R + 256 * BM_GROUPS - 1) / (256 * BM_GROUPS)) + 7u) / 8u * 8u, BM_MAX_WGS);      // (whole rounds of the 8 XCDs)
     StageTimer timer(ST_BLOCK_MASKS, stream);
     SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(BM_EXTRA + nblocks), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("block_masks", stream, prm.debug);

@@ -20,7 +20,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
-from typing import NamedTuple, Optional, Tuple
+from typing import Dict, NamedTuple, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -39,6 +39,49 @@ DETERMINISTIC_BACKWARD = os.environ.get("SOAR_DETERMINISTIC_BACKWARD", "0") == "
 # running totals over forward calls (read by bench.py to price the algorithmic bytes with the REAL num_rendered)
 stats = {"forward_calls": 0, "num_rendered": 0, "backward_calls": 0, "num_rendered_bwd": 0}
 last_num_rendered = 0        # num_rendered of the most recent forward call
+
+# ---- binning buffers sized from earlier frames (capacity=AUTO) ------------------------------------------------------------------
+# The reference blocks the host in every forward call to read num_rendered and size the binning buffer (rasterizer_impl.cu:250).
+# AUTO does that for the FIRST frame of an image size only and sizes the later ones with a wide margin over what those frames
+# needed (the buffers are megabytes on a 288 GB device): nothing is read back, the host runs ahead of the device.  The device
+# checks every frame (rast_tilebin.hip: nothing is rendered when the lists do not fit); the two status words come back through
+# page-locked memory behind the frame and are looked at when a later call finds them complete: the margin grows before it is
+# used up, and an overflow -- a frame that needed AUTO_MARGIN times more than any frame before it -- raises then, loudly, at the
+# next call (``auto_binning_poll(block=True)`` or ``check_binning()`` look at once).
+AUTO = "auto"
+AUTO_MARGIN = 4              # capacity = AUTO_MARGIN x the largest number of instances seen for the key
+AUTO_FLOOR = 1 << 18
+_auto_capacity: Dict[tuple, int] = {}
+_auto_pending: list = []     # (event, pinned status words, key, capacity the frame ran with)
+_auto_pinned_free: list = []
+
+
+def auto_binning_poll(block: bool = False) -> None:
+    """Look at the status words of AUTO frames whose copies have completed (all of them with ``block``): raise the capacities of
+    their keys where more than half was used, raise RuntimeError for a frame that did not fit."""
+    global _auto_pending
+    still = []
+    overflow = None
+    for ev, words, key, cap in _auto_pending:
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            still.append((ev, words, key, cap))
+            continue
+        total, over = int(words[0]) & 0xFFFFFFFF, int(words[1]) & 0xFFFFFFFF
+        _auto_pinned_free.append(words)
+        need = max(total, over)
+        if need * 2 > _auto_capacity.get(key, 0):
+            _auto_capacity[key] = max(_auto_capacity.get(key, 0), AUTO_MARGIN * need, AUTO_FLOOR)
+        if over:
+            overflow = (key, over, cap)
+    _auto_pending = still
+    if overflow is not None:
+        key, over, cap = overflow
+        raise RuntimeError(f"an earlier frame ({key[1]}x{key[2]}) needed {over} (tile, Gaussian) instances, {over / cap:.1f} times the "
+                           f"binning buffer sized from the frames before it ({cap}): that frame was rendered as background.  The bound "
+                           "has been raised; set Config.binning_capacity (or capacity=) for scenes that change this abruptly, or 0 for "
+                           "the reference's blocking read-back")
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -272,6 +315,11 @@ class _NativeOps:
                                                  out[2].data_ptr(), out[3].data_ptr(), stream), "rasterize_gaussians")
                 return 0
             global last_num_rendered
+            auto_key = None
+            if capacity == AUTO:
+                auto_binning_poll()
+                auto_key = (str(device), st["W"], st["H"], bool(st["ctx"].params.render_front))
+                capacity = _auto_capacity.get(auto_key) if not st["ctx"].params.sort_descending else None
             if capacity is not None:
                 # sync-free: the binning buffer is sized by the caller's bound, the device checks that it was enough
                 num_rendered = int(capacity)
@@ -283,6 +331,9 @@ class _NativeOps:
                 last_num_rendered = num_rendered
                 stats["forward_calls"] += 1
                 stats["num_rendered"] += num_rendered
+                if auto_key is not None and not st["ctx"].params.sort_descending:      # the first frame of its kind: learnt the hard way
+                    _auto_capacity[auto_key] = max(AUTO_MARGIN * num_rendered, AUTO_FLOOR)
+                    auto_key = None
             nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             st["binning"] = _scratch(nbytes.value, device)
@@ -296,6 +347,12 @@ class _NativeOps:
                                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                                      out[3].data_ptr(), occ_ptr, occ_out_ptr, stream),
                       "rasterize_gaussians (render stage)")
+                if auto_key is not None and capacity is not None:
+                    words = _auto_pinned_free.pop() if _auto_pinned_free else torch.zeros(2, dtype=torch.int32).pin_memory()
+                    check(L.soar_rast_binning_status_async(st["geom"].data_ptr(), P, st["M"], words.data_ptr(), stream), "binning_status_async")
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.ExternalStream(stream, device=device))
+                    _auto_pending.append((ev, words, auto_key, int(capacity)))
             if defer is not None:
                 defer.append(launch)
             else:
@@ -502,7 +559,7 @@ class _RasterizeViews(torch.autograd.Function):
                 rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config,
                 side=_view_stream(means3D.device, i) if use_sides else None)
         calls = [] if use_sides else None
-        if capacity is not None and any(rs.sort_descending for rs in settings_list):
+        if capacity is not None and capacity != AUTO and any(rs.sort_descending for rs in settings_list):
             raise ValueError("the sync-free capacity mode needs sort_descending = False on every view")
         L = hip_lib.lib()
         ctx.num_rendered = [0] * len(states)
@@ -634,6 +691,7 @@ def check_binning():
     """After sync-free (`capacity=`) calls: synchronise and return [(instances, overflow)] of the views of the last batch;
     raises if a binning buffer was too small (that view rendered nothing: its images are the background)."""
     L = hip_lib.lib()
+    auto_binning_poll(block=True)
     out = []
     for geom, P, M, device in _last_batch:
         n, o = C.c_int64(0), C.c_int64(0)

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .. import lbs
-from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
+from ..rasterizer import AUTO, GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
 from . import registry
 from .batch import GaussianBatchRenderer
 from .cameras import device_constant
@@ -74,11 +74,12 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         back_ground_color: Tuple[float, float, float] = (1, 1, 1)
         offset: bool = False
         use_explicit: bool = False
-        # not in the reference: > 0 = upper bound of the (tile, Gaussian) instances of a view.  The reference blocks the host
-        # in every forward call to read that count back (rasterizer_impl.cu:250); with a bound the binning buffer is sized by
-        # it, nothing is read back and the host runs ahead of the device.  The device checks the bound:
-        # ``soar_amd.rasterizer.check_binning()`` (e.g. once per step or per epoch) raises if it was exceeded.
-        binning_capacity: int = 0
+        # not in the reference.  The reference blocks the host in every forward call to read the number of (tile, Gaussian)
+        # instances back and size the binning buffer (rasterizer_impl.cu:250).  -1 (default): only the first frame of an image size
+        # is read back, later ones get a buffer 4x what the frames before needed (rasterizer.AUTO: the device checks every frame, a
+        # frame that does not fit raises at a later call).  > 0: a fixed bound, nothing is ever read back
+        # (``soar_amd.rasterizer.check_binning()`` raises if it was exceeded).  0: the reference's read-back in every call.
+        binning_capacity: int = -1
 
     cfg: Config
 
@@ -86,6 +87,10 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         registry.info("[Note] Gaussian Splatting doesn't support material and background now.")
         super().configure(geometry, material, background)
         self.background_tensor = torch.tensor(self.cfg.back_ground_color, dtype=torch.float32, device="cuda")
+
+    def _binning_capacity(self):
+        c = int(getattr(self.cfg, "binning_capacity", -1))
+        return AUTO if c < 0 else (c or None)
 
     # -----------------------------------------------------------------------------------------------------------------
     def _warp(self, pc, points, rot, offsets, axis_perm, zero_out, kwargs):
@@ -126,7 +131,7 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         (image, normal, depth, pred_normal, opac, occ, curv, radii) = render_view(
             points, rot, pc.get_colors if self.cfg.use_explicit else attribute_color,
             pc.get_scaling if self.cfg.use_explicit else attribute_scale, screenspace_points, pc.get_occ, w, mats, offsets,
-            axis_perm, rs, cam, capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None, back=back)
+            axis_perm, rs, cam, capacity=self._binning_capacity(), back=back)
         return {
             "render": image, "normal": normal, "depth": depth, "pred_normal": pred_normal, "mask": opac, "occ": occ, "curv": curv,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
@@ -168,7 +173,7 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         outs = render_views(points, rot, pc.get_colors if self.cfg.use_explicit else fields["shs"],
                             pc.get_scaling if self.cfg.use_explicit else fields["scales"], carriers, pc.get_occ, w, mats, offsets,
                             axis_perm, settings, cams, [not v.get("render_front", True) for v in views],
-                            capacity=int(getattr(self.cfg, "binning_capacity", 0)) or None)
+                            capacity=self._binning_capacity())
         return [{"render": o[0], "normal": o[1], "depth": o[2], "pred_normal": o[3], "mask": o[4], "occ": o[5], "curv": o[6],
                  "viewspace_points": c, "visibility_filter": o[7] > 0, "radii": o[7]} for o, c in zip(outs, carriers)]
 

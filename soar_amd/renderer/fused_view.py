@@ -20,7 +20,7 @@ import torch
 
 from .. import hip_lib, rasterizer
 from ..hip_lib import check, ptr
-from ..rasterizer import _NativeOps, _dev_f32, _stream
+from ..rasterizer import AUTO, _NativeOps, _dev_f32, _stream
 from .postops import fov2focal
 
 _ones = {}
@@ -214,13 +214,20 @@ def _focal(camera):
     return (float(fov2focal(float(camera.FoVy), camera.image_height)), float(fov2focal(float(camera.FoVx), camera.image_width)))
 
 
+def _capacity(capacity, back):
+    """None (the reference's blocking read-back), rasterizer.AUTO or a number of instances; back views (descending sort) read back"""
+    if not capacity or back:
+        return None
+    return capacity if capacity == AUTO else int(capacity)
+
+
 def render_view(xyz, rot, colors, scale_src, means2D, occ, weights, joint_mats, offsets: Optional[torch.Tensor], axis_perm, rs,
                 camera, capacity: Optional[int] = None, back: bool = False):
     """-> (render, normal, depth, pred_normal, mask, occ, curv, radii) of one view; see the module docstring.
     capacity: the sync-free form of ``rasterizer.rasterize_views`` (binning buffer sized by this bound, nothing read back;
     ``rasterizer.check_binning()`` afterwards).  back: the ``render_front=False`` form (main pass sorted back-to-front, occlusion
     pass rasterized separately; always with the read-back)."""
-    spec = (rs, _focal(camera), int(capacity) if capacity and not back else None, bool(back))
+    spec = (rs, _focal(camera), _capacity(capacity, back), bool(back))
     return _RenderViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, [spec], means2D)
 
 
@@ -229,7 +236,7 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
     """Several views of one pose (``GaussianBatchRenderer.gt_forward``: the video frame at video resolution, the normal view and
     the back normal view): the surfels are warped once each way and the geometry stages of all views are enqueued in front of the
     first read-back.  -> list of the per-view 8-tuples of ``render_view``."""
-    specs = [(rs, _focal(cam), int(capacity) if capacity and not back else None, bool(back))
+    specs = [(rs, _focal(cam), _capacity(capacity, back), bool(back))
              for rs, cam, back in zip(settings_list, cameras, backs)]
     outs = _RenderViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, *means2D_list)
     n = _RenderViews.N_OUT

@@ -203,7 +203,8 @@ def test_plugin_binning_capacity_config_renders_without_read_back(world):
     from soar_amd.renderer import registry
     w = world
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
-    want = w.renderer(w.cam, bg, gt=True, gt_index=4)
+    blocking = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=w.pc)
+    want = blocking(w.cam, bg, gt=True, gt_index=4)
     n = rasterizer.last_num_rendered
     free = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 2 * n}, geometry=w.pc)
     got = free(w.cam, bg, gt=True, gt_index=4)
@@ -218,6 +219,43 @@ def test_plugin_binning_capacity_config_renders_without_read_back(world):
         rasterizer.check_binning()
     for t in (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color):
         t.grad = None
+
+
+def test_plugin_default_sizes_binning_buffers_from_earlier_frames(world):
+    """The default (Config.binning_capacity = -1, rasterizer.AUTO): the first frame of an image size reads its instance count back
+    like the reference, later frames get a buffer AUTO_MARGIN times what the frames before needed and nothing is read back; the
+    images are those of the blocking form; a frame that does not fit raises at a later look (never silently: that frame is all
+    background), and the bound has grown by then."""
+    from soar_amd import rasterizer
+    from soar_amd.renderer import registry
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    blocking = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=w.pc)
+    auto = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=w.pc)
+    rasterizer.auto_binning_poll(block=True)
+    rasterizer._auto_capacity.clear()
+    for f in (2, 3, 4):                                      # frame 2 learns the bound, 3 and 4 run without a read-back
+        want = blocking(w.cam, bg, gt=True, gt_index=f)
+        n = rasterizer.last_num_rendered
+        calls = rasterizer.stats["num_rendered"]
+        got = auto(w.cam, bg, gt=True, gt_index=f)
+        if f > 2:
+            assert rasterizer.stats["num_rendered"] == calls, "a read-back happened"
+        for k in ("render", "normal", "depth", "pred_normal", "mask", "occ", "curv", "radii"):
+            assert torch.equal(got[k], want[k]), (f, k)
+    rasterizer.auto_binning_poll(block=True)
+    (key, cap), = [(k, c) for k, c in rasterizer._auto_capacity.items() if not k[3]]
+    assert cap >= rasterizer.AUTO_MARGIN * n // 2
+    # a frame that needs more than the bound: rendered as background, reported at the next look, bound raised
+    rasterizer._auto_capacity[key] = n // 3
+    out = auto(w.cam, bg, gt=True, gt_index=4)
+    with pytest.raises(RuntimeError, match="rendered as background"):
+        rasterizer.auto_binning_poll(block=True)
+    assert float((out["render"].detach() - bg[:, None, None]).abs().max()) < 1e-5
+    assert rasterizer._auto_capacity[key] >= rasterizer.AUTO_MARGIN * n // 2
+    got = auto(w.cam, bg, gt=True, gt_index=4)
+    assert torch.equal(got["render"], want["render"])
+    rasterizer.auto_binning_poll(block=True)
 
 
 def test_plugin_occlusion_image_carries_gradient_to_the_occ_parameter(world):
