@@ -32,8 +32,11 @@ extern "C" {
 /* ABI history.  1: round 1.  2: the KNN query's sort scratch is caller-owned (soar_lbs_knn_query_bytes).  3 (round 2): soar_frame_loss
  * takes SOAR_FRAME_LOSS_SCRATCH_FLOATS floats of scratch, the background colour and the normalize_depth switch; new entry points
  * soar_lbs_warp_forward_batch / soar_lbs_warp_backward_sum, soar_view_finish[_backward], soar_rast_occ_backward;
- * soar_sum_frames_when_last (introduced and withdrawn within round 2) is gone. */
-#define SOAR_HIP_ABI_VERSION 4
+ * soar_sum_frames_when_last (introduced and withdrawn within round 2) is gone.  4 (round 3): soar_lbs_knn_state_bytes / _query_state /
+ * _refresh, soar_adam_step, soar_rast_prefilter_violations, soar_selftest_affine_scan.  5 (round 3): soar_rast_binning_status_async;
+ * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
+ * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout). */
+#define SOAR_HIP_ABI_VERSION 5
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */

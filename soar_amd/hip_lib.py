@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libsoar_hip.so")
 
 FRAME_LOSS_SCRATCH_FLOATS = 4 * 2048   # SOAR_FRAME_LOSS_SCRATCH_FLOATS: the scratch argument of soar_frame_loss[_pooled]
-ABI_VERSION = 4          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
+ABI_VERSION = 5          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 
