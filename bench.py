@@ -492,14 +492,24 @@ def main():
                 lrs["occ"] = 1e-2
             adam = FusedAdam(flat, lr=lrs)
 
-            def stepper(frames):
-                # a whole training step: gradients of the step's frames (plan.run), their sum over the ranks (two asynchronous
-                # buckets; the stream waits, the host does not), Adam on every leaf.  The positions move every step, so the next
-                # step's KNN blend weights are recomputed from new positions (certified neighbour sets or a seeded search)
-                plan.run(frames)
-                flat.all_reduce_buckets()
-                flat.wait_all()
-                adam.step()
+            if plan.graphs is None:
+                # a whole training step = the optimizer's update from the previous step's gradients, in two parts inside the plan
+                # (the positions behind the first bucket of the gradient reduction and in front of the KNN refresh that needs them, the
+                # rest behind the second bucket, which travels while the refresh runs: FrameStepPlan._run_eager), then the step's
+                # frames, then its gradients' sum over the ranks (two asynchronous buckets; the stream waits, the host does not).
+                # The positions move every step: every step's KNN blend weights come from new positions (certified neighbour sets or a
+                # seeded search).  K timed steps hold K optimizer updates (the first one applies the last untimed step's gradients).
+                plan.optimizer = adam
+
+                def stepper(frames):
+                    plan.run(frames)
+                    flat.all_reduce_buckets()
+            else:
+                def stepper(frames):
+                    plan.run(frames)
+                    flat.all_reduce_buckets()
+                    flat.wait_all()
+                    adam.step()
         except Exception as e:
             fallback = "graph" if (mode == "plan" and world == 1) else "async"
             print(f"[bench] step plan unavailable ({type(e).__name__}: {e}); falling back to --mode {fallback}", file=sys.stderr)

@@ -479,6 +479,11 @@ typedef struct SoarAdamRow {
     int32_t pad_;
 } SoarAdamRow;
 int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev, void *stream);
+/* The same step in parts: `advance` != 0 moves the step counter (and the bias corrections) on before the rows are updated, 0 updates
+ * further rows of the SAME step -- a caller whose gradients arrive in buckets updates the leaves of a bucket as soon as it is there
+ * (soar_amd/step_plan.py: the positions behind the first bucket, in front of the KNN refresh; the rest behind the second). */
+int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows, float beta1, float beta2, float eps, void *state_dev, int32_t advance,
+                        void *stream);
 
 /* soar_prof_timestamp: one-thread kernel that appends {tag, device wall clock (100 MHz ticks)} to a ring in device memory when
  * `stream` gets there: ring[0] counts the stamps, stamp n lies at ring[1 + 2 (n mod capacity)].  Timelines of launch chains

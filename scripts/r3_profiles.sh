@@ -26,3 +26,6 @@ cat $out/batched_launches.txt
 for f in default avatar forced_dist C5; do python3 -c "
 import json,sys
 d=json.load(open('$out/bench_$f.json')); print('$f', d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('frac'), (d.get('roofline') or {}).get('traffic'))"; done
+# 5. the plugin path and the scenes whose gradients miss the bar against the reference's kernels
+python3 scripts/plugin_time.py 2>&1 | grep -v Warning > $out/plugin_path.txt
+python3 scripts/gradient_gap.py 2>&1 | grep -v Warning > $out/gradient_gap.txt

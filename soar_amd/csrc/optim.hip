@@ -71,6 +71,12 @@ using namespace soar;
 extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
                               void *stream_)
 {
+    return soar_adam_step_rows(n_rows, rows_host, beta1, beta2, eps, state_dev, 1, stream_);
+}
+
+extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
+                                   int32_t advance, void *stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_rows < 0 || n_rows > ADAM_MAX_ROWS || (n_rows && !rows_host) || !state_dev) {
         set_error("soar_adam_step: 0 <= n_rows <= %d, rows and the 16-byte device state must be given", ADAM_MAX_ROWS);
@@ -92,7 +98,7 @@ extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, floa
     for (int r = n_rows; r <= ADAM_MAX_ROWS; r++) tab.first_block[r] = blocks;
     AdamState *st = static_cast<AdamState *>(state_dev);
     StageTimer timer(ST_OPTIMIZER, stream);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, (double)beta1, (double)beta2);
+    if (advance) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, (double)beta1, (double)beta2);
     if (blocks > 0)
         hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, beta1, beta2, eps);
     SOAR_LAUNCH_OK("adam_step", stream, 0);

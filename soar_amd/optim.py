@@ -30,9 +30,10 @@ class FusedAdam:
         self.state = torch.zeros((4,), dtype=torch.int32, device=dev)          # {step, bias corrections} on the device
         self._rows = None
 
-    def _table(self):
-        rows = (hip_lib.SoarAdamRow * len(self.names))()
-        for k, n in enumerate(self.names):
+    def _table(self, names=None):
+        names = self.names if names is None else names
+        rows = (hip_lib.SoarAdamRow * len(names))()
+        for k, n in enumerate(names):
             p = self.flat.leaves[n]
             if not p.is_contiguous():
                 raise ValueError(f"leaf {n} must be contiguous")
@@ -41,13 +42,15 @@ class FusedAdam:
             rows[k].count, rows[k].lr = p.numel(), self.lr[n]
         return rows
 
-    def step(self, stream: Optional[int] = None) -> None:
+    def step(self, stream: Optional[int] = None, names=None, advance: bool = True) -> None:
         """One Adam step of every leaf from the gradients in the flat buffer (behind whatever the stream already holds -- make it
-        wait for pending reductions first: ``flat.wait_all()``)."""
+        wait for pending reductions first: ``flat.wait_all()``).  ``names``: only these leaves; ``advance=False``: they belong to the
+        step a former call started (the positions behind the first gradient bucket, the rest behind the second)."""
         self.flat.check_views()
         dev = self.flat.flat.device
-        rows = self._table()
+        names = self.names if names is None else [n for n in self.names if n in names]
+        rows = self._table(names)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-            check(hip_lib.lib().soar_adam_step(len(self.names), rows, self.betas[0], self.betas[1], self.eps, ptr(self.state), stream),
-                  "soar_adam_step")
+            check(hip_lib.lib().soar_adam_step_rows(len(names), rows, self.betas[0], self.betas[1], self.eps, ptr(self.state),
+                                                    1 if advance else 0, stream), "soar_adam_step_rows")

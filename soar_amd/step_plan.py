@@ -156,6 +156,8 @@ class FrameStepPlan:
             env = os.environ.get("SOAR_PLAN_BATCHED")
             batched = (env != "0") if env in ("0", "1") else True
         self.batched = bool(batched) and self.n <= 8
+        self.optimizer = None                     # see _run_eager
+        self.optimizer_in_two_parts = None        # None: when a gradient reduction is in flight; True / False force it (tests)
         self.graphs = None
         if use_graphs:
             if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
@@ -431,9 +433,19 @@ class FrameStepPlan:
         dev = self.device
         main = torch.cuda.current_stream(dev)
         with torch.cuda.device(dev):
+            # ``self.optimizer`` (an optim.FusedAdam over the same flat buffer): the update from the PREVIOUS step's gradients happens
+            # here, in two parts -- the positions as soon as their bucket of the gradient reduction is there, in front of the KNN
+            # refresh that needs them; everything else behind the second bucket, which travels while the refresh runs
+            opt = self.optimizer if (self.optimizer is not None and self.steps > 0) else None
+            in_flight = any(p is not None for p in self.flat.pending) if self.optimizer_in_two_parts is None else self.optimizer_in_two_parts
+            # (no reduction pending: one launch for all leaves)
             self.flat.wait_bucket(0)
+            if opt is not None:
+                opt.step(main.cuda_stream, names=("xyz",) if in_flight else None, advance=True)
             self._prologue(main.cuda_stream, self.steps % self.RESORT_EVERY == 0)
             self.flat.wait_all()
+            if opt is not None and in_flight:
+                opt.step(main.cuda_stream, names=tuple(n for n in opt.names if n != "xyz"), advance=False)
             self._warp_all(main.cuda_stream)
             if self.batched:
                 self._frames_batched(main.cuda_stream)

@@ -240,3 +240,36 @@ def test_adam_keeps_torchs_overflow_behaviour():
     torch.cuda.synchronize()
     assert torch.equal(p.detach()[0, :2], torch.tensor([1.0, 2.0], device=DEV))
     torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=0)
+
+
+def test_plan_optimizer_hook_is_the_explicit_optimizer_step():
+    """FrameStepPlan.optimizer: the update from the previous step's gradients inside the next run -- the positions behind the first
+    gradient bucket and in front of the KNN refresh, the rest behind the second (soar_adam_step_rows) -- gives the losses of
+    `plan.run(); adam.step()` step for step."""
+    from soar_amd import optim, rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+
+    def run(hooked):
+        seq, leaves, cam, bg, pool = _avatar_scene()
+        leaves = seq.leaves()
+        flat = FlatGradBuffer(leaves)
+        with torch.no_grad():
+            seq.render_frames(_AV["frames"], bg, with_occ=True)
+        plan = FrameStepPlan(seq, 4, pool, bg, 3 * rasterizer.last_num_rendered, flat, use_graphs=False)
+        adam = optim.FusedAdam(flat, lr={k: v for k, v in _AV["lr"].items() if k in leaves})
+        if hooked:
+            plan.optimizer = adam
+            plan.optimizer_in_two_parts = hooked == "two parts"
+        out = []
+        for _ in range(6):
+            out.append(plan.run(_AV["frames"]).clone())
+            if not hooked:
+                adam.step()
+        plan.check()
+        return torch.stack(out)
+
+    a, b, c = run(False), run("one launch"), run("two parts")
+    assert float(a[0].sum()) != float(a[-1].sum())
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
