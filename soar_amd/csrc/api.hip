@@ -186,8 +186,8 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->sort_slot, n);
     take(p, out->sort_pairs, n);
     take(p, out->ids_sorted, n);
-    take(p, out->bucket_mat, (8192 + 8) * ((n + 16383) / 16384));
-    take(p, out->bucket_base, 8192 + 1);
+    take(p, out->bucket_mat, (size_t)(BKT_MAX + BKT_MAX / 1024) * ((n + 16383) / 16384));
+    take(p, out->bucket_base, BKT_MAX + 1);
     take(p, out->blk_stats, ((n + 255) / 256) * BLK_STATS);
     take(p, out->band_cnt, 64 * ((n + 1023) / 1024));
     take(p, out->band_info, 128);

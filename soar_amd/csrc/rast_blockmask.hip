@@ -44,6 +44,7 @@ struct BlockMaskArgs {
     int normalize_depth;
     uint32_t *bg_state;
 };
+constexpr unsigned BM_THREADS = 256;  // (1024: the same at 4K, +3 us at 1080p)
 constexpr unsigned BM_MAX_WGS = 4096; // mask workgroups per frame (2 M list positions per round)
 constexpr unsigned BM_EXTRA = 8;     // workgroups at the front of every grid row that make no masks (one XCD round: the rest of the row
                                      // keeps its place on the XCDs); those of row 0 build the tile orders, one frame each
@@ -109,7 +110,7 @@ __device__ __forceinline__ void block_words(const int lane, bool valid, float x,
     }
 }
 
-__global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> batch)
+__global__ void __launch_bounds__(BM_THREADS) block_mask_kernel(Batch<BlockMaskArgs> batch)
 {
     // Which part of which frame's lists this workgroup takes follows from the XCD it runs on (the dispatcher deals consecutive
     // workgroups to the 8 XCDs in turn): every XCD walks ONE contiguous part of ONE frame's list positions, front to back.  List
@@ -138,14 +139,14 @@ __global__ void __launch_bounds__(256) block_mask_kernel(Batch<BlockMaskArgs> ba
     // (an overflow of the caller's binning buffer leaves every tile range empty and the lists unwritten)
     if (a.header && (a.header[H_OVERFLOW] | a.header[H_BAND_OVERFLOW]) != 0u) return;
     const uint32_t total = a.header ? min(a.header[H_TOTAL], a.total) : a.total;
-    constexpr uint32_t PER_WG = 256u * (uint32_t)BM_GROUPS;
+    constexpr uint32_t PER_WG = BM_THREADS * (uint32_t)BM_GROUPS;
     const uint32_t nb = (total + PER_WG - 1u) / PER_WG, per = (nb + parts - 1u) / parts;
     // (the grid is sized for at most BM_MAX_WGS workgroups per frame; longer lists -- a binning buffer sized with a wide margin holds
     // far fewer instances than it could -- take further rounds)
     const uint32_t wgs = (gridDim.x - BM_EXTRA) * n, round = parted ? wgs / 8u : wgs / n;
     for (uint32_t kk = parted ? k : l / n; kk < per; kk += round) {
         const uint32_t bx = part * per + kk;
-        const uint32_t g0 = (bx * 4u + (threadIdx.x >> 6)) * (uint32_t)BM_GROUPS;
+        const uint32_t g0 = (bx * (BM_THREADS / 64u) + (threadIdx.x >> 6)) * (uint32_t)BM_GROUPS;
         if ((uint64_t)g0 * 64u >= total) return;
         float x[BM_GROUPS], y[BM_GROUPS], A[BM_GROUPS], B[BM_GROUPS], C[BM_GROUPS], thr[BM_GROUPS], tx0[BM_GROUPS], ty0[BM_GROUPS];
 #pragma unroll
@@ -185,9 +186,10 @@ int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, I
     a.tile_count = img.tile_count; a.ranges = img.ranges;
     a.tile_order = prm.sort_descending ? nullptr : img.tile_order;       // (the key-sort path builds its own: rast_binning.hip)
     a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
-    const unsigned nblocks = min(((unsigned)((R + 256 * BM_GROUPS - 1) / (256 * BM_GROUPS)) + 7u) / 8u * 8u, BM_MAX_WGS);      // (whole rounds of the 8 XCDs)
+    const unsigned per_wg = BM_THREADS * BM_GROUPS;
+    const unsigned nblocks = min(((unsigned)((R + per_wg - 1) / per_wg) + 7u) / 8u * 8u, BM_MAX_WGS);      // (whole rounds of the 8 XCDs)
     StageTimer timer(ST_BLOCK_MASKS, stream);
-    SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(BM_EXTRA + nblocks), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED(block_mask_kernel, dim3(BM_EXTRA + nblocks), dim3(BM_THREADS), 0, stream, a);
     SOAR_LAUNCH_OK("block_masks", stream, prm.debug);
     return 0;
 }

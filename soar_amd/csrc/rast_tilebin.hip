@@ -41,7 +41,6 @@ __device__ __forceinline__ int prefix_in_mask(unsigned long long m)
 // gets from its radix sort.  Keys are spread over B buckets by a monotone map of [kmin, kmax] (both reduced by
 // preprocess); a bucket holds a few dozen pairs and is sorted by one wavefront in registers.  Larger buckets are sorted by
 // the whole workgroup in LDS, and the (pathological: thousands of equal depths) ones beyond that in global memory.
-constexpr int BKT_MAX = 8192;            // buckets (upper bound)
 constexpr int BKT_LDS = 2048;            // pairs one workgroup sorts in LDS
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float scale, int B)
@@ -120,17 +119,18 @@ __global__ void __launch_bounds__(1024) bucket_count_kernel(Batch<BucketCountArg
     __syncthreads();
     uint32_t *row = a.bucket_mat + (size_t)blockIdx.x * B;
     uint32_t *gtot = a.bucket_mat + (size_t)gridDim.x * B + (size_t)blockIdx.x * BKT_GROUPS;   // members per group of 1024 buckets
-    if (tid < BKT_GROUPS) red[0][tid] = 0u;       // (BKT_GROUPS <= BLK_STATS * 16: the statistics are not needed any more)
+    static_assert(BKT_GROUPS <= 16 * BLK_STATS, "the group totals reuse the statistics' LDS");
+    if (tid < BKT_GROUPS) (&red[0][0])[tid] = 0u;  // (the statistics are not needed any more)
     __syncthreads();
     for (int b = tid, grp = 0; b - tid < B; b += 1024, grp++) {
         uint32_t c = b < B ? cnt[b] : 0u;
         if (b < B) row[b] = c;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
-        if (lane == 0 && c) atomicAdd(&red[0][grp], c);
+        if (lane == 0 && c) atomicAdd(&(&red[0][0])[grp], c);
     }
     __syncthreads();
-    if (tid < BKT_GROUPS) gtot[tid] = red[0][tid];
+    if (tid < BKT_GROUPS) gtot[tid] = (&red[0][0])[tid];
 }
 
 // The [workgroups][B] counts become starts: one workgroup per 1024 consecutive buckets, one bucket per thread (consecutive threads

@@ -120,9 +120,9 @@ struct GeomBuf {
     uint32_t *sort_slot;     // [P] slot of each visible Gaussian inside its depth bucket
     uint64_t *sort_pairs;    // [P] (depth key << 32 | index), bucket after bucket
     uint32_t *ids_sorted;    // [P] Gaussian ids in depth order (first header[H_NVIS] entries)
-    uint32_t *bucket_mat;    // [W = ceil(P / 16384)][B <= 8192] depth buckets: members per counting workgroup, then where they start;
-                             // behind it [W][8]: members per group of 1024 buckets
-    uint32_t *bucket_base;   // [8192 + 1]
+    uint32_t *bucket_mat;    // [W = ceil(P / 16384)][B <= BKT_MAX] depth buckets: members per counting workgroup, then where they start;
+                             // behind it [W][BKT_MAX / 1024]: members per group of 1024 buckets
+    uint32_t *bucket_base;   // [BKT_MAX + 1]
     uint32_t *blk_stats;     // [ceil(P/256)][BLK_STATS] per-block maxima written by preprocess
     uint32_t *band_cnt;      // [64][ceil(P/1024)] entries per (band of tile rows, chunk of the depth order) (rast_tilebin.hip)
     uint32_t *band_info;     // [128] start / length of every band's list
@@ -142,6 +142,7 @@ constexpr int H_TOTAL = 8;      // instances (sum of the tile counts) found by t
 constexpr int H_OVERFLOW = 9;   // 0, or H_TOTAL when it exceeded the capacity of the caller's binning buffer
 constexpr int H_BAND_OVERFLOW = 10;   // 0, or the entries the band lists needed when they exceeded that capacity
 constexpr int H_PREFILTER_VIOLATIONS = 11;   // Gaussians culled although SoarRastParams.prefiltered was set (auxiliary.h:163-167, 195-199)
+constexpr int BKT_MAX = 16384;  // depth buckets (upper bound; the counters of a counting workgroup live in LDS: 64 KB)
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
     uint2 *ranges;           // [T]
