@@ -23,3 +23,10 @@ print("sum iters %.3e  (per SIMD: %.0f)   sum list entries over waves %.3e (phas
 busy = (a[..., 2] > 0)
 print("waves with a non-empty list:", int(busy.sum()), " iters/wave among them mean %.1f max %d" % (it[busy].mean(), it.max()))
 print("useful (pixel, entry) pairs: %.3e of %.3e evaluated lanes = %.1f %%" % (useful.sum(), it.sum() * 64, 100 * useful.sum() / max(it.sum() * 64, 1)))
+# where a wavefront's time goes: least squares of its duration against its list length (staging + phase A) and its blend steps
+sel = busy.ravel()
+A = np.stack([np.ones(sel.sum()), ln.ravel()[sel], it.ravel()[sel]], axis=1)
+coef, *_ = np.linalg.lstsq(A, dur.ravel()[sel], rcond=None)
+res = dur.ravel()[sel] - A @ coef
+print("duration ~ %.2f us + %.2f ns per list entry + %.1f ns per blend step (4 entries x 16 pixels); residual rms %.2f us; mean list %.0f, mean steps %.1f"
+      % (coef[0], 1e3 * coef[1], 1e3 * coef[2], float(np.sqrt((res ** 2).mean())), ln.ravel()[sel].mean(), it.ravel()[sel].mean()))
