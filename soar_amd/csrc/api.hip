@@ -304,6 +304,7 @@ int soar_batch_begin(int32_t n_frames)
     if (soar::batch_ctx().n) { soar::set_error("soar_batch_begin: a batch is already open on this thread"); return 1; }
     soar::batch_ctx().n = n_frames;
     soar::batch_ctx().f = 0;
+    soar::batch_ctx().serial++;
     return 0;
 }
 int soar_batch_frame(int32_t frame)

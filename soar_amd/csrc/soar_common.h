@@ -62,17 +62,35 @@ __device__ __forceinline__ void batch_interleave1(int &frame, int &bx)
 }
 struct BatchCtx {
     int n = 0, f = 0;             // n == 0: no batch open
+    unsigned serial = 0;          // counts the batches of this thread (a launch site tells a frame of this batch from a stale block)
 };
 BatchCtx &batch_ctx();
+// A launch site trusts nobody: the frames of a batch must come to it one after the other, all of them, with the same grid -- a frame
+// whose call was skipped (an error further up, a form of the entry point that is not batch-safe) would otherwise be launched with the
+// argument block of an earlier batch.  (A site may serve several stages of one batch -- zero_ranges does: frame 0 starts a new record.)
 #define SOAR_LAUNCH_BATCHED(kernel, grid, block, lds, stream, args)                                   \
     do {                                                                                                \
         using SoarArgsT_ = std::decay_t<decltype(args)>;                                                \
         static thread_local ::soar::Batch<SoarArgsT_> soar_pending_;                                    \
+        static thread_local unsigned soar_serial_ = 0u, soar_seen_ = 0u;                                \
+        static thread_local dim3 soar_grid0_;                                                           \
         const ::soar::BatchCtx &soar_c_ = ::soar::batch_ctx();                                          \
         const int soar_f_ = soar_c_.n ? soar_c_.f : 0, soar_n_ = soar_c_.n ? soar_c_.n : 1;             \
+        dim3 soar_g_ = (grid);                                                                          \
+        if (soar_c_.n) {                                                                                \
+            if (soar_serial_ != soar_c_.serial || soar_f_ == 0) { soar_serial_ = soar_c_.serial; soar_seen_ = 0u; soar_grid0_ = soar_g_; }   \
+            if (soar_g_.x != soar_grid0_.x || soar_g_.z != soar_grid0_.z) {                              \
+                ::soar::set_error("%s: the frames of a batch must agree in size (grid %u against %u)", #kernel, soar_g_.x, soar_grid0_.x); \
+                return 1;                                                                               \
+            }                                                                                           \
+            soar_seen_ |= 1u << soar_f_;                                                                \
+        }                                                                                               \
         soar_pending_.v[soar_f_] = (args);                                                              \
         if (soar_f_ == soar_n_ - 1) {                                                                   \
-            dim3 soar_g_ = (grid);                                                                      \
+            if (soar_c_.n && soar_seen_ != (1u << soar_n_) - 1u) {                                      \
+                ::soar::set_error("%s: frames %#x of the batch never reached this launch", #kernel, ((1u << soar_n_) - 1u) & ~soar_seen_); \
+                return 1;                                                                               \
+            }                                                                                           \
             soar_g_.y = (unsigned)soar_n_;                                                              \
             hipLaunchKernelGGL(kernel, soar_g_, block, lds, stream, soar_pending_);                     \
         }                                                                                               \
