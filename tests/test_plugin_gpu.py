@@ -673,6 +673,30 @@ def test_step_plan_batched_launches_equal_the_per_frame_chains():
         assert b.abs().max() > 0 and (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
 
 
+def test_step_plan_batched_with_float64_rows_equals_the_per_frame_chains_bit_for_bit(monkeypatch):
+    """The order-insensitive backward (rasterizer.DETERMINISTIC_BACKWARD: float64 accumulation rows, narrowed behind the blend) inside
+    a batch: the narrowing launch takes its frame from the batch like the launches around it (it used to run per call, in front of
+    the batched blend, for all frames but the last).  Batched against per-frame chains: identical gradients, bit for bit."""
+    import bench
+    from soar_amd import rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.step_plan import FrameStepPlan
+    seq, pool, _ = bench.build_sequence("tiny", DEV)
+    flats = [FlatGradBuffer(seq.leaves()) for _ in range(2)]
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    bench.run_step(seq, pool, flats[0], [0, 1, 2, 3], bg)
+    cap = 2 * rasterizer.last_num_rendered
+    monkeypatch.setattr(rasterizer, "DETERMINISTIC_BACKWARD", True)
+    plans = [FrameStepPlan(seq, 4, pool, bg, cap, flats[k], use_graphs=False, batched=(k == 0)) for k in range(2)]
+    assert plans[0].ctx.params.debug & 2 and plans[0].batched and not plans[1].batched
+    for frames in ([0, 1, 2, 3], [9, 2, 30, 17], [3, 2, 1, 0]):
+        for plan in plans:
+            plan.run(frames)
+            torch.cuda.synchronize()
+        a, b = flats[0].flat, flats[1].flat
+        assert b.abs().max() > 0 and torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_step_plan_keeps_background_of_empty_tiles_only():
     """From its second step on the plan asks the forward blend not to rewrite tiles that stay empty (SoarRastParams.debug bit 2:
     85 % of the output bytes of a 1080p frame).  With the allocator's free blocks full of junk, and frames whose silhouettes
