@@ -383,8 +383,11 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
 
     GeomBuf g;
     carve_geom(geom_buffer, prm->P, prm->M, &g);
-    // header (kmin / kmax / n_vis) and the depth-bucket counters start from zero
-    {
+    // The header starts from zero where something accumulates into it or may be read without having been written: the count of
+    // `prefiltered` violations (atomics of preprocess) and the key-sort path of back views.  On the tile-binning path every word is
+    // written before it is read (H_KMAX.. by bucket_count, H_NVIS by bucket_scan, H_TOTAL / H_OVERFLOW / H_BAND_OVERFLOW by
+    // band_place; preprocess clears the violation count itself when nothing can add to it): no launch for 256 bytes
+    if (prm->prefiltered || prm->sort_descending) {
         const ZeroRange zr[1] = {{g.header, 64 * sizeof(uint32_t)}};
         if (launch_zero_ranges(zr, 1, stream)) return 1;
     }

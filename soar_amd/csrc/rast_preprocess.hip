@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(Batch<PreArgs> batch)
     a.front_out[idx] = faces_camera ? 1.f : 0.f;
     a.radii[idx] = out_radius;
     a.tiles_touched[idx] = out_tiles;
+    if (!a.prefiltered && blockIdx.x == 0 && threadIdx.x == 0) a.header[H_PREFILTER_VIOLATIONS] = 0u;    // (nobody zeroed the header)
     if (a.prefiltered) {                                         // (uniform: SOAR never sets it)
         const unsigned long long bad = __ballot(prefilter_violation);
         if (bad != 0ull && (threadIdx.x & 63) == 0) atomicAdd(a.header + H_PREFILTER_VIOLATIONS, (uint32_t)__builtin_popcountll(bad));
