@@ -9,6 +9,8 @@
 // folds them; the backward kernel reads the count and the upstream scalar from device memory (no host round trip).
 #include "soar_common.h"
 
+#include <cstdint>
+
 namespace soar {
 
 namespace {
@@ -37,44 +39,106 @@ __device__ __forceinline__ void block_sum2(float s, float c, float *partials)
     }
 }
 
-template <bool BACKWARD>
+// V = 4: four consecutive pixels per thread and trip through 16-byte loads / stores (pixel count a multiple of 4, planes 16-byte
+// aligned: every image of the path); V = 1: any size
+template <int V> struct PixVec;
+template <> struct PixVec<4> { typedef float4 F; typedef uchar4 M; };
+template <> struct PixVec<1> { typedef float F; typedef uint8_t M; };
+__device__ __forceinline__ void unpack(const float4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void unpack(const float &v, float (&o)[1]) { o[0] = v; }
+__device__ __forceinline__ void unpack(const uchar4 &v, bool (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void unpack(const uint8_t &v, bool (&o)[1]) { o[0] = v; }
+__device__ __forceinline__ float4 pack(const float (&o)[4]) { return make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ float pack(const float (&o)[1]) { return o[0]; }
+
+template <bool BACKWARD, int V>
 __global__ void __launch_bounds__(256) masked_l1_kernel(LossArgs a)
 {
+    typedef typename PixVec<V>::F F;
+    typedef typename PixVec<V>::M M;
     float s = 0.f, cnt = 0.f;
     float scale = 0.f;
     if (BACKWARD) scale = (a.upstream ? *a.upstream : 1.f) / fmaxf(a.stats[1] * a.C, 1.f);
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < a.n; p += gridDim.x * 256) {
-        const bool sel = !a.mask || a.mask[p];
-        if (!BACKWARD) cnt += sel ? 1.f : 0.f;
+    const int nv = a.n / V;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < nv; p += gridDim.x * 256) {
+        bool sel[V];
+        if (a.mask) unpack(reinterpret_cast<const M *>(a.mask)[p], sel);
+        else
+#pragma unroll
+            for (int k = 0; k < V; k++) sel[k] = true;
+        if (!BACKWARD)
+#pragma unroll
+            for (int k = 0; k < V; k++) cnt += sel[k] ? 1.f : 0.f;
         for (int c = 0; c < a.C; c++) {
-            const float d = a.a[(size_t)c * a.n + p] - a.b[(size_t)c * a.n + p];
-            if (BACKWARD) a.grad[(size_t)c * a.n + p] = sel ? (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) : 0.f;
-            else s += sel ? fabsf(d) : 0.f;
+            float x[V], y[V], g[V];
+            unpack(reinterpret_cast<const F *>(a.a + (size_t)c * a.n)[p], x);
+            unpack(reinterpret_cast<const F *>(a.b + (size_t)c * a.n)[p], y);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const float d = x[k] - y[k];
+                if (BACKWARD) g[k] = sel[k] ? (d > 0.f ? scale : (d < 0.f ? -scale : 0.f)) : 0.f;
+                else s += sel[k] ? fabsf(d) : 0.f;
+            }
+            if (BACKWARD) reinterpret_cast<F *>(a.grad + (size_t)c * a.n)[p] = pack(g);
         }
     }
     if (!BACKWARD) block_sum2(s, cnt, a.partials);
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, int V>
 __global__ void __launch_bounds__(256) cos_loss_kernel(LossArgs a)
 {
+    typedef typename PixVec<V>::F F;
+    typedef typename PixVec<V>::M M;
     float s = 0.f, cnt = 0.f;
     float scale = 0.f;
     if (BACKWARD) scale = (a.upstream ? *a.upstream : 1.f) / fmaxf(a.stats[1], 1.f);
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < a.n; p += gridDim.x * 256) {
-        float cs = 0.f;
-        for (int c = 0; c < a.C; c++) cs += (a.a[(size_t)c * a.n + p] * 2.f - 1.f) * (a.b[(size_t)c * a.n + p] * 2.f - 1.f) * a.weight;
-        const bool sel = (!a.mask || a.mask[p]) && cs < a.cos_limit;
+    const int nv = a.n / V;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < nv; p += gridDim.x * 256) {
+        bool sel[V];
+        if (a.mask) unpack(reinterpret_cast<const M *>(a.mask)[p], sel);
+        else
+#pragma unroll
+            for (int k = 0; k < V; k++) sel[k] = true;
+        float cs[V], gt[3][V];
+#pragma unroll
+        for (int k = 0; k < V; k++) cs[k] = 0.f;
+        for (int c = 0; c < a.C; c++) {
+            float x[V], y[V];
+            unpack(reinterpret_cast<const F *>(a.a + (size_t)c * a.n)[p], x);
+            unpack(reinterpret_cast<const F *>(a.b + (size_t)c * a.n)[p], y);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                cs[k] += (x[k] * 2.f - 1.f) * (y[k] * 2.f - 1.f) * a.weight;
+                if (c < 3) gt[c][k] = y[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) sel[k] = sel[k] && cs[k] < a.cos_limit;
         if (BACKWARD) {
             // d (1 - cos) / d output_c = -2 weight (2 gt_c - 1)
-            for (int c = 0; c < a.C; c++)
-                a.grad[(size_t)c * a.n + p] = sel ? -2.f * a.weight * (a.b[(size_t)c * a.n + p] * 2.f - 1.f) * scale : 0.f;
+            for (int c = 0; c < a.C; c++) {
+                float g[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    const float y = c < 3 ? gt[c < 3 ? c : 0][k] : a.b[(size_t)c * a.n + (size_t)p * V + k];
+                    g[k] = sel[k] ? -2.f * a.weight * (y * 2.f - 1.f) * scale : 0.f;
+                }
+                reinterpret_cast<F *>(a.grad + (size_t)c * a.n)[p] = pack(g);
+            }
         } else {
-            s += sel ? 1.f - cs : 0.f;
-            cnt += sel ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < V; k++) { s += sel[k] ? 1.f - cs[k] : 0.f; cnt += sel[k] ? 1.f : 0.f; }
         }
     }
     if (!BACKWARD) block_sum2(s, cnt, a.partials);
+}
+
+// (16-byte loads need the pixel count to be a multiple of 4 and every plane 16-byte aligned)
+static bool loss_vec4(const LossArgs &a)
+{
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0u; };
+    return (a.n & 3) == 0 && al(a.a) && al(a.b) && (!a.mask || (reinterpret_cast<uintptr_t>(a.mask) & 3u) == 0u) && (!a.grad || al(a.grad));
 }
 
 // stats = {sum / (count * per), count}; an empty selection gives NaN like the reference's mean of an empty tensor
@@ -122,9 +186,10 @@ extern "C" int soar_masked_l1(int32_t C, int32_t H, int32_t W, const float *img,
     if (check_loss_args("soar_masked_l1", C, H, W, img, gt, stats2, scratch)) return 1;
     LossArgs a = {};
     a.C = C; a.n = H * W; a.a = img; a.b = gt; a.mask = mask; a.partials = scratch;
-    const int blocks = min(LOSS_BLOCKS, (a.n + 255) / 256);
+    const int blocks = min(LOSS_BLOCKS, ((loss_vec4(a) ? a.n / 4 : a.n) + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    hipLaunchKernelGGL(masked_l1_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) hipLaunchKernelGGL((masked_l1_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((masked_l1_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, (float)C, stats2);
     SOAR_LAUNCH_OK("masked_l1", stream, 0);
     return 0;
@@ -138,7 +203,8 @@ extern "C" int soar_masked_l1_backward(int32_t C, int32_t H, int32_t W, const fl
     LossArgs a = {};
     a.C = C; a.n = H * W; a.a = img; a.b = gt; a.mask = mask; a.stats = stats2; a.upstream = upstream_dev; a.grad = dL_dimg;
     StageTimer timer(ST_FRAME_LOSS, stream);
-    hipLaunchKernelGGL(masked_l1_kernel<true>, dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) hipLaunchKernelGGL((masked_l1_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((masked_l1_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("masked_l1_backward", stream, 0);
     return 0;
 }
@@ -150,9 +216,10 @@ extern "C" int soar_cos_loss(int32_t C, int32_t H, int32_t W, const float *outpu
     if (check_loss_args("soar_cos_loss", C, H, W, output, gt, stats2, scratch)) return 1;
     LossArgs a = {};
     a.C = C; a.n = H * W; a.a = output; a.b = gt; a.mask = mask; a.cos_limit = cos_thrsh; a.weight = weight; a.partials = scratch;
-    const int blocks = min(LOSS_BLOCKS, (a.n + 255) / 256);
+    const int blocks = min(LOSS_BLOCKS, ((loss_vec4(a) ? a.n / 4 : a.n) + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    hipLaunchKernelGGL(cos_loss_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) hipLaunchKernelGGL((cos_loss_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((cos_loss_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, 1.0f, stats2);
     SOAR_LAUNCH_OK("cos_loss", stream, 0);
     return 0;
@@ -168,7 +235,8 @@ extern "C" int soar_cos_loss_backward(int32_t C, int32_t H, int32_t W, const flo
     a.C = C; a.n = H * W; a.a = output; a.b = gt; a.mask = mask; a.cos_limit = cos_thrsh; a.weight = weight; a.stats = stats2;
     a.upstream = upstream_dev; a.grad = dL_doutput;
     StageTimer timer(ST_FRAME_LOSS, stream);
-    hipLaunchKernelGGL(cos_loss_kernel<true>, dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) hipLaunchKernelGGL((cos_loss_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((cos_loss_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("cos_loss_backward", stream, 0);
     return 0;
 }
