@@ -2,6 +2,9 @@
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 4)
+t_ready = ((a[..., 2] >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.float64) / 100.0     # us from the start to the first staged chunk
+t_tail = ((a[..., 2] >> np.uint64(44)) & np.uint64(0xFFFFF)).astype(np.float64) / 100.0      # us from the end of the blending to the end
+a[..., 2] &= np.uint64((1 << 24) - 1)
 t0 = a[..., 0][a[..., 0] > 0].min()
 start = (a[..., 0].astype(np.int64) - int(t0)) / 100.0      # us
 end = (a[..., 1].astype(np.int64) - int(t0)) / 100.0
@@ -30,3 +33,6 @@ coef, *_ = np.linalg.lstsq(A, dur.ravel()[sel], rcond=None)
 res = dur.ravel()[sel] - A @ coef
 print("duration ~ %.2f us + %.2f ns per list entry + %.1f ns per blend step (4 entries x 16 pixels); residual rms %.2f us; mean list %.0f, mean steps %.1f"
       % (coef[0], 1e3 * coef[1], 1e3 * coef[2], float(np.sqrt((res ** 2).mean())), ln.ravel()[sel].mean(), it.ravel()[sel].mean()))
+print("of a wavefront's life: start -> first chunk staged %.2f us (p50 %.2f, p90 %.2f); end of blending -> end %.2f us (p50 %.2f, p90 %.2f)"
+      % (t_ready.ravel()[sel].mean(), np.percentile(t_ready.ravel()[sel], 50), np.percentile(t_ready.ravel()[sel], 90),
+         t_tail.ravel()[sel].mean(), np.percentile(t_tail.ravel()[sel], 50), np.percentile(t_tail.ravel()[sel], 90)))

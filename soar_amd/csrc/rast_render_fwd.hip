@@ -137,7 +137,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
     __shared__ int wave_alive[2][4];
     __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: LDS slots of a sub-chunk's relevant entries
-    unsigned long long t_start = 0, n_iter = 0, n_useful = 0;
+    unsigned long long t_start = 0, t_ready = 0, t_blended = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -200,6 +200,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         }
         if (base + 2 * CHUNK + tid < range.y) id_next = a.point_list[base + 2 * CHUNK + tid];
         lds_barrier();           // LDS only: the gathers of the next chunk stay in flight while this one is blended
+        if (LOG && base == range.x) t_ready = wall_clock64();
 
         if (!wave_done) {
             // The entries only matter for the pixels that are still blending: the test rectangle of phase A is the bounding
@@ -362,6 +363,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         if ((wave_alive[parity][0] | wave_alive[parity][1] | wave_alive[parity][2] | wave_alive[parity][3]) == 0) break;
     }
 
+    if (LOG) t_blended = wall_clock64();
     // fold the four slots of every pixel
     D += quad_move<DPP_QUAD_XOR1>(D); D += quad_move<DPP_QUAD_XOR2>(D);
     C0 += quad_move<DPP_QUAD_XOR1>(C0); C0 += quad_move<DPP_QUAD_XOR2>(C0);
@@ -399,7 +401,10 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     }
     if (LOG && lane == 0) {
         unsigned long long *w = a.wave_log + ((size_t)seq * 4 + wave) * 4;
-        w[0] = t_start; w[1] = wall_clock64(); w[2] = range.y - range.x; w[3] = n_iter | (n_useful << 24);
+        // (w[2]: list length | time to the first staged chunk << 24 | time from the end of the blending to here << 44, in 10 ns)
+        const unsigned long long t_end = wall_clock64();
+        w[0] = t_start; w[1] = t_end; w[2] = (unsigned long long)(range.y - range.x) | (min(t_ready - t_start, 0xFFFFFull) << 24) | (min(t_end - t_blended, 0xFFFFFull) << 44);
+        w[3] = n_iter | (n_useful << 24);
     }
 }
 
