@@ -127,8 +127,8 @@ int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int6
                              void *stream);
 
 /* The same two words without blocking: copied into `status_pinned` (two uint32 of page-locked host memory: instances found, 0 or the
- * number that did not fit) behind whatever `stream` already holds; the caller reads them once an event recorded behind this call has
- * completed.  What a caller that sizes its binning buffers from earlier frames polls between frames. */
+ * number that did not fit) behind whatever `stream` already holds.  Both words are set to 0xFFFFFFFF by this call and overwritten when
+ * the copy lands: the caller polls them (or waits for an event it records behind this call).  What a caller that sizes its binning buffers from earlier frames polls between frames. */
 int soar_rast_binning_status_async(const void *geom_buffer, int32_t P, int32_t M, uint32_t *status_pinned, void *stream);
 
 /* `prefiltered` (GaussianRasterizationSettings.prefiltered): the caller promises that no Gaussian is culled.  The reference prints

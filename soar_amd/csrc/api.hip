@@ -467,6 +467,8 @@ int soar_rast_binning_status_async(const void *geom_buffer, int32_t P, int32_t M
     status_pinned[0] = 0u;
     status_pinned[1] = 0u;
     if (P == 0) return 0;
+    status_pinned[0] = 0xFFFFFFFFu;              // "not there yet": neither word can be this (counts of 32-bit list positions)
+    status_pinned[1] = 0xFFFFFFFFu;
     if (check_aligned(geom_buffer, "geom_buffer")) return 1;
     GeomBuf g;
     carve_geom(const_cast<void *>(geom_buffer), P, M, &g);

@@ -52,7 +52,7 @@ AUTO = "auto"
 AUTO_MARGIN = 4              # capacity = AUTO_MARGIN x the largest number of instances seen for the key
 AUTO_FLOOR = 1 << 18
 _auto_capacity: Dict[tuple, int] = {}
-_auto_pending: list = []     # (event, pinned status words, key, capacity the frame ran with)
+_auto_pending: list = []     # (pinned status words, key, capacity the frame ran with); the words hold -1 until the copy has landed
 _auto_pinned_free: list = []
 
 
@@ -62,13 +62,16 @@ def auto_binning_poll(block: bool = False) -> None:
     global _auto_pending
     still = []
     overflow = None
-    for ev, words, key, cap in _auto_pending:
+    for words, key, cap in _auto_pending:
+        # (no event per frame: creating and recording one costs ~80 us of host time; the copy overwrites a sentinel instead)
+        w = words.numpy()                         # (a view of the page-locked memory the copy lands in)
         if block:
-            ev.synchronize()
-        elif not ev.query():
-            still.append((ev, words, key, cap))
+            while w[0] == -1 or w[1] == -1:
+                torch.cuda.synchronize()
+        elif w[0] == -1 or w[1] == -1:
+            still.append((words, key, cap))
             continue
-        total, over = int(words[0]) & 0xFFFFFFFF, int(words[1]) & 0xFFFFFFFF
+        total, over = int(w[0]) & 0xFFFFFFFF, int(w[1]) & 0xFFFFFFFF
         _auto_pinned_free.append(words)
         need = max(total, over)
         if need * 2 > _auto_capacity.get(key, 0):
@@ -350,9 +353,7 @@ class _NativeOps:
                 if auto_key is not None and capacity is not None:
                     words = _auto_pinned_free.pop() if _auto_pinned_free else torch.zeros(2, dtype=torch.int32).pin_memory()
                     check(L.soar_rast_binning_status_async(st["geom"].data_ptr(), P, st["M"], words.data_ptr(), stream), "binning_status_async")
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.ExternalStream(stream, device=device))
-                    _auto_pending.append((ev, words, auto_key, int(capacity)))
+                    _auto_pending.append((words, auto_key, int(capacity)))
             if defer is not None:
                 defer.append(launch)
             else:
