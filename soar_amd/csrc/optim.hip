@@ -14,6 +14,7 @@
 #include "soar_common.h"
 
 #include <cmath>
+#include <cstdint>
 
 namespace soar {
 
@@ -47,16 +48,32 @@ __global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const A
     const int64_t i0 = ((int64_t)blockIdx.x - tab.first_block[r]) * 1024 + threadIdx.x * 4;
     const float step_size = row.lr / st->bias_correction1, bc2s = st->bias_correction2_sqrt;
     const float one_minus_b1 = 1.f - beta1, one_minus_b2 = 1.f - beta2;
-    for (int k = 0; k < 4; k++) {
+    auto update = [&](float g, float &p, float &m, float &v) {
 #pragma clang fp contract(off)
-        const int64_t i = i0 + k;
-        if (i >= row.count) break;
-        const float g = row.grad[i];
-        float m = row.exp_avg[i], v = row.exp_avg_sq[i];
         m = m + (g - m) * one_minus_b1;
         v = beta2 * v + one_minus_b2 * (g * g);        // (torch squares first: a gradient beyond 1.8e19 makes v infinite and the value stops moving -- kept)
         const float denom = sqrtf(v) / bc2s + eps;
-        row.param[i] = row.param[i] - step_size * (m / denom);
+        p = p - step_size * (m / denom);
+    };
+    // four consecutive elements per thread: one 16-byte load / store per array where the row allows it (every leaf of a model whose
+    // size is a multiple of four; the slices of the flat gradient buffer start on 16-byte boundaries then)
+    const bool vec = i0 + 3 < row.count && (((uintptr_t)row.param | (uintptr_t)row.grad | (uintptr_t)row.exp_avg | (uintptr_t)row.exp_avg_sq) & 15u) == 0u;
+    if (vec) {
+        const float4 g = *reinterpret_cast<const float4 *>(row.grad + i0);
+        float4 p = *reinterpret_cast<const float4 *>(row.param + i0), m = *reinterpret_cast<const float4 *>(row.exp_avg + i0),
+               v = *reinterpret_cast<const float4 *>(row.exp_avg_sq + i0);
+        update(g.x, p.x, m.x, v.x); update(g.y, p.y, m.y, v.y); update(g.z, p.z, m.z, v.z); update(g.w, p.w, m.w, v.w);
+        *reinterpret_cast<float4 *>(row.param + i0) = p;
+        *reinterpret_cast<float4 *>(row.exp_avg + i0) = m;
+        *reinterpret_cast<float4 *>(row.exp_avg_sq + i0) = v;
+        return;
+    }
+    for (int k = 0; k < 4; k++) {
+        const int64_t i = i0 + k;
+        if (i >= row.count) break;
+        float p = row.param[i], m = row.exp_avg[i], v = row.exp_avg_sq[i];
+        update(row.grad[i], p, m, v);
+        row.param[i] = p;
         row.exp_avg[i] = m;
         row.exp_avg_sq[i] = v;
     }
