@@ -130,6 +130,10 @@ def build_sequence(workload, device, seed=0):
     from soar_amd.frame_step import AvatarSequence
     P, W, H, F = WORKLOADS[workload]
     surfels = syn.make_surfels(P, seed)
+    if os.environ.get("SOAR_BENCH_RANDOM_ORDER", "0") != "1":
+        # the model in a spatially coherent order (Morton order of the canonical positions), as a model initialised from the SMPL-X
+        # vertices is: same surfels, same images; neighbours in space are neighbours in memory (synthetic.sort_surfels_spatially)
+        surfels = syn.sort_surfels_spatially(surfels)
     body = syn.make_body_model(seed)
     poses = syn.make_pose_sequence(max(F, 4), seed)
     cam = syn.make_camera(W, H)
@@ -663,6 +667,10 @@ def main():
                    "knn": (f"neighbour sets kept on the device: {int(plan.knn.searched.item())} of {plan.steps * P} query refreshes "
                            f"needed the seeded search, the others were certified; full search every {plan.RESORT_EVERY} steps"
                            if plan is not None else "full grid search per step"),
+                   "model_order": ("generator's random order (SOAR_BENCH_RANDOM_ORDER=1)" if os.environ.get("SOAR_BENCH_RANDOM_ORDER", "0") == "1" else
+                                   "Morton order of the canonical positions (synthetic.sort_surfels_spatially: the same surfels, neighbours in "
+                                   "space are neighbours in memory, as in a model initialised from the SMPL-X vertices; "
+                                   "SOAR_BENCH_RANDOM_ORDER=1 keeps the generator's random order: -2 % at C3)"),
                    "build_digest": build.source_digest(),
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},

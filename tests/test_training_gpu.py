@@ -273,3 +273,19 @@ def test_plan_optimizer_hook_is_the_explicit_optimizer_step():
     assert float(a[0].sum()) != float(a[-1].sum())
     torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
+
+
+def test_spatially_sorted_model_renders_the_same_images():
+    """bench.py keeps its synthetic model in Morton order (synthetic.sort_surfels_spatially): a permutation of the surfels -- the
+    images are those of the generator's order (only exactly equal depths could be blended in another order)."""
+    body, poses, cam = syn.make_body_model(0, V=2048), syn.make_pose_sequence(4, 0), syn.make_camera(160, 128)
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    surf = syn.make_surfels(4000, 0)
+    outs = []
+    for s in (surf, syn.sort_surfels_spatially(surf)):
+        seq = AvatarSequence(s, body, poses, cam, DEV)
+        with torch.no_grad():
+            outs.append(seq.render_frame(1, bg, with_occ=True))
+    for name in ("render", "normal", "depth", "mask", "occ"):
+        a, b = getattr(outs[0], name), getattr(outs[1], name)
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1.0), name
