@@ -52,8 +52,9 @@ __device__ __forceinline__ float4 pack(const float (&o)[4]) { return make_float4
 __device__ __forceinline__ float pack(const float (&o)[1]) { return o[0]; }
 
 template <bool BACKWARD, int V>
-__global__ void __launch_bounds__(256) masked_l1_kernel(LossArgs a)
+__global__ void __launch_bounds__(256) masked_l1_kernel(Batch<LossArgs> batch)
 {
+    const LossArgs &a = batch.v[blockIdx.y];
     typedef typename PixVec<V>::F F;
     typedef typename PixVec<V>::M M;
     float s = 0.f, cnt = 0.f;
@@ -86,8 +87,9 @@ __global__ void __launch_bounds__(256) masked_l1_kernel(LossArgs a)
 }
 
 template <bool BACKWARD, int V>
-__global__ void __launch_bounds__(256) cos_loss_kernel(LossArgs a)
+__global__ void __launch_bounds__(256) cos_loss_kernel(Batch<LossArgs> batch)
 {
+    const LossArgs &a = batch.v[blockIdx.y];
     typedef typename PixVec<V>::F F;
     typedef typename PixVec<V>::M M;
     float s = 0.f, cnt = 0.f;
@@ -142,8 +144,19 @@ static bool loss_vec4(const LossArgs &a)
 }
 
 // stats = {sum / (count * per), count}; an empty selection gives NaN like the reference's mean of an empty tensor
-__global__ void __launch_bounds__(256) mean_finish_kernel(const float *__restrict__ partials, int nblocks, float per, float *__restrict__ stats)
+struct MeanFinishArgs {
+    const float *partials;
+    int nblocks;
+    float per;
+    float *stats;
+};
+__global__ void __launch_bounds__(256) mean_finish_kernel(Batch<MeanFinishArgs> batch)
 {
+    const MeanFinishArgs &fa = batch.v[blockIdx.y];
+    const float *partials = fa.partials;
+    const int nblocks = fa.nblocks;
+    const float per = fa.per;
+    float *stats = fa.stats;
     __shared__ float red[4][2];
     float s = 0.f, c = 0.f;
     for (int k = threadIdx.x; k < nblocks; k += 256) { s += partials[2 * k]; c += partials[2 * k + 1]; }
@@ -188,9 +201,10 @@ extern "C" int soar_masked_l1(int32_t C, int32_t H, int32_t W, const float *img,
     a.C = C; a.n = H * W; a.a = img; a.b = gt; a.mask = mask; a.partials = scratch;
     const int blocks = min(LOSS_BLOCKS, ((loss_vec4(a) ? a.n / 4 : a.n) + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    if (loss_vec4(a)) hipLaunchKernelGGL((masked_l1_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((masked_l1_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, (float)C, stats2);
+    if (loss_vec4(a)) SOAR_LAUNCH_BATCHED((masked_l1_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((masked_l1_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
+    const MeanFinishArgs fa = {scratch, blocks, (float)C, stats2};
+    SOAR_LAUNCH_BATCHED(mean_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
     SOAR_LAUNCH_OK("masked_l1", stream, 0);
     return 0;
 }
@@ -203,8 +217,8 @@ extern "C" int soar_masked_l1_backward(int32_t C, int32_t H, int32_t W, const fl
     LossArgs a = {};
     a.C = C; a.n = H * W; a.a = img; a.b = gt; a.mask = mask; a.stats = stats2; a.upstream = upstream_dev; a.grad = dL_dimg;
     StageTimer timer(ST_FRAME_LOSS, stream);
-    if (loss_vec4(a)) hipLaunchKernelGGL((masked_l1_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((masked_l1_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) SOAR_LAUNCH_BATCHED((masked_l1_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((masked_l1_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("masked_l1_backward", stream, 0);
     return 0;
 }
@@ -218,9 +232,10 @@ extern "C" int soar_cos_loss(int32_t C, int32_t H, int32_t W, const float *outpu
     a.C = C; a.n = H * W; a.a = output; a.b = gt; a.mask = mask; a.cos_limit = cos_thrsh; a.weight = weight; a.partials = scratch;
     const int blocks = min(LOSS_BLOCKS, ((loss_vec4(a) ? a.n / 4 : a.n) + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    if (loss_vec4(a)) hipLaunchKernelGGL((cos_loss_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((cos_loss_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, 1.0f, stats2);
+    if (loss_vec4(a)) SOAR_LAUNCH_BATCHED((cos_loss_kernel<false, 4>), dim3(blocks), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((cos_loss_kernel<false, 1>), dim3(blocks), dim3(256), 0, stream, a);
+    const MeanFinishArgs fa = {scratch, blocks, 1.0f, stats2};
+    SOAR_LAUNCH_BATCHED(mean_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
     SOAR_LAUNCH_OK("cos_loss", stream, 0);
     return 0;
 }
@@ -235,8 +250,8 @@ extern "C" int soar_cos_loss_backward(int32_t C, int32_t H, int32_t W, const flo
     a.C = C; a.n = H * W; a.a = output; a.b = gt; a.mask = mask; a.cos_limit = cos_thrsh; a.weight = weight; a.stats = stats2;
     a.upstream = upstream_dev; a.grad = dL_doutput;
     StageTimer timer(ST_FRAME_LOSS, stream);
-    if (loss_vec4(a)) hipLaunchKernelGGL((cos_loss_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((cos_loss_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
+    if (loss_vec4(a)) SOAR_LAUNCH_BATCHED((cos_loss_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((cos_loss_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("cos_loss_backward", stream, 0);
     return 0;
 }

@@ -157,9 +157,11 @@ __device__ __forceinline__ Stencil stencil_of_opac(int x, int y, int W, int H, c
     s.mb = opac[s.ib] > 1e-5f ? 1.f : 0.f; s.mr = opac[s.ir] > 1e-5f ? 1.f : 0.f;
     return s;
 }
+// (frames of a batch lie along gridDim.z)
 template <bool BACKWARD>
-__global__ void __launch_bounds__(256) view_finish_kernel(ViewArgs a)
+__global__ void __launch_bounds__(256) view_finish_kernel(Batch<ViewArgs> batch)
 {
+    const ViewArgs &a = batch.v[blockIdx.z];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= a.W || y >= a.H) return;
     const Stencil s = stencil_of_opac(x, y, a.W, a.H, a.opac);
@@ -307,7 +309,7 @@ extern "C" int soar_view_finish(int32_t W, int32_t H, const float *normal, const
     a.normal = normal; a.depth = depth; a.opac = opac;
     a.normal_out = normal_out; a.curv_out = curv_out; a.pred_out = pred_normal_out;
     StageTimer timer(ST_POSTOPS, stream);
-    hipLaunchKernelGGL(view_finish_kernel<false>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED_Z(view_finish_kernel<false>, pix_grid(W, H), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("view_finish", stream, 0);
     return 0;
 }
@@ -330,7 +332,7 @@ extern "C" int soar_view_finish_backward(int32_t W, int32_t H, const float *norm
     a.g_normal = dL_dnormal_and_depth; a.g_depth = dL_dnormal_and_depth + 3 * hw;
     SOAR_HIP_OK(hipMemsetAsync(dL_dnormal_and_depth, 0, sizeof(float) * 4 * hw, stream));
     StageTimer timer(ST_POSTOPS, stream);
-    hipLaunchKernelGGL(view_finish_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED_Z(view_finish_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("view_finish_backward", stream, 0);
     return 0;
 }

@@ -68,7 +68,7 @@ BatchCtx &batch_ctx();
 // A launch site trusts nobody: the frames of a batch must come to it one after the other, all of them, with the same grid -- a frame
 // whose call was skipped (an error further up, a form of the entry point that is not batch-safe) would otherwise be launched with the
 // argument block of an earlier batch.  (A site may serve several stages of one batch -- zero_ranges does: frame 0 starts a new record.)
-#define SOAR_LAUNCH_BATCHED(kernel, grid, block, lds, stream, args)                                   \
+#define SOAR_LAUNCH_BATCHED_IMPL(kernel, grid, block, lds, stream, args, ALONG_Z)                     \
     do {                                                                                                \
         using SoarArgsT_ = std::decay_t<decltype(args)>;                                                \
         static thread_local ::soar::Batch<SoarArgsT_> soar_pending_;                                    \
@@ -79,7 +79,7 @@ BatchCtx &batch_ctx();
         dim3 soar_g_ = (grid);                                                                          \
         if (soar_c_.n) {                                                                                \
             if (soar_serial_ != soar_c_.serial || soar_f_ == 0) { soar_serial_ = soar_c_.serial; soar_seen_ = 0u; soar_grid0_ = soar_g_; }   \
-            if (soar_g_.x != soar_grid0_.x || soar_g_.z != soar_grid0_.z) {                              \
+            if (soar_g_.x != soar_grid0_.x || soar_g_.z != soar_grid0_.z || ((ALONG_Z) && soar_g_.y != soar_grid0_.y)) { \
                 ::soar::set_error("%s: the frames of a batch must agree in size (grid %u against %u)", #kernel, soar_g_.x, soar_grid0_.x); \
                 return 1;                                                                               \
             }                                                                                           \
@@ -91,10 +91,16 @@ BatchCtx &batch_ctx();
                 ::soar::set_error("%s: frames %#x of the batch never reached this launch", #kernel, ((1u << soar_n_) - 1u) & ~soar_seen_); \
                 return 1;                                                                               \
             }                                                                                           \
-            soar_g_.y = (unsigned)soar_n_;                                                              \
+            if (ALONG_Z) soar_g_.z *= (unsigned)soar_n_; else soar_g_.y = (unsigned)soar_n_;            \
             hipLaunchKernelGGL(kernel, soar_g_, block, lds, stream, soar_pending_);                     \
         }                                                                                               \
     } while (0)
+
+// frames along gridDim.y (kernels with one-dimensional grids: frame = blockIdx.y) ...
+#define SOAR_LAUNCH_BATCHED(kernel, grid, block, lds, stream, args) SOAR_LAUNCH_BATCHED_IMPL(kernel, grid, block, lds, stream, args, 0)
+// ... or along gridDim.z, behind the kernel's own z extent Z (image kernels with two- or three-dimensional grids:
+// frame = blockIdx.z / Z, own z = blockIdx.z % Z)
+#define SOAR_LAUNCH_BATCHED_Z(kernel, grid, block, lds, stream, args) SOAR_LAUNCH_BATCHED_IMPL(kernel, grid, block, lds, stream, args, 1)
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg) ----
 enum Stage {

@@ -38,13 +38,16 @@ __device__ __forceinline__ float load_px(const float *img, int c, int x, int y, 
 // reads once (the first version read 11 inputs per output and recomputed the products x^2, y^2, xy for every tap: it was bound
 // by instruction issue at 103 + 80 us for a 1080p RGB pair).  Every output is still accumulated tap by tap in window order,
 // so the values are those of the unblocked loops.
-__global__ void __launch_bounds__(256) ssim_forward_kernel(SsimArgs a)
+// (frames of a batch lie along gridDim.z behind the channels: frame = blockIdx.z / C, channel = blockIdx.z % C)
+__global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch)
 {
+    const int C0 = batch.v[0].C;
+    const SsimArgs &a = batch.v[blockIdx.z / C0];
     __shared__ float s1[SH][SH + 1], s2[SH][SH + 1];
     __shared__ float h[5][SH][ST + 1];
     __shared__ float red[4];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z % C0;
     {
         // all loads of the halo in flight before the first LDS store (7 per image and thread)
         constexpr int NL = (SH * SH + 255) / 256;
@@ -128,15 +131,17 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(SsimArgs a)
     for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
     if ((tid & 63) == 0) red[tid >> 6] = val;
     __syncthreads();
-    if (tid == 0) a.partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) a.partials[(c * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void __launch_bounds__(256) ssim_backward_kernel(SsimArgs a)
+__global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batch)
 {
+    const int C0 = batch.v[0].C;
+    const SsimArgs &a = batch.v[blockIdx.z / C0];
     __shared__ float s[3][SH][SH + 1];
     __shared__ float h[3][SH][ST + 1];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z;
+    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z % C0;
     const size_t plane = (size_t)a.C * a.H * a.W;
     {
         constexpr int NL = (SH * SH + 255) / 256;
@@ -206,8 +211,19 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(SsimArgs a)
     }
 }
 
-__global__ void __launch_bounds__(1024) ssim_finish_kernel(const float *__restrict__ partials, int n, float scale, float *__restrict__ out)
+struct SsimFinishArgs {
+    const float *partials;
+    int n;
+    float scale;
+    float *out;
+};
+__global__ void __launch_bounds__(1024) ssim_finish_kernel(Batch<SsimFinishArgs> batch)
 {
+    const SsimFinishArgs &fa = batch.v[blockIdx.y];
+    const float *partials = fa.partials;
+    const int n = fa.n;
+    const float scale = fa.scale;
+    float *out = fa.out;
     __shared__ float red[16];
     float s = 0.f;
     for (int k = threadIdx.x; k < n; k += 1024) s += partials[k];
@@ -262,9 +278,10 @@ extern "C" int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, con
     fill_window(a.w);
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, C);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, a.partials, (int)(grid.x * grid.y * grid.z), a.gscale, ssim_out);
-    if (dssim_dimg1) hipLaunchKernelGGL(ssim_backward_kernel, grid, dim3(256), 0, stream, a);
+    SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel, grid, dim3(256), 0, stream, a);
+    const SsimFinishArgs fa = {a.partials, (int)(grid.x * grid.y * grid.z), a.gscale, ssim_out};
+    SOAR_LAUNCH_BATCHED(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, fa);
+    if (dssim_dimg1) SOAR_LAUNCH_BATCHED_Z(ssim_backward_kernel, grid, dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("ssim", stream, 0);
     return 0;
 }

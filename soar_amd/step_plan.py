@@ -195,49 +195,93 @@ class FrameStepPlan:
         self.av_ones3 = torch.ones((3, H, W), **f)
         self.av_focal = (H / (2.0 * self.seq.camera.tanfovy), W / (2.0 * self.seq.camera.tanfovx))     # fov2focal(FoVy, H), (FoVx, W)
         self.g_occ_all = torch.empty((self.n, P), **f)
-        for v in self.views:
+        # per-frame tensors that one torch call touches for all frames are slices of one allocation
+        self.av_gC_all, self.av_g_ssim_all = torch.empty((self.n, 3, H, W), **f), torch.empty((self.n, 3, H, W), **f)
+        self.av_terms_all, self.av_occ_terms_all = torch.zeros((self.n, S.N), **f), torch.zeros((self.n, 2), **f)
+        self.av_terms_all[:, S.ONE] = 1.0
+        for i, v in enumerate(self.views):
             g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
             v.update(normal_out=torch.empty((3, H, W), **f), curv=torch.empty((1, H, W), **f), pred=torch.empty((3, H, W), **f),
-                     g_ssim=torch.empty((3, H, W), **f), g_n=torch.empty((3, H, W), **f), g_nd=g_nd, g_occ_img=torch.empty((3, H, W), **f),
-                     terms=torch.zeros((S.N,), **f), occ_terms=torch.zeros((2,), **f),
+                     gC=self.av_gC_all[i], g_ssim=self.av_g_ssim_all[i], g_n=torch.empty((3, H, W), **f), g_nd=g_nd,
+                     g_occ_img=torch.empty((3, H, W), **f), terms=self.av_terms_all[i], occ_terms=self.av_occ_terms_all[i],
                      av_scratch=torch.empty((max(n_loss, int(k.value)),), **f))
-            v["terms"][S.ONE] = 1.0
             v["gN"], v["gD"] = g_nd[:3], g_nd[3:]                       # what the rasterizer backward reads
+
+    # ---- the avatar-stage loss block, kernel by kernel (each is batchable: one launch for the frames of a step) ------------------
+    def _av(self, i: int):
+        from .losses import _AvatarStageLoss as S
+        v = self.views[i]
+        k = self._frames_now[i] % int(self.pool.shape[0])
+        at = lambda t, j: t.data_ptr() + 4 * j
+        return S, self.L, v, self.W, self.H, self.av, k, at, ptr(v["av_scratch"]), v["terms"], self.av_coef
+
+    def _av_finish(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_view_finish(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.ctx.keep[3]), self.av_focal[0],
+                                 self.av_focal[1], ptr(v["normal_out"]), ptr(v["curv"]), ptr(v["pred"]), stream), "soar_view_finish")
+
+    def _av_l1(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), sc, stream), "soar_masked_l1")
+
+    def _av_ssim(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_ssim(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), stream), "soar_ssim")
+
+    def _av_l1m(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), sc, stream), "soar_masked_l1")
+
+    def _av_cos(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_cos_loss(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS), sc, stream),
+              "soar_cos_loss")
+
+    def _av_l1occ(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]), sc, stream),
+              "soar_masked_l1")
+
+    def _av_l1_b(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1_backward(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), at(up, S.L1),
+                                        ptr(v["gC"]), stream), "soar_masked_l1_backward")
+
+    def _av_l1m_b(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1_backward(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), at(up, S.L1M), ptr(v["gO"]),
+                                        stream), "soar_masked_l1_backward")
+
+    def _av_cos_b(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_cos_loss_backward(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS),
+                                       at(up, S.COS), ptr(v["g_n"]), stream), "soar_cos_loss_backward")
+
+    def _av_l1occ_b(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_masked_l1_backward(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]),
+                                        ptr(self.av_occ_up), ptr(v["g_occ_img"]), stream), "soar_masked_l1_backward")
+
+    def _av_finish_b(self, i, stream):
+        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
+        check(L.soar_view_finish_backward(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.ctx.keep[3]), self.av_focal[0],
+                                          self.av_focal[1], ptr(v["g_n"]), None, None, None, ptr(v["g_nd"]), stream),
+              "soar_view_finish_backward")
+
+    AV_FORWARD = ("_av_finish", "_av_l1", "_av_ssim", "_av_l1m", "_av_cos", "_av_l1occ")
+    AV_BACKWARD = ("_av_l1_b", "_av_l1m_b", "_av_cos_b", "_av_l1occ_b")
 
     def _f_avatar_loss(self, i: int, frame: int, stream: int) -> None:
         """post-ops -> the four image-loss kernels and the occlusion term -> their backwards -> post-ops backward: everything
-        between the blend and the rasterizer backward of one frame (plain launches: outside a batch)"""
+        between the blend and the rasterizer backward of ONE frame (the form with one stream per frame)"""
         from .losses import _AvatarStageLoss as S
-        L, v, W, H, a = self.L, self.views[i], self.W, self.H, self.av
-        k = frame % int(self.pool.shape[0])
-        prcp = self.ctx.keep[3]
-        at = lambda t, j: t.data_ptr() + 4 * j
-        sc = ptr(v["av_scratch"])
-        check(L.soar_view_finish(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(prcp), self.av_focal[0], self.av_focal[1],
-                                 ptr(v["normal_out"]), ptr(v["curv"]), ptr(v["pred"]), stream), "soar_view_finish")
-        t = v["terms"]
-        check(L.soar_masked_l1(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), sc, stream), "soar_masked_l1")
-        check(L.soar_ssim(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), stream), "soar_ssim")
-        check(L.soar_masked_l1(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), sc, stream), "soar_masked_l1")
-        check(L.soar_cos_loss(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS), sc, stream),
-              "soar_cos_loss")
-        check(L.soar_masked_l1(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]), sc, stream),
-              "soar_masked_l1")
-        up = self.av_coef
-        check(L.soar_masked_l1_backward(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), at(up, S.L1),
-                                        ptr(v["gC"]), stream), "soar_masked_l1_backward")
-        check(L.soar_masked_l1_backward(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), at(up, S.L1M), ptr(v["gO"]),
-                                        stream), "soar_masked_l1_backward")
-        check(L.soar_cos_loss_backward(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS),
-                                       at(up, S.COS), ptr(v["g_n"]), stream), "soar_cos_loss_backward")
-        check(L.soar_masked_l1_backward(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]),
-                                        ptr(self.av_occ_up), ptr(v["g_occ_img"]), stream), "soar_masked_l1_backward")
+        v, up = self.views[i], self.av_coef
+        for name in self.AV_FORWARD + self.AV_BACKWARD:
+            getattr(self, name)(i, stream)
         v["gC"].addcmul_(v["g_ssim"], up[S.SSIM])
-        check(L.soar_view_finish_backward(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(prcp), self.av_focal[0],
-                                          self.av_focal[1], ptr(v["g_n"]), None, None, None, ptr(v["g_nd"]), stream),
-              "soar_view_finish_backward")
+        self._av_finish_b(i, stream)
         # the frame's loss value (device side): terms . coef + lambda_occ mean(1 - occ[mask])
-        torch.add(torch.dot(t, up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
+        torch.add(torch.dot(v["terms"], up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
 
     def _f_occ_backward(self, i: int, stream: int) -> None:
         v = self.views[i]
@@ -369,11 +413,22 @@ class FrameStepPlan:
             finally:
                 L.soar_batch_end()
         if self.loss_kind == "avatar":
-            # the loss block's kernels take one frame per launch: between two batches
-            batch((self._f_geometry, self._f_render))
-            for i in frames:
-                self._f_avatar_loss(i, self._frames_now[i], stream)
-            batch((self._f_backward, self._f_occ_backward))
+            from .losses import _AvatarStageLoss as S
+            batch((self._f_geometry, self._f_render) + tuple(getattr(self, name) for name in self.AV_FORWARD + self.AV_BACKWARD))
+            if len(frames) == self.n:
+                # (what torch does between two kernels of the block: once for all frames, on slices of one allocation)
+                self.av_gC_all.addcmul_(self.av_g_ssim_all, self.av_coef[S.SSIM])
+            else:
+                for i in frames:
+                    self.views[i]["gC"].addcmul_(self.views[i]["g_ssim"], self.av_coef[S.SSIM])
+            batch((self._av_finish_b, self._f_backward, self._f_occ_backward))
+            # the frames' loss values: terms . coef + lambda_occ mean(1 - occ[mask])
+            if len(frames) == self.n:
+                torch.addmv(self.av_occ_terms_all[:, 0] * self.av_occ_up[0], self.av_terms_all, self.av_coef, out=self.losses)
+            else:
+                for i in frames:
+                    v = self.views[i]
+                    torch.add(torch.dot(v["terms"], self.av_coef), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
         else:
             batch((self._f_geometry, self._f_render, self._f_loss, self._f_backward))
         for i in frames:
