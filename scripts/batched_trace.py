@@ -9,10 +9,10 @@ for r in rows:
     if gy == n:
         d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000)
 tot = 0.0
+steps = min(len(v) for v in d.values()) if d else 1            # (a kernel launched once per step)
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]) / len(kv[1])):
     m = sum(v) / len(v)
-    per_step = 2 if "zero_ranges" in k else 1
-    tot += m * per_step
+    tot += m * len(v) / steps
     m_ = re.search(r"(\w+_kernel)", k)
     name = m_.group(1) if m_ else k[:60]
     print(f"{m:8.1f} us x{len(v):3d}  {name}")
