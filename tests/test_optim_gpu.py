@@ -28,3 +28,48 @@ def test_fused_adam_matches_torch_adam():
         for n in widths:
             torch.testing.assert_close(ours[n].detach(), ref[n].detach(), rtol=3e-5, atol=5e-7, msg=lambda m: f"step {step} leaf {n}: {m}")
     assert int(adam.state[0].item()) == 25
+
+
+def test_batched_launch_sites_refuse_frames_that_disagree():
+    """soar_batch_begin / _frame / _end: every stage is launched once for all frames with the LAST frame's grid -- a frame of another
+    size (or a frame whose call never came) must fail loudly instead of being launched with a stale or mis-sized argument block."""
+    import ctypes as C
+    from soar_amd import hip_lib
+    from soar_amd.hip_lib import ptr
+    L = hip_lib.lib()
+    dev = torch.device("cuda:0")
+    k = C.c_size_t(0)
+    assert L.soar_image_loss_scratch_floats(C.byref(k)) == 0
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def l1(H, W):
+        a, b = torch.rand(3, H, W, device=dev), torch.rand(3, H, W, device=dev)
+        stats, scratch = torch.zeros(2, device=dev), torch.zeros(int(k.value), device=dev)
+        keep.extend([a, b, stats, scratch])
+        return L.soar_masked_l1(3, H, W, ptr(a), ptr(b), None, ptr(stats), ptr(scratch), stream), stats, (a - b).abs().mean()
+
+    keep = []
+    # two frames of one size: one launch, both right
+    assert L.soar_batch_begin(2) == 0
+    try:
+        assert L.soar_batch_frame(0) == 0
+        rc0, s0, want0 = l1(64, 96)
+        assert L.soar_batch_frame(1) == 0
+        rc1, s1, want1 = l1(64, 96)
+    finally:
+        L.soar_batch_end()
+    torch.cuda.synchronize()
+    assert rc0 == 0 and rc1 == 0
+    torch.testing.assert_close(s0[0], want0, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s1[0], want1, rtol=1e-5, atol=1e-7)
+    # a second frame of another size: refused
+    assert L.soar_batch_begin(2) == 0
+    try:
+        assert L.soar_batch_frame(0) == 0
+        rc0, _, _ = l1(64, 96)
+        assert L.soar_batch_frame(1) == 0
+        rc1, _, _ = l1(256, 256)
+    finally:
+        L.soar_batch_end()
+    torch.cuda.synchronize()
+    assert rc0 == 0 and rc1 != 0 and "agree in size" in hip_lib.last_error()
