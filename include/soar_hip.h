@@ -479,6 +479,10 @@ typedef struct SoarAdamRow {
     int32_t pad_;
 } SoarAdamRow;
 int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev, void *stream);
+/* The same update with the step number (1, 2, ...) kept by the caller, as torch.optim.Adam keeps it: the bias corrections are worked
+ * out on the host in double precision, there is no device counter and no launch to advance it.  Several calls with the same `step`
+ * update further rows of that step.  Not inside a captured graph (a replay would repeat the step number). */
+int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows, float beta1, float beta2, float eps, int64_t step, void *stream);
 /* The same step in parts: `advance` != 0 moves the step counter (and the bias corrections) on before the rows are updated, 0 updates
  * further rows of the SAME step -- a caller whose gradients arrive in buckets updates the leaves of a bucket as soon as it is there
  * (soar_amd/step_plan.py: the positions behind the first bucket, in front of the KNN refresh; the rest behind the second). */

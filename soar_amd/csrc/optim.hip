@@ -40,8 +40,9 @@ __global__ void adam_tick_kernel(AdamState *st, double beta1, double beta2)
     st->bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
 
-__global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const AdamState *__restrict__ st, float beta1, float beta2, float eps)
+__global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const AdamState *__restrict__ st_dev, AdamState st_host, float beta1, float beta2, float eps)
 {
+    const AdamState *st = st_dev ? st_dev : &st_host;      // the step's bias corrections: from the device counter, or worked out by the host
     int r = 0;
     while (r + 1 < tab.n && (int64_t)blockIdx.x >= tab.first_block[r + 1]) r++;
     const SoarAdamRow row = tab.row[r];
@@ -91,6 +92,42 @@ extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, floa
     return soar_adam_step_rows(n_rows, rows_host, beta1, beta2, eps, state_dev, 1, stream_);
 }
 
+// The same update with the step number kept by the caller (as torch.optim.Adam does: its bias corrections are Python floats): no
+// device counter, no launch to advance it.  Not for a captured graph -- a replay would repeat the same step number.
+extern "C" int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, int64_t step,
+                                 void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_rows < 0 || n_rows > ADAM_MAX_ROWS || (n_rows && !rows_host) || step < 1) {
+        set_error("soar_adam_step_at: 0 <= n_rows <= %d, rows must be given, step >= 1", ADAM_MAX_ROWS);
+        return 1;
+    }
+    AdamTable tab;
+    tab.n = n_rows;
+    int64_t blocks = 0;
+    for (int r = 0; r < n_rows; r++) {
+        const SoarAdamRow &w = rows_host[r];
+        if (w.count < 0 || (w.count && (!w.param || !w.grad || !w.exp_avg || !w.exp_avg_sq))) {
+            set_error("soar_adam_step_at: row %d has a NULL pointer or a negative count", r);
+            return 1;
+        }
+        tab.row[r] = w;
+        tab.first_block[r] = blocks;
+        blocks += (w.count + 1023) / 1024;
+    }
+    for (int r = n_rows; r <= ADAM_MAX_ROWS; r++) tab.first_block[r] = blocks;
+    AdamState st;
+    st.step = (int32_t)step;
+    st.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
+    st.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    st.pad = 0;
+    StageTimer timer(ST_OPTIMIZER, stream);
+    if (blocks > 0)
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, (const AdamState *)nullptr, st, beta1, beta2, eps);
+    SOAR_LAUNCH_OK("adam_step_at", stream, 0);
+    return 0;
+}
+
 extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
                                    int32_t advance, void *stream_)
 {
@@ -117,7 +154,7 @@ extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host,
     StageTimer timer(ST_OPTIMIZER, stream);
     if (advance) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, (double)beta1, (double)beta2);
     if (blocks > 0)
-        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, beta1, beta2, eps);
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, AdamState{}, beta1, beta2, eps);
     SOAR_LAUNCH_OK("adam_step", stream, 0);
     return 0;
 }

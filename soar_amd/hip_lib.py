@@ -121,6 +121,7 @@ SIGNATURES = {
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "soar_adam_step": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, _vp, _vp]),
+    "soar_adam_step_at": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     "soar_adam_step_rows": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, _vp, C.c_int32, _vp]),
 }
 

@@ -28,6 +28,9 @@ class FusedAdam:
         self.exp_avg = {n: torch.zeros_like(flat.leaves[n]) for n in self.names}
         self.exp_avg_sq = {n: torch.zeros_like(flat.leaves[n]) for n in self.names}
         self.state = torch.zeros((4,), dtype=torch.int32, device=dev)          # {step, bias corrections} on the device
+        # device_counter = True keeps the step number on the device (soar_adam_step_rows: one more launch per step, but the launches
+        # can sit in a captured graph)
+        self.device_counter, self.steps = False, 0
         self._rows = None
 
     def _table(self, names=None):
@@ -52,5 +55,12 @@ class FusedAdam:
         rows = self._table(names)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-            check(hip_lib.lib().soar_adam_step_rows(len(names), rows, self.betas[0], self.betas[1], self.eps, ptr(self.state),
-                                                    1 if advance else 0, stream), "soar_adam_step_rows")
+            if self.device_counter:
+                check(hip_lib.lib().soar_adam_step_rows(len(names), rows, self.betas[0], self.betas[1], self.eps, ptr(self.state),
+                                                        1 if advance else 0, stream), "soar_adam_step_rows")
+            else:
+                # the step number lives here, like torch.optim.Adam's: no device counter, no launch to advance it
+                if advance:
+                    self.steps += 1
+                check(hip_lib.lib().soar_adam_step_at(len(names), rows, self.betas[0], self.betas[1], self.eps, self.steps, stream),
+                      "soar_adam_step_at")

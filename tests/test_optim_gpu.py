@@ -7,7 +7,8 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def test_fused_adam_matches_torch_adam():
+@pytest.mark.parametrize("device_counter", [False, True], ids=["step kept by the host", "step kept on the device"])
+def test_fused_adam_matches_torch_adam(device_counter):
     from soar_amd import frame_dp, optim
     g = torch.Generator().manual_seed(0)
     P = 5000
@@ -17,6 +18,7 @@ def test_fused_adam_matches_torch_adam():
     ref = {n: t.clone().to(DEV).requires_grad_(True) for n, t in init.items()}
     flat = frame_dp.FlatGradBuffer(ours)
     adam = optim.FusedAdam(flat)
+    adam.device_counter = device_counter          # soar_adam_step_rows (a launch advances a counter) / soar_adam_step_at
     tadam = torch.optim.Adam([{"params": [ref[n]], "lr": optim.REFERENCE_LR[n]} for n in widths], lr=0.0, eps=1e-15)
     for step in range(25):
         for n, w in widths.items():
@@ -27,7 +29,7 @@ def test_fused_adam_matches_torch_adam():
         tadam.step()
         for n in widths:
             torch.testing.assert_close(ours[n].detach(), ref[n].detach(), rtol=3e-5, atol=5e-7, msg=lambda m: f"step {step} leaf {n}: {m}")
-    assert int(adam.state[0].item()) == 25
+    assert (int(adam.state[0].item()) if device_counter else adam.steps) == 25
 
 
 def test_batched_launch_sites_refuse_frames_that_disagree():
