@@ -256,14 +256,17 @@ __device__ __forceinline__ void emit_sorted(const BucketSortArgs &a, uint32_t po
 }
 
 // workgroup = 4 wavefronts, wavefront = BKT_RUN consecutive buckets
-constexpr int BKT_RUN = 4;
+#ifndef SOAR_BKT_RUN
+#define SOAR_BKT_RUN 2       // (1 / 2 / 4 / 8 buckets per wavefront: 46.8 / 41.7 / 45.4 / 53.6 us for the depth order of a 4-frame step at C3)
+#endif
+constexpr int BKT_RUN = SOAR_BKT_RUN;
 __global__ void __launch_bounds__(256) bucket_sort_kernel(Batch<BucketSortArgs> batch)
 {
     const BucketSortArgs &a = batch.v[blockIdx.y];
     __shared__ uint64_t lds[BKT_LDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // phase 1: consecutive buckets are consecutive in `pairs` and ordered among each other (the bucket map is monotone): a run of
-    // buckets that fits one value per lane is sorted as ONE sequence -- with ~12 pairs per bucket most runs of four do.
+    // buckets that fits one value per lane is sorted as ONE sequence -- with ~12 pairs per bucket runs of two nearly always do.
     // Otherwise bucket by bucket, whichever of them fit.
     {
         const int b0 = (blockIdx.x * 4 + wave) * BKT_RUN, b1 = min(a.B, b0 + BKT_RUN);
@@ -723,7 +726,10 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
                 if (c) atomicAdd(&tile_cnt[lane], c);
             }
         };
-        constexpr int CU_ = 8;                    // rectangles per lane and trip of this pass
+#ifndef SOAR_BIN_COUNT_UNROLL
+#define SOAR_BIN_COUNT_UNROLL 4   // (2 / 4 / 8 / 16: 66.0 / 65.3 / 67.1 / 71.2 us for the tile lists)
+#endif
+        constexpr int CU_ = SOAR_BIN_COUNT_UNROLL;   // rectangles per lane and trip of this pass
         constexpr int CCHUNK = BIN_THREADS * CU_;
         int since = 0;
         uint2 rc[CU_];
