@@ -36,6 +36,19 @@ def test_bench_line_schema(mode):
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
 
 
+def test_bench_avatar_loss_line():
+    """`bench.py --loss avatar`: the second line -- the reference's avatar-stage losses in the step plan, Adam also on the occlusion
+    values -- keeps the one-line contract; its roofline kernel is one of the stages that are one launch per step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                        "--loss", "avatar", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["loss"].startswith("avatar") and d["config"]["plan_form"] == "batched, eager" and d["value"] > 0
+    assert d["roofline"]["kernel"] not in ("frame_loss", "postops") and d["roofline"]["launches"] == 3
+
+
 def test_bench_forced_dist_path_runs_rccl():
     """SOAR_BENCH_FORCE_DIST=1: the multi-rank code path (RCCL process group, barriers, bucketed asynchronous all-reduce, the
     same default mode as a real multi-rank job) with a single rank -- the only way to exercise it on a one-GPU box.  stdout
