@@ -35,8 +35,9 @@ extern "C" {
  * soar_sum_frames_when_last (introduced and withdrawn within round 2) is gone.  4 (round 3): soar_lbs_knn_state_bytes / _query_state /
  * _refresh, soar_adam_step, soar_rast_prefilter_violations, soar_selftest_affine_scan.  5 (round 3): soar_rast_binning_status_async;
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
- * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout). */
-#define SOAR_HIP_ABI_VERSION 5
+ * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
+ * of soar_adam_step / _at / _rows are doubles. */
+#define SOAR_HIP_ABI_VERSION 6
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
@@ -468,7 +469,10 @@ int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t fl
  * (TS/geometry/surfel_base.py:596-681 training_setup, TS/system/gaussian_surfel_mvdream.py:471-472 optimizer.step()) as ONE launch
  * over a table of up to 8 rows, a row = one leaf {parameter, gradient, first moment, second moment, number of floats, learning
  * rate}.  No weight decay, no amsgrad.  state_dev: 16 bytes of zero-initialised device memory owned by the caller = {int32 step,
- * float 1 - beta1^step, float sqrt(1 - beta2^step), pad}; every call advances the step on the device (graph-capturable). */
+ * float 1 - beta1^step, float sqrt(1 - beta2^step), pad}; every call advances the step on the device (graph-capturable).
+ * beta1 / beta2 / eps are doubles (ABI 6), as torch keeps them: 1 - beta is formed in double and rounded once (float(1 - 0.9) = 0.1,
+ * whereas 1.f - 0.9f = 0.100000024).  Rows of a step that was never started (soar_adam_step_rows with advance = 0 on a zeroed state)
+ * are left untouched. */
 typedef struct SoarAdamRow {
     float *param;
     const float *grad;
@@ -478,15 +482,15 @@ typedef struct SoarAdamRow {
     float lr;
     int32_t pad_;
 } SoarAdamRow;
-int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev, void *stream);
+int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, double beta1, double beta2, double eps, void *state_dev, void *stream);
 /* The same update with the step number (1, 2, ...) kept by the caller, as torch.optim.Adam keeps it: the bias corrections are worked
  * out on the host in double precision, there is no device counter and no launch to advance it.  Several calls with the same `step`
  * update further rows of that step.  Not inside a captured graph (a replay would repeat the step number). */
-int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows, float beta1, float beta2, float eps, int64_t step, void *stream);
+int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows, double beta1, double beta2, double eps, int64_t step, void *stream);
 /* The same step in parts: `advance` != 0 moves the step counter (and the bias corrections) on before the rows are updated, 0 updates
  * further rows of the SAME step -- a caller whose gradients arrive in buckets updates the leaves of a bucket as soon as it is there
  * (soar_amd/step_plan.py: the positions behind the first bucket, in front of the KNN refresh; the rest behind the second). */
-int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows, float beta1, float beta2, float eps, void *state_dev, int32_t advance,
+int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows, double beta1, double beta2, double eps, void *state_dev, int32_t advance,
                         void *stream);
 
 /* soar_prof_timestamp: one-thread kernel that appends {tag, device wall clock (100 MHz ticks)} to a ring in device memory when

@@ -748,14 +748,23 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
         carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
         const size_t R = (size_t)num_rendered;
         if (!prm->sort_descending && image_buffer && (point_list || ranges)) {
+            // (debugging entry point: a synchronous scratch allocation is fine here; freed on every way out)
             uint2 *packed = nullptr;
             SOAR_HIP_OK(hipMalloc(&packed, tiles * sizeof(uint2)));
-            hipLaunchKernelGGL(soar::export_pack_ranges_kernel, dim3(1), dim3(1024), 0, stream, (int)tiles, img.ranges, packed);
-            if (point_list)
-                hipLaunchKernelGGL(soar::export_pack_lists_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, img.ranges, packed, b.vals_sorted,
-                                   point_list);
-            if (ranges) SOAR_HIP_OK(hipMemcpyAsync(ranges, packed, tiles * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
-            SOAR_HIP_OK(hipStreamSynchronize(stream));
+            auto pack = [&]() -> int {
+                hipLaunchKernelGGL(soar::export_pack_ranges_kernel, dim3(1), dim3(1024), 0, stream, (int)tiles, img.ranges, packed);
+                SOAR_LAUNCH_OK("export_pack_ranges", stream, prm->debug);
+                if (point_list) {
+                    hipLaunchKernelGGL(soar::export_pack_lists_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, img.ranges, packed,
+                                       b.vals_sorted, point_list);
+                    SOAR_LAUNCH_OK("export_pack_lists", stream, prm->debug);
+                }
+                if (ranges) SOAR_HIP_OK(hipMemcpyAsync(ranges, packed, tiles * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+                SOAR_HIP_OK(hipStreamSynchronize(stream));
+                return 0;
+            };
+            const int rc = pack();
+            if (rc) { (void)hipStreamSynchronize(stream); (void)hipFree(packed); return rc; }
             SOAR_HIP_OK(hipFree(packed));
         } else {
             COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));

@@ -853,11 +853,19 @@ knn_search_kernel(const float *__restrict__ xyz, const GridMeta *__restrict__ me
         const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
         int n_in = 0;                                                 // candidates held in (cp, cd), ascending grid position
         float next_d2 = 3.0e38f, ball2 = 0.f;
+        // A query that is not a number (a parameter that diverged under the optimizer) compares false with every radius: its ball
+        // would never hold a vertex and the loop below would never end.  It gets NaN weights (what the full search's arithmetic
+        // gives it) and certificates that fail, so that it comes back here until it is a number again.
+        bool sane = (x - x == 0.f) && (y - y == 0.f) && (z - z == 0.f) && (tau_ub >= 0.f);
+        int growths = 0;
         // ... and a fifteenth further: what the search proves about the vertices it does NOT return is "at least the ball's radius
         // away" -- with the bare radius the gap behind the set would always be measured as zero (on a surface the K-th and
         // (K+1)-th distances differ by ~1/60 of the K-th on average).  Enlarged again should the ball hold fewer than KEEP vertices
         // (the state of a fresh full search only knows K of them)
-        for (float grow = 1.0f + 1.0f / 15.0f;; grow *= 1.3f) {
+        for (float grow = 1.0f + 1.0f / 15.0f; sane; grow *= 1.3f) {
+            // (V >= KEEP is checked by the host: a ball that holds every vertex ends the loop; the count bounds it whatever happens:
+            // 1.3^96 is 1e11 times the first radius)
+            if (++growths > 96) { sane = false; break; }
             const float ball = sqrtf(tau_ub) * grow + 1.0e-6f;
             ball2 = ball * ball;
             const float rho = ball * 1.0001f + 1.0e-7f;
@@ -993,6 +1001,15 @@ knn_search_kernel(const float *__restrict__ xyz, const GridMeta *__restrict__ me
                 __builtin_amdgcn_wave_barrier();
             }
             if (n_in >= KEEP) { select_keep(); break; }               // n_in == KEEP now
+        }
+        if (!sane) {                                                  // (wave-uniform)
+            const float nan = __uint_as_float(0x7FC00000u);
+            if (lane < J) weights_out[(size_t)p * J + lane] = nan;
+            if (lane == 0) {
+                st.ref30[q] = make_float4(x, y, z, -1.f);
+                st.ref32[q] = make_float4(x, y, z, -1.f);
+            }
+            continue;
         }
         const uint32_t pos = lane < KEEP ? cp[lane] : 0u;
         const float d2 = lane < KEEP ? cd[lane] : 3.0e38f;
@@ -1281,6 +1298,7 @@ extern "C" int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, cons
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_knn_sizes(P, V, J, KNN_K)) return 1;
+    if (V < KNN_STATE_STRIDE) { set_error("soar_lbs_knn_query_state: the neighbour state keeps %d vertices per query, V=%d", KNN_STATE_STRIDE, V); return 1; }
     if (P == 0) return 0;
     if (!grid_buffer || !xyz || !vert_weights || !weights_out || !order || !state_buffer) { set_error("soar_lbs_knn_query_state: NULL pointer"); return 1; }
     if (check_ws("soar_lbs_knn_query_state", query_workspace, query_workspace_bytes) || check_ws("soar_lbs_knn_query_state", state_buffer, 0)) return 1;
@@ -1301,6 +1319,7 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_knn_sizes(P, V, J, KNN_K)) return 1;
     if (J > KNN_JMAX) { set_error("soar_lbs_knn_refresh: J <= %d", KNN_JMAX); return 1; }
+    if (V < KNN_STATE_STRIDE) { set_error("soar_lbs_knn_refresh: the neighbour state keeps %d vertices per query, V=%d", KNN_STATE_STRIDE, V); return 1; }
     if (P == 0) return 0;
     if (!grid_buffer || !xyz || !weights_out || !state_buffer || !order) { set_error("soar_lbs_knn_refresh: NULL pointer"); return 1; }
     if (check_ws("soar_lbs_knn_refresh", state_buffer, 0)) return 1;

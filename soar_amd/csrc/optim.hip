@@ -40,15 +40,19 @@ __global__ void adam_tick_kernel(AdamState *st, double beta1, double beta2)
     st->bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
 
-__global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const AdamState *__restrict__ st_dev, AdamState st_host, float beta1, float beta2, float eps)
+// one_minus_b1 / one_minus_b2: 1 - beta worked out in double by the host and rounded once, as torch does with its Python floats
+// (1.f - 0.9f is 0.100000024, float(1 - 0.9) is 0.1: the lerp weight would differ in its last bits)
+__global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const AdamState *__restrict__ st_dev, AdamState st_host, float beta2,
+                                                          float one_minus_b1, float one_minus_b2, float eps)
 {
     const AdamState *st = st_dev ? st_dev : &st_host;      // the step's bias corrections: from the device counter, or worked out by the host
+    // rows of a step that was never started (advance = 0 on a fresh, zeroed state): 1 - beta1^0 = 0 would make the step size infinite
+    if (st->step <= 0) return;
     int r = 0;
     while (r + 1 < tab.n && (int64_t)blockIdx.x >= tab.first_block[r + 1]) r++;
     const SoarAdamRow row = tab.row[r];
     const int64_t i0 = ((int64_t)blockIdx.x - tab.first_block[r]) * 1024 + threadIdx.x * 4;
     const float step_size = row.lr / st->bias_correction1, bc2s = st->bias_correction2_sqrt;
-    const float one_minus_b1 = 1.f - beta1, one_minus_b2 = 1.f - beta2;
     auto update = [&](float g, float &p, float &m, float &v) {
 #pragma clang fp contract(off)
         m = m + (g - m) * one_minus_b1;
@@ -86,7 +90,7 @@ __global__ void __launch_bounds__(256) adam_update_kernel(AdamTable tab, const A
 
 using namespace soar;
 
-extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
+extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, double beta1, double beta2, double eps, void *state_dev,
                               void *stream_)
 {
     return soar_adam_step_rows(n_rows, rows_host, beta1, beta2, eps, state_dev, 1, stream_);
@@ -94,7 +98,7 @@ extern "C" int soar_adam_step(int32_t n_rows, const SoarAdamRow *rows_host, floa
 
 // The same update with the step number kept by the caller (as torch.optim.Adam does: its bias corrections are Python floats): no
 // device counter, no launch to advance it.  Not for a captured graph -- a replay would repeat the same step number.
-extern "C" int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, int64_t step,
+extern "C" int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows_host, double beta1, double beta2, double eps, int64_t step,
                                  void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -118,17 +122,18 @@ extern "C" int soar_adam_step_at(int32_t n_rows, const SoarAdamRow *rows_host, f
     for (int r = n_rows; r <= ADAM_MAX_ROWS; r++) tab.first_block[r] = blocks;
     AdamState st;
     st.step = (int32_t)step;
-    st.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
-    st.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    st.bias_correction1 = (float)(1.0 - pow(beta1, (double)step));
+    st.bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     st.pad = 0;
     StageTimer timer(ST_OPTIMIZER, stream);
     if (blocks > 0)
-        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, (const AdamState *)nullptr, st, beta1, beta2, eps);
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, (const AdamState *)nullptr, st, (float)beta2,
+                           (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
     SOAR_LAUNCH_OK("adam_step_at", stream, 0);
     return 0;
 }
 
-extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host, float beta1, float beta2, float eps, void *state_dev,
+extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host, double beta1, double beta2, double eps, void *state_dev,
                                    int32_t advance, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -152,9 +157,10 @@ extern "C" int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows_host,
     for (int r = n_rows; r <= ADAM_MAX_ROWS; r++) tab.first_block[r] = blocks;
     AdamState *st = static_cast<AdamState *>(state_dev);
     StageTimer timer(ST_OPTIMIZER, stream);
-    if (advance) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, (double)beta1, (double)beta2);
+    if (advance) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, st, beta1, beta2);
     if (blocks > 0)
-        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, AdamState{}, beta1, beta2, eps);
+        hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, st, AdamState{}, (float)beta2, (float)(1.0 - beta1),
+                           (float)(1.0 - beta2), (float)eps);
     SOAR_LAUNCH_OK("adam_step", stream, 0);
     return 0;
 }

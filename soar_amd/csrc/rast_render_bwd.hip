@@ -19,6 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef SOAR_BWD_DIV
+#define SOAR_BWD_DIV 0   // 0: v_rcp_f32 x multiply; 1: + one residual step; 2: IEEE division (development A/B, profiles/README.md)
+#endif
+
 
 namespace soar {
 
@@ -965,11 +969,26 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             const float d_cur = edepth - (dx * epa + dy * epb);
             const float u = er * c0.z + eg * c0.w + eb * c1.x + enx * c1.y + eny * c1.z + enz * c1.w + d_cur * c2.y;
             float m = 1.f - a_eff, b = a_eff * u;
+#if SOAR_BWD_DIV
+            const float om = m;
+#endif
             const PairProducts pp = affine_scan_with_products(m, b, dx, dy, eA, eB, eC);
             const float P_front = __builtin_fmaf(m, P_in, b);
+#if SOAR_BWD_DIV == 2
+            // the reference divides (backward.cu:683, :791): IEEE quotients instead of v_rcp_f32 (1 ulp) x multiply
+            const float T_mine = T_in / m;
+            const float r_om = 1.f / om;
+#elif SOAR_BWD_DIV == 1
+            // v_rcp_f32 + one residual step each: the quotient T_in / m and the reciprocal 1 / (1 - alpha) to the last bit or next to it
+            const float r_m = __builtin_amdgcn_rcpf(m);
+            const float q0 = T_in * r_m;
+            const float T_mine = __builtin_fmaf(__builtin_fmaf(-m, q0, T_in), r_m, q0);
+            const float r_om = __builtin_fmaf(__builtin_fmaf(-om, pp.r_om, 1.f), pp.r_om, pp.r_om);
+#else
             const float T_mine = T_in * __builtin_amdgcn_rcpf(m);
-            const float P_mine = dpp_or<DPP_WAVE_SHR1, 0xf>(P_in, P_front);
             const float r_om = pp.r_om;
+#endif
+            const float P_mine = dpp_or<DPP_WAVE_SHR1, 0xf>(P_in, P_front);
             const float wgt = a_eff * T_mine;                                            // dchannel_dcolor
             acc[6] = __builtin_fmaf(wgt, c0.z, acc[6]); acc[7] = __builtin_fmaf(wgt, c0.w, acc[7]);      // :711
             acc[8] = __builtin_fmaf(wgt, c1.x, acc[8]);

@@ -9,10 +9,11 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libsoar_hip.so")
+# SOAR_HIP_LIB: another build of the same library (development A/B runs: scripts/variant.py); still no fallback of any kind
+LIB_PATH = os.environ.get("SOAR_HIP_LIB") or os.path.join(_HERE, "_lib", "libsoar_hip.so")
 
 FRAME_LOSS_SCRATCH_FLOATS = 4 * 2048   # SOAR_FRAME_LOSS_SCRATCH_FLOATS: the scratch argument of soar_frame_loss[_pooled]
-ABI_VERSION = 5          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
+ABI_VERSION = 6          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 
@@ -120,9 +121,9 @@ SIGNATURES = {
     "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
-    "soar_adam_step": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, _vp, _vp]),
-    "soar_adam_step_at": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
-    "soar_adam_step_rows": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_float, C.c_float, C.c_float, _vp, C.c_int32, _vp]),
+    "soar_adam_step": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, _vp, _vp]),
+    "soar_adam_step_at": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, C.c_int64, _vp]),
+    "soar_adam_step_rows": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, _vp, C.c_int32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

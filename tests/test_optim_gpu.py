@@ -32,6 +32,29 @@ def test_fused_adam_matches_torch_adam(device_counter):
     assert (int(adam.state[0].item()) if device_counter else adam.steps) == 25
 
 
+def test_rows_of_a_step_that_was_never_started_are_left_alone():
+    """soar_adam_step_rows(advance=0) on a fresh, zeroed state: 1 - beta1^0 = 0 would make the step size infinite.  The rows are
+    left untouched (parameters and moments); the first advancing call then is step 1."""
+    from soar_amd import frame_dp, optim
+    g = torch.Generator().manual_seed(1)
+    P = 1000
+    leaves = {n: torch.randn(P, w, generator=g).to(DEV).requires_grad_(True) for n, w in dict(frame_dp.LEAVES).items()}
+    before = {n: t.detach().clone() for n, t in leaves.items()}
+    flat = frame_dp.FlatGradBuffer(leaves)
+    flat.flat.copy_(torch.randn(flat.flat.shape, generator=g).to(DEV))
+    adam = optim.FusedAdam(flat)
+    adam.device_counter = True
+    adam.step(advance=False)
+    torch.cuda.synchronize()
+    for n in leaves:
+        assert torch.equal(leaves[n].detach(), before[n]) and torch.isfinite(leaves[n]).all(), n
+        assert not adam.exp_avg[n].any() and not adam.exp_avg_sq[n].any()
+    assert int(adam.state[0].item()) == 0
+    adam.step()
+    assert int(adam.state[0].item()) == 1 and all(torch.isfinite(t).all() for t in leaves.values())
+    assert not torch.equal(leaves["xyz"].detach(), before["xyz"])
+
+
 def test_batched_launch_sites_refuse_frames_that_disagree():
     """soar_batch_begin / _frame / _end: every stage is launched once for all frames with the LAST frame's grid -- a frame of another
     size (or a frame whose call never came) must fail loudly instead of being launched with a stale or mis-sized argument block."""

@@ -1,6 +1,11 @@
 """Randomised parity sweep: the product against the REFERENCE's own kernels (oracle/_ref) on N random scenes (scene family,
 size, image size, config switches, order, opacity, principal point drawn from a seeded generator).  Integer state must be
-bit-exact, images and gradients within the bars of tests/test_rasterizer_gpu.py.  usage: python tests/tools/fuzz_vs_reference.py [N] [seed0]"""
+bit-exact, images and gradients within the bars of tests/test_rasterizer_gpu.py.  usage: python tests/tools/fuzz_vs_reference.py [N] [seed0]
+
+With --ratios (round 4) EVERY scene is also run through the double-accumulating C oracle, and per gradient tensor the sweep prints
+the distribution of  (product -> oracle) / (reference's kernels -> oracle): median, p95, p99, max over all scenes -- raw, and with
+both distances floored at 1e-6 (a hundredth of the 1e-4 bar: below it a ratio compares rounding noise with rounding noise).
+SOAR_HIP_LIB=<path> selects another build of the library (scripts/variant.py; read by soar_amd/hip_lib.py)."""
 import os
 import sys
 import traceback
@@ -40,9 +45,18 @@ def random_scene(rng):
     return S.big_splats_scene(P=int(rng.integers(200, 3000)), W=W, H=H, seed=seed)
 
 
+RATIO_TENSORS = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations", "dL_dsh")
+
+
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    want_ratios = "--ratios" in sys.argv
+    N = int(argv[0]) if len(argv) > 0 else 100
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
+    n_threads = int(os.environ.get("SOAR_FUZZ_THREADS", "8"))
+    dist_p = {k: [] for k in RATIO_TENSORS}
+    dist_r = {k: [] for k in RATIO_TENSORS}
+    families = []
     ref = rr.RefRasterizer()
     bad = 0
     benign = {}
@@ -71,6 +85,15 @@ def main():
                 if e > 2e-5:
                     print(f"[{it}] note: {scene.name} {scene.W}x{scene.H} cfg={scene.config.tolist()} {name} rel err {e:.2e}", flush=True)
                 assert e <= REL, (name, e)
+            if want_ratios and np.isfinite(r["dL_dmeans3D"]).all():
+                _, bw_o = S.run_oracle(scene, grads=grads, n_threads=n_threads)
+                families.append(scene.name.split("_")[0])
+                for k in RATIO_TENSORS:
+                    o = getattr(bw_o, k, None)
+                    if o is None or o.size == 0 or not np.isfinite(o).all() or not np.abs(o).max() > 0:
+                        dist_p[k].append(np.nan); dist_r[k].append(np.nan)
+                        continue
+                    dist_p[k].append(rel_err(h[k].reshape(o.shape), o)); dist_r[k].append(rel_err(r[k].reshape(o.shape), o))
             if np.isfinite(r["dL_dmeans3D"]).all():
                 check_backward(scene, h, _AsOracle(r, scene))
         except Exception as e:                                   # classify, report and go on: the sweep is a survey
@@ -106,6 +129,25 @@ def main():
                 benign[kind.split(" (")[0]] = benign.get(kind.split(" (")[0], 0) + 1
             print(f"[{it}] {kind}: {scene.name} {scene.W}x{scene.H} cfg={scene.config.tolist()} front={scene.render_front} "
                   f"desc={scene.sort_descending}:{detail if detail else ' ' + str(e)[:300]}", flush=True)
+    if want_ratios:
+        fam = np.array(families)
+        print("\nmax-norm relative distance to the double-accumulating oracle: product / reference's kernels, per tensor over the scenes "
+              "that have it (raw | both distances floored at 1e-6)")
+        print(f"{'tensor':14s} {'scenes':>6s} | {'median':>7s} {'p95':>7s} {'p99':>7s} {'max':>8s} | {'median':>7s} {'p95':>7s} {'p99':>7s} {'max':>8s} |"
+              f" {'product p50/p99/max':>28s} | {'reference p50/p99/max':>28s}")
+        for sel_name, sel in (("all scenes", np.ones(len(fam), bool)), ("person (surfel) scenes", fam == "person"), ("blob scenes", fam == "blob")):
+            print(f"-- {sel_name}: {int(sel.sum())}")
+            for k in RATIO_TENSORS:
+                ep, er = np.array(dist_p[k])[sel], np.array(dist_r[k])[sel]
+                ok = np.isfinite(ep) & np.isfinite(er)
+                if not ok.any():
+                    continue
+                ep, er = ep[ok], er[ok]
+                raw = ep / np.maximum(er, 1e-30)
+                flo = np.maximum(ep, 1e-6) / np.maximum(er, 1e-6)
+                q = lambda a: " ".join(f"{np.percentile(a, p):7.2f}" for p in (50, 95, 99)) + f" {a.max():8.2f}"
+                d = lambda a: f"{np.percentile(a, 50):.1e} / {np.percentile(a, 99):.1e} / {a.max():.1e}"
+                print(f"{k:14s} {int(ok.sum()):6d} | {q(raw)} | {q(flo)} | {d(ep):>28s} | {d(er):>28s}")
     print(f"{N} scenes, {bad} with a mismatch, explained differences: {benign}; worst image rel err {worst_img:.2e}, "
           f"worst n_contrib mismatch {worst_nc:.2e}")
     return 1 if bad else 0
