@@ -36,7 +36,8 @@ extern "C" {
  * _refresh, soar_adam_step, soar_rast_prefilter_violations, soar_selftest_affine_scan.  5 (round 3): soar_rast_binning_status_async;
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
- * of soar_adam_step / _at / _rows are doubles. */
+ * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
+ * soar_rast_forward_render_status, soar_lbs_warp_backward_views. */
 #define SOAR_HIP_ABI_VERSION 6
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
@@ -443,6 +444,64 @@ int soar_view_finish_backward(int32_t W, int32_t H, const float *normal, const f
                               const float *prcppoint_dev, float focal_k00, float focal_k11, const float *dL_dnormal_out,
                               const float *dL_dcurv, const float *dL_dpred_normal, const float *dL_ddepth_direct,
                               float *dL_dnormal_and_depth, void *stream);
+
+/* ---- the views of one pose behind ONE call each way (round 4, ABI 6) ----
+ * DiffGaussian.forward (TS/renderer/diff_gaussian_rasterizer.py:52-318) per view: LBS warp (:77-149), scales.repeat(1, 3) with the
+ * third column overwritten and opacities = 1 (:232-234), main rasterization (:173-191, :236-279), occlusion rasterization
+ * (:193-211, :280-291), image post-ops (:292-303); gt_forward / batch_forward (TS/renderer/gaussian_batch_renderer.py:243-398,
+ * :10-241) call it for several views of one pose.  soar_views_forward issues the launches of all of that for up to 8 views of ONE
+ * pose (warp once; views of one size and capacity share their launches, one per stage); soar_views_backward takes the gradients of
+ * the views' images back to the canonical model (the views' contributions summed in view order).  Same kernels as the per-stage
+ * entry points above, same results bit for bit.  Front-to-back form only (main pass ascending, occlusion image fused into its blend).
+ * Nothing is read back: the binning part of a view's buffer holds `capacity` instances, and the two status words {instances found,
+ * 0 or the number needed} are copied to status_pinned right behind the binning chain (0xFFFFFFFF until they land); a view that did
+ * not fit renders as background, and the caller -- who polls the words before it runs the backward -- renders it again. */
+typedef struct SoarPoseArgs {
+    int32_t P, J;
+    int32_t scale_width;         /* columns of scale_src: 1 */
+    int32_t warp;                /* forward: != 0 warp into `posed` (0: `posed` already holds this pose) */
+    const float *xyz, *rot;      /* canonical surfels [P,3], [P,4] */
+    const float *weights;        /* blend weights [P,J] */
+    const float *joint_mats;     /* cano2live [J,16] */
+    const float *offsets;        /* [P,3] or NULL (cfg.offset) */
+    const float *axis_perm;      /* row-major 3x3 or NULL */
+    const float *colors;         /* colors_precomp [P,3] */
+    const float *scale_src;      /* get_scaling [P,scale_width] */
+    const float *occ;            /* get_occ [P] or NULL: no occlusion image */
+    float *posed;                /* caller-owned [11][P] floats: xyz' [P,3] | rot' [P,4] | scales3 [P,3] | ones [P]; kept for the backward */
+    /* backward only */
+    float *grad_scratch;         /* soar_views_grad_scratch_floats(P, n_views) floats */
+    float *dL_dxyz, *dL_drot, *dL_dcolors, *dL_dscale;    /* [P,3] [P,4] [P,3] [P,scale_width]: written */
+    float *dL_docc;              /* [P] or NULL: the occlusion values are not trained */
+} SoarPoseArgs;
+typedef struct SoarViewArgs {
+    SoarRastParams rast;         /* P of the pose, M = 0, render_front = 0, sort_descending = 0 */
+    float focal_k00, focal_k11;  /* fov2focal(FoVy, H), fov2focal(FoVx, W): depth2normal's intrinsics */
+    int64_t capacity;            /* (tile, Gaussian) instances the binning part of `buffer` holds */
+    void *buffer;                /* soar_view_buffer_bytes(P, W, H, capacity) bytes, 256-byte aligned; kept for the backward */
+    size_t buffer_bytes;
+    float *out;                  /* [18][H][W]: render 0-2 | normal 3-5 | depth 6 | pred_normal 7-9 | mask 10 | occ 11-13 | curv 14 |
+                                  * the rasterizer's own normal image 15-17 (read by the backward) */
+    int32_t *radii;              /* [P] */
+    uint32_t *status_pinned;     /* 2 words of page-locked host memory, or NULL */
+    /* backward only: gradients of the images (each [c][H][W], NULL: not used by the loss) and this view's dL_dmeans2D [P,3] */
+    const float *g_render, *g_normal, *g_depth, *g_pred_normal, *g_mask, *g_occ, *g_curv;
+    float *dL_dmeans2D;
+} SoarViewArgs;
+int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, size_t *bytes);
+int soar_views_grad_scratch_floats(int32_t P, int32_t n_views, size_t *floats);
+int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);
+int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);
+/* soar_rast_forward_render_occ with the status words of soar_rast_binning_status_async copied out right behind the binning chain,
+ * in front of the blend (status_pinned may be NULL). */
+int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                                    void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal, float *out_depth,
+                                    float *out_opac, const float *occ_values, float *out_occ, uint32_t *status_pinned, void *stream);
+/* soar_lbs_warp_backward_sum for n VIEWS of one pose: one set of joint transforms [J,16], optional axis permutation. */
+int soar_lbs_warp_backward_views(const float *xyz, const float *rot, const float *weights, const float *joint_mats, const float *axis_perm,
+                                 int32_t n, int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out, float *dL_dxyz,
+                                 float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                                 const int32_t *extra_width, void *stream);
 
 /* ---- per-stage timing (no reference counterpart; used by bench.py for the roofline figure) ----
  * When enabled, every kernel stage is bracketed by two hipEvents recorded on the launch stream.

@@ -83,7 +83,6 @@ if VARIANTS:
     renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=pc)
     timed("avatar_stage_loss, Config.binning_capacity = 0 (the reference's read-back per forward call)", "fused")
     renderer = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=pc)
-    capacity = 3 * rasterizer.last_num_rendered        # of the main pass of the last frame (the model moves under Adam: generous bound)
     # the occlusion parameter trained, as in the reference's configs: the occlusion pass is then a rasterization of its own with
     # a backward of its own (the fused blend gives the occlusion image without a gradient)
     pc._occ.requires_grad_(True)
@@ -97,7 +96,8 @@ if VARIANTS:
     pc._occ.grad = None
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4)
     timed("avatar_stage_loss (default config again)", "fused")
-    print("   binning status (instances, overflow):", rasterizer.check_binning(), " learnt capacities:", rasterizer._auto_capacity)
+    from soar_amd.renderer import fused_view
+    print("   instances of the last frame:", rasterizer.last_num_rendered, " learnt capacities:", fused_view.capacity_book.bound)
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color], lr=1e-4, fused=True)
     timed("avatar_stage_loss, default config and torch.optim.Adam(fused=True)", "fused")
 

@@ -43,7 +43,7 @@ EXTRA_FLAGS = {
     "rast_render_bwd.hip": ["-fno-slp-vectorize"],
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_blockmask.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
-           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip", "densify.hip", "optim.hip"]
+           "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip", "densify.hip", "optim.hip", "view.hip"]
 HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
 
 

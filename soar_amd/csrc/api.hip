@@ -441,6 +441,11 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
                                  void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
                                  float *out_depth, float *out_opac, const float *occ_values, float *out_occ, void *stream_);
 
+int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                                    void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
+                                    float *out_depth, float *out_opac, const float *occ_values, float *out_occ,
+                                    uint32_t *status_pinned, void *stream_);
+
 int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
                              void *stream_)
 {
@@ -504,8 +509,22 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
                                  void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
                                  float *out_depth, float *out_opac, const float *occ_values, float *out_occ, void *stream_)
 {
+    return soar_rast_forward_render_status(prm, radii, geom_buffer, binning_buffer, image_buffer, num_rendered, out_color, out_normal,
+                                           out_depth, out_opac, occ_values, out_occ, nullptr, stream_);
+}
+
+// status_pinned (2 words of page-locked host memory, or NULL): {instances the tile binning found, 0 or what it would have needed},
+// copied out right behind the binning chain -- IN FRONT of the block masks and the blend, so that the words have landed long before
+// the host comes back for the backward pass (soar_amd/renderer/fused_view.py polls them there).  Inside a batch the stage launches
+// happen at the last frame's call: the frames' copies are kept until then.
+int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,
+                                    void *image_buffer, int64_t num_rendered, float *out_color, float *out_normal,
+                                    float *out_depth, float *out_opac, const float *occ_values, float *out_occ,
+                                    uint32_t *status_pinned, void *stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
+    if (status_pinned) { status_pinned[0] = 0u; status_pinned[1] = 0u; }
     if (!out_color || !out_normal || !out_depth || !out_opac) { set_error("output image pointers must not be NULL"); return 1; }
     const size_t pix = (size_t)prm->W * prm->H;
     if ((occ_values == nullptr) != (out_occ == nullptr)) { set_error("occ_values and out_occ must be given together"); return 1; }
@@ -534,6 +553,18 @@ int soar_rast_forward_render_occ(const SoarRastParams *prm, const int32_t *radii
     // of back views keeps the 64-bit key sort (rast_binning.hip)
     if (num_rendered > 0 && !prm->sort_descending) {
         if (launch_tile_binning(*prm, g, b, img, num_rendered, stream)) return 1;
+        if (status_pinned) {
+            static thread_local std::vector<std::pair<uint32_t *, const uint32_t *>> pending;
+            status_pinned[0] = 0xFFFFFFFFu;          // "not there yet": neither word can be this (counts of 32-bit list positions)
+            status_pinned[1] = 0xFFFFFFFFu;
+            pending.push_back({status_pinned, g.header + H_TOTAL});
+            const soar::BatchCtx &bc = soar::batch_ctx();
+            if (!bc.n || bc.f == bc.n - 1) {
+                for (const auto &c : pending)
+                    SOAR_HIP_OK(hipMemcpyAsync(c.first, c.second, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                pending.clear();
+            }
+        }
     } else {
         if (launch_scan(*prm, g, stream)) return 1;                // key emission needs the prefix sum of tiles_touched
         if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;

@@ -520,10 +520,34 @@ int soar_lbs_warp_forward_batch(const float *xyz, const float *rot, const float 
     return 0;
 }
 
+static int warp_backward_frames(const float *xyz, const float *rot, const float *weights, const float *joint_mats, const float *axis_perm,
+                                size_t mats_stride, int32_t n, int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out,
+                                float *dL_dxyz, float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                                const int32_t *extra_width, void *stream_);
+
 int soar_lbs_warp_backward_sum(const float *xyz, const float *rot, const float *weights, const float *joint_mats, int32_t n,
                                int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out, float *dL_dxyz,
                                float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
                                const int32_t *extra_width, void *stream_)
+{
+    return warp_backward_frames(xyz, rot, weights, joint_mats, nullptr, (size_t)J * 16, n, P, J, dL_dxyz_out, dL_drot_out, dL_dxyz, dL_drot,
+                                n_extra, extra_src, extra_dst, extra_width, stream_);
+}
+
+// n views of ONE pose (soar_views_backward): the frames share the joint transforms; the plugin's SDS views carry an axis permutation
+int soar_lbs_warp_backward_views(const float *xyz, const float *rot, const float *weights, const float *joint_mats, const float *axis_perm,
+                                 int32_t n, int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out, float *dL_dxyz,
+                                 float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                                 const int32_t *extra_width, void *stream_)
+{
+    return warp_backward_frames(xyz, rot, weights, joint_mats, axis_perm, 0, n, P, J, dL_dxyz_out, dL_drot_out, dL_dxyz, dL_drot, n_extra,
+                                extra_src, extra_dst, extra_width, stream_);
+}
+
+static int warp_backward_frames(const float *xyz, const float *rot, const float *weights, const float *joint_mats, const float *axis_perm,
+                                size_t mats_stride, int32_t n, int32_t P, int32_t J, const float *dL_dxyz_out, const float *dL_drot_out,
+                                float *dL_dxyz, float *dL_drot, int32_t n_extra, const float *const *extra_src, float *const *extra_dst,
+                                const int32_t *extra_width, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n <= 0 || !weights) { set_error("soar_lbs_warp_backward_sum: need n > 0 and blend weights"); return 1; }
@@ -537,7 +561,8 @@ int soar_lbs_warp_backward_sum(const float *xyz, const float *rot, const float *
     WarpArgs a{};
     a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats;
     a.g_xyz_out = dL_dxyz_out; a.g_rot_out = dL_drot_out; a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
-    a.mats_stride = (size_t)J * 16; a.xyz_stride = (size_t)P * 3; a.rot_stride = (size_t)P * 4;
+    a.axis_perm = axis_perm;
+    a.mats_stride = mats_stride; a.xyz_stride = (size_t)P * 3; a.rot_stride = (size_t)P * 4;
     FrameSums fs{};
     fs.n_extra = n_extra;
     for (int e = 0; e < n_extra; e++) {

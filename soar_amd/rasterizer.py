@@ -42,49 +42,17 @@ last_num_rendered = 0        # num_rendered of the most recent forward call
 
 # ---- binning buffers sized from earlier frames (capacity=AUTO) ------------------------------------------------------------------
 # The reference blocks the host in every forward call to read num_rendered and size the binning buffer (rasterizer_impl.cu:250).
-# AUTO does that for the FIRST frame of an image size only and sizes the later ones with a wide margin over what those frames
-# needed (the buffers are megabytes on a 288 GB device): nothing is read back, the host runs ahead of the device.  The device
-# checks every frame (rast_tilebin.hip: nothing is rendered when the lists do not fit); the two status words come back through
-# page-locked memory behind the frame and are looked at when a later call finds them complete: the margin grows before it is
-# used up, and an overflow -- a frame that needed AUTO_MARGIN times more than any frame before it -- raises then, loudly, at the
-# next call (``auto_binning_poll(block=True)`` or ``check_binning()`` look at once).
+# AUTO (the plugin's default, Config.binning_capacity = -1) is served by the one-call view path (soar_amd/renderer/fused_view.py:
+# CapacityBook, status words polled before the backward pass, BinningOverflow); the per-stage entry points of this module take a
+# number (`capacity=`: sync-free, `check_binning()` afterwards) or None (the reference's read-back).
 AUTO = "auto"
-AUTO_MARGIN = 4              # capacity = AUTO_MARGIN x the largest number of instances seen for the key
-AUTO_FLOOR = 1 << 18
-_auto_capacity: Dict[tuple, int] = {}
-_auto_pending: list = []     # (pinned status words, key, capacity the frame ran with); the words hold -1 until the copy has landed
-_auto_pinned_free: list = []
 
 
-def auto_binning_poll(block: bool = False) -> None:
-    """Look at the status words of AUTO frames whose copies have completed (all of them with ``block``): raise the capacities of
-    their keys where more than half was used, raise RuntimeError for a frame that did not fit."""
-    global _auto_pending
-    still = []
-    overflow = None
-    for words, key, cap in _auto_pending:
-        # (no event per frame: creating and recording one costs ~80 us of host time; the copy overwrites a sentinel instead)
-        w = words.numpy()                         # (a view of the page-locked memory the copy lands in)
-        if block:
-            while w[0] == -1 or w[1] == -1:
-                torch.cuda.synchronize()
-        elif w[0] == -1 or w[1] == -1:
-            still.append((words, key, cap))
-            continue
-        total, over = int(w[0]) & 0xFFFFFFFF, int(w[1]) & 0xFFFFFFFF
-        _auto_pinned_free.append(words)
-        need = max(total, over)
-        if need * 2 > _auto_capacity.get(key, 0):
-            _auto_capacity[key] = max(_auto_capacity.get(key, 0), AUTO_MARGIN * need, AUTO_FLOOR)
-        if over:
-            overflow = (key, over, cap)
-    _auto_pending = still
-    if overflow is not None:
-        key, over, cap = overflow
-        raise RuntimeError(f"an earlier frame ({key[1]}x{key[2]}) needed {over} (tile, Gaussian) instances, {over / cap:.1f} times the "
-                           f"binning buffer sized from the frames before it ({cap}): that frame was rendered as background.  The bound "
-                           "has been raised; set Config.binning_capacity (or capacity=) for scenes that change this abruptly, or 0 for "
-                           "the reference's blocking read-back")
+def note_num_rendered(n: int) -> None:
+    """A frame's instance count learnt from its status words (sync-free forms): what `stats` and `last_num_rendered` report."""
+    global last_num_rendered
+    last_num_rendered = int(n)
+    stats["num_rendered"] += int(n)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -318,11 +286,8 @@ class _NativeOps:
                                                  out[2].data_ptr(), out[3].data_ptr(), stream), "rasterize_gaussians")
                 return 0
             global last_num_rendered
-            auto_key = None
             if capacity == AUTO:
-                auto_binning_poll()
-                auto_key = (str(device), st["W"], st["H"], bool(st["ctx"].params.render_front))
-                capacity = _auto_capacity.get(auto_key) if not st["ctx"].params.sort_descending else None
+                raise ValueError("capacity=AUTO is served by soar_amd.renderer.fused_view (the one-call view path); pass a number or None here")
             if capacity is not None:
                 # sync-free: the binning buffer is sized by the caller's bound, the device checks that it was enough
                 num_rendered = int(capacity)
@@ -334,9 +299,6 @@ class _NativeOps:
                 last_num_rendered = num_rendered
                 stats["forward_calls"] += 1
                 stats["num_rendered"] += num_rendered
-                if auto_key is not None and not st["ctx"].params.sort_descending:      # the first frame of its kind: learnt the hard way
-                    _auto_capacity[auto_key] = max(AUTO_MARGIN * num_rendered, AUTO_FLOOR)
-                    auto_key = None
             nbytes = C.c_size_t(0)
             check(L.soar_rast_binning_bytes(num_rendered, C.byref(nbytes)), "binning_bytes")
             st["binning"] = _scratch(nbytes.value, device)
@@ -350,10 +312,6 @@ class _NativeOps:
                                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                                      out[3].data_ptr(), occ_ptr, occ_out_ptr, stream),
                       "rasterize_gaussians (render stage)")
-                if auto_key is not None and capacity is not None:
-                    words = _auto_pinned_free.pop() if _auto_pinned_free else torch.zeros(2, dtype=torch.int32).pin_memory()
-                    check(L.soar_rast_binning_status_async(st["geom"].data_ptr(), P, st["M"], words.data_ptr(), stream), "binning_status_async")
-                    _auto_pending.append((words, auto_key, int(capacity)))
             if defer is not None:
                 defer.append(launch)
             else:
@@ -692,7 +650,6 @@ def check_binning():
     """After sync-free (`capacity=`) calls: synchronise and return [(instances, overflow)] of the views of the last batch;
     raises if a binning buffer was too small (that view rendered nothing: its images are the background)."""
     L = hip_lib.lib()
-    auto_binning_poll(block=True)
     out = []
     for geom, P, M, device in _last_batch:
         n, o = C.c_int64(0), C.c_int64(0)

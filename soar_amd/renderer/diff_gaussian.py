@@ -75,10 +75,12 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
         offset: bool = False
         use_explicit: bool = False
         # not in the reference.  The reference blocks the host in every forward call to read the number of (tile, Gaussian)
-        # instances back and size the binning buffer (rasterizer_impl.cu:250).  -1 (default): only the first frame of an image size
-        # is read back, later ones get a buffer 4x what the frames before needed (rasterizer.AUTO: the device checks every frame, a
-        # frame that does not fit raises at a later call).  > 0: a fixed bound, nothing is ever read back
-        # (``soar_amd.rasterizer.check_binning()`` raises if it was exceeded).  0: the reference's read-back in every call.
+        # instances back and size the binning buffer (rasterizer_impl.cu:250).  -1 (default): only the first frame of a kind (image
+        # size, model size, field of view) is read back; later ones get a buffer 8x what the frames before needed and are issued by
+        # ONE call without a read-back (fused_view.CapacityBook).  The device checks every frame and the host looks at the result
+        # before the backward pass: a frame that did not fit raises ``fused_view.BinningOverflow`` THERE -- before any gradient
+        # exists, before ``optimizer.step()`` -- and is rendered again transparently when no backward pass will follow
+        # (``torch.no_grad()``).  > 0: a fixed bound instead of the learnt one.  0: the reference's read-back in every call.
         binning_capacity: int = -1
 
     cfg: Config

@@ -223,5 +223,6 @@ def test_c5_frame_matches_the_reference_kernels():
         a, b = hip[k].reshape(ref[k].shape), ref[k]
         assert np.isfinite(a).all(), k
         worst[k] = (rel_err(a, b), l2_err(a, b))
+    print("C5", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
     assert all(v[1] <= 3e-4 for v in worst.values()), worst
     assert all(worst[k][0] <= 1e-4 for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity")), worst

@@ -148,6 +148,12 @@ def main():
                 q = lambda a: " ".join(f"{np.percentile(a, p):7.2f}" for p in (50, 95, 99)) + f" {a.max():8.2f}"
                 d = lambda a: f"{np.percentile(a, 50):.1e} / {np.percentile(a, 99):.1e} / {a.max():.1e}"
                 print(f"{k:14s} {int(ok.sum()):6d} | {q(raw)} | {q(flo)} | {d(ep):>28s} | {d(er):>28s}")
+                # the same ratio the other way round, and who is closer where it matters: two implementations whose rounding noise has
+                # the same size give a heavy-tailed ratio in BOTH directions (neither shares the other's sequence of roundings)
+                inv = np.maximum(er, 1e-6) / np.maximum(ep, 1e-6)
+                big = (ep > 1e-5) | (er > 1e-5)
+                share = f"{(ep[big] < er[big]).mean():.2f} of {int(big.sum())}" if big.any() else "-"
+                print(f"{'':14s} {'':6s} | reference / product, floored: {q(inv)} | product closer where either is beyond 1e-5: {share}")
     print(f"{N} scenes, {bad} with a mismatch, explained differences: {benign}; worst image rel err {worst_img:.2e}, "
           f"worst n_contrib mismatch {worst_nc:.2e}")
     return 1 if bad else 0
