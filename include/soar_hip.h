@@ -37,7 +37,7 @@ extern "C" {
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
- * soar_rast_forward_render_status, soar_lbs_warp_backward_views. */
+ * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky. */
 #define SOAR_HIP_ABI_VERSION 6
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
@@ -127,6 +127,14 @@ int soar_rast_num_rendered(const void *geom_buffer, int32_t P, int32_t M, int64_
  * Synchronises `stream`.  *instances_host = instances found, *overflow_host = 0 or the number that did not fit. */
 int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int64_t *instances_host, int64_t *overflow_host,
                              void *stream);
+
+/* The largest instance count and the largest overflow over ALL frames binned through this geometry buffer since the two words were
+ * last cleared (the tile binning keeps running maxima in the buffer's header; reset != 0 clears them behind the read).  For a
+ * caller that keeps its geometry buffers between frames (soar_amd/step_plan.py): one look covers a whole timed region, where
+ * soar_rast_binning_status only sees the last frame.  A freshly allocated buffer must be cleared (one call with reset) before its
+ * first frame.  Synchronises `stream`. */
+int soar_rast_binning_status_sticky(void *geom_buffer, int32_t P, int32_t M, int64_t *max_instances_host, int64_t *max_overflow_host,
+                                    int32_t reset, void *stream);
 
 /* The same two words without blocking: copied into `status_pinned` (two uint32 of page-locked host memory: instances found, 0 or the
  * number that did not fit) behind whatever `stream` already holds.  Both words are set to 0xFFFFFFFF by this call and overwritten when

@@ -465,6 +465,28 @@ int soar_rast_binning_status(const void *geom_buffer, int32_t P, int32_t M, int6
     return 0;
 }
 
+// The largest instance count and the largest overflow of ALL the frames binned through this geometry buffer since the words were
+// last cleared (reset != 0 clears them behind the read): one look after a whole timed region instead of one per frame.  Synchronises.
+int soar_rast_binning_status_sticky(void *geom_buffer, int32_t P, int32_t M, int64_t *max_instances_host, int64_t *max_overflow_host,
+                                    int32_t reset, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!max_instances_host || !max_overflow_host || P < 0) { set_error("soar_rast_binning_status_sticky: bad arguments"); return 1; }
+    *max_instances_host = 0;
+    *max_overflow_host = 0;
+    if (P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer")) return 1;
+    GeomBuf g;
+    carve_geom(geom_buffer, P, M, &g);
+    uint32_t w[2] = {0u, 0u};
+    SOAR_HIP_OK(hipMemcpyAsync(w, g.header + H_STICKY_TOTAL, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (reset) SOAR_HIP_OK(hipMemsetAsync(g.header + H_STICKY_TOTAL, 0, 2 * sizeof(uint32_t), stream));
+    SOAR_HIP_OK(hipStreamSynchronize(stream));
+    *max_instances_host = (int64_t)w[0];
+    *max_overflow_host = (int64_t)w[1];
+    return 0;
+}
+
 int soar_rast_binning_status_async(const void *geom_buffer, int32_t P, int32_t M, uint32_t *status_pinned, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

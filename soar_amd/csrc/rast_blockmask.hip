@@ -124,6 +124,13 @@ __global__ void __launch_bounds__(BM_THREADS) block_mask_kernel(Batch<BlockMaskA
             const BlockMaskArgs &o = batch.v[blockIdx.x];
             if (o.tile_order) {
                 const bool overflow = (o.header[H_OVERFLOW] | o.header[H_BAND_OVERFLOW]) != 0u;
+                // what a caller that keeps its geometry buffer between frames (soar_amd/step_plan.py) reads ONCE after many frames:
+                // the largest instance count and the largest overflow since it last cleared the two words
+                if (threadIdx.x == 0) {
+                    uint32_t *h = const_cast<uint32_t *>(o.header);
+                    h[H_STICKY_TOTAL] = max(h[H_STICKY_TOTAL], h[H_TOTAL]);
+                    h[H_STICKY_OVERFLOW] = max(h[H_STICKY_OVERFLOW], max(h[H_OVERFLOW], h[H_BAND_OVERFLOW]));
+                }
                 tile_order_block(o.T, (o.T + 7) / 8 * 8, o.tile_count, o.ranges, o.tile_order, o.bg, o.normalize_depth, o.bg_state,
                                  overflow ? o.ranges : nullptr);
             }

@@ -166,6 +166,8 @@ constexpr int H_TOTAL = 8;      // instances (sum of the tile counts) found by t
 constexpr int H_OVERFLOW = 9;   // 0, or H_TOTAL when it exceeded the capacity of the caller's binning buffer
 constexpr int H_BAND_OVERFLOW = 10;   // 0, or the entries the band lists needed when they exceeded that capacity
 constexpr int H_PREFILTER_VIOLATIONS = 11;   // Gaussians culled although SoarRastParams.prefiltered was set (auxiliary.h:163-167, 195-199)
+constexpr int H_STICKY_TOTAL = 12;      // max of H_TOTAL / of H_OVERFLOW | H_BAND_OVERFLOW over the frames since the caller cleared them
+constexpr int H_STICKY_OVERFLOW = 13;   //   (soar_rast_binning_status_sticky; only meaningful in a geometry buffer kept between frames)
 constexpr int BKT_MAX = 16384;  // depth buckets (upper bound; the counters of a counting workgroup live in LDS: 64 KB)
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {

@@ -69,6 +69,7 @@ SIGNATURES = {
     "soar_rast_forward_geometry": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, C.POINTER(C.c_int64), _vp]),
     "soar_rast_num_rendered": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _vp]),
     "soar_rast_binning_status": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
+    "soar_rast_binning_status_sticky": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, _vp]),
     "soar_rast_binning_status_async": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "soar_rast_prefilter_violations": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _vp]),
     "soar_rast_forward_render": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),

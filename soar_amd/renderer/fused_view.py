@@ -386,7 +386,7 @@ class _PoseViews(torch.autograd.Function):
         return views, per_view
 
     @staticmethod
-    def forward(ctx, xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, *means2D):
+    def forward(ctx, xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, grad_mode, *means2D):
         L = hip_lib.lib()
         dev = xyz.device
         x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
@@ -410,7 +410,9 @@ class _PoseViews(torch.autograd.Function):
         stream = cur.cuda_stream
         keep = [x, q, w, A, off, T, cols, ssrc, occ_v]
         views, per_view = _PoseViews._launch(L, dev, stream, pose, specs, P, keep)
-        training = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # can a backward pass come?  (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off,
+        # and needs_input_grad only says which inputs require gradients)
+        training = bool(grad_mode) and any(ctx.needs_input_grad)
         if not training:
             # nobody will come back for a backward pass: look at the status words now and render a view that did not fit again,
             # transparently (the reference resizes its binning buffer and never drops a frame, rasterizer_impl.cu:250-257)
@@ -511,7 +513,7 @@ class _PoseViews(torch.autograd.Function):
             (a.g_render, a.g_normal, a.g_depth, a.g_pred_normal, a.g_mask, a.g_occ, a.g_curv) = [ptr(g) for g in gs]
             a.dL_dmeans2D = g2d[v].data_ptr()
         if not any_live:
-            return (None,) * (10 + n)
+            return (None,) * (11 + n)
         with torch.cuda.device(dev):
             check(L.soar_views_backward(C.byref(pose), n, views, torch.cuda.current_stream(dev).cuda_stream), "soar_views_backward")
         g_off = None
@@ -519,7 +521,7 @@ class _PoseViews(torch.autograd.Function):
             g_means3D = scratch[:3 * n * P].reshape(n, P, 3).sum(0)
             g_off = g_means3D if T is None else g_means3D @ T.t()                  # p'' = (p' + offsets) T
         return (g_xyz, g_rot, g_colors, g_scale.reshape(ctx.scale_shape), g_occ.reshape(ctx.occ_shape) if g_occ is not None else None,
-                None, None, g_off, None, None, *[g2d[v] for v in range(n)])
+                None, None, g_off, None, None, None, *[g2d[v] for v in range(n)])
 
 
 def _focal(camera):
@@ -561,7 +563,7 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
             size = (int(settings_list[i].image_width), int(settings_list[i].image_height))
             caps[i] = max(caps[j] for j in one_call if (int(settings_list[j].image_width), int(settings_list[j].image_height)) == size)
         specs = [(settings_list[i], _focal(cameras[i]), caps[i], keys[i]) for i in one_call]
-        outs = _PoseViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs,
+        outs = _PoseViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, torch.is_grad_enabled(),
                                 *[means2D_list[i] for i in one_call])
         result = {i: tuple(outs[j * n:(j + 1) * n]) for j, i in enumerate(one_call)}
         rest = [i for i in range(len(backs)) if i not in result]

@@ -46,6 +46,7 @@ class SMPLGuidance:
         Tm = torch.einsum("vj,jxy->vxy", self.ori_lbs[0], A_cano[0])
         self.cano_vertices = (torch.einsum("vxy,vy->vx", Tm[:, :3, :3], v_shaped) + Tm[:, :3, 3]).contiguous()
         self._w_cache = None
+        self._follower = None
         self._mats_cache, self._mats_cache_src = {}, None
         self._knn_grid = lbs.KnnGrid(self.cano_vertices, self.ori_lbs[0])         # canonical vertices are static
 
@@ -115,7 +116,17 @@ class SMPLGuidance:
         only, so all renderer calls of one optimizer step share them."""
         key = (points.data_ptr(), points._version, points.shape[0])
         if refresh or self._w_cache is None or self._w_cache[0] != key:
-            self._w_cache = (key, self.query_weights_smpl(points))
+            # positions that moved by an optimizer step since the last call: the neighbour sets are kept on the device and only
+            # re-ranked / searched again where a certificate fails (lbs.KnnFollower: the full search's weights, bit for bit).
+            # The follower keeps its state for as long as the number of points stays (densification builds a new one); a parameter
+            # that was REPLACED by another tensor of the same size (not stepped) is still served exactly: certificates compare the
+            # positions themselves, not the tensor
+            P = int(points.shape[0])
+            fol = self._follower
+            if fol is None or fol.P != P or P == 0 or self._knn_grid.V < 32:
+                fol = self._follower = lbs.KnnFollower(self._knn_grid, P) if (P > 0 and self._knn_grid.V >= 32) else None
+            w = fol(points.detach()) if fol is not None else self.query_weights_smpl(points)
+            self._w_cache = (key, w)
         return self._w_cache[1]
 
     # ---- reference surface ------------------------------------------------------------------------------------------

@@ -113,6 +113,7 @@ class FrameStepPlan:
                 g_means3D=self.g_means3D_all[i], g_cov3D=torch.empty((P, 6), **f), g_scales=torch.empty((P, 3), **f),
                 g_rot_p=self.g_rot_p_all[i], g_view=torch.empty((4, 4), **f), g_proj=torch.empty((4, 4), **f),
                 g_campos=torch.empty((3,), **f))
+            v["geom"][:256].zero_()          # (the header's running maxima of `check()` start from zero)
             self.views.append(v)
         # per-frame gradients of the leaves, frame-major so that one reduction per leaf sums them
         self.g_xyz = torch.empty((self.n, P, 3), **f)
@@ -581,16 +582,20 @@ class FrameStepPlan:
         self.steps += 1
         return self.losses
 
-    def check(self):
-        """Synchronise and verify that no frame exceeded the binning capacity (see rasterize_views(capacity=...))."""
+    def check(self, reset: bool = True):
+        """Synchronise and verify that no frame of ANY step since the last check (or since the plan was built) exceeded the binning
+        capacity: the tile binning keeps the largest instance count and the largest overflow of the frames that went through a
+        view's geometry buffer in the buffer itself (soar_rast_binning_status_sticky), so one look after a timed region covers every
+        step of it, not just the last one.  -> [(largest instance count, 0)] per view slot."""
         out = []
         for v in self.views:
             n, o = C.c_int64(0), C.c_int64(0)
             with torch.cuda.device(self.device):
-                check(self.L.soar_rast_binning_status(ptr(v["geom"]), self.P, 0, C.byref(n), C.byref(o),
-                                                      torch.cuda.current_stream(self.device).cuda_stream), "binning_status")
+                check(self.L.soar_rast_binning_status_sticky(ptr(v["geom"]), self.P, 0, C.byref(n), C.byref(o), 1 if reset else 0,
+                                                             torch.cuda.current_stream(self.device).cuda_stream), "binning_status_sticky")
             out.append((int(n.value), int(o.value)))
         bad = [o for _, o in out if o]
         if bad:
-            raise RuntimeError(f"binning capacity exceeded: {max(bad)} (tile, Gaussian) instances needed; raise `capacity`")
+            raise RuntimeError(f"binning capacity exceeded in a step since the last check: {max(bad)} (tile, Gaussian) instances needed; "
+                               "raise `capacity`")
         return out
