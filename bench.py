@@ -288,9 +288,18 @@ def torch_cpu_baseline(workload, parts, w, A_cano, threads, tg):
     dt = time.perf_counter() - t0
     where = "the whole frame" if crop is None else (f"the {crop[2] - crop[0]} x {crop[3] - crop[1]} tiles at the image centre "
                                                     f"({stats['tiles_blended']} of them with work)")
-    return {"value": 1.0 / dt, "unit": "frames/s" if crop is None else "crops/s", "cores": threads,
-            "sample": f"1 frame of {workload}: LBS warp + preprocess + (tile, depth) sort of all {stats['num_rendered']} instances + blend of "
-                      f"{where} forward and backward (autograd), oracle/torch_rasterizer.py on torch CPU, {threads} threads; {dt:.1f} s wall"}
+    out = {"value": 1.0 / dt, "unit": "frames/s" if crop is None else "crops/s", "cores": threads,
+           "sample": f"1 frame of {workload}: LBS warp + preprocess + (tile, depth) sort of all {stats['num_rendered']} instances + blend of "
+                     f"{where} forward and backward (autograd), oracle/torch_rasterizer.py on torch CPU, {threads} threads; {dt:.1f} s wall"}
+    if crop is not None:
+        # what the crop says about a whole frame: its blend handled `share` of the frame's (tile, Gaussian) instances (the time of
+        # the blend and its autograd backward grows with them; warp, preprocess and the sort already ran on the whole frame) --
+        # an estimate, and an optimistic one for the CPU
+        share = stats["instances_blended"] / max(stats["num_rendered"], 1)
+        out["estimated_frames_per_s"] = round(share / dt, 4)
+        out["estimate"] = (f"crops/s x share of the frame's instances the crop blended ({stats['instances_blended']} of {stats['num_rendered']} = "
+                           f"{share:.3f}; {stats['tiles_blended']} of {stats['tiles_with_work']} tiles with work)")
+    return out
 
 
 def visible_gpu_count():
@@ -542,13 +551,40 @@ def main():
         stepper(frames_of(args.warmup + s))
     flat.wait_all()                                              # the last step's gradient buckets
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0                     # this rank's own K steps (before it waits for the others)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    binning_status = None
     if plan is not None:
-        plan.check()                                             # raises if a binning buffer of the last step was too small
+        binning_status = plan.check()                            # raises if a binning buffer of ANY timed step was too small (sticky words)
     elif capacity is not None:
         rasterizer.check_binning()
+    # ---- several ranks: what a first run on real hardware needs to explain itself.  Per-rank step time (the
+    #      max is the job's; the spread is the per-frame load imbalance SURVEY 8e expects), instances per rank, and -- from K more
+    #      steps with HIP events around the stream-side waits -- what of each gradient bucket's flight the step did NOT hide.
+    dist_diag = None
+    if use_dist:
+        flat.time_waits = True
+        for s in range(args.steps):
+            stepper(frames_of(args.warmup + s))
+        flat.wait_all()
+        waits = flat.wait_stats()
+        flat.time_waits = False
+        mine = torch.tensor([1e3 * local_elapsed / args.steps, float(max((n for n, _ in binning_status), default=0)) if binning_status else 0.0,
+                             waits.get("bucket0_wait_us", 0.0), waits.get("bucket1_wait_us", 0.0)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [t.tolist() for t in allr]
+        per_rank_ms = [round(r[0], 4) for r in rows]
+        dist_diag = {"per_rank_ms_per_step": per_rank_ms,
+                     "imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
+                     "max_num_rendered_per_rank": [int(r[1]) for r in rows],
+                     "bucket_wait_us_per_rank": [[round(r[2], 2), round(r[3], 2)] for r in rows],
+                     "buckets": flat.n_buckets,
+                     "how": ("per_rank_ms_per_step: each rank's own wall time for the K timed steps up to its device synchronisation, before the "
+                             "closing barrier; bucket_wait_us: mean stall of the waiting stream per gradient bucket (HIP events around the "
+                             f"stream-side wait), {args.steps} more steps after the timed region; buckets: SOAR_DP_BUCKETS")}
     stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
     # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
     #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views
@@ -676,6 +712,8 @@ def main():
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,
     }
+    if dist_diag is not None:
+        result["ranks"] = dist_diag
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -145,10 +145,12 @@ def rasterize(st, means3D, opacities, colors, scales, rotations, crop: Optional[
     py, px = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
     cols = colors[g["idx"]]
     pieces = []
+    instances_blended = 0
     for t, b, e in zip(tiles.tolist(), begins.tolist(), ends.tolist()):
         tx, ty = t % gx, t // gx
         if crop is not None and not (crop[0] <= tx < crop[2] and crop[1] <= ty < crop[3]):
             continue
+        instances_blended += e - b
         k = owner_s[b:e]
         fxp = (tx * TILE + px).reshape(-1, 1).float()
         fyp = (ty * TILE + py).reshape(-1, 1).float()
@@ -182,4 +184,5 @@ def rasterize(st, means3D, opacities, colors, scales, rotations, crop: Optional[
         normal[(slice(None),) + sl] = N.t().reshape(3, TILE, TILE)[:, :hs, :ws]
         depth[(0,) + sl] = D.reshape(TILE, TILE)[:hs, :ws]
         opac[(0,) + sl] = O.reshape(TILE, TILE)[:hs, :ws]
-    return color, normal, depth, opac, dict(num_rendered=int(owner.shape[0]), tiles_blended=len(pieces), radii=g["radii"], keep=g["keep"])
+    return color, normal, depth, opac, dict(num_rendered=int(owner.shape[0]), tiles_blended=len(pieces), tiles_with_work=int(tiles.shape[0]),
+                                             instances_blended=int(instances_blended), radii=g["radii"], keep=g["keep"])

@@ -12,6 +12,8 @@ One process per GPU; parameters are replicated and every rank applies the identi
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Iterable, List, Sequence, Tuple
 
 import torch
@@ -73,6 +75,13 @@ class FlatGradBuffer:
                     self.leaves[name] = t
             start += P * width
         self.split = P * LEAVES[0][1]             # end of the xyz slice = boundary between the two buckets
+        # SOAR_DP_BUCKETS=1: ONE collective for the whole buffer (one RCCL launch fewer per step; the positions then arrive together
+        # with everything else, and the KNN refresh no longer hides part of the flight).  Which is faster depends on the flight time
+        # of 6 MB over the node's links against the refresh (~80 us) and an RCCL launch (~20-30 us): bench.py reports the waits
+        self.n_buckets = 1 if os.environ.get("SOAR_DP_BUCKETS", "2") == "1" else 2
+        # diagnostics (bench.py, world > 1): HIP events around every stream-side wait for a bucket -- what the stream stalled for
+        self.time_waits = False
+        self._wait_events: List = []
 
     def attach(self):
         """(Re-)install the views as the leaves' ``.grad`` (after something set them to None)."""
@@ -114,14 +123,38 @@ class FlatGradBuffer:
         self.check_views()
         self.wait_all()
         if self._collectives_on():
-            self.pending = [dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM, async_op=True),
-                            dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
+            if self.n_buckets == 1:
+                self.pending = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)]
+            else:
+                self.pending = [dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM, async_op=True),
+                                dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)]
         return self.pending
 
     def wait_bucket(self, k: int):
         if k < len(self.pending) and self.pending[k] is not None:
-            self.pending[k].wait()
+            if self.time_waits:
+                dev = self.flat.device
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(dev))
+                self.pending[k].wait()
+                e1.record(torch.cuda.current_stream(dev))
+                self._wait_events.append((k, e0, e1))
+            else:
+                self.pending[k].wait()
             self.pending[k] = None
+
+    def wait_stats(self) -> Dict[str, float]:
+        """Mean time (us) the waiting stream stalled for each bucket since ``time_waits`` was switched on (synchronises): what of a
+        collective's flight the step did NOT hide.  {"bucket0_wait_us": .., "bucket1_wait_us": .., "waits": n}"""
+        torch.cuda.synchronize(self.flat.device)
+        tot, cnt = {}, {}
+        for k, e0, e1 in self._wait_events:
+            tot[k] = tot.get(k, 0.0) + e0.elapsed_time(e1) * 1e3
+            cnt[k] = cnt.get(k, 0) + 1
+        self._wait_events = []
+        out = {f"bucket{k}_wait_us": round(tot[k] / cnt[k], 2) for k in sorted(tot)}
+        out["waits"] = sum(cnt.values())
+        return out
 
     def wait_all(self):
         for k in range(len(self.pending)):

@@ -494,6 +494,7 @@ class FrameStepPlan:
             # refresh that needs them; everything else behind the second bucket, which travels while the refresh runs
             opt = self.optimizer if (self.optimizer is not None and self.steps > 0) else None
             in_flight = any(p is not None for p in self.flat.pending) if self.optimizer_in_two_parts is None else self.optimizer_in_two_parts
+            in_flight = in_flight and self.flat.n_buckets > 1      # (one bucket: everything arrives together, one optimizer launch)
             # (no reduction pending: one launch for all leaves)
             self.flat.wait_bucket(0)
             if opt is not None:

@@ -72,6 +72,16 @@ def _worker(rank, world, port, P, out_dir):
         buf.wait_bucket(0)
         buf.wait_all()
         assert buf.pending == []
+        # the same sum as ONE collective (SOAR_DP_BUCKETS=1): a second buffer over copies of the leaves, same frames
+        leaves1 = _make_leaves(P)
+        buf1 = frame_dp.FlatGradBuffer(leaves1)
+        buf1.n_buckets = 1
+        for f in frame_dp.shard_frames(batch, rank, world):
+            _frame_loss(leaves1, f).backward()
+        assert len(buf1.all_reduce_buckets()) == 1
+        buf1.wait_bucket(0)
+        buf1.wait_all()
+        assert torch.equal(buf1.flat, buf.flat)
         # split noise of the densifier: ranks with different RNG states must end up with rank 0's draw
         from soar_amd.densify import SurfelDensifier
         dens = SurfelDensifier.__new__(SurfelDensifier)
