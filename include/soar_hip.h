@@ -37,7 +37,8 @@ extern "C" {
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
- * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky. */
+ * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky;
+ * soar_selftest_wave_reduce is gone with the backward form it tested. */
 #define SOAR_HIP_ABI_VERSION 6
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
@@ -564,11 +565,6 @@ int soar_adam_step_rows(int32_t n_rows, const SoarAdamRow *rows, double beta1, d
  * `stream` gets there: ring[0] counts the stamps, stamp n lies at ring[1 + 2 (n mod capacity)].  Timelines of launch chains
  * without host synchronisation; capturable in a HIP graph (every replay appends). */
 int soar_prof_timestamp(unsigned long long *ring_dev, int64_t capacity, int64_t tag, void *stream);
-
-/* ---- device self-test of the 16-value transpose-reduce of the backward blend (sum over the 16 pixel-lanes of each slot,
- * lane = 4 * pixel + slot).  out128_dev [128] floats: [0..63] the total each lane ends up with, [64..127] the value index
- * q(lane) that total belongs to. */
-int soar_selftest_wave_reduce(float *out128_dev, void *stream);
 
 /* ---- device self-test of the 64-lane scan of affine maps of the backward blend's entry-lane form (rast_render_bwd.hip):
  * m64_dev / b64_dev [64] = the map P -> m P + b of every lane; out192_dev [192]: [0..63] m and [64..127] b of the composition of

@@ -209,6 +209,7 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->n_contrib, pix > 0 ? pix : 1);
     take(p, out->final_D, pix > 0 ? pix : 1);
     take(p, out->tile_order, (tiles + 7) / 8 * 8 + 8);
+    take(p, out->order_rec, (tiles + 7) / 8 * 8 + 8);
     take(p, out->tile_count, tiles > 0 ? tiles : 1);
     take(p, out->bg_state, 8);
     take(p, out->bg_tiles, tiles > 0 ? tiles : 1);

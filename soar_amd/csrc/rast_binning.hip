@@ -104,9 +104,10 @@ tile_ranges_kernel(int64_t L, const uint64_t *__restrict__ keys, uint2 *__restri
 }
 
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, int Tpad, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order,
-                                                          const float *__restrict__ bg, int normalize_depth, uint32_t *__restrict__ bg_state)
+                                                          uint4 *__restrict__ order_rec, const float *__restrict__ bg, int normalize_depth,
+                                                          uint32_t *__restrict__ bg_state)
 {
-    tile_order_block(T, Tpad, nullptr, ranges, order, bg, normalize_depth, bg_state);
+    tile_order_block(T, Tpad, nullptr, ranges, order, order_rec, bg, normalize_depth, bg_state);
 }
 
 }  // namespace
@@ -115,8 +116,8 @@ int launch_tile_order(const SoarRastParams &prm, ImageBuf &img, hipStream_t stre
 {
     const int T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
     const int Tpad = (T + 7) / 8 * 8;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, T, Tpad, img.ranges, img.tile_order, prm.bg_dev,
-                       prm.cfg_normalize_depth, img.bg_state);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, T, Tpad, img.ranges, img.tile_order, img.order_rec,
+                       prm.bg_dev, prm.cfg_normalize_depth, img.bg_state);
     SOAR_LAUNCH_OK("tile_order", stream, prm.debug);
     return 0;
 }

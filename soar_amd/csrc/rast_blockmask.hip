@@ -40,6 +40,7 @@ struct BlockMaskArgs {
     const uint32_t *tile_count;
     uint2 *ranges;
     uint32_t *tile_order;
+    uint4 *order_rec;
     const float *bg;
     int normalize_depth;
     uint32_t *bg_state;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(BM_THREADS) block_mask_kernel(Batch<BlockMaskA
                     h[H_STICKY_TOTAL] = max(h[H_STICKY_TOTAL], h[H_TOTAL]);
                     h[H_STICKY_OVERFLOW] = max(h[H_STICKY_OVERFLOW], max(h[H_OVERFLOW], h[H_BAND_OVERFLOW]));
                 }
-                tile_order_block(o.T, (o.T + 7) / 8 * 8, o.tile_count, o.ranges, o.tile_order, o.bg, o.normalize_depth, o.bg_state,
+                tile_order_block(o.T, (o.T + 7) / 8 * 8, o.tile_count, o.ranges, o.tile_order, o.order_rec, o.bg, o.normalize_depth, o.bg_state,
                                  overflow ? o.ranges : nullptr);
             }
         }
@@ -192,6 +193,7 @@ int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, I
     a.T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
     a.tile_count = img.tile_count; a.ranges = img.ranges;
     a.tile_order = prm.sort_descending ? nullptr : img.tile_order;       // (the key-sort path builds its own: rast_binning.hip)
+    a.order_rec = img.order_rec;
     a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
     const unsigned per_wg = BM_THREADS * BM_GROUPS;
     const unsigned nblocks = min(((unsigned)((R + per_wg - 1) / per_wg) + 7u) / 8u * 8u, BM_MAX_WGS);      // (whole rounds of the 8 XCDs)

@@ -47,6 +47,7 @@ struct FwdArgs {
     int normalize_depth;
     const uint2 *ranges;
     const uint32_t *tile_order;
+    const uint4 *order_rec;
     const uint32_t *point_list;
     const GaussRec *rec;
     const float *bg;
@@ -141,9 +142,10 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     if (LOG) t_start = wall_clock64();
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t tile_u = a.tile_order[rank];
-    if (tile_u == 0xFFFFFFFFu) return;
-    const int tile = (int)tile_u, seq = rank * 4 + quad;
+    // tile and list range in ONE load (ImageBuf::order_rec; the ranks walked here are tiles with work)
+    if (LOG && a.tile_order[rank] == 0xFFFFFFFFu) return;        // (the logging build walks the padded order)
+    const uint4 orec = a.order_rec[rank];
+    const int tile = (int)orec.x, seq = rank * 4 + quad;
     const int tx = tile % a.gx, ty = tile / a.gx;
     // 4x4 pixel block of this wave inside the 8x8 quad of this workgroup inside the 16x16 tile
     const int bx0 = tx * TILE + (quad & 1) * 8 + (wave & 1) * 4, by0 = ty * TILE + (quad >> 1) * 8 + (wave >> 1) * 4;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     const bool inside = px < a.W && py < a.H;
     const float fx = (float)px, fy = (float)py;
 
-    const uint2 range = a.ranges[tile];
+    const uint2 range = make_uint2(orec.y, orec.z);
     set_wave_priority_by_length(range.y - range.x);
 
     float T = 1.0f;                                  // replicated in the four lanes of a pixel
@@ -291,22 +293,6 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                         some_stop = true;
                     }
                     const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
-#ifdef SOAR_EXP_PAD_VALU
-                    {   // timing experiment: extra independent vector instructions (results never used for real)
-                        float pz = w;
-#pragma unroll
-                        for (int k = 0; k < SOAR_EXP_PAD_VALU; k++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(pz) : "v"(dx), "v"(dy));
-                        if (pz == 123456.f) C0 += 1.f;
-                    }
-#endif
-#ifdef SOAR_EXP_PAD_SALU
-                    {
-                        int sz = it;
-#pragma unroll
-                        for (int k = 0; k < SOAR_EXP_PAD_SALU; k++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sz));
-                        if (sz == -12345) C0 += 1.f;
-                    }
-#endif
                     const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
                     D = __builtin_fmaf(depth, w, D);
                     C0 = __builtin_fmaf(q2.y, w, C0);
@@ -466,6 +452,7 @@ struct OccGradArgs {
     int W, H, gx, gy, ntiles;
     const uint2 *ranges;
     const uint32_t *tile_order;
+    const uint4 *order_rec;
     const uint32_t *point_list;
     const GaussRec *rec;
     const float *front;              // [P] 1 = camera-facing (preprocess)
@@ -645,7 +632,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
     a.ntiles = a.gx * a.gy;
     a.normalize_depth = prm.cfg_normalize_depth;
-    a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
+    a.ranges = img.ranges; a.tile_order = img.tile_order; a.order_rec = img.order_rec; a.point_list = b.vals_sorted; a.rec = g.rec; a.bg = prm.bg_dev;
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
@@ -686,7 +673,7 @@ int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBu
     a.W = prm.W; a.H = prm.H;
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
     a.ntiles = a.gx * a.gy;
-    a.ranges = img.ranges; a.tile_order = img.tile_order; a.point_list = b.vals_sorted; a.rec = g.rec; a.front = g.front;
+    a.ranges = img.ranges; a.tile_order = img.tile_order; a.order_rec = img.order_rec; a.point_list = b.vals_sorted; a.rec = g.rec; a.front = g.front;
     a.g_occ = dL_dout_occ; a.g_values = dL_docc;
     const int Tpad = (a.ntiles + 7) / 8 * 8;
     const int nblocks = 4 * min(Tpad, blend_grid_ranks(a.ntiles));

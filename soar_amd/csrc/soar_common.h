@@ -177,6 +177,8 @@ struct ImageBuf {
     float *final_D;          // [pix]
     uint32_t *tile_order;    // [Tpad = T rounded up to 8]: tile ids, longest list first (0xFFFFFFFF = padding); [Tpad]: the
                              // number of tiles with a non-empty list (the first ones of the order)
+    uint4 *order_rec;        // [Tpad] {tile, range.x, range.y, 0} of the same order: what a blend wavefront needs of its tile in ONE load
+                             // (tile_order -> ranges is two dependent round trips at the start of every wavefront)
     uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
     uint32_t *bg_state;      // [8] {background bits x3, normalize_depth} of the last forward, [4]: they differ from the one before
     uint32_t *bg_tiles;      // [T] 1: every output plane of the tile holds the background values of the last forward blend.
@@ -332,7 +334,7 @@ __device__ __forceinline__ uint32_t class_slot(uint32_t *counter, int cls, bool 
 // from the ranges (descending / key-sort path).  `empty_ranges` != NULL: the lists did not fit the caller's buffer -- every tile
 // counts as empty and every range is emptied (nothing is rendered; whichever lists were written before the overflow are dropped).
 static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const uint32_t *tile_count, const uint2 *ranges, uint32_t *order,
-                                                        const float *bg, int normalize_depth, uint32_t *bg_state,
+                                                        uint4 *order_rec, const float *bg, int normalize_depth, uint32_t *bg_state,
                                                         uint2 *empty_ranges = nullptr)
 {
     __shared__ uint32_t count[16], cursor[16];
@@ -364,17 +366,22 @@ static __device__ __forceinline__ void tile_order_block(int T, int Tpad, const u
     __syncthreads();
     for (int t0 = 0; t0 < T; t0 += 8 * NTH) {
         uint32_t len[8];
+        uint2 rg[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int t = t0 + k * NTH + tid;
             len[k] = t < T ? len_of(t) : 0u;
+            rg[k] = (t < T && !empty_ranges) ? ranges[t] : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int t = t0 + k * NTH + tid;
             const int cls = 15 - min(15, 32 - __clz((int)len[k]));
             const uint32_t at = class_slot(cursor, cls, t < T);
-            if (t < T) order[at] = (uint32_t)t;
+            if (t < T) {
+                order[at] = (uint32_t)t;
+                order_rec[at] = make_uint4((uint32_t)t, rg[k].x, rg[k].y, 0u);
+            }
         }
     }
     for (int t = T + tid; t < Tpad; t += NTH) order[t] = 0xFFFFFFFFu;

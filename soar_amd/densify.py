@@ -29,13 +29,29 @@ PARAMS = ("xyz", "f_dc", "f_rest", "color", "opacity", "scaling", "rotation")
 _MODE = {"xyz": 2, "scaling": 3}
 
 
+def spatial_permutation(xyz: torch.Tensor, cell: float = 0.02) -> torch.Tensor:
+    """Row order that puts points in Morton order of their positions (cells of `cell`, 10 bits per axis; stable: rows of one cell keep
+    their order).  The device form of ``synthetic.sort_surfels_spatially``; plain tensor ops -- densification is rare."""
+    x = xyz.detach()
+    q = ((x - x.min(0).values) / cell).long().clamp_(0, 1023)
+
+    def spread(v):                     # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(key, stable=True)
+
+
 class SurfelDensifier:
     """params: name -> tensor [P, ...] on a HIP device for the seven optimised tensors of the reference (``xyz, f_dc, f_rest,
     color, opacity, scaling, rotation``; ``training_setup`` :560-640).  optimizer: a ``torch.optim.Adam`` whose param groups
     carry those names (groups whose name contains "attribute" are left alone, :911), or None."""
 
     def __init__(self, params: Dict[str, torch.Tensor], optimizer: Optional[torch.optim.Optimizer] = None,
-                 percent_dense: float = 0.01, surface: bool = True):
+                 percent_dense: float = 0.01, surface: bool = True, spatial_order: bool = False):
         missing = [k for k in PARAMS if k not in params]
         if missing:
             raise ValueError(f"missing parameter tensors: {missing}")
@@ -45,6 +61,11 @@ class SurfelDensifier:
         self.optimizer = optimizer
         self.percent_dense = percent_dense
         self.surface = surface
+        # spatial_order (not in the reference, which appends clones and splits at the end, TS/geometry/surfel_base.py:982-1136): every
+        # densification leaves the model in Morton order of its canonical positions -- the order bench.py's headline is quoted on
+        # (neighbours in space are neighbours in memory: the gathers of a tile's records share cache lines, +2 % at C3).  A permutation
+        # of the rows of every parameter and of its optimizer moments; images do not change (up to the order of exactly equal depths)
+        self.spatial_order = bool(spatial_order)
         self.device = params["xyz"].device
         self.generation = 0              # bumped whenever parameter tensors are replaced
         self._dependents = []
@@ -188,6 +209,12 @@ class SurfelDensifier:
             with torch.cuda.device(self.device):
                 check(L.soar_densify_apply(P, N, ptr(plan), len(rows), arr, ptr(scaling), ptr(rotation), ptr(noise), int(self.surface),
                                            self._stream()), "soar_densify_apply")
+        if self.spatial_order and P_new > 1:
+            perm = spatial_permutation(news["xyz"])
+            for k in PARAMS:
+                news[k] = news[k].index_select(0, perm)
+                for mk in states.get(k, {}):
+                    states[k][mk] = states[k][mk].index_select(0, perm)
         self._install(news, states)
         self._reset_stats()
         return dict(kept=kept, cloned=cloned, split=split, pruned=P - kept - split, num_points=P_new)

@@ -128,7 +128,6 @@ SIGNATURES = {
     "soar_frame_loss_pooled": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_float, C.c_float, C.c_float,
                                          C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "soar_selftest_exp": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
-    "soar_selftest_wave_reduce": (C.c_int, [_vp, _vp]),
     "soar_selftest_affine_scan": (C.c_int, [_vp, _vp, _vp, _vp]),
     "soar_prof_enable": (C.c_int, [C.c_int]),
     "soar_prof_reset": (C.c_int, []),

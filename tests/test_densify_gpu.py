@@ -126,3 +126,37 @@ def test_densify_edge_cases_and_determinism():
     assert r is not None and r["num_points"] == d.num_points and float(d.accum.sum()) == 0
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         SurfelDensifier({k: v.cpu()[:4] for k, v in base.items()})
+
+
+def test_densifier_can_keep_the_model_in_spatial_order():
+    """SurfelDensifier(spatial_order=True): after a densification the model is the reference's densified model (same rows, same
+    optimizer moments row for row) in Morton order of the canonical positions -- the order bench.py's headline is quoted on --
+    and the rendered images do not change (a permutation of the Gaussians only reorders exactly equal depths)."""
+    import scenes as S
+    from soar_amd.densify import SurfelDensifier, spatial_permutation
+    from test_rasterizer_gpu import run_hip
+    d_ref, st, views, cfg, noise = make("a")
+    d_ord, _, _, _, _ = make("a")
+    d_ord.spatial_order = True
+    for d in (d_ref, d_ord):
+        for radii, grad2d, sgrad in views:
+            d.add_densification_stats(radii.to(DEV), grad2d.to(DEV), sgrad.to(DEV))
+        d.prune_and_densify(cfg["min_opac"], cfg["max_grad"], cfg["extent"], noise=noise)
+    perm = spatial_permutation(d_ref.params["xyz"])
+    assert not torch.equal(perm, torch.arange(perm.numel(), device=DEV))
+    for k in do.PARAMS:
+        assert torch.equal(d_ord.params[k].detach(), d_ref.params[k].detach()[perm]), k
+        assert torch.equal(d_ord.optimizer.state[d_ord.params[k]]["exp_avg_sq"], d_ref.optimizer.state[d_ref.params[k]]["exp_avg_sq"][perm]), k
+        assert d_ord.optimizer.param_groups[do.PARAMS.index(k)]["params"][0] is d_ord.params[k]
+    q = spatial_permutation(d_ord.params["xyz"])
+    assert torch.equal(q, torch.arange(q.numel(), device=DEV))          # already in order: sorting again changes nothing
+    # the same picture from both orders (a person-sized surfel scene densified by cloning every third surfel)
+    scene = S.person_scene(P=4000, W=160, H=120, seed=41, config=(1, 1, 1, 0), opacity=None)
+    order = spatial_permutation(torch.from_numpy(scene.means3D).to(DEV)).cpu().numpy()
+    a = run_hip(scene, None, export=False)
+    for name in ("means3D", "opacities", "scales", "rotations", "colors"):
+        setattr(scene, name, np.ascontiguousarray(getattr(scene, name)[order]))
+    b = run_hip(scene, None, export=False)
+    assert a["R"] == b["R"]
+    for k in ("color", "normal", "depth", "opac"):
+        assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(np.abs(a[k]).max(), 1.0), k

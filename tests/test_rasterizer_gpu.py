@@ -247,21 +247,6 @@ def test_camera_gradients_when_lrn_cam():
     assert np.abs(bw.dL_dviewmat).max() > 0 and np.abs(bw.dL_dprojmat).max() > 0 and np.abs(bw.dL_dcampos).max() > 0
 
 
-def test_wave_transpose_reduce_selftest():
-    """The transpose-reduce of the backward blend (v_permlane32/16_swap + DPP): 16 values per lane are summed over the 16
-    pixel-lanes of each slot (lane = 4 * pixel + slot); lane (q, slot) ends up with the total of value q for its slot."""
-    from soar_amd import hip_lib
-    out = torch.zeros(128, device=_dev())
-    hip_lib.check(hip_lib.lib().soar_selftest_wave_reduce(out.data_ptr(), torch.cuda.current_stream().cuda_stream), "selftest")
-    out = out.cpu().numpy()
-    lane = np.arange(64)
-    q_of = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
-    np.testing.assert_array_equal(out[64:].astype(int), q_of)
-    expect = np.array([[sum((l + 1) * (q + 1) + 0.25 * ((l * 7 + q * 3) % 5) for l in range(s, 64, 4)) for q in range(16)]
-                       for s in range(4)])
-    np.testing.assert_allclose(out[:64], expect[lane & 3, q_of], rtol=1e-6)
-
-
 def test_affine_scan_of_the_entry_lane_backward():
     """The 64-lane scan of affine maps behind the backward blend's two recurrences (rast_render_bwd.hip affine_scan): lane i ends
     with the composition of the maps of the lanes 0..i, lane 0's applied first; wave_shr:1 hands lane i the value of lane i - 1."""
