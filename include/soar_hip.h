@@ -461,7 +461,8 @@ int soar_view_finish_backward(int32_t W, int32_t H, const float *normal, const f
  * :10-241) call it for several views of one pose.  soar_views_forward issues the launches of all of that for up to 8 views of ONE
  * pose (warp once; views of one size and capacity share their launches, one per stage); soar_views_backward takes the gradients of
  * the views' images back to the canonical model (the views' contributions summed in view order).  Same kernels as the per-stage
- * entry points above, same results bit for bit.  Front-to-back form only (main pass ascending, occlusion image fused into its blend).
+ * entry points above, same results bit for bit.  Front views (main pass front to back, occlusion image fused into its blend) and back
+ * views (`back`: main pass back to front, occlusion image a pass of its own) alike.
  * Nothing is read back: the binning part of a view's buffer holds `capacity` instances, and the two status words {instances found,
  * 0 or the number needed} are copied to status_pinned right behind the binning chain (0xFFFFFFFF until they land); a view that did
  * not fit renders as background, and the caller -- who polls the words before it runs the backward -- renders it again. */
@@ -477,6 +478,7 @@ typedef struct SoarPoseArgs {
     const float *colors;         /* colors_precomp [P,3] */
     const float *scale_src;      /* get_scaling [P,scale_width] */
     const float *occ;            /* get_occ [P] or NULL: no occlusion image */
+    float *occ3;                 /* caller-owned [P,3] (written when warp != 0) or NULL: occ.repeat(1, 3), needed by back views */
     float *posed;                /* caller-owned [11][P] floats: xyz' [P,3] | rot' [P,4] | scales3 [P,3] | ones [P]; kept for the backward */
     /* backward only */
     float *grad_scratch;         /* soar_views_grad_scratch_floats(P, n_views) floats */
@@ -484,20 +486,24 @@ typedef struct SoarPoseArgs {
     float *dL_docc;              /* [P] or NULL: the occlusion values are not trained */
 } SoarPoseArgs;
 typedef struct SoarViewArgs {
-    SoarRastParams rast;         /* P of the pose, M = 0, render_front = 0, sort_descending = 0 */
+    SoarRastParams rast;         /* P of the pose, M = 0, render_front = 0; sort_descending = back */
     float focal_k00, focal_k11;  /* fov2focal(FoVy, H), fov2focal(FoVx, W): depth2normal's intrinsics */
+    int32_t back;                /* != 0: the plugin's render_front = False -- main pass sorted back to front (:173-191), the occlusion image a
+                                  * front-to-back rasterization of its own (:193-211) */
+    int32_t pad_;
     int64_t capacity;            /* (tile, Gaussian) instances the binning part of `buffer` holds */
     void *buffer;                /* soar_view_buffer_bytes(P, W, H, capacity) bytes, 256-byte aligned; kept for the backward */
     size_t buffer_bytes;
     float *out;                  /* [18][H][W]: render 0-2 | normal 3-5 | depth 6 | pred_normal 7-9 | mask 10 | occ 11-13 | curv 14 |
                                   * the rasterizer's own normal image 15-17 (read by the backward) */
     int32_t *radii;              /* [P] */
-    uint32_t *status_pinned;     /* 2 words of page-locked host memory, or NULL */
+    uint32_t *status_pinned;     /* 4 words of page-locked host memory, or NULL: {instances found, 0 or the number needed} of the main pass,
+                                  * then of a back view's occlusion pass */
     /* backward only: gradients of the images (each [c][H][W], NULL: not used by the loss) and this view's dL_dmeans2D [P,3] */
     const float *g_render, *g_normal, *g_depth, *g_pred_normal, *g_mask, *g_occ, *g_curv;
     float *dL_dmeans2D;
 } SoarViewArgs;
-int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, size_t *bytes);
+int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, int32_t back, size_t *bytes);
 int soar_views_grad_scratch_floats(int32_t P, int32_t n_views, size_t *floats);
 int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);
 int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);

@@ -388,8 +388,8 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
     // `prefiltered` violations (atomics of preprocess) and the key-sort path of back views.  On the tile-binning path every word is
     // written before it is read (H_KMAX.. by bucket_count, H_NVIS by bucket_scan, H_TOTAL / H_OVERFLOW / H_BAND_OVERFLOW by
     // band_place; preprocess clears the violation count itself when nothing can add to it): no launch for 256 bytes
-    if (prm->prefiltered || prm->sort_descending) {
-        const ZeroRange zr[1] = {{g.header, 64 * sizeof(uint32_t)}};
+    if (prm->prefiltered) {
+        const ZeroRange zr[1] = {{g.header, 12 * sizeof(uint32_t)}};          // (not the running maxima behind them: H_STICKY_*)
         if (launch_zero_ranges(zr, 1, stream)) return 1;
     }
     if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
@@ -406,7 +406,7 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
             return 1;
         }
     }
-    if (!prm->sort_descending && launch_depth_buckets(*prm, g, stream)) return 1;
+    if (launch_depth_buckets(*prm, g, stream)) return 1;
     // asynchronous form: R (and the prefix sum of tiles_touched it comes from) is produced by soar_rast_num_rendered() if
     // the caller asks for it; the sync-free form never needs it
     if (!num_rendered_host) return 0;
@@ -572,9 +572,9 @@ int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *ra
     carve_geom(geom_buffer, prm->P, prm->M, &g);
     carve_image(image_buffer, prm->W, prm->H, &img);
     carve_binning(binning_buffer, num_rendered, &b);
-    // ascending sort: per-tile lists straight from the depth-ordered Gaussians (rast_tilebin.hip); the descending sort
-    // of back views keeps the 64-bit key sort (rast_binning.hip)
-    if (num_rendered > 0 && !prm->sort_descending) {
+    // per-tile lists straight from the depth-ordered Gaussians (rast_tilebin.hip), front to back or -- back views -- back to
+    // front; the 64-bit key sort (rast_binning.hip) only serves the key export and the empty case
+    if (num_rendered > 0) {
         if (launch_tile_binning(*prm, g, b, img, num_rendered, stream)) return 1;
         if (status_pinned) {
             static thread_local std::vector<std::pair<uint32_t *, const uint32_t *>> pending;
@@ -733,12 +733,16 @@ __global__ void export_records_kernel(int P, const GaussRec *rec, float *means2D
 }
 // The tile binning lays the tiles' lists out in the order its workgroups reserved room (rast_tilebin.hip); the reference's
 // binningState.point_list has them in tile order (rasterizer_impl.cu:266-295).  The export re-packs: ranges in tile order ...
-__global__ void __launch_bounds__(1024) export_pack_ranges_kernel(int T, const uint2 *__restrict__ ranges, uint2 *__restrict__ packed)
+// (descending: the reference's SortPairsDescending also puts the TILES in descending order, rasterizer_impl.cu:277-285: the list of
+// the last tile comes first)
+__global__ void __launch_bounds__(1024) export_pack_ranges_kernel(int T, const uint2 *__restrict__ ranges, uint2 *__restrict__ packed,
+                                                                  int descending)
 {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x, per = (T + 1023) / 1024, t0 = tid * per, t1 = min(T, t0 + per);
+    auto tile = [&](int k) { return descending ? T - 1 - k : k; };          // k-th tile in memory order
     uint32_t s = 0;
-    for (int t = t0; t < t1; t++) s += ranges[t].y - ranges[t].x;
+    for (int k = t0; k < t1; k++) s += ranges[tile(k)].y - ranges[tile(k)].x;
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
@@ -747,7 +751,8 @@ __global__ void __launch_bounds__(1024) export_pack_ranges_kernel(int T, const u
     }
     __syncthreads();
     uint32_t run = part[tid];
-    for (int t = t0; t < t1; t++) {
+    for (int k = t0; k < t1; k++) {
+        const int t = tile(k);
         const uint32_t c = ranges[t].y - ranges[t].x;
         packed[t] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);
         run += c;
@@ -801,12 +806,13 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
     if (binning_buffer && num_rendered > 0) {
         carve_binning(const_cast<void *>(binning_buffer), num_rendered, &b);
         const size_t R = (size_t)num_rendered;
-        if (!prm->sort_descending && image_buffer && (point_list || ranges)) {
+        if (image_buffer && (point_list || ranges)) {
             // (debugging entry point: a synchronous scratch allocation is fine here; freed on every way out)
             uint2 *packed = nullptr;
             SOAR_HIP_OK(hipMalloc(&packed, tiles * sizeof(uint2)));
             auto pack = [&]() -> int {
-                hipLaunchKernelGGL(soar::export_pack_ranges_kernel, dim3(1), dim3(1024), 0, stream, (int)tiles, img.ranges, packed);
+                hipLaunchKernelGGL(soar::export_pack_ranges_kernel, dim3(1), dim3(1024), 0, stream, (int)tiles, img.ranges, packed,
+                                   prm->sort_descending ? 1 : 0);
                 SOAR_LAUNCH_OK("export_pack_ranges", stream, prm->debug);
                 if (point_list) {
                     hipLaunchKernelGGL(soar::export_pack_lists_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, img.ranges, packed,
@@ -823,8 +829,8 @@ extern "C" int soar_rast_export_state(const SoarRastParams *prm, const void *geo
         } else {
             COPY(point_list, b.vals_sorted, R * sizeof(uint32_t));
         }
-        if (!prm->sort_descending && image_buffer && (keys_unsorted || vals_unsorted || keys_sorted)) {
-            // the ascending path never materialises the 64-bit keys: produce them for inspection with the key sort
+        if (image_buffer && (keys_unsorted || vals_unsorted || keys_sorted)) {
+            // the tile binning never materialises the 64-bit keys: produce them for inspection with the key sort
             // (point_list and ranges above were copied out first; the key sort rewrites them with its own result)
             if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
             // ... the lists now lie in tile order: the block masks (one bit per list position) follow

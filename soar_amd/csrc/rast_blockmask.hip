@@ -185,14 +185,14 @@ __global__ void __launch_bounds__(BM_THREADS) block_mask_kernel(Batch<BlockMaskA
 int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream)
 {
     BlockMaskArgs a;
-    a.header = prm.sort_descending ? nullptr : g.header;
+    a.header = g.header;
     a.total = (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R);
     a.P = (uint32_t)prm.P;
     a.tile_xy = b.tile_xy; a.point_list = b.vals_sorted; a.rec = g.rec;
     a.masks = b.block_masks; a.plane = b.mask_plane;
     a.T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
     a.tile_count = img.tile_count; a.ranges = img.ranges;
-    a.tile_order = prm.sort_descending ? nullptr : img.tile_order;       // (the key-sort path builds its own: rast_binning.hip)
+    a.tile_order = img.tile_order;
     a.order_rec = img.order_rec;
     a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
     const unsigned per_wg = BM_THREADS * BM_GROUPS;

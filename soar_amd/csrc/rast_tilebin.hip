@@ -58,9 +58,13 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float
 // the scan of the counters.)
 constexpr int BKT_CHUNK = 16384;         // Gaussians per counting workgroup
 constexpr int BKT_GROUPS = BKT_MAX / 1024; // groups of 1024 buckets: one scanning workgroup each
+// Back views (SoarRastParams.sort_descending: the reference's SortPairsDescending, rasterizer_impl.cu:277-285) are the same order of
+// the flipped keys: ~key ascending = key descending, and pairs of equal depth still come out in index order -- what a stable
+// descending sort of the (tile | depth) keys leaves inside a tile.  Only the two kernels that look at a key know about it.
 struct BucketCountArgs {
     int P;
     int B;
+    int descending;
     const uint32_t *depth_key;
     const uint32_t *blk_stats;
     int nblk;
@@ -100,7 +104,8 @@ __global__ void __launch_bounds__(1024) bucket_count_kernel(Batch<BucketCountArg
         }
         __syncthreads();
     }
-    const uint32_t kmin = ~red[0][1], kmax = red[0][0];
+    // (statistics: max key, max ~key.  Of the flipped keys the largest is max ~key and the smallest ~(max key))
+    const uint32_t kmin = a.descending ? ~red[0][0] : ~red[0][1], kmax = a.descending ? red[0][1] : red[0][0];
     const float scale = (float)B / ((float)(kmax - kmin) + 1.0f);
     const int i0 = (int)blockIdx.x * BKT_CHUNK;
     constexpr int PER = BKT_CHUNK / 1024;
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(1024) bucket_count_kernel(Batch<BucketCountArg
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = i0 + k * 1024 + tid;
-        if (i < a.P) a.slot[i] = key[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&cnt[bucket_of(key[k], kmin, scale, B)], 1u);
+        if (i < a.P) a.slot[i] = key[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&cnt[bucket_of(a.descending ? ~key[k] : key[k], kmin, scale, B)], 1u);
     }
     __syncthreads();
     uint32_t *row = a.bucket_mat + (size_t)blockIdx.x * B;
@@ -196,6 +201,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(Batch<BucketCountArgs
 struct BucketScatterArgs {
     int P;
     int B;
+    int descending;
     const uint32_t *depth_key;
     const uint32_t *header;
     const uint32_t *bucket_mat;
@@ -207,9 +213,10 @@ __global__ void __launch_bounds__(256) bucket_scatter_kernel(Batch<BucketScatter
     const BucketScatterArgs &a = batch.v[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
-    const uint32_t key = a.depth_key[i], place = a.slot[i];
-    if (key == 0xFFFFFFFFu) return;
-    const uint32_t kmin = ~a.header[H_NOT_KMIN], kmax = a.header[H_KMAX];
+    const uint32_t key_raw = a.depth_key[i], place = a.slot[i];
+    if (key_raw == 0xFFFFFFFFu) return;
+    const uint32_t key = a.descending ? ~key_raw : key_raw;
+    const uint32_t kmin = a.descending ? ~a.header[H_KMAX] : ~a.header[H_NOT_KMIN], kmax = a.descending ? a.header[H_NOT_KMIN] : a.header[H_KMAX];
     const float scale = (float)a.B / ((float)(kmax - kmin) + 1.0f);
     const uint32_t start = a.bucket_mat[(size_t)(i / BKT_CHUNK) * a.B + bucket_of(key, kmin, scale, a.B)];
     a.pairs[start + place] = ((uint64_t)key << 32) | (uint32_t)i;
@@ -813,10 +820,10 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
     const int nblk = (prm.P + 255) / 256;               // = preprocess grid: one statistics row per block
     const int nw = (prm.P + BKT_CHUNK - 1) / BKT_CHUNK;
     StageTimer timer(ST_SORT, stream);
-    const BucketCountArgs ca = {prm.P, B, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot};
+    const BucketCountArgs ca = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot};
     SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nw), dim3(1024), 0, stream, ca);
     SOAR_LAUNCH_BATCHED(bucket_scan_kernel, dim3((B + 1023) / 1024), dim3(1024), 0, stream, ca);
-    const BucketScatterArgs sa = {prm.P, B, g.depth_key, g.header, g.bucket_mat, g.sort_slot, g.sort_pairs};
+    const BucketScatterArgs sa = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.header, g.bucket_mat, g.sort_slot, g.sort_pairs};
     SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, stream, sa);
     SOAR_LAUNCH_OK("depth_buckets", stream, prm.debug);
     return 0;

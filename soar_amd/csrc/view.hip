@@ -10,8 +10,9 @@
 // occlusion pass -> post-ops per view; views of one size go through the launch sites as a batch, one launch per stage) and
 // soar_views_backward (post-ops backward -> blend backward -> geometry backward per view, then ONE launch that sums the views'
 // gradients in view order and takes them through the warp).  Same kernels as the per-stage entry points: the results are theirs
-// bit for bit (tests/test_plugin_gpu.py).  Only the front-to-back form (render_front = True in the plugin's sense: main pass sorted
-// ascending, the occlusion image a subsequence of it) is served; back views keep the per-stage path.
+// bit for bit (tests/test_plugin_gpu.py).  Front views (render_front = True in the plugin's sense: main pass sorted front to back, the
+// occlusion image a subsequence of it, fused into its blend) and back views (main pass sorted back to front -- the tile binning
+// orders the flipped depth keys --, the occlusion image a rasterization of its own) are both served; back views one after the other.
 #include "soar_common.h"
 
 #include <cstdint>
@@ -27,6 +28,8 @@ struct ExpandArgs {
     int P, width;
     const float *scale_src;
     float *scales3, *ones;
+    const float *occ;            // [P] or null
+    float *occ3;                 // [P][3] or null: occ.repeat(1, 3), the colours of a back view's occlusion pass (:281-291)
 };
 // scales = get_scaling.repeat(1, 3); scales[..., -1] = -1e10  (TS/renderer/diff_gaussian_rasterizer.py:233-234); opacities = 1 (:232)
 __global__ void __launch_bounds__(256) expand_scales_kernel(ExpandArgs a)
@@ -38,6 +41,7 @@ __global__ void __launch_bounds__(256) expand_scales_kernel(ExpandArgs a)
     a.scales3[3 * (size_t)p + 1] = s0;
     a.scales3[3 * (size_t)p + 2] = -1e10f;
     a.ones[p] = 1.f;
+    if (a.occ3) { const float o = a.occ[p]; a.occ3[3 * (size_t)p] = o; a.occ3[3 * (size_t)p + 1] = o; a.occ3[3 * (size_t)p + 2] = o; }
 }
 
 struct FoldArgs {
@@ -62,13 +66,25 @@ __global__ void __launch_bounds__(256) fold_scale_kernel(FoldArgs a)
     }
 }
 
+struct SumColsArgs { int P; const float *src3; float *dst; };
+__global__ void __launch_bounds__(256) sum_cols3_kernel(SumColsArgs a)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < a.P) a.dst[p] = (a.src3[3 * (size_t)p] + a.src3[3 * (size_t)p + 1]) + a.src3[3 * (size_t)p + 2];
+}
+
 struct ViewBuf {
     void *geom, *img, *binning, *work;
     float *g_nd;                 // [4][H][W]: gradient of the rasterizer's normal [3] and depth [1] images
     float *zero4;                // [4][H][W] of zeros (an upstream gradient that was not given)
+    // a back view's occlusion pass is a rasterization of its own (front-to-back, camera-facing surfels only): its buffers, the
+    // three images it produces besides the occlusion image, its radii and the status words' place holder
+    void *geom_o, *img_o, *binning_o;
+    float *scratch7;             // [7][H][W]: normal, depth, opacity of that pass (never used)
+    int32_t *radii_o;            // [P]
     size_t work_bytes, total;
 };
-int carve_view(void *base, int32_t P, int32_t W, int32_t H, int64_t capacity, ViewBuf *out)
+int carve_view(void *base, int32_t P, int32_t W, int32_t H, int64_t capacity, int back, ViewBuf *out)
 {
     size_t gb = 0, ib = 0, bb = 0, wb = 0;
     if (soar_rast_geometry_bytes(P, 0, &gb) || soar_rast_image_bytes(W, H, &ib) || soar_rast_binning_bytes(capacity, &bb) ||
@@ -83,6 +99,14 @@ int carve_view(void *base, int32_t P, int32_t W, int32_t H, int64_t capacity, Vi
     out->work_bytes = wb;
     out->g_nd = reinterpret_cast<float *>(take(sizeof(float) * 4 * (size_t)W * H));
     out->zero4 = reinterpret_cast<float *>(take(sizeof(float) * 4 * (size_t)W * H));
+    out->geom_o = out->img_o = out->binning_o = nullptr; out->scratch7 = nullptr; out->radii_o = nullptr;
+    if (back) {
+        out->geom_o = take(gb);
+        out->img_o = take(ib);
+        out->binning_o = take(bb);
+        out->scratch7 = reinterpret_cast<float *>(take(sizeof(float) * 7 * (size_t)W * H));
+        out->radii_o = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)(P > 0 ? P : 1)));
+    }
     out->total = (size_t)(p - static_cast<char *>(base)) + ALIGN;
     return 0;
 }
@@ -103,17 +127,19 @@ int check_views(const SoarPoseArgs *pose, int32_t n, const SoarViewArgs *views, 
     for (int v = 0; v < n; v++) {
         const SoarViewArgs &a = views[v];
         if (a.rast.P != pose->P || a.rast.M != 0) { set_error("%s: view %d does not belong to the pose (P, M)", who, v); return 1; }
-        if (a.rast.render_front || a.rast.sort_descending) { set_error("%s: only the front-to-back form is served here (view %d)", who, v); return 1; }
+        if (a.rast.render_front) { set_error("%s: view %d: render_front belongs to the occlusion pass, not to the view", who, v); return 1; }
+        if ((a.back != 0) != (a.rast.sort_descending != 0)) { set_error("%s: view %d: a back view is the one whose main pass is sorted back to front", who, v); return 1; }
         if (a.capacity <= 0 || !a.buffer || !a.out || !a.radii) { set_error("%s: view %d: capacity, buffer, out and radii must be given", who, v); return 1; }
         if (reinterpret_cast<size_t>(a.buffer) % ALIGN) { set_error("%s: view %d: the buffer must be %zu-byte aligned", who, v, ALIGN); return 1; }
     }
     return 0;
 }
-// views that can share their launches: one size, one capacity (the grids of the binning stages depend on it)
+// views that can share their launches: front views of one size and one capacity (the grids of the binning stages depend on it)
 bool one_batch(int32_t n, const SoarViewArgs *views)
 {
-    for (int v = 1; v < n; v++)
-        if (views[v].rast.W != views[0].rast.W || views[v].rast.H != views[0].rast.H || views[v].capacity != views[0].capacity) return false;
+    for (int v = 0; v < n; v++)
+        if (views[v].back || views[v].rast.W != views[0].rast.W || views[v].rast.H != views[0].rast.H || views[v].capacity != views[0].capacity)
+            return false;
     return n > 1;
 }
 
@@ -127,11 +153,11 @@ int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *ra
                                     float *out_depth, float *out_opac, const float *occ_values, float *out_occ,
                                     uint32_t *status_pinned, void *stream_);
 
-int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, size_t *bytes)
+int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, int32_t back, size_t *bytes)
 {
     if (!bytes || P < 0 || W <= 0 || H <= 0 || capacity < 0) { set_error("soar_view_buffer_bytes: bad arguments"); return 1; }
     ViewBuf b;
-    if (carve_view(nullptr, P, W, H, capacity, &b)) return 1;
+    if (carve_view(nullptr, P, W, H, capacity, back, &b)) return 1;
     *bytes = b.total;
     return 0;
 }
@@ -147,7 +173,7 @@ int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarView
         if (soar_lbs_warp_forward(pose->xyz, pose->rot, pose->weights, pose->joint_mats, pose->offsets, pose->axis_perm, P, pose->J,
                                   xyz_p, rot_p, nullptr, stream_))
             return 1;
-        ExpandArgs e = {P, pose->scale_width, pose->scale_src, scales3, ones};
+        ExpandArgs e = {P, pose->scale_width, pose->scale_src, scales3, ones, pose->occ, pose->occ3};
         hipLaunchKernelGGL(expand_scales_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, e);
         SOAR_LAUNCH_OK("expand_scales", stream, 0);
     }
@@ -155,8 +181,9 @@ int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarView
     ViewBuf vb[MAX_BATCH];
     for (int v = 0; v < n_views; v++) {
         const SoarViewArgs &a = views[v];
-        if (carve_view(a.buffer, P, a.rast.W, a.rast.H, a.capacity, &vb[v])) return 1;
+        if (carve_view(a.buffer, P, a.rast.W, a.rast.H, a.capacity, a.back, &vb[v])) return 1;
         if (a.buffer_bytes < vb[v].total - ALIGN) { set_error("soar_views_forward: view %d: buffer too small (%zu < %zu)", v, a.buffer_bytes, vb[v].total); return 1; }
+        if (a.back && pose->occ && !pose->occ3) { set_error("soar_views_forward: a back view needs SoarPoseArgs::occ3"); return 1; }
     }
     auto plane = [](const SoarViewArgs &a, int k) { return a.out + (size_t)k * a.rast.W * a.rast.H; };
     // stage by stage over the views: inside a batch every launch site sees the views one after the other and launches once
@@ -166,11 +193,30 @@ int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarView
         case 0:
             return soar_rast_forward_geometry(&a.rast, xyz_p, nullptr, pose->colors, ones, scales3, rot_p, nullptr, vb[v].geom, a.radii,
                                               nullptr, stream_);
-        case 1:
+        case 1: {
             // planes of `out`: render 0-2 | normal' 3-5 | depth 6 | pred_normal 7-9 | mask 10 | occ 11-13 | curv 14 | raw normal 15-17
-            return soar_rast_forward_render_status(&a.rast, a.radii, vb[v].geom, vb[v].binning, vb[v].img, a.capacity, plane(a, 0),
-                                                   plane(a, 15), plane(a, 6), plane(a, 10), pose->occ, pose->occ ? plane(a, 11) : nullptr,
-                                                   a.status_pinned, stream_);
+            const bool fused_occ = pose->occ && !a.back;
+            if (soar_rast_forward_render_status(&a.rast, a.radii, vb[v].geom, vb[v].binning, vb[v].img, a.capacity, plane(a, 0),
+                                                plane(a, 15), plane(a, 6), plane(a, 10), fused_occ ? pose->occ : nullptr,
+                                                fused_occ ? plane(a, 11) : nullptr, a.status_pinned, stream_))
+                return 1;
+            if (a.back && pose->occ) {
+                // render_front = False (TS/renderer/diff_gaussian_rasterizer.py:173-211, :280-291): the main pass above is sorted back
+                // to front, the occlusion image is a rasterization of its own -- front to back over the camera-facing surfels, colours
+                // = occ.repeat(1, 3) -- with its own binning (status words behind the main pass's: a.status_pinned + 2)
+                SoarRastParams po = a.rast;
+                po.render_front = 1; po.sort_descending = 0;
+                const size_t pix = (size_t)a.rast.W * a.rast.H;
+                float *s7 = vb[v].scratch7;
+                if (soar_rast_forward_geometry(&po, xyz_p, nullptr, pose->occ3, ones, scales3, rot_p, nullptr, vb[v].geom_o, vb[v].radii_o,
+                                               nullptr, stream_))
+                    return 1;
+                return soar_rast_forward_render_status(&po, vb[v].radii_o, vb[v].geom_o, vb[v].binning_o, vb[v].img_o, a.capacity, plane(a, 11),
+                                                       s7, s7 + 3 * pix, s7 + 4 * pix, nullptr, nullptr,
+                                                       a.status_pinned ? a.status_pinned + 2 : nullptr, stream_);
+            }
+            return 0;
+        }
         default:
             return soar_view_finish(a.rast.W, a.rast.H, plane(a, 15), plane(a, 6), plane(a, 10),
                                     static_cast<const float *>(a.rast.prcppoint_dev), a.focal_k00, a.focal_k11, plane(a, 3), plane(a, 14),
@@ -205,14 +251,15 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
     // then throw-away rows [n][P][7] (opacity 1 + cov3D 6) and the camera gradients [n][35]
     const size_t nP = (size_t)n_views * P;
     float *Gx = pose->grad_scratch, *Gr = Gx + 3 * nP, *Gc = Gr + 4 * nP, *Gs = Gc + 3 * nP, *Go = Gs + 3 * nP, *Gjunk = Go + nP,
-          *Gcam = Gjunk + 7 * nP, *Gsum_s = Gcam + 35 * (size_t)n_views;       // + [P][3]: the scales3 gradient summed over the views
+          *Gcam = Gjunk + 7 * nP, *Gsum_s = Gcam + 35 * (size_t)n_views,       // + [P][3]: the scales3 gradient summed over the views
+          *Gocc3 = Gsum_s + 3 * (size_t)P;                                       // + [P][16]: a back view's occlusion-pass backward
     const bool batched = one_batch(n_views, views);
     ViewBuf vb[MAX_BATCH];
     bool live[MAX_BATCH];
     int n_live = 0;
     for (int v = 0; v < n_views; v++) {
         const SoarViewArgs &a = views[v];
-        if (carve_view(a.buffer, P, a.rast.W, a.rast.H, a.capacity, &vb[v])) return 1;
+        if (carve_view(a.buffer, P, a.rast.W, a.rast.H, a.capacity, a.back, &vb[v])) return 1;
         if (!a.dL_dmeans2D) { set_error("soar_views_backward: view %d: dL_dmeans2D must be given", v); return 1; }
         live[v] = a.g_render || a.g_normal || a.g_depth || a.g_pred_normal || a.g_mask || a.g_curv;
         n_live += live[v] ? 1 : 0;
@@ -265,7 +312,25 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
     const bool occ_grad = pose->dL_docc != nullptr;
     for (int v = 0; v < n_views && occ_grad; v++) {
         const SoarViewArgs &a = views[v];
-        if (a.g_occ) {
+        if (a.g_occ && a.back) {
+            // that occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient.  A full
+            // backward of the pass with zero normal / depth / opacity gradients; what it leaves in the colour block [P][3] is summed
+            // over the three columns into this view's occ gradient
+            SoarRastParams po = a.rast;
+            po.render_front = 1; po.sort_descending = 0;
+            const size_t pix = (size_t)a.rast.W * a.rast.H;
+            SOAR_HIP_OK(hipMemsetAsync(vb[v].zero4, 0, sizeof(float) * 4 * pix, stream));
+            float *junk = Gjunk + 7 * (size_t)v * P, *cam = Gcam + 35 * (size_t)v;
+            float *gc3 = Gocc3;                              // [P][3] + the throw-away blocks of a backward
+            if (soar_rast_backward(&po, xyz_p, vb[v].radii_o, nullptr, pose->occ3, scales3, rot_p, nullptr, vb[v].geom_o, vb[v].binning_o,
+                                   vb[v].img_o, a.capacity, a.g_occ, vb[v].zero4, vb[v].zero4 + 3 * pix, vb[v].zero4 + 3 * pix,
+                                   gc3 + 3 * (size_t)P, gc3, junk, gc3 + 6 * (size_t)P, junk + P, nullptr, gc3 + 9 * (size_t)P,
+                                   gc3 + 12 * (size_t)P, cam, cam + 16, cam + 32, vb[v].work, vb[v].work_bytes, stream_))
+                return 1;
+            SumColsArgs sc = {P, gc3, Go + (size_t)v * P};
+            hipLaunchKernelGGL(sum_cols3_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, sc);
+            SOAR_LAUNCH_OK("sum_cols3", stream, 0);
+        } else if (a.g_occ) {
             if (soar_rast_occ_backward(&a.rast, vb[v].geom, vb[v].binning, vb[v].img, a.capacity, a.g_occ, Go + (size_t)v * P, stream_)) return 1;
         } else {
             SOAR_HIP_OK(hipMemsetAsync(Go + (size_t)v * P, 0, sizeof(float) * P, stream));
@@ -288,7 +353,7 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
 int soar_views_grad_scratch_floats(int32_t P, int32_t n_views, size_t *floats)
 {
     if (!floats || P < 0 || n_views < 1 || n_views > MAX_BATCH) { set_error("soar_views_grad_scratch_floats: bad arguments"); return 1; }
-    *floats = (size_t)n_views * P * (3 + 4 + 3 + 3 + 1 + 7) + 35 * (size_t)n_views + 3 * (size_t)P;
+    *floats = (size_t)n_views * P * (3 + 4 + 3 + 3 + 1 + 7) + 35 * (size_t)n_views + 3 * (size_t)P + 16 * (size_t)P;
     return 0;
 }
 

@@ -46,13 +46,14 @@ class SoarPoseArgs(C.Structure):
     """Mirror of ``struct SoarPoseArgs`` (include/soar_hip.h)."""
     _fields_ = [("P", C.c_int32), ("J", C.c_int32), ("scale_width", C.c_int32), ("warp", C.c_int32),
                 ("xyz", _vp), ("rot", _vp), ("weights", _vp), ("joint_mats", _vp), ("offsets", _vp), ("axis_perm", _vp),
-                ("colors", _vp), ("scale_src", _vp), ("occ", _vp), ("posed", _vp),
+                ("colors", _vp), ("scale_src", _vp), ("occ", _vp), ("occ3", _vp), ("posed", _vp),
                 ("grad_scratch", _vp), ("dL_dxyz", _vp), ("dL_drot", _vp), ("dL_dcolors", _vp), ("dL_dscale", _vp), ("dL_docc", _vp)]
 
 
 class SoarViewArgs(C.Structure):
     """Mirror of ``struct SoarViewArgs`` (include/soar_hip.h)."""
-    _fields_ = [("rast", SoarRastParams), ("focal_k00", C.c_float), ("focal_k11", C.c_float), ("capacity", C.c_int64),
+    _fields_ = [("rast", SoarRastParams), ("focal_k00", C.c_float), ("focal_k11", C.c_float), ("back", C.c_int32), ("pad_", C.c_int32),
+                ("capacity", C.c_int64),
                 ("buffer", _vp), ("buffer_bytes", C.c_size_t), ("out", _vp), ("radii", _vp), ("status_pinned", _vp),
                 ("g_render", _vp), ("g_normal", _vp), ("g_depth", _vp), ("g_pred_normal", _vp), ("g_mask", _vp), ("g_occ", _vp),
                 ("g_curv", _vp), ("dL_dmeans2D", _vp)]
@@ -137,7 +138,7 @@ SIGNATURES = {
     "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
-    "soar_view_buffer_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_size_t)]),
+    "soar_view_buffer_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_views_grad_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_views_forward": (C.c_int, [C.POINTER(SoarPoseArgs), C.c_int32, C.POINTER(SoarViewArgs), _vp]),
     "soar_views_backward": (C.c_int, [C.POINTER(SoarPoseArgs), C.c_int32, C.POINTER(SoarViewArgs), _vp]),

@@ -518,8 +518,6 @@ class _RasterizeViews(torch.autograd.Function):
                 rs.prefiltered, rs.render_front, rs.sort_descending, rs.debug, rs.config,
                 side=_view_stream(means3D.device, i) if use_sides else None)
         calls = [] if use_sides else None
-        if capacity is not None and capacity != AUTO and any(rs.sort_descending for rs in settings_list):
-            raise ValueError("the sync-free capacity mode needs sort_descending = False on every view")
         L = hip_lib.lib()
         ctx.num_rendered = [0] * len(states)
         for i in order:

@@ -268,7 +268,7 @@ def _status_words():
     with _pinned_lock:
         if _pinned_free:
             return _pinned_free.pop()
-    return torch.zeros(2, dtype=torch.int32).pin_memory()
+    return torch.zeros(4, dtype=torch.int32).pin_memory()      # {instances, overflow} of the main pass, then of a back view's occlusion pass
 
 
 def _release_words(words):
@@ -282,15 +282,17 @@ def _wait_words(words, device, stream):
     copied out behind the binning chain, in front of the blend.  Bounded: after POLL_TIMEOUT_S the stream the copy sits on is
     synchronised once, and a copy that still has not landed is an error."""
     w = words.numpy()
-    if w[0] == -1 or w[1] == -1:
+    pending = lambda: w[0] == -1 or w[1] == -1 or w[2] == -1 or w[3] == -1
+    if pending():
         t_end = time.perf_counter() + POLL_TIMEOUT_S
-        while (w[0] == -1 or w[1] == -1) and time.perf_counter() < t_end:
+        while pending() and time.perf_counter() < t_end:
             pass
-        if w[0] == -1 or w[1] == -1:
+        if pending():
             stream.synchronize()
-            if w[0] == -1 or w[1] == -1:
+            if pending():
                 raise RuntimeError(f"the binning status words of a view on {device} never arrived")
-    return int(w[0]) & 0xFFFFFFFF, int(w[1]) & 0xFFFFFFFF
+    # (a back view's occlusion pass bins the camera-facing surfels only: never more than the main pass; reported together)
+    return max(int(w[0]) & 0xFFFFFFFF, int(w[2]) & 0xFFFFFFFF), max(int(w[1]) & 0xFFFFFFFF, int(w[3]) & 0xFFFFFFFF)
 
 
 class _PendingStatus:
@@ -307,14 +309,14 @@ class _PendingStatus:
         if words is None:
             return None
         worst = None
-        for (rs, _f, cap, key), wd in zip(self.specs, words):
+        for (rs, _f, cap, key, _back), wd in zip(self.specs, words):
             if block:
                 total, over = _wait_words(wd, self.device, self.stream)
             else:
                 w = wd.numpy()
-                if w[0] == -1 or w[1] == -1:
+                if w[0] == -1 or w[1] == -1 or w[2] == -1 or w[3] == -1:
                     continue                         # (not landed and nobody waits: nothing learnt from this view)
-                total, over = int(w[0]) & 0xFFFFFFFF, int(w[1]) & 0xFFFFFFFF
+                total, over = max(int(w[0]) & 0xFFFFFFFF, int(w[2]) & 0xFFFFFFFF), max(int(w[1]) & 0xFFFFFFFF, int(w[3]) & 0xFFFFFFFF)
             bound = capacity_book.learn(key, max(total, over))
             rasterizer.note_num_rendered(total)
             if over and (worst is None or over > worst[0]):
@@ -343,12 +345,12 @@ def _carve(base: torch.Tensor, offset: int, shape) -> torch.Tensor:
     return t
 
 
-def _view_bytes(P, W, H, cap):
-    k = (P, W, H, cap)
+def _view_bytes(P, W, H, cap, back):
+    k = (P, W, H, cap, back)
     n = _buffer_bytes.get(k)
     if n is None:
         c = C.c_size_t(0)
-        check(hip_lib.lib().soar_view_buffer_bytes(P, W, H, cap, C.byref(c)), "soar_view_buffer_bytes")
+        check(hip_lib.lib().soar_view_buffer_bytes(P, W, H, cap, int(back), C.byref(c)), "soar_view_buffer_bytes")
         if len(_buffer_bytes) > 256:
             _buffer_bytes.clear()
         n = _buffer_bytes[k] = int(c.value)
@@ -356,8 +358,8 @@ def _view_bytes(P, W, H, cap):
 
 
 class _PoseViews(torch.autograd.Function):
-    """n front-to-back views of one pose, one C call each way.  Per view 8 outputs like `_RenderViews`.  specs[i] = (settings,
-    (focal_k00, focal_k11), capacity, book key)."""
+    """n views of one pose, one C call each way.  Per view 8 outputs like `_RenderViews`.  specs[i] = (settings, (focal_k00,
+    focal_k11), capacity, book key, back): `settings` of a back view (the plugin's render_front = False) carry sort_descending."""
     N_OUT = 8
     PLANES = 18
 
@@ -367,18 +369,19 @@ class _PoseViews(torch.autograd.Function):
         n = len(specs)
         views = (SoarViewArgs * n)()
         per_view = []
-        for v, (rs, focal, cap, _key) in enumerate(specs):
+        for v, (rs, focal, cap, _key, back) in enumerate(specs):
             H, W = int(rs.image_height), int(rs.image_width)
-            c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, False, rs.debug, rs.bg,
+            c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, bool(back), rs.debug, rs.bg,
                      rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
-            nbytes = _view_bytes(P, W, H, int(cap))
+            nbytes = _view_bytes(P, W, H, int(cap), bool(back))
             buf = _scratch(nbytes, dev)
             out = torch.empty((_PoseViews.PLANES * H * W,), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             words = _status_words()
+            words.numpy()[2:] = 0                       # (only a back view's occlusion pass writes the second pair)
             a = views[v]
             a.rast = c.params
-            a.focal_k00, a.focal_k11, a.capacity = focal[0], focal[1], int(cap)
+            a.focal_k00, a.focal_k11, a.capacity, a.back = focal[0], focal[1], int(cap), int(bool(back))
             a.buffer, a.buffer_bytes, a.out, a.radii, a.status_pinned = buf.data_ptr(), nbytes, out.data_ptr(), radii.data_ptr(), words.data_ptr()
             per_view.append((c, buf, out, radii, words))
         with torch.cuda.device(dev):
@@ -406,6 +409,8 @@ class _PoseViews(torch.autograd.Function):
         pose.xyz, pose.rot, pose.weights, pose.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
         pose.offsets, pose.axis_perm = ptr(off), ptr(T)
         pose.colors, pose.scale_src, pose.occ, pose.posed = cols.data_ptr(), ssrc.data_ptr(), occ_v.data_ptr(), posed.data_ptr()
+        occ3 = torch.empty((P, 3), dtype=torch.float32, device=dev) if any(sp[4] for sp in specs) else None
+        pose.occ3 = ptr(occ3)
         cur = torch.cuda.current_stream(dev)
         stream = cur.cuda_stream
         keep = [x, q, w, A, off, T, cols, ssrc, occ_v]
@@ -419,14 +424,14 @@ class _PoseViews(torch.autograd.Function):
             for _attempt in range(6):
                 again = False
                 new_specs = []
-                for (rs, focal, cap, key), (_c, _b, _o, _r, words) in zip(specs, per_view):
+                for (rs, focal, cap, key, back), (_c, _b, _o, _r, words) in zip(specs, per_view):
                     total, over = _wait_words(words, dev, cur)
                     bound = capacity_book.learn(key, max(total, over))
                     rasterizer.note_num_rendered(total)
                     if over:
                         again = True
                         cap = max(bound, 2 * over)
-                    new_specs.append((rs, focal, cap, key))
+                    new_specs.append((rs, focal, cap, key, back))
                 _release_words([pv[4] for pv in per_view])
                 if not again:
                     break
@@ -437,7 +442,7 @@ class _PoseViews(torch.autograd.Function):
                 raise BinningOverflow("a view did not fit its binning buffer after six enlargements")
         occ_grad = bool(ctx.needs_input_grad[4])
         outs, nondiff, saved = [], [], [x, q, w, A, cols, ssrc, posed]
-        for (rs, _f, _cap, _k), (_c, buf, out, radii, _words) in zip(specs, per_view):
+        for (rs, _f, _cap, _k, _back), (_c, buf, out, radii, _words) in zip(specs, per_view):
             H, W = int(rs.image_height), int(rs.image_width)
             hw = H * W
             render, normal, depth = _carve(out, 0, (3, H, W)), _carve(out, 3 * hw, (3, H, W)), _carve(out, 6 * hw, (1, H, W))
@@ -448,7 +453,7 @@ class _PoseViews(torch.autograd.Function):
             if not occ_grad:
                 nondiff.append(occ_img)
             saved += [depth, mask, raw_normal, buf, radii]       # what the backward reads of a view (depth and mask are outputs:
-        ctx.pose_keep = (off, T, occ_v)                          # modifying them in place is caught by autograd's version check)
+        ctx.pose_keep = (off, T, occ_v, occ3)                    # modifying them in place is caught by autograd's version check)
         ctx.view_ctx = [(pv[0], pv[2]) for pv in per_view]       # parameter blocks (camera tensors kept alive) and the image blocks
         ctx.pending = _PendingStatus(specs, [pv[4] for pv in per_view], dev, cur) if training else None
         ctx.specs, ctx.J, ctx.occ_grad, ctx.stream = specs, J, occ_grad, cur
@@ -464,7 +469,7 @@ class _PoseViews(torch.autograd.Function):
         L = hip_lib.lib()
         saved = ctx.saved_tensors
         x, q, w, A, cols, ssrc, posed = saved[:7]
-        off, T, occ_v = ctx.pose_keep
+        off, T, occ_v, occ3 = ctx.pose_keep
         dev = x.device
         P, n = x.shape[0], len(ctx.specs)
         # FIRST: did every view fit its binning buffer?  The words landed while the blend and the loss ran.
@@ -492,6 +497,7 @@ class _PoseViews(torch.autograd.Function):
         pose.xyz, pose.rot, pose.weights, pose.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
         pose.offsets, pose.axis_perm = ptr(off), ptr(T)
         pose.colors, pose.scale_src, pose.occ, pose.posed = cols.data_ptr(), ssrc.data_ptr(), occ_v.data_ptr(), posed.data_ptr()
+        pose.occ3 = ptr(occ3)
         pose.grad_scratch = scratch.data_ptr()
         pose.dL_dxyz, pose.dL_drot, pose.dL_dcolors, pose.dL_dscale = g_xyz.data_ptr(), g_rot.data_ptr(), g_colors.data_ptr(), g_scale.data_ptr()
         pose.dL_docc = g_occ.data_ptr() if g_occ is not None else None
@@ -499,7 +505,7 @@ class _PoseViews(torch.autograd.Function):
         keep = []
         NO = _PoseViews.N_OUT
         any_live = False
-        for v, ((rs, focal, cap, _key), (c, out)) in enumerate(zip(ctx.specs, ctx.view_ctx)):
+        for v, ((rs, focal, cap, _key, back), (c, out)) in enumerate(zip(ctx.specs, ctx.view_ctx)):
             depth, mask, raw_normal, buf, radii = saved[7 + 5 * v:12 + 5 * v]
             g_color, g_normal, g_depth, g_pred, g_mask, g_occ_img, g_curv, _gr = gouts[v * NO:(v + 1) * NO]
             opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
@@ -508,7 +514,7 @@ class _PoseViews(torch.autograd.Function):
             any_live = any_live or any(g is not None for g in gs)
             a = views[v]
             a.rast = c.params
-            a.focal_k00, a.focal_k11, a.capacity = focal[0], focal[1], int(cap)
+            a.focal_k00, a.focal_k11, a.capacity, a.back = focal[0], focal[1], int(cap), int(bool(back))
             a.buffer, a.buffer_bytes, a.out, a.radii = buf.data_ptr(), buf.numel(), out.data_ptr(), radii.data_ptr()
             (a.g_render, a.g_normal, a.g_depth, a.g_pred_normal, a.g_mask, a.g_occ, a.g_curv) = [ptr(g) for g in gs]
             a.dL_dmeans2D = g2d[v].data_ptr()
@@ -552,17 +558,16 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
     first read-back.  -> list of the per-view 8-tuples of ``render_view``."""
     n = _RenderViews.N_OUT
     dev, P = xyz.device, int(xyz.shape[0])
-    # the one-call form serves front-to-back views of a non-empty model whose scale source is [P,1]; AUTO sizes their binning
-    # buffers from the book, a number is taken as it is; None (Config.binning_capacity = 0) keeps the reference's read-back
-    one_call = [i for i, back in enumerate(backs) if not back] if (capacity and P > 0 and tuple(scale_src.shape) == (P, 1)
-                                                                   and len(backs) <= 8) else []
+    # the one-call form serves the views of a non-empty model whose scale source is [P,1]; AUTO sizes their binning buffers from the
+    # book, a number is taken as it is; None (Config.binning_capacity = 0) keeps the reference's read-back
+    one_call = list(range(len(backs))) if (capacity and P > 0 and tuple(scale_src.shape) == (P, 1) and len(backs) <= 8) else []
     keys = {i: CapacityBook.key(dev, settings_list[i], P) for i in one_call}
     caps = {i: (capacity_book.get(keys[i]) if capacity == AUTO else int(capacity)) for i in one_call}
     if one_call and all(caps[i] for i in one_call):
         for i in one_call:                       # views of one size share the largest bound among them: they go out as one batch
             size = (int(settings_list[i].image_width), int(settings_list[i].image_height))
             caps[i] = max(caps[j] for j in one_call if (int(settings_list[j].image_width), int(settings_list[j].image_height)) == size)
-        specs = [(settings_list[i], _focal(cameras[i]), caps[i], keys[i]) for i in one_call]
+        specs = [(settings_list[i]._replace(sort_descending=bool(backs[i])), _focal(cameras[i]), caps[i], keys[i], bool(backs[i])) for i in one_call]
         outs = _PoseViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, torch.is_grad_enabled(),
                                 *[means2D_list[i] for i in one_call])
         result = {i: tuple(outs[j * n:(j + 1) * n]) for j, i in enumerate(one_call)}
@@ -570,12 +575,12 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
     else:
         result, rest = {}, list(range(len(backs)))
     if rest:
-        # per-stage path: back views (descending sort), and the first frame of a kind, whose read-back teaches the book
+        # per-stage path: the first frame of a kind, whose read-back teaches the book (and Config.binning_capacity = 0)
         specs = [(settings_list[i], _focal(cameras[i]), None if capacity == AUTO else _capacity(capacity, backs[i]), bool(backs[i])) for i in rest]
         outs = _RenderViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs,
                                   *[means2D_list[i] for i in rest])
         for j, i in enumerate(rest):
             result[i] = tuple(outs[j * n:(j + 1) * n])
-            if capacity == AUTO and not backs[i]:
+            if capacity == AUTO:
                 capacity_book.learn(CapacityBook.key(dev, settings_list[i], P), _RenderViews.last_num_rendered[j])
     return [result[i] for i in range(len(backs))]
