@@ -151,11 +151,12 @@ class FrameStepPlan:
         # take their frame from blockIdx.y) -- no fork / join per step and a quarter of the launches, but every stage ends in a
         # barrier over all frames.  Not batched: the frames' chains on streams of their own, whose small latency-bound kernels
         # fill the tails of the other chains' blends.  Measured (bench.py, frames/s batched against streams; round 3): 1080p 3850 /
-        # 3500, 1080p next to a live RCCL communicator 3640 / 3410, 4K 858 / 871 -- the batched form is the default everywhere (the
-        # 1.5 % the streams form keeps at 4K do not pay for a second default); SOAR_PLAN_BATCHED=0 / 1 or the argument force one.
+        # 3500, 1080p next to a live RCCL communicator 3640 / 3410, 4K 858 / 871; round 4: 4K 934 / 958).  Default by image size:
+        # batched up to 3 Mpixel, the frames' own streams above (at 4K a frame's blends are long enough for the other frames' small
+        # kernels to hide in); SOAR_PLAN_BATCHED=0 / 1 or the argument force one.
         if batched is None:
             env = os.environ.get("SOAR_PLAN_BATCHED")
-            batched = (env != "0") if env in ("0", "1") else True
+            batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 3_000_000)
         self.batched = bool(batched) and self.n <= 8
         self.optimizer = None                     # see _run_eager
         self.optimizer_in_two_parts = None        # None: when a gradient reduction is in flight; True / False force it (tests)
