@@ -58,7 +58,8 @@ STAGE_KERNELS = {
     "tile_lists": ["bin_tiles_kernel"],
     "render_forward": ["render_forward_kernel"],
     "render_backward": ["render_backward_blocks_kernel", "zero_ranges_kernel"],
-    "block_masks": ["block_mask_kernel", "(one of its workgroups builds the tile order)"],
+    "block_masks": ["tile_order_binned_kernel", "(tile order + cleared mask words; the masks themselves are left behind by render_forward_kernel since "
+                    "round 4; block_mask_kernel only behind the key export)"],
     "geometry_backward": ["geometry_backward_kernel"],
     "lbs_knn_weights": ["knn_follow_kernel", "knn_search_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
     "optimizer": ["adam_update_kernel", "adam_tick_kernel"],

@@ -592,7 +592,8 @@ int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *ra
         if (launch_scan(*prm, g, stream)) return 1;                // key emission needs the prefix sum of tiles_touched
         if (launch_binning(*prm, g, b, img, num_rendered, stream)) return 1;
     }
-    if (num_rendered > 0 && launch_block_masks(*prm, g, b, img, num_rendered, stream)) return 1;
+    // (the forward blend leaves the block masks behind itself: what precedes it is the tile order and cleared mask words)
+    if (num_rendered > 0 && launch_tile_order_binned(*prm, g, b, img, num_rendered, stream)) return 1;
     if (launch_render_forward(*prm, g, b, img, out_color, out_normal, out_depth, out_opac, occ_values, out_occ, stream)) return 1;
     return 0;
 }

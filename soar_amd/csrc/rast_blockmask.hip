@@ -178,7 +178,56 @@ __global__ void __launch_bounds__(BM_THREADS) block_mask_kernel(Batch<BlockMaskA
     }
 }
 
+// Round 4: on the tile-binning path the forward blend leaves its phase-A survivor words behind as the masks (rast_render_fwd.hip) --
+// what remains of this pass there is the tile order (it needs every tile's count: one launch behind the binning) and clearing the
+// words the forward will OR into: workgroup 0 of a frame builds the order, all of them clear a share of the 16 planes.
+constexpr unsigned TO_WGS = 16, TO_THREADS = 1024;     // (the order's two passes over the tiles are chains of load latencies: 1024 threads)
+__global__ void __launch_bounds__(TO_THREADS) tile_order_binned_kernel(Batch<BlockMaskArgs> batch)
+{
+    const BlockMaskArgs &o = batch.v[blockIdx.y];
+    const bool overflow = (o.header[H_OVERFLOW] | o.header[H_BAND_OVERFLOW]) != 0u;
+    // (one word of slack behind the last position's word: a straddling survivor word ORs into it)
+    const size_t words = overflow ? 0u : (size_t)(min(o.header[H_TOTAL], o.total) >> 6) + 2u;
+    for (int plane = 0; plane < 16; plane++)
+        for (size_t g = (size_t)blockIdx.x * TO_THREADS + threadIdx.x; g < words; g += (size_t)gridDim.x * TO_THREADS)
+            o.masks[(size_t)plane * o.plane + g] = 0ull;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            uint32_t *h = const_cast<uint32_t *>(o.header);
+            h[H_STICKY_TOTAL] = max(h[H_STICKY_TOTAL], h[H_TOTAL]);
+            h[H_STICKY_OVERFLOW] = max(h[H_STICKY_OVERFLOW], max(h[H_OVERFLOW], h[H_BAND_OVERFLOW]));
+        }
+        tile_order_block(o.T, (o.T + 7) / 8 * 8, o.tile_count, o.ranges, o.tile_order, o.order_rec, o.bg, o.normalize_depth, o.bg_state,
+                         overflow ? o.ranges : nullptr);
+    }
+}
+
 }  // namespace
+
+static void fill_order_args(BlockMaskArgs &a, const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R)
+{
+    a.header = g.header;
+    a.total = (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R);
+    a.P = (uint32_t)prm.P;
+    a.tile_xy = b.tile_xy; a.point_list = b.vals_sorted; a.rec = g.rec;
+    a.masks = b.block_masks; a.plane = b.mask_plane;
+    a.T = ((prm.W + TILE - 1) / TILE) * ((prm.H + TILE - 1) / TILE);
+    a.tile_count = img.tile_count; a.ranges = img.ranges;
+    a.tile_order = img.tile_order;
+    a.order_rec = img.order_rec;
+    a.bg = prm.bg_dev; a.normalize_depth = prm.cfg_normalize_depth; a.bg_state = img.bg_state;
+}
+
+// the tile order of the blends and cleared mask words, behind launch_tile_binning (capacity `R`)
+int launch_tile_order_binned(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream)
+{
+    BlockMaskArgs a;
+    fill_order_args(a, prm, g, b, img, R);
+    StageTimer timer(ST_BLOCK_MASKS, stream);
+    SOAR_LAUNCH_BATCHED(tile_order_binned_kernel, dim3(TO_WGS), dim3(TO_THREADS), 0, stream, a);
+    SOAR_LAUNCH_OK("tile_order_binned", stream, prm.debug);
+    return 0;
+}
 
 // `R`: the instances the lists hold -- exact on the key-sort path, the capacity of the caller's binning buffer on the tile-binning
 // path (the real number is then read on the device; nothing is written when it overflowed: every range is empty)

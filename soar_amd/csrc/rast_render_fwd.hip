@@ -62,6 +62,10 @@ struct FwdArgs {
     const uint32_t *bg_state;        // ImageBuf::bg_state
     int keep_background;             // SoarRastParams.debug bit 2
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
+    // BinBuf::block_masks (rast_blockmask.hip describes the layout): phase A's survivor word of every 64 list positions a block's
+    // wavefront tests is what the backward blend walks -- left behind here instead of being derived again by a pass of its own
+    unsigned long long *masks;       // or null: nothing is emitted
+    size_t mask_plane;
 };
 
 constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST1 = 0x55, DPP_QUAD_BCAST2 = 0xAA, DPP_QUAD_BCAST3 = 0xFF;
@@ -138,6 +142,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
     __shared__ int wave_alive[2][4];
     __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: LDS slots of a sub-chunk's relevant entries
+    __shared__ unsigned long long wmask[4][CHUNK / WAVE];                                 // per wavefront: phase A's survivor words of a chunk
     unsigned long long t_start = 0, t_ready = 0, t_blended = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
 
@@ -188,12 +193,35 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     }
     if (range.x + CHUNK + tid < range.y) id_next = a.point_list[range.x + CHUNK + tid];
     int parity = 0;
+    // Phase A's survivor word of every 64 list positions this wavefront tests IS the block mask the backward blend walks
+    // (BinBuf::block_masks: bit l of word g of plane `block` = list position 64 g + l; a superset of what the backward needs: an
+    // entry dropped here touches no pixel that still blends).  The words of a chunk wait in LDS and leave at the top of the NEXT
+    // iteration -- behind the wait for that chunk's records, in front of the gathers issued there: memory operations complete in
+    // order, and an atomic issued right in front of a wait for older loads is waited for as well (+15 us on the launch when the
+    // words left where they are made).  A word may straddle two words of the plane and share them with the tile in front or
+    // behind: OR, into words that tile_order_binned_kernel cleared one launch ago.
+    int emit_n = 0;                                  // survivor words waiting in wmask[wave][..] (wave-uniform)
+    uint32_t emit_base = 0;                          // list position of bit 0 of the first one
+    auto emit_masks = [&]() {
+        if (a.masks && lane < emit_n) {
+            const unsigned long long wd = wmask[wave][lane];
+            if (wd != 0ull) {
+                const uint32_t p0 = emit_base + (uint32_t)lane * WAVE, sh = p0 & 63u;
+                unsigned long long *row = a.masks + (size_t)(quad * 4 + wave) * a.mask_plane + (p0 >> 6);
+                __hip_atomic_fetch_or(row, wd << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sh) __hip_atomic_fetch_or(row + 1, wd >> (64u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        emit_n = 0;
+    };
     for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
         const int n = min((uint32_t)CHUNK, range.y - base);
         if (tid < n) {
             sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3;
             if (OCC) sq4[tid] = r4;
         }
+        emit_masks();                                // (the chunk before)
+        emit_base = base;
         if (base + CHUNK + tid < range.y) {
             const uint32_t id = id_next;
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
@@ -235,6 +263,8 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                 const int n_todo = (int)__builtin_popcountll(todo);
                 if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(sub + lane);
                 if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)CHUNK;
+                if (lane == 0) wmask[wave][sub / WAVE] = todo;                  // left behind for the backward blend: emit_masks below
+                emit_n = sub / WAVE + 1;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -348,6 +378,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         lds_barrier();
         if ((wave_alive[parity][0] | wave_alive[parity][1] | wave_alive[parity][2] | wave_alive[parity][3]) == 0) break;
     }
+    emit_masks();                                    // (the last chunk this wavefront tested)
 
     if (LOG) t_blended = wall_clock64();
     // fold the four slots of every pixel
@@ -638,6 +669,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
     a.bg_tiles = img.bg_tiles; a.bg_state = img.bg_state; a.keep_background = (prm.debug & 4) ? 1 : 0;
     a.wave_log = nullptr;
+    a.masks = reinterpret_cast<unsigned long long *>(b.block_masks); a.mask_plane = b.mask_plane;
     const char *log_path = getenv("SOAR_WAVE_LOG");          // diagnostic: dump per-wave timelines of ONE launch
     const int grid_ranks = blend_grid_ranks(a.ntiles);
     const int Tpad = (a.ntiles + 7) / 8 * 8;

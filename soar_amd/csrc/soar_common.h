@@ -433,6 +433,7 @@ inline int blend_grid_ranks(int ntiles)
 // the others changes no result): one bit per (block, list position), BinBuf::block_masks[block][position >> 6] bit position & 63.
 // A word may hold positions of two or more tiles (lists follow each other without padding): a reader masks it to its own range.
 int launch_block_masks(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream);
+int launch_tile_order_binned(const SoarRastParams &prm, const GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t R, hipStream_t stream);
 
 int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, ImageBuf &img,
                           float *out_color, float *out_normal, float *out_depth, float *out_opac,

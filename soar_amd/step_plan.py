@@ -158,6 +158,7 @@ class FrameStepPlan:
             env = os.environ.get("SOAR_PLAN_BATCHED")
             batched = (env != "0") if env in ("0", "1") else (self.W * self.H <= 3_000_000)
         self.batched = bool(batched) and self.n <= 8
+        self._call_cache = {}
         self.optimizer = None                     # see _run_eager
         self.optimizer_in_two_parts = None        # None: when a gradient reduction is in flight; True / False force it (tests)
         self.graphs = None
@@ -343,42 +344,59 @@ class FrameStepPlan:
                                             self.P, J, ptr(self.xyz_p_all), ptr(self.rot_p_all), stream), "warp_forward_batch")
 
     # ---- the frame chain, stage by stage -----------------------------------------------------------------------------------
+    # Every pointer of these calls is fixed for the life of the plan (its own buffers; the leaves it was built on, which `run` checks
+    # on every step): the argument tuples are made once per (stage, frame, stream) and a step is `fn(*args)` per call -- what the host
+    # spends per step fell from ~0.45 to ~0.2 ms, which matters on a box whose host is busy (the timed steps there went host-bound).
+    def _call(self, key, build) -> None:
+        c = self._call_cache.get(key)
+        if c is None:
+            c = self._call_cache[key] = build()
+        if c[0](*c[1]) != 0:
+            check(1, c[2])
+
     def _f_geometry(self, i: int, stream: int) -> None:
-        L, s, v = self.L, self.seq, self.views[i]
-        check(L.soar_rast_forward_geometry(C.byref(self.ctx.params), ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones),
-                                           ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream),
-              "geometry")
+        def build():
+            L, s, v = self.L, self.seq, self.views[i]
+            return (L.soar_rast_forward_geometry, (C.byref(self.ctx.params), ptr(v["xyz_p"]), None, ptr(s.colors.detach()), ptr(self.ones),
+                                                   ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["radii"]), None, stream),
+                    "geometry")
+        self._call(("geometry", i, stream), build)
 
     def _f_render(self, i: int, stream: int) -> None:
-        L, s, v = self.L, self.seq, self.views[i]
-        check(L.soar_rast_forward_render_occ(C.byref(self.ctx.params), ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
-                                             self.capacity, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(s.occ),
-                                             ptr(v["occ"]), stream), "render")
+        def build():
+            L, s, v = self.L, self.seq, self.views[i]
+            return (L.soar_rast_forward_render_occ, (C.byref(self.ctx.params), ptr(v["radii"]), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
+                                                     self.capacity, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]),
+                                                     ptr(s.occ), ptr(v["occ"]), stream), "render")
+        self._call(("render", i, stream), build)
 
     def _f_loss(self, i: int, stream: int) -> None:
-        L, v, W, H = self.L, self.views[i], self.W, self.H
-        wc, wm, wn, wd = self.weights
-        if self.pool is not None:
-            check(L.soar_frame_loss_pooled(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
-                                           int(self.pool.shape[0]), ptr(self.frame_sel[i]), wc, wm, wn, wd, ptr(self.losses[i]),
-                                           ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["img"]),
-                                           self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
-                  "frame_loss_pooled")
-        else:
+        def build():
+            L, v, W, H = self.L, self.views[i], self.W, self.H
+            wc, wm, wn, wd = self.weights
+            if self.pool is not None:
+                return (L.soar_frame_loss_pooled, (W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.pool),
+                                                   int(self.pool.shape[0]), ptr(self.frame_sel[i]), wc, wm, wn, wd, ptr(self.losses[i]),
+                                                   ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["img"]),
+                                                   self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
+                        "frame_loss_pooled")
             tc, tm, tn = self.targets
-            check(L.soar_frame_loss(W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
-                                    wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
-                                    ptr(v["gO"]), ptr(v["img"]), self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
-                  "frame_loss")
+            return (L.soar_frame_loss, (W, H, ptr(v["color"]), ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(tc), ptr(tm), ptr(tn),
+                                        wc, wm, wn, wd, ptr(self.losses[i]), ptr(v["sums"]), ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]),
+                                        ptr(v["gO"]), ptr(v["img"]), self.ctx.params.bg_dev, int(self.ctx.params.cfg_normalize_depth), stream),
+                    "frame_loss")
+        self._call(("loss", i, stream), build)
 
     def _f_backward(self, i: int, stream: int) -> None:
-        L, s, v = self.L, self.seq, self.views[i]
-        check(L.soar_rast_backward(C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
-                                   ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
-                                   self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
-                                   ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]), ptr(v["g_cov3D"]), None,
-                                   ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
-                                   ptr(v["work"]), v["work"].numel(), stream), "backward")
+        def build():
+            L, s, v = self.L, self.seq, self.views[i]
+            return (L.soar_rast_backward, (C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
+                                           ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
+                                           self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_means2D"]),
+                                           ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]), ptr(v["g_cov3D"]), None,
+                                           ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]), ptr(v["g_proj"]), ptr(v["g_campos"]),
+                                           ptr(v["work"]), v["work"].numel(), stream), "backward")
+        self._call(("backward", i, stream), build)
 
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
