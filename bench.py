@@ -696,7 +696,8 @@ def main():
                             "through the occlusion image's backward; Adam also on the occlusion values"),
                    "plan_form": (("batched" if plan.batched else "streams") + (", graphs" if plan.graphs is not None else ", eager")
                                  if plan is not None else None),
-                   "collectives": ("rccl: two asynchronous all-reduce buckets per step (xyz, rest)" if plan is not None else "rccl")
+                   "collectives": ((f"rccl: {flat.n_buckets} asynchronous all-reduce bucket(s) per step" + (" (xyz, rest)" if flat.n_buckets == 2 else ""))
+                                   if plan is not None else "rccl")
                    if use_dist else "none",
                    "optimizer": ("Adam (eps 1e-15), one launch over all leaves, the reference's learning rates on the activated leaves "
                                  "(xyz 1.6e-5, rotation 1e-3, scale 5e-5 = 0.5 %, colour 2.5e-3): inside the timed step"

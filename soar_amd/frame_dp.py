@@ -75,10 +75,12 @@ class FlatGradBuffer:
                     self.leaves[name] = t
             start += P * width
         self.split = P * LEAVES[0][1]             # end of the xyz slice = boundary between the two buckets
-        # SOAR_DP_BUCKETS=1: ONE collective for the whole buffer (one RCCL launch fewer per step; the positions then arrive together
-        # with everything else, and the KNN refresh no longer hides part of the flight).  Which is faster depends on the flight time
-        # of 6 MB over the node's links against the refresh (~80 us) and an RCCL launch (~20-30 us): bench.py reports the waits
-        self.n_buckets = 1 if os.environ.get("SOAR_DP_BUCKETS", "2") == "1" else 2
+        # One collective for the whole buffer (default since round 4), or SOAR_DP_BUCKETS=2: the xyz slice first, so that the KNN
+        # refresh (which only needs the positions) hides the flight of the rest.  Every collective is a hand-off to RCCL's stream and
+        # back (~20-30 us each on this stack): with a one-rank group the step pays +4 % for one bucket and +15 % for two
+        # (profiles/r04c_forced_dist_vs_plain.txt); what two buckets hide -- the flight of 4.8 MB over xGMI against an ~80 us
+        # refresh -- is of the same size.  bench.py reports the stalls per bucket and rank (`ranks`): the first multi-GPU run decides.
+        self.n_buckets = 2 if os.environ.get("SOAR_DP_BUCKETS", "1") == "2" else 1
         # diagnostics (bench.py, world > 1): HIP events around every stream-side wait for a bucket -- what the stream stalled for
         self.time_waits = False
         self._wait_events: List = []

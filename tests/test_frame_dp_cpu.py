@@ -64,6 +64,7 @@ def _worker(rank, world, port, P, out_dir):
         batch = frame_dp.global_batch(3, 2, world, num_frames=50)
         for f in frame_dp.shard_frames(batch, rank, world):
             _frame_loss(leaves, f).backward()
+        buf.n_buckets = 2
         if rank == 0:
             works = buf.all_reduce_buckets()           # two asynchronous buckets: xyz first, then the rest
             assert len(works) == 2
