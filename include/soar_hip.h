@@ -37,7 +37,7 @@ extern "C" {
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
- * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky;
+ * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses;
  * soar_selftest_wave_reduce is gone with the backward form it tested. */
 #define SOAR_HIP_ABI_VERSION 6
 
@@ -357,6 +357,33 @@ int soar_frame_loss_pooled(int32_t W, int32_t H, const float *color, const float
                            float w_color, float w_mask, float w_normal, float w_depth, float *loss_out, float *scratch,
                            float *dL_dcolor, float *dL_dnormal, float *dL_ddepth, float *dL_dopac, const void *image_buffer,
                            const float *background, int32_t normalize_depth, void *stream);
+
+/* ---- the same terms in ONE pass over the images (round 4, ABI 6): masked L1 of the colours over `sel`, L1 of the mask image over
+ * every pixel, cosine loss of the normals over `sel_normal`, and -- when `occ` is given -- masked L1 of the occlusion image against 1
+ * over `sel_occ` (loss_occ, TS/system/gaussian_surfel_mvdream.py:412-417).  mode bit 0: the values, stats [6] = {loss, count} of L1,
+ * mask L1, cosine (and stats_occ [2]); mode bit 1: the gradient planes, scaled by the device scalars up_* (NULL: 1) and by the
+ * selected counts, which come from `stats` (the two-pass form: a values call first) or from `counts` [4] given by the caller (the
+ * masks are constants of the target: mode 3 = value and gradient in one pass).  g_render optionally takes the SSIM term's gradient
+ * on the way (+ up_ssim * g_ssim).  Same per-pixel expressions and the same order of additions as soar_masked_l1 / soar_cos_loss:
+ * the same values bit for bit.  H * W a multiple of 4, planes 16-byte aligned (every image of the path).
+ * scratch: soar_avatar_loss_scratch_floats() floats. */
+typedef struct SoarAvatarLossArgs {
+    int32_t H, W;
+    float cos_limit, cos_weight;                 /* cos(thrsh), weight of cos_loss */
+    const float *render, *gt_rgb;                /* [3,H,W] */
+    const float *mask_img, *gt_mask;             /* [1,H,W] */
+    const float *normal, *gt_normal;             /* [3,H,W] */
+    const float *occ;                            /* [3,H,W] or NULL */
+    const uint8_t *sel, *sel_normal, *sel_occ;   /* [H,W] one byte per pixel; sel_occ NULL iff occ is */
+    float *stats, *stats_occ;                    /* device: [6], [2] */
+    float *scratch;
+    const float *counts;                         /* device [4] or NULL */
+    const float *up_l1, *up_l1m, *up_cos, *up_occ, *up_ssim;
+    const float *g_ssim;                         /* [3,H,W] or NULL */
+    float *g_render, *g_mask, *g_normal, *g_occ; /* [3,H,W], [1,H,W], [3,H,W], [3,H,W] */
+} SoarAvatarLossArgs;
+int soar_avatar_loss_scratch_floats(size_t *count);
+int soar_avatar_pixel_losses(const SoarAvatarLossArgs *args, int32_t mode, void *stream);
 
 /* ---- SSIM (TS/utils/loss_utils.py:36-76: 11x11 Gaussian window, sigma 1.5, zero padding):
  *      mean SSIM of img1, img2 [C,H,W] and, when dssim_dimg1 != NULL, its gradient w.r.t. img1 -- one kernel per

@@ -173,6 +173,173 @@ __global__ void __launch_bounds__(256) mean_finish_kernel(Batch<MeanFinishArgs> 
 
 constexpr int LOSS_BLOCKS = 1024;
 
+// ---- the avatar stage's per-pixel losses in ONE pass over the images (round 4) --------------------------------------------------
+// masked L1 of the colours, L1 of the mask image, cosine loss of the normals, masked L1 of the occlusion image against 1
+// (TS/system/gaussian_surfel_mvdream.py:311-338, 412-417): four kernels each way above, each bound by the bytes it reads -- and
+// between them they read every image twice and a plane of ones.  Here a pixel's 14 floats and 3 mask bytes are read once.  Per
+// pixel the expressions, and per thread the order of the additions, are those of masked_l1_kernel / cos_loss_kernel (same grid,
+// same grid-stride walk, V = 4): the four {sum, count} pairs a workgroup leaves are the ones those kernels leave, bit for bit.
+//   VALUES: the partial sums (folded by avatar_finish_kernel into stats = {loss, count} x 4)
+//   GRADS : the gradient planes, scaled by the upstream factors and the counts -- from `stats` (the two-pass form: values first) or
+//           from `counts` given by the caller (a target's masks are constants of the target: value and gradient in ONE pass);
+//           the colour gradient optionally takes the SSIM term's on the way (g_render = L1 part + ssim_upstream * g_ssim).
+struct AvatarArgs {
+    int n;                                         // pixels (a multiple of 4; every plane 16-byte aligned)
+    const float *render, *gt_rgb, *mask_img, *gt_mask, *normal, *gt_normal, *occ;      // occ may be null: no occlusion term
+    const uint8_t *sel, *sel_normal, *sel_occ;
+    float cos_limit, cos_weight;
+    float *partials;                               // [gridDim.x][8]
+    const float *stats, *stats_occ;                // {loss, count} x 3 (L1, L1M, COS) and {loss, count} of the occlusion term
+    const float *counts;                           // [4] or null
+    const float *up_l1, *up_l1m, *up_cos, *up_occ; // device scalars (null: 1)
+    const float *g_ssim, *up_ssim;                 // optional
+    float *g_render, *g_mask, *g_normal, *g_occ;
+};
+
+template <bool VALUES, bool GRADS>
+__global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> batch)
+{
+    const AvatarArgs &a = batch.v[blockIdx.y];
+    constexpr int V = 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, cnt[4] = {0.f, 0.f, 0.f, 0.f};
+    float sc_l1 = 0.f, sc_l1m = 0.f, sc_cos = 0.f, sc_occ = 0.f, k_ssim = 0.f;
+    if (GRADS) {
+        auto up = [](const float *p) { return p ? *p : 1.f; };
+        const float c_l1 = a.counts ? a.counts[0] : a.stats[1], c_l1m = a.counts ? a.counts[1] : a.stats[3];
+        const float c_cos = a.counts ? a.counts[2] : a.stats[5];
+        sc_l1 = up(a.up_l1) / fmaxf(c_l1 * 3.f, 1.f);
+        sc_l1m = up(a.up_l1m) / fmaxf(c_l1m * 1.f, 1.f);
+        sc_cos = up(a.up_cos) / fmaxf(c_cos, 1.f);
+        if (a.occ) sc_occ = up(a.up_occ) / fmaxf((a.counts ? a.counts[3] : a.stats_occ[1]) * 3.f, 1.f);
+        if (a.g_ssim) k_ssim = up(a.up_ssim);
+    }
+    const int nv = a.n / V;
+    const size_t n = (size_t)a.n;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < nv; p += gridDim.x * 256) {
+        bool sel[V], seln[V], selo[V];
+        unpack(reinterpret_cast<const uchar4 *>(a.sel)[p], sel);
+        unpack(reinterpret_cast<const uchar4 *>(a.sel_normal)[p], seln);
+        if (a.occ) unpack(reinterpret_cast<const uchar4 *>(a.sel_occ)[p], selo);
+        if (VALUES)
+#pragma unroll
+            for (int k = 0; k < V; k++) { cnt[0] += sel[k] ? 1.f : 0.f; cnt[1] += 1.f; if (a.occ) cnt[3] += selo[k] ? 1.f : 0.f; }
+        // ---- colours
+        for (int c = 0; c < 3; c++) {
+            float x[V], y[V], g[V], gs[V];
+            unpack(reinterpret_cast<const float4 *>(a.render + c * n)[p], x);
+            unpack(reinterpret_cast<const float4 *>(a.gt_rgb + c * n)[p], y);
+            if (GRADS && a.g_ssim) unpack(reinterpret_cast<const float4 *>(a.g_ssim + c * n)[p], gs);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const float d = x[k] - y[k];
+                if (VALUES) s[0] += sel[k] ? fabsf(d) : 0.f;
+                if (GRADS) {
+                    g[k] = sel[k] ? (d > 0.f ? sc_l1 : (d < 0.f ? -sc_l1 : 0.f)) : 0.f;
+                    if (a.g_ssim) g[k] = g[k] + gs[k] * k_ssim;
+                }
+            }
+            if (GRADS) reinterpret_cast<float4 *>(a.g_render + c * n)[p] = pack(g);
+        }
+        // ---- mask image (every pixel)
+        {
+            float x[V], y[V], g[V];
+            unpack(reinterpret_cast<const float4 *>(a.mask_img)[p], x);
+            unpack(reinterpret_cast<const float4 *>(a.gt_mask)[p], y);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const float d = x[k] - y[k];
+                if (VALUES) s[1] += fabsf(d);
+                if (GRADS) g[k] = d > 0.f ? sc_l1m : (d < 0.f ? -sc_l1m : 0.f);
+            }
+            if (GRADS) reinterpret_cast<float4 *>(a.g_mask)[p] = pack(g);
+        }
+        // ---- normals: cosine loss
+        {
+            float cs[V], gt[3][V];
+#pragma unroll
+            for (int k = 0; k < V; k++) cs[k] = 0.f;
+            for (int c = 0; c < 3; c++) {
+                float x[V], y[V];
+                unpack(reinterpret_cast<const float4 *>(a.normal + c * n)[p], x);
+                unpack(reinterpret_cast<const float4 *>(a.gt_normal + c * n)[p], y);
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    cs[k] += (x[k] * 2.f - 1.f) * (y[k] * 2.f - 1.f) * a.cos_weight;
+                    gt[c][k] = y[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < V; k++) seln[k] = seln[k] && cs[k] < a.cos_limit;
+            if (VALUES)
+#pragma unroll
+                for (int k = 0; k < V; k++) { s[2] += seln[k] ? 1.f - cs[k] : 0.f; cnt[2] += seln[k] ? 1.f : 0.f; }
+            if (GRADS)
+                for (int c = 0; c < 3; c++) {
+                    float g[V];
+#pragma unroll
+                    for (int k = 0; k < V; k++) g[k] = seln[k] ? -2.f * a.cos_weight * (gt[c][k] * 2.f - 1.f) * sc_cos : 0.f;
+                    reinterpret_cast<float4 *>(a.g_normal + c * n)[p] = pack(g);
+                }
+        }
+        // ---- occlusion image against 1 over its own selection
+        if (a.occ)
+            for (int c = 0; c < 3; c++) {
+                float x[V], g[V];
+                unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    const float d = x[k] - 1.f;
+                    if (VALUES) s[3] += selo[k] ? fabsf(d) : 0.f;
+                    if (GRADS) g[k] = selo[k] ? (d > 0.f ? sc_occ : (d < 0.f ? -sc_occ : 0.f)) : 0.f;
+                }
+                if (GRADS) reinterpret_cast<float4 *>(a.g_occ + c * n)[p] = pack(g);
+            }
+    }
+    if (VALUES) {
+        __shared__ float red[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s[t] += __shfl_xor(s[t], off); cnt[t] += __shfl_xor(cnt[t], off); }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { red[threadIdx.x >> 6][2 * t] = s[t]; red[threadIdx.x >> 6][2 * t + 1] = cnt[t]; }
+        __syncthreads();
+        if (threadIdx.x < 8) a.partials[8 * blockIdx.x + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+struct AvatarFinishArgs {
+    const float *partials;
+    int nblocks;
+    float *stats, *stats_occ;
+};
+// {sum / (count * channels), count} of the four terms (an empty selection gives NaN like the reference's mean of an empty tensor)
+__global__ void __launch_bounds__(256) avatar_finish_kernel(Batch<AvatarFinishArgs> batch)
+{
+    const AvatarFinishArgs &fa = batch.v[blockIdx.y];
+    __shared__ float red[4][8];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < fa.nblocks; k += 256)
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] += fa.partials[8 * k + t];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[t] += __shfl_xor(v[t], off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = v[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int t = threadIdx.x;
+        const float st = (red[0][2 * t] + red[1][2 * t]) + (red[2][2 * t] + red[3][2 * t]);
+        const float ct = (red[0][2 * t + 1] + red[1][2 * t + 1]) + (red[2][2 * t + 1] + red[3][2 * t + 1]);
+        const float per = (t == 0 || t == 3) ? 3.f : 1.f;
+        float *dst = t < 3 ? fa.stats + 2 * t : fa.stats_occ;
+        if (dst) { dst[0] = st / (ct * per); dst[1] = ct; }
+    }
+}
+
 }  // namespace
 
 }  // namespace soar
@@ -253,5 +420,59 @@ extern "C" int soar_cos_loss_backward(int32_t C, int32_t H, int32_t W, const flo
     if (loss_vec4(a)) SOAR_LAUNCH_BATCHED((cos_loss_kernel<true, 4>), dim3(min(LOSS_BLOCKS, (a.n / 4 + 255) / 256)), dim3(256), 0, stream, a);
     else SOAR_LAUNCH_BATCHED((cos_loss_kernel<true, 1>), dim3(min(LOSS_BLOCKS, (a.n + 255) / 256)), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("cos_loss_backward", stream, 0);
+    return 0;
+}
+
+
+extern "C" int soar_avatar_loss_scratch_floats(size_t *count)
+{
+    if (!count) { set_error("soar_avatar_loss_scratch_floats: NULL"); return 1; }
+    *count = 8 * LOSS_BLOCKS;
+    return 0;
+}
+
+extern "C" int soar_avatar_pixel_losses(const SoarAvatarLossArgs *q, int32_t mode, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool values = (mode & 1) != 0, grads = (mode & 2) != 0;
+    if (!q || q->H <= 0 || q->W <= 0 || !(values || grads)) { set_error("soar_avatar_pixel_losses: bad arguments"); return 1; }
+    if (!q->render || !q->gt_rgb || !q->sel || !q->mask_img || !q->gt_mask || !q->normal || !q->gt_normal || !q->sel_normal) {
+        set_error("soar_avatar_pixel_losses: an image, a target or a selection is NULL");
+        return 1;
+    }
+    if ((q->occ == nullptr) != (q->sel_occ == nullptr)) { set_error("soar_avatar_pixel_losses: occ and sel_occ go together"); return 1; }
+    if (values && (!q->stats || !q->scratch || (q->occ && !q->stats_occ))) { set_error("soar_avatar_pixel_losses: stats and scratch are needed for the values"); return 1; }
+    if (grads && (!q->g_render || !q->g_mask || !q->g_normal || (q->occ && !q->g_occ))) { set_error("soar_avatar_pixel_losses: a gradient plane is NULL"); return 1; }
+    if (grads && !q->counts && (values || !q->stats || (q->occ && !q->stats_occ))) {
+        set_error("soar_avatar_pixel_losses: gradients need the counts -- from a values pass before (stats), or given (counts) for the one-pass form");
+        return 1;
+    }
+    const int64_t n64 = (int64_t)q->H * q->W;
+    auto al = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0u; };
+    auto al4 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 3u) == 0u; };
+    if ((n64 & 3) != 0 || !al(q->render) || !al(q->gt_rgb) || !al(q->mask_img) || !al(q->gt_mask) || !al(q->normal) || !al(q->gt_normal) ||
+        !al(q->occ) || !al(q->g_ssim) || !al(q->g_render) || !al(q->g_mask) || !al(q->g_normal) || !al(q->g_occ) || !al4(q->sel) ||
+        !al4(q->sel_normal) || !al4(q->sel_occ)) {
+        set_error("soar_avatar_pixel_losses: H * W must be a multiple of 4 and every plane 16-byte aligned (the separate kernels take any size)");
+        return 1;
+    }
+    AvatarArgs a = {};
+    a.n = (int)n64;
+    a.render = q->render; a.gt_rgb = q->gt_rgb; a.mask_img = q->mask_img; a.gt_mask = q->gt_mask; a.normal = q->normal; a.gt_normal = q->gt_normal;
+    a.occ = q->occ; a.sel = q->sel; a.sel_normal = q->sel_normal; a.sel_occ = q->sel_occ;
+    a.cos_limit = q->cos_limit; a.cos_weight = q->cos_weight;
+    a.partials = q->scratch; a.stats = q->stats; a.stats_occ = q->stats_occ; a.counts = q->counts;
+    a.up_l1 = q->up_l1; a.up_l1m = q->up_l1m; a.up_cos = q->up_cos; a.up_occ = q->up_occ; a.g_ssim = q->g_ssim; a.up_ssim = q->up_ssim;
+    a.g_render = q->g_render; a.g_mask = q->g_mask; a.g_normal = q->g_normal; a.g_occ = q->g_occ;
+    const int blocks = min(LOSS_BLOCKS, (a.n / 4 + 255) / 256);
+    StageTimer timer(ST_FRAME_LOSS, stream);
+    if (values && grads) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);
+    else if (values) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, a);
+    if (values) {
+        const AvatarFinishArgs fa = {q->scratch, blocks, q->stats, q->stats_occ};
+        SOAR_LAUNCH_BATCHED(avatar_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
+    }
+    SOAR_LAUNCH_OK("avatar_pixel_losses", stream, 0);
     return 0;
 }

@@ -59,6 +59,15 @@ class SoarViewArgs(C.Structure):
                 ("g_curv", _vp), ("dL_dmeans2D", _vp)]
 
 
+class SoarAvatarLossArgs(C.Structure):
+    """Mirror of ``struct SoarAvatarLossArgs`` (include/soar_hip.h)."""
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("cos_limit", C.c_float), ("cos_weight", C.c_float),
+                ("render", _vp), ("gt_rgb", _vp), ("mask_img", _vp), ("gt_mask", _vp), ("normal", _vp), ("gt_normal", _vp), ("occ", _vp),
+                ("sel", _vp), ("sel_normal", _vp), ("sel_occ", _vp), ("stats", _vp), ("stats_occ", _vp), ("scratch", _vp), ("counts", _vp),
+                ("up_l1", _vp), ("up_l1m", _vp), ("up_cos", _vp), ("up_occ", _vp), ("up_ssim", _vp), ("g_ssim", _vp),
+                ("g_render", _vp), ("g_mask", _vp), ("g_normal", _vp), ("g_occ", _vp)]
+
+
 # name -> (restype, argtypes); every symbol include/soar_hip.h declares
 SIGNATURES = {
     "soar_last_error": (C.c_char_p, []),
@@ -145,6 +154,8 @@ SIGNATURES = {
     "soar_rast_forward_render_status": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                                   _vp, _vp, _vp, _vp]),
     "soar_lbs_warp_backward_views": (C.c_int, [_vp] * 5 + [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp, _vp, _vp, _vp]),
+    "soar_avatar_loss_scratch_floats": (C.c_int, [C.POINTER(C.c_size_t)]),
+    "soar_avatar_pixel_losses": (C.c_int, [C.POINTER(SoarAvatarLossArgs), C.c_int32, _vp]),
     "soar_adam_step": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "soar_adam_step_at": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, C.c_int64, _vp]),
     "soar_adam_step_rows": (C.c_int, [C.c_int32, C.POINTER(SoarAdamRow), C.c_double, C.c_double, C.c_double, _vp, C.c_int32, _vp]),

@@ -234,19 +234,31 @@ class _AvatarStageLoss(torch.autograd.Function):
             if t is not None and t.numel() != count:
                 raise ValueError(f"avatar_stage_loss: {name} must have {count} elements, got {tuple(t.shape)}")
         k = C.c_size_t(0)
-        check(L.soar_image_loss_scratch_floats(C.byref(k)), "soar_image_loss_scratch_floats")
-        n_loss = int(k.value)
+        check(L.soar_avatar_loss_scratch_floats(C.byref(k)), "soar_avatar_loss_scratch_floats")
+        n_pix = int(k.value)
         check(L.soar_ssim_scratch_floats(Cn, H, W, C.byref(k)), "soar_ssim_scratch_floats")
-        scratch = torch.empty((max(n_loss, int(k.value)),), dtype=torch.float32, device=dev)
+        scratch = torch.empty((n_pix + int(k.value),), dtype=torch.float32, device=dev)
         terms = _unit_terms(dev).clone()                            # zeros, a one in the last slot
         g_ssim = torch.empty_like(r)
         stream = torch.cuda.current_stream(dev).cuda_stream
         at = lambda i: terms.data_ptr() + 4 * i
+        # the three per-pixel terms in one pass over the images (when the planes allow 16-byte trips: every image of the path),
+        # else kernel by kernel
+        fused = Cn == 3 and m_sel is not None and m_nrm is not None and (H * W) % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (r, mo, n, tr, tm, tn)) and \
+            all(t.data_ptr() % 4 == 0 for t in (m_sel, m_nrm))
+        args = None
         with torch.cuda.device(dev):
-            check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(S.L1), ptr(scratch), stream), "soar_masked_l1")
-            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), at(S.SSIM), ptr(scratch), ptr(g_ssim), stream), "soar_ssim")
-            check(L.soar_masked_l1(1, H, W, ptr(mo), ptr(tm), None, at(S.L1M), ptr(scratch), stream), "soar_masked_l1")
-            check(L.soar_cos_loss(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(S.COS), ptr(scratch), stream), "soar_cos_loss")
+            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), at(S.SSIM), scratch.data_ptr() + 4 * n_pix, ptr(g_ssim), stream), "soar_ssim")
+            if fused:
+                args = hip_lib.SoarAvatarLossArgs(H=H, W=W, cos_limit=1.0, cos_weight=1.0, render=ptr(r), gt_rgb=ptr(tr), mask_img=ptr(mo),
+                                                  gt_mask=ptr(tm), normal=ptr(n), gt_normal=ptr(tn), sel=ptr(m_sel), sel_normal=ptr(m_nrm),
+                                                  stats=at(S.L1), scratch=ptr(scratch), g_ssim=ptr(g_ssim))
+                check(L.soar_avatar_pixel_losses(C.byref(args), 1, stream), "soar_avatar_pixel_losses")
+            else:
+                check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(S.L1), ptr(scratch), stream), "soar_masked_l1")
+                check(L.soar_masked_l1(1, H, W, ptr(mo), ptr(tm), None, at(S.L1M), ptr(scratch), stream), "soar_masked_l1")
+                check(L.soar_cos_loss(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(S.COS), ptr(scratch), stream), "soar_cos_loss")
+        ctx.pixel_args = args
         coef = [0.0] * S.N
         coef[S.L1], coef[S.SSIM], coef[S.ONE] = 0.8 * lam["recon"], -0.2 * lam["recon"], 0.2 * lam["recon"]
         coef[S.L1M], coef[S.COS] = lam["mask"], 0.2 * lam["normal"]
@@ -269,6 +281,7 @@ class _AvatarStageLoss(torch.autograd.Function):
     def backward(ctx, g, _g_terms):
         if g is None:
             return (None,) * 12
+        import ctypes as C
         S = _AvatarStageLoss
         L = hip_lib.lib()
         r, mo, n, tr, tm, tn, m_sel, m_nrm, terms, g_ssim = ctx.saved
@@ -280,13 +293,20 @@ class _AvatarStageLoss(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         at = lambda t, i: t.data_ptr() + 4 * i
         with torch.cuda.device(dev):
-            check(L.soar_masked_l1_backward(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(terms, S.L1), at(up, S.L1), ptr(g_r), stream),
-                  "soar_masked_l1_backward")
-            check(L.soar_masked_l1_backward(1, H, W, ptr(mo), ptr(tm), None, at(terms, S.L1M), at(up, S.L1M), ptr(g_mo), stream),
-                  "soar_masked_l1_backward")
-            check(L.soar_cos_loss_backward(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(terms, S.COS), at(up, S.COS), ptr(g_n),
-                                           stream), "soar_cos_loss_backward")
-        g_r.addcmul_(g_ssim, up[S.SSIM])
+            if ctx.pixel_args is not None:
+                # one pass: the three gradient planes, the colours' taking the SSIM term's on the way
+                a = ctx.pixel_args
+                a.up_l1, a.up_l1m, a.up_cos, a.up_ssim = at(up, S.L1), at(up, S.L1M), at(up, S.COS), at(up, S.SSIM)
+                a.g_render, a.g_mask, a.g_normal = ptr(g_r), ptr(g_mo), ptr(g_n)
+                check(L.soar_avatar_pixel_losses(C.byref(a), 2, stream), "soar_avatar_pixel_losses")
+            else:
+                check(L.soar_masked_l1_backward(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(terms, S.L1), at(up, S.L1), ptr(g_r), stream),
+                      "soar_masked_l1_backward")
+                check(L.soar_masked_l1_backward(1, H, W, ptr(mo), ptr(tm), None, at(terms, S.L1M), at(up, S.L1M), ptr(g_mo), stream),
+                      "soar_masked_l1_backward")
+                check(L.soar_cos_loss_backward(3, H, W, ptr(n), ptr(tn), ptr(m_nrm), 1.0, 1.0, at(terms, S.COS), at(up, S.COS), ptr(g_n),
+                                               stream), "soar_cos_loss_backward")
+                g_r.addcmul_(g_ssim, up[S.SSIM])
         sr, sm, sn, sd, sc = ctx.shapes
         g_d = None if sd is None or back[S.DEPTH] == 0.0 else up[S.DEPTH].expand(sd)
         g_c = None if sc is None or back[S.CURV] == 0.0 else up[S.CURV].expand(sc)

@@ -190,12 +190,15 @@ class FrameStepPlan:
         check(L.soar_image_loss_scratch_floats(C.byref(k)), "soar_image_loss_scratch_floats")
         n_loss = int(k.value)
         check(L.soar_ssim_scratch_floats(3, H, W, C.byref(k)), "soar_ssim_scratch_floats")
+        n_ssim = int(k.value)
         coef = [0.0] * S.N
         coef[S.L1], coef[S.SSIM], coef[S.ONE] = 0.8 * lam["recon"], -0.2 * lam["recon"], 0.2 * lam["recon"]
         coef[S.L1M], coef[S.COS] = lam["mask"], 0.2 * lam["normal"]
         self.av_coef = torch.tensor(coef, **f)                         # loss = terms . coef; also the upstream factor of every term
         self.av_occ_up = torch.tensor([lam["occ"]], **f)
-        self.av_ones3 = torch.ones((3, H, W), **f)
+        check(L.soar_avatar_loss_scratch_floats(C.byref(k)), "soar_avatar_loss_scratch_floats")
+        n_pix = int(k.value)
+        self._av_args = {}
         self.av_focal = (H / (2.0 * self.seq.camera.tanfovy), W / (2.0 * self.seq.camera.tanfovx))     # fov2focal(FoVy, H), (FoVx, W)
         self.g_occ_all = torch.empty((self.n, P), **f)
         # per-frame tensors that one torch call touches for all frames are slices of one allocation
@@ -207,7 +210,7 @@ class FrameStepPlan:
             v.update(normal_out=torch.empty((3, H, W), **f), curv=torch.empty((1, H, W), **f), pred=torch.empty((3, H, W), **f),
                      gC=self.av_gC_all[i], g_ssim=self.av_g_ssim_all[i], g_n=torch.empty((3, H, W), **f), g_nd=g_nd,
                      g_occ_img=torch.empty((3, H, W), **f), terms=self.av_terms_all[i], occ_terms=self.av_occ_terms_all[i],
-                     av_scratch=torch.empty((max(n_loss, int(k.value)),), **f))
+                     av_scratch=torch.empty((max(n_loss, n_ssim),), **f), av_pix_scratch=torch.empty((n_pix,), **f))
             v["gN"], v["gD"] = g_nd[:3], g_nd[3:]                       # what the rasterizer backward reads
 
     # ---- the avatar-stage loss block, kernel by kernel (each is batchable: one launch for the frames of a step) ------------------
@@ -223,47 +226,35 @@ class FrameStepPlan:
         check(L.soar_view_finish(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.ctx.keep[3]), self.av_focal[0],
                                  self.av_focal[1], ptr(v["normal_out"]), ptr(v["curv"]), ptr(v["pred"]), stream), "soar_view_finish")
 
-    def _av_l1(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), sc, stream), "soar_masked_l1")
-
     def _av_ssim(self, i, stream):
         S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
         check(L.soar_ssim(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), stream), "soar_ssim")
 
-    def _av_l1m(self, i, stream):
+    def _av_pixel_args(self, i):
+        """the frame's SoarAvatarLossArgs: colour L1 over gt_mask > 1e-5, mask L1, cosine loss over the same selection, occlusion
+        L1 against 1 over gt_mask > 0 -- every image and target read once per pass (include/soar_hip.h)"""
         S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), sc, stream), "soar_masked_l1")
+        return hip_lib.SoarAvatarLossArgs(
+            H=H, W=W, cos_limit=1.0, cos_weight=1.0, render=ptr(v["color"]), gt_rgb=ptr(a["rgb"][k]), mask_img=ptr(v["opac"]),
+            gt_mask=ptr(a["mask"][k]), normal=ptr(v["normal_out"]), gt_normal=ptr(a["normal"][k]), occ=ptr(v["occ"]),
+            sel=ptr(a["sel"][k]), sel_normal=ptr(a["sel"][k]), sel_occ=ptr(a["sel_occ"][k]), stats=at(t, S.L1), stats_occ=ptr(v["occ_terms"]),
+            scratch=ptr(v["av_pix_scratch"]), counts=None, up_l1=at(up, S.L1), up_l1m=at(up, S.L1M), up_cos=at(up, S.COS),
+            up_occ=ptr(self.av_occ_up), up_ssim=at(up, S.SSIM), g_ssim=ptr(v["g_ssim"]), g_render=ptr(v["gC"]), g_mask=ptr(v["gO"]),
+            g_normal=ptr(v["g_n"]), g_occ=ptr(v["g_occ_img"]))
 
-    def _av_cos(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_cos_loss(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS), sc, stream),
-              "soar_cos_loss")
+    def _av_pixel(self, i, stream, mode):
+        key = ("av_pixel", i, self._frames_now[i] % int(self.pool.shape[0]))
+        args = self._av_args.get(key)
+        if args is None:
+            args = self._av_args[key] = self._av_pixel_args(i)
+        check(self.L.soar_avatar_pixel_losses(C.byref(args), mode, stream), "soar_avatar_pixel_losses")
 
-    def _av_l1occ(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]), sc, stream),
-              "soar_masked_l1")
+    def _av_values(self, i, stream):
+        self._av_pixel(i, stream, 1)
 
-    def _av_l1_b(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1_backward(3, H, W, ptr(v["color"]), ptr(a["rgb"][k]), ptr(a["sel"][k]), at(t, S.L1), at(up, S.L1),
-                                        ptr(v["gC"]), stream), "soar_masked_l1_backward")
-
-    def _av_l1m_b(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1_backward(1, H, W, ptr(v["opac"]), ptr(a["mask"][k]), None, at(t, S.L1M), at(up, S.L1M), ptr(v["gO"]),
-                                        stream), "soar_masked_l1_backward")
-
-    def _av_cos_b(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_cos_loss_backward(3, H, W, ptr(v["normal_out"]), ptr(a["normal"][k]), ptr(a["sel"][k]), 1.0, 1.0, at(t, S.COS),
-                                       at(up, S.COS), ptr(v["g_n"]), stream), "soar_cos_loss_backward")
-
-    def _av_l1occ_b(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_masked_l1_backward(3, H, W, ptr(v["occ"]), ptr(self.av_ones3), ptr(a["sel_occ"][k]), ptr(v["occ_terms"]),
-                                        ptr(self.av_occ_up), ptr(v["g_occ_img"]), stream), "soar_masked_l1_backward")
+    def _av_grads(self, i, stream):
+        # (the colour gradient takes the SSIM term's on the way: g_render = L1 part + coef[SSIM] * g_ssim)
+        self._av_pixel(i, stream, 2)
 
     def _av_finish_b(self, i, stream):
         S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
@@ -271,17 +262,15 @@ class FrameStepPlan:
                                           self.av_focal[1], ptr(v["g_n"]), None, None, None, ptr(v["g_nd"]), stream),
               "soar_view_finish_backward")
 
-    AV_FORWARD = ("_av_finish", "_av_l1", "_av_ssim", "_av_l1m", "_av_cos", "_av_l1occ")
-    AV_BACKWARD = ("_av_l1_b", "_av_l1m_b", "_av_cos_b", "_av_l1occ_b")
+    AV_FORWARD = ("_av_finish", "_av_ssim", "_av_values")
+    AV_BACKWARD = ("_av_grads",)
 
     def _f_avatar_loss(self, i: int, frame: int, stream: int) -> None:
-        """post-ops -> the four image-loss kernels and the occlusion term -> their backwards -> post-ops backward: everything
+        """post-ops -> SSIM, the per-pixel terms' values (one pass), their gradients (one pass) -> post-ops backward: everything
         between the blend and the rasterizer backward of ONE frame (the form with one stream per frame)"""
-        from .losses import _AvatarStageLoss as S
         v, up = self.views[i], self.av_coef
         for name in self.AV_FORWARD + self.AV_BACKWARD:
             getattr(self, name)(i, stream)
-        v["gC"].addcmul_(v["g_ssim"], up[S.SSIM])
         self._av_finish_b(i, stream)
         # the frame's loss value (device side): terms . coef + lambda_occ mean(1 - occ[mask])
         torch.add(torch.dot(v["terms"], up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
@@ -434,14 +423,8 @@ class FrameStepPlan:
                 L.soar_batch_end()
         if self.loss_kind == "avatar":
             from .losses import _AvatarStageLoss as S
-            batch((self._f_geometry, self._f_render) + tuple(getattr(self, name) for name in self.AV_FORWARD + self.AV_BACKWARD))
-            if len(frames) == self.n:
-                # (what torch does between two kernels of the block: once for all frames, on slices of one allocation)
-                self.av_gC_all.addcmul_(self.av_g_ssim_all, self.av_coef[S.SSIM])
-            else:
-                for i in frames:
-                    self.views[i]["gC"].addcmul_(self.views[i]["g_ssim"], self.av_coef[S.SSIM])
-            batch((self._av_finish_b, self._f_backward, self._f_occ_backward))
+            batch((self._f_geometry, self._f_render) + tuple(getattr(self, name) for name in self.AV_FORWARD + self.AV_BACKWARD) +
+                  (self._av_finish_b, self._f_backward, self._f_occ_backward))
             # the frames' loss values: terms . coef + lambda_occ mean(1 - occ[mask])
             if len(frames) == self.n:
                 torch.addmv(self.av_occ_terms_all[:, 0] * self.av_occ_up[0], self.av_terms_all, self.av_coef, out=self.losses)

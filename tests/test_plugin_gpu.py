@@ -1020,3 +1020,78 @@ def test_avatar_stage_loss_is_the_composed_losses_in_one_node(hw):
            for k, c in (("render", 3), ("mask", 1), ("normal", 3), ("depth", 1), ("curv", 1))}
     avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, mask).backward()
     assert out["depth"].grad is None and out["curv"].grad is None and out["render"].grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("hw,with_occ", [((128, 200), True), ((540, 960), True), ((64, 96), False)])
+def test_avatar_pixel_losses_in_one_pass_equal_the_separate_kernels(hw, with_occ):
+    """soar_avatar_pixel_losses (colour L1 + mask L1 + cosine loss + occlusion L1 against 1, one read of every image) against
+    soar_masked_l1 / soar_cos_loss and their backwards: the same values and counts bit for bit, the same gradient planes, the
+    SSIM term's gradient folded into the colours'; values-then-gradients (mode 1, 2) and -- where the counts are known to the
+    caller -- both in one pass (mode 3)."""
+    import ctypes as C
+    from soar_amd import hip_lib
+    from soar_amd.hip_lib import check, ptr
+    L = hip_lib.lib()
+    H, W = hw
+    gen = torch.Generator().manual_seed(H + W)
+    rnd = lambda *s: torch.rand(*s, generator=gen).to(DEV)
+    render, gt_rgb, mask_img, normal, gt_normal, occ = rnd(3, H, W), rnd(3, H, W), rnd(1, H, W), rnd(3, H, W), rnd(3, H, W), rnd(3, H, W)
+    gt_mask = (rnd(1, H, W) > 0.4).float() * rnd(1, H, W)
+    render[:, :4] = gt_rgb[:, :4]                                   # zero differences: the sign's third case
+    occ[:, 5:9] = 1.0
+    normal[:, 9:12] = gt_normal[:, 9:12] = 1.0                      # cosine 3 > the limit: dropped from the selection
+    sel, sel_n, sel_o = (gt_mask[0] > 1e-5).view(torch.uint8), (rnd(H, W) > 0.3).view(torch.uint8), (gt_mask[0] > 0).view(torch.uint8)
+    g_ssim, ups = torch.randn(3, H, W, generator=gen).to(DEV), torch.tensor([0.8, 0.7, 0.18, 0.1, -0.2], device=DEV)
+    limit, weight = 0.95, 1.0
+    stream = torch.cuda.current_stream().cuda_stream
+    k = C.c_size_t(0)
+    check(L.soar_image_loss_scratch_floats(C.byref(k)), "scratch")
+    sc = torch.empty(int(k.value), device=DEV)
+    at = lambda t, i: t.data_ptr() + 4 * i
+    # ---- kernel by kernel
+    want = torch.zeros(8, device=DEV)
+    check(L.soar_masked_l1(3, H, W, ptr(render), ptr(gt_rgb), ptr(sel), at(want, 0), ptr(sc), stream), "l1")
+    check(L.soar_masked_l1(1, H, W, ptr(mask_img), ptr(gt_mask), None, at(want, 2), ptr(sc), stream), "l1m")
+    check(L.soar_cos_loss(3, H, W, ptr(normal), ptr(gt_normal), ptr(sel_n), limit, weight, at(want, 4), ptr(sc), stream), "cos")
+    ones = torch.ones(3, H, W, device=DEV)
+    check(L.soar_masked_l1(3, H, W, ptr(occ), ptr(ones), ptr(sel_o), at(want, 6), ptr(sc), stream), "l1occ")
+    w_r, w_m, w_n, w_o = torch.empty_like(render), torch.empty_like(mask_img), torch.empty_like(normal), torch.empty_like(occ)
+    check(L.soar_masked_l1_backward(3, H, W, ptr(render), ptr(gt_rgb), ptr(sel), at(want, 0), at(ups, 0), ptr(w_r), stream), "l1b")
+    check(L.soar_masked_l1_backward(1, H, W, ptr(mask_img), ptr(gt_mask), None, at(want, 2), at(ups, 1), ptr(w_m), stream), "l1mb")
+    check(L.soar_cos_loss_backward(3, H, W, ptr(normal), ptr(gt_normal), ptr(sel_n), limit, weight, at(want, 4), at(ups, 2), ptr(w_n),
+                                   stream), "cosb")
+    check(L.soar_masked_l1_backward(3, H, W, ptr(occ), ptr(ones), ptr(sel_o), at(want, 6), at(ups, 3), ptr(w_o), stream), "l1ob")
+    w_r = torch.addcmul(w_r, g_ssim, ups[4])
+    assert int(want[5]) < int(sel_n.sum())                          # the limit did drop pixels
+    # ---- one pass
+    check(L.soar_avatar_loss_scratch_floats(C.byref(k)), "scratch")
+    sc2 = torch.empty(int(k.value), device=DEV)
+    for counts in (None, want[1::2].contiguous()):
+        got = torch.full((8,), float("nan"), device=DEV)
+        g_r, g_m, g_n, g_o = (torch.full_like(t, float("nan")) for t in (render, mask_img, normal, occ))
+        a = hip_lib.SoarAvatarLossArgs(H=H, W=W, cos_limit=limit, cos_weight=weight, render=ptr(render), gt_rgb=ptr(gt_rgb),
+                                       mask_img=ptr(mask_img), gt_mask=ptr(gt_mask), normal=ptr(normal), gt_normal=ptr(gt_normal),
+                                       occ=ptr(occ) if with_occ else None, sel=ptr(sel), sel_normal=ptr(sel_n),
+                                       sel_occ=ptr(sel_o) if with_occ else None, stats=at(got, 0), stats_occ=at(got, 6) if with_occ else None,
+                                       scratch=ptr(sc2), counts=ptr(counts), up_l1=at(ups, 0), up_l1m=at(ups, 1), up_cos=at(ups, 2),
+                                       up_occ=at(ups, 3), up_ssim=at(ups, 4), g_ssim=ptr(g_ssim), g_render=ptr(g_r), g_mask=ptr(g_m),
+                                       g_normal=ptr(g_n), g_occ=ptr(g_o) if with_occ else None)
+        if counts is None:
+            check(L.soar_avatar_pixel_losses(C.byref(a), 1, stream), "values")
+            assert torch.isnan(g_r).all()
+            check(L.soar_avatar_pixel_losses(C.byref(a), 2, stream), "gradients")
+        else:
+            check(L.soar_avatar_pixel_losses(C.byref(a), 3, stream), "both")
+        n_terms = 8 if with_occ else 6
+        assert torch.equal(got[:n_terms], want[:n_terms]), (got, want)
+        for name, g, w in (("render", g_r, w_r), ("mask", g_m, w_m), ("normal", g_n, w_n)) + ((("occ", g_o, w_o),) if with_occ else ()):
+            assert (g - w).abs().max().item() <= 1e-6 * w.abs().max().item(), name
+        assert torch.equal(g_m, w_m) and torch.equal(g_n, w_n)
+    # ---- refusals: nothing to do, gradients without counts, occ without its selection, a pixel count that is no multiple of 4
+    a.counts = None
+    assert L.soar_avatar_pixel_losses(C.byref(a), 0, stream) != 0
+    assert L.soar_avatar_pixel_losses(C.byref(a), 3, stream) != 0 and "counts" in hip_lib.last_error()
+    a.sel_occ, a.occ = None, ptr(occ)
+    assert L.soar_avatar_pixel_losses(C.byref(a), 1, stream) != 0
+    a.occ, a.H, a.W = None, 1, 6
+    assert L.soar_avatar_pixel_losses(C.byref(a), 1, stream) != 0 and "multiple of 4" in hip_lib.last_error()
