@@ -18,12 +18,19 @@ constexpr int ST = 32;                 // tile side: 256 threads, every thread o
 constexpr int SR = 5;                  // window radius
 constexpr int SH = ST + 2 * SR;        // 42: tile + halo
 constexpr int SB = 4;                  // outputs per thread and pass (a sliding window over SB + 10 inputs)
+constexpr int SQ = 12;                 // 16-byte units staged per halo row: columns x0 - 8 .. x0 + 39 (aligned; 42 of the 48 are used)
+constexpr int SOFF = 3;                // the first used column (x0 - 5) inside the staged row
+constexpr int SS = 49;                 // staged row stride (odd: a wave's 8 rows x 8 column groups spread over the banks)
+constexpr int HS = ST + 1;
+
+typedef float f2 __attribute__((ext_vector_type(2)));     // two maps side by side: one v_pk_fma_f32 / v_pk_mul_f32 per pair
 
 struct SsimArgs {
     int C, H, W;
+    int tiles_x, tiles;                // 32x32 tiles per row of an image, per plane
     const float *img1, *img2;
     float *dmaps;                      // [3][C][H][W]
-    float *partials;                   // [gridDim.x * gridDim.y * gridDim.z]
+    float *partials;                   // [tiles * C * 4]: one per tile and wave
     float *grad;                       // backward out [C][H][W]
     float gscale;                      // 1 / (C H W)
     float w[2 * SR + 1];               // the normalised 1-D window (float32, as the reference builds it)
@@ -34,179 +41,242 @@ __device__ __forceinline__ float load_px(const float *img, int c, int x, int y, 
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[((size_t)c * H + y) * W + x] : 0.f;
 }
 
-// Both passes of the separable window are register-blocked: a thread produces SB consecutive outputs from SB + 10 inputs it
-// reads once (the first version read 11 inputs per output and recomputed the products x^2, y^2, xy for every tap: it was bound
-// by instruction issue at 103 + 80 us for a 1080p RGB pair).  Every output is still accumulated tap by tap in window order,
-// so the values are those of the unblocked loops.
-// (frames of a batch lie along gridDim.z behind the channels: frame = blockIdx.z / C, channel = blockIdx.z % C)
-__global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch)
+// Workgroups go to the 8 XCDs round-robin in launch order: handing every XCD a contiguous run of tiles keeps the halo two
+// neighbouring tiles share inside one L2 (before: every L2 fetched its own copy -- 3.7x the images' bytes left HBM for the forward,
+// 2.6x for the backward, which was bound by exactly that).  Bijective for any workgroup count.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n)
 {
-    const int C0 = batch.v[0].C;
-    const SsimArgs &a = batch.v[blockIdx.z / C0];
-    __shared__ float s1[SH][SH + 1], s2[SH][SH + 1];
-    __shared__ float h[5][SH][ST + 1];
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z % C0;
-    {
-        // all loads of the halo in flight before the first LDS store (7 per image and thread)
-        constexpr int NL = (SH * SH + 255) / 256;
-        float r1[NL], r2[NL];
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int k = tid + 256 * i, yy = k / SH, xx = k % SH;
-            const bool in = k < SH * SH;
-            r1[i] = in ? load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W) : 0.f;
-            r2[i] = in ? load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int k = tid + 256 * i, yy = k / SH, xx = k % SH;
-            if (k < SH * SH) { s1[yy][xx] = r1[i]; s2[yy][xx] = r2[i]; }
-        }
-    }
-    __syncthreads();
-    // horizontal pass: 42 rows x 32 columns, a task = SB consecutive columns of one row
-    for (int k = tid; k < SH * (ST / SB); k += 256) {
-        const int yy = k / (ST / SB), xb = (k % (ST / SB)) * SB;
-        float p[SB + 2 * SR], q[SB + 2 * SR];
-#pragma unroll
-        for (int t = 0; t < SB + 2 * SR; t++) { p[t] = s1[yy][xb + t]; q[t] = s2[yy][xb + t]; }
-        float pp[SB + 2 * SR], qq[SB + 2 * SR], pq[SB + 2 * SR];
-#pragma unroll
-        for (int t = 0; t < SB + 2 * SR; t++) { pp[t] = p[t] * p[t]; qq[t] = q[t] * q[t]; pq[t] = p[t] * q[t]; }
-#pragma unroll
-        for (int o = 0; o < SB; o++) {
-            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2 * SR + 1; t++) {
-                const float wt = a.w[t];
-                m1 += wt * p[o + t]; m2 += wt * q[o + t]; e11 += wt * pp[o + t]; e22 += wt * qq[o + t]; e12 += wt * pq[o + t];
-            }
-            h[0][yy][xb + o] = m1; h[1][yy][xb + o] = m2; h[2][yy][xb + o] = e11; h[3][yy][xb + o] = e22; h[4][yy][xb + o] = e12;
-        }
-    }
-    __syncthreads();
-    // vertical pass: thread = column tx, rows 4 tyb .. 4 tyb + 3
-    const int tx = tid & 31, tyb = (tid >> 5) * SB;
-    float mu1[SB], mu2[SB], e11[SB], e22[SB], e12[SB];
-#pragma unroll
-    for (int o = 0; o < SB; o++) { mu1[o] = mu2[o] = e11[o] = e22[o] = e12[o] = 0.f; }
-    {
-        float v[5][SB + 2 * SR];
-#pragma unroll
-        for (int t = 0; t < SB + 2 * SR; t++)
-#pragma unroll
-            for (int m = 0; m < 5; m++) v[m][t] = h[m][tyb + t][tx];
-#pragma unroll
-        for (int o = 0; o < SB; o++)
-#pragma unroll
-            for (int t = 0; t < 2 * SR + 1; t++) {
-                const float wt = a.w[t];
-                mu1[o] += wt * v[0][o + t]; mu2[o] += wt * v[1][o + t]; e11[o] += wt * v[2][o + t];
-                e22[o] += wt * v[3][o + t]; e12[o] += wt * v[4][o + t];
-            }
-    }
-    const int x = x0 + tx;
-    float val = 0.f;
-    const size_t plane = (size_t)a.C * a.H * a.W;
-#pragma unroll
-    for (int o = 0; o < SB; o++) {
-        const int y = y0 + tyb + o;
-        if (x < a.W && y < a.H) {
-            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            const float mu1_sq = mu1[o] * mu1[o], mu2_sq = mu2[o] * mu2[o], mu12 = mu1[o] * mu2[o];
-            const float s1sq = e11[o] - mu1_sq, s2sq = e22[o] - mu2_sq, s12 = e12[o] - mu12;
-            const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1sq + s2sq + C2;
-            val += (A * B) / (Cc * D);
-            // map(mu1, E11, E12) with sigma1_sq = E11 - mu1^2 and sigma12 = E12 - mu1 mu2
-            const float dE11 = -(A * B) / (Cc * D * D);
-            const float dE12 = 2.f * A / (Cc * D);
-            const float dmu1 = (2.f * mu2[o] * B) / (Cc * D) - (2.f * mu1[o] * A * B) / (Cc * Cc * D) - 2.f * mu1[o] * dE11 - mu2[o] * dE12;
-            const size_t at = ((size_t)c * a.H + y) * a.W + x;
-            a.dmaps[at] = dmu1; a.dmaps[plane + at] = dE11; a.dmaps[2 * plane + at] = dE12;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
-    if ((tid & 63) == 0) red[tid >> 6] = val;
-    __syncthreads();
-    if (tid == 0) a.partials[(c * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    const unsigned q = n / 8u, r = n % 8u, xcd = id % 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + id / 8u;
 }
 
-__global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batch)
+// grid = (tiles * C, 1, frames of the batch): the workgroup's tile, t = (frame * C + c) * tiles + tile, after the XCD remap
+struct TileAt {
+    int frame, c, tile, x0, y0;
+};
+__device__ __forceinline__ TileAt tile_of_block(const SsimArgs &a0)
 {
-    const int C0 = batch.v[0].C;
-    const SsimArgs &a = batch.v[blockIdx.z / C0];
-    __shared__ float s[3][SH][SH + 1];
-    __shared__ float h[3][SH][ST + 1];
+    const unsigned t = xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+    const unsigned z = t / (unsigned)a0.tiles, tile = t % (unsigned)a0.tiles;
+    TileAt r;
+    r.frame = (int)(z / (unsigned)a0.C); r.c = (int)(z % (unsigned)a0.C); r.tile = (int)tile;
+    r.x0 = (int)(tile % (unsigned)a0.tiles_x) * ST; r.y0 = (int)(tile / (unsigned)a0.tiles_x) * ST;
+    return r;
+}
+
+// the 16-byte unit u of the 42-row halo (row u / 12, staged columns 4 (u % 12) ..): always loaded from a clamped, valid address
+// -- no branch around the load, nothing waits for it until it is staged -- and `in` says whether it lies inside the image
+// (W % 4 == 0 and 16-byte aligned planes: a unit is inside or outside as a whole)
+__device__ __forceinline__ float4 load_unit(const float *plane, int x0, int y0, int u, int H, int W, bool &in)
+{
+    const int yy = u / SQ, gx = x0 - 8 + 4 * (u % SQ), gy = y0 - SR + yy;
+    in = u < SH * SQ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    return *reinterpret_cast<const float4 *>(plane + (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 4));
+}
+__device__ __forceinline__ float4 keep(float4 v, bool in) { return in ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Both passes of the separable window are register-blocked: a thread produces SB consecutive outputs from SB + 10 inputs it
+// reads once.  Every output is accumulated tap by tap in window order with fused multiply-adds, so the values are those of the
+// unblocked loops; the maps travel in pairs -- (mu1, mu2) and (E[x^2], E[y^2]) -- so that a tap costs two packed FMAs and one
+// plain one instead of five (the forward was bound by instruction issue: 340 vector instructions per pixel and channel).
+template <bool VEC>
+__global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch)
+{
+    const SsimArgs &a0 = batch.v[0];
+    __shared__ f2 s[SH][SS];                            // (img1, img2)
+    __shared__ f2 h01[SH][HS], h23[SH][HS];             // rows after the horizontal pass: (mu1, mu2), (E11, E22)
+    __shared__ float h4[SH][HS];                        // E12
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST, c = blockIdx.z % C0;
-    const size_t plane = (size_t)a.C * a.H * a.W;
+    const TileAt cur = tile_of_block(a0);
+    const SsimArgs &a = batch.v[cur.frame];
+    const int x0 = cur.x0, y0 = cur.y0, c = cur.c;
     {
-        constexpr int NL = (SH * SH + 255) / 256;
-        float r[3][NL];
+        if (VEC) {
+            // all loads of the halo in flight before the first LDS store (2 float4 per image and thread)
+            const size_t off = (size_t)c * a.H * a.W;
+            float4 r1[2], r2[2];
+            bool in[2];
 #pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int k = tid + 256 * i, yy = k / SH, xx = k % SH;
+            for (int i = 0; i < 2; i++) {
+                r1[i] = load_unit(a.img1 + off, x0, y0, tid + 256 * i, a.H, a.W, in[i]);
+                r2[i] = load_unit(a.img2 + off, x0, y0, tid + 256 * i, a.H, a.W, in[i]);
+            }
 #pragma unroll
-            for (int m = 0; m < 3; m++)
-                r[m][i] = k < SH * SH ? load_px(a.dmaps + m * plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int k = tid + 256 * i, yy = k / SH, xx = k % SH;
-            if (k < SH * SH) {
-#pragma unroll
-                for (int m = 0; m < 3; m++) s[m][yy][xx] = r[m][i];
+            for (int i = 0; i < 2; i++) {
+                const int u = tid + 256 * i, yy = u / SQ, xx = 4 * (u % SQ);
+                const float4 p = keep(r1[i], in[i]), q = keep(r2[i], in[i]);
+                if (u < SH * SQ) { s[yy][xx] = f2{p.x, q.x}; s[yy][xx + 1] = f2{p.y, q.y}; s[yy][xx + 2] = f2{p.z, q.z}; s[yy][xx + 3] = f2{p.w, q.w}; }
+            }
+        } else {
+            for (int k = tid; k < SH * SH; k += 256) {
+                const int yy = k / SH, xx = k % SH;
+                s[yy][xx + SOFF] = f2{load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W), load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
             }
         }
-    }
-    __syncthreads();
-    for (int k = tid; k < SH * (ST / SB); k += 256) {
-        const int yy = k / (ST / SB), xb = (k % (ST / SB)) * SB;
-        float v[3][SB + 2 * SR];
+        __syncthreads();
+        // horizontal pass: 42 rows x 32 columns, a task = SB consecutive columns of one row (336 tasks: the 80 of the second
+        // trip go to waves 0-1 for even tiles, to waves 2-3 for odd ones -- a workgroup's waves sit on different SIMDs)
+        for (int k = (tid + ((cur.tile & 1) ? 128 : 0)) & 255; k < SH * (ST / SB); k += 256) {
+            const int yy = k / (ST / SB), xb = (k % (ST / SB)) * SB;
+            f2 v[SB + 2 * SR], sq[SB + 2 * SR];
+            float pq[SB + 2 * SR];
 #pragma unroll
-        for (int t = 0; t < SB + 2 * SR; t++)
+            for (int tt = 0; tt < SB + 2 * SR; tt++) v[tt] = s[yy][xb + SOFF + tt];
 #pragma unroll
-            for (int m = 0; m < 3; m++) v[m][t] = s[m][yy][xb + t];
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { sq[tt] = v[tt] * v[tt]; pq[tt] = v[tt].x * v[tt].y; }
+#pragma unroll
+            for (int o = 0; o < SB; o++) {
+                f2 m = {0.f, 0.f}, e = {0.f, 0.f};
+                float e12 = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 2 * SR + 1; tt++) {
+                    const float wt = a.w[tt];
+                    m += wt * v[o + tt]; e += wt * sq[o + tt]; e12 += wt * pq[o + tt];
+                }
+                h01[yy][xb + o] = m; h23[yy][xb + o] = e; h4[yy][xb + o] = e12;
+            }
+        }
+        __syncthreads();
+        // vertical pass: thread = column tx, rows 4 tyb .. 4 tyb + 3
+        const int tx = tid & 31, tyb = (tid >> 5) * SB;
+        f2 mu[SB], ee[SB];
+        float e12[SB];
+#pragma unroll
+        for (int o = 0; o < SB; o++) { mu[o] = f2{0.f, 0.f}; ee[o] = f2{0.f, 0.f}; e12[o] = 0.f; }
+        {
+            f2 v0[SB + 2 * SR], v1[SB + 2 * SR];
+            float v2[SB + 2 * SR];
+#pragma unroll
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { v0[tt] = h01[tyb + tt][tx]; v1[tt] = h23[tyb + tt][tx]; v2[tt] = h4[tyb + tt][tx]; }
+#pragma unroll
+            for (int o = 0; o < SB; o++)
+#pragma unroll
+                for (int tt = 0; tt < 2 * SR + 1; tt++) {
+                    const float wt = a.w[tt];
+                    mu[o] += wt * v0[o + tt]; ee[o] += wt * v1[o + tt]; e12[o] += wt * v2[o + tt];
+                }
+        }
+        const int x = x0 + tx;
+        float val = 0.f;
+        const size_t plane = (size_t)a.C * a.H * a.W;
 #pragma unroll
         for (int o = 0; o < SB; o++) {
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2 * SR + 1; t++) {
-                const float wt = a.w[t];
-                v0 += wt * v[0][o + t]; v1 += wt * v[1][o + t]; v2 += wt * v[2][o + t];
+            const int y = y0 + tyb + o;
+            if (x < a.W && y < a.H) {
+                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+                const float mu1 = mu[o].x, mu2 = mu[o].y;
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s1sq = ee[o].x - mu1_sq, s2sq = ee[o].y - mu2_sq, s12 = e12[o] - mu12;
+                const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1sq + s2sq + C2;
+                val += (A * B) / (Cc * D);                 // the map: the reference's expression, IEEE division
+                // its derivatives through map(mu1, E11, E12) with sigma1_sq = E11 - mu1^2 and sigma12 = E12 - mu1 mu2; the two
+                // reciprocals (Cc >= 1e-4, D >= 9e-4: 1 ulp each) instead of five divisions
+                const float rC = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D), rCD = rC * rD;
+                const float map = A * B * rCD;
+                const float dE11 = -map * rD;
+                const float dE12 = 2.f * A * rCD;
+                const float dmu1 = 2.f * mu2 * B * rCD - 2.f * mu1 * map * rC - 2.f * mu1 * dE11 - mu2 * dE12;
+                const size_t at = ((size_t)c * a.H + y) * a.W + x;
+                a.dmaps[at] = dmu1; a.dmaps[plane + at] = dE11; a.dmaps[2 * plane + at] = dE12;
             }
-            h[0][yy][xb + o] = v0; h[1][yy][xb + o] = v1; h[2][yy][xb + o] = v2;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
+        if ((tid & 63) == 0) a.partials[4 * (c * a.tiles + cur.tile) + (tid >> 6)] = val;
     }
-    __syncthreads();
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batch)
+{
+    const SsimArgs &a0 = batch.v[0];
+    __shared__ f2 s01[SH][SS];                          // (dmu1, dE11)
+    __shared__ float s2[SH][SS];                        // dE12
+    __shared__ f2 h01[SH][HS];
+    __shared__ float h2[SH][HS];
+    const int tid = threadIdx.x;
     const int tx = tid & 31, tyb = (tid >> 5) * SB;
-    float g0[SB], g1[SB], g2[SB];
-#pragma unroll
-    for (int o = 0; o < SB; o++) { g0[o] = g1[o] = g2[o] = 0.f; }
+    const TileAt cur = tile_of_block(a0);
+    const SsimArgs &a = batch.v[cur.frame];
+    const int x0 = cur.x0, y0 = cur.y0, c = cur.c, x = x0 + tx;
+    const size_t plane = (size_t)a.C * a.H * a.W;
     {
-        float v[3][SB + 2 * SR];
+        // the centre pixels of the two images (clamped addresses: no branch around the loads), in flight across both passes
+        float i1[SB], i2[SB];
 #pragma unroll
-        for (int t = 0; t < SB + 2 * SR; t++)
+        for (int o = 0; o < SB; o++) {
+            const size_t at = ((size_t)c * a.H + min(y0 + tyb + o, a.H - 1)) * a.W + min(x, a.W - 1);
+            i1[o] = a.img1[at]; i2[o] = a.img2[at];
+        }
+        if (VEC) {
+            const float *p = a.dmaps + (size_t)c * a.H * a.W;
+            float4 r[3][2];
+            bool in[2];
 #pragma unroll
-            for (int m = 0; m < 3; m++) v[m][t] = h[m][tyb + t][tx];
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int o = 0; o < SB; o++)
+                for (int m = 0; m < 3; m++) r[m][i] = load_unit(p + m * plane, x0, y0, tid + 256 * i, a.H, a.W, in[i]);
 #pragma unroll
-            for (int t = 0; t < 2 * SR + 1; t++) {
-                const float wt = a.w[t];
-                g0[o] += wt * v[0][o + t]; g1[o] += wt * v[1][o + t]; g2[o] += wt * v[2][o + t];
+            for (int i = 0; i < 2; i++) {
+                const int u = tid + 256 * i, yy = u / SQ, xx = 4 * (u % SQ);
+                const float4 d0 = keep(r[0][i], in[i]), d1 = keep(r[1][i], in[i]), d2 = keep(r[2][i], in[i]);
+                if (u < SH * SQ) {
+                    s01[yy][xx] = f2{d0.x, d1.x}; s01[yy][xx + 1] = f2{d0.y, d1.y}; s01[yy][xx + 2] = f2{d0.z, d1.z}; s01[yy][xx + 3] = f2{d0.w, d1.w};
+                    s2[yy][xx] = d2.x; s2[yy][xx + 1] = d2.y; s2[yy][xx + 2] = d2.z; s2[yy][xx + 3] = d2.w;
+                }
             }
-    }
-    const int x = x0 + tx;
+        } else {
+            for (int k = tid; k < SH * SH; k += 256) {
+                const int yy = k / SH, xx = k % SH;
+                s01[yy][xx + SOFF] = f2{load_px(a.dmaps, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W),
+                                        load_px(a.dmaps + plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
+                s2[yy][xx + SOFF] = load_px(a.dmaps + 2 * plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W);
+            }
+        }
+        __syncthreads();
+        for (int k = (tid + ((cur.tile & 1) ? 128 : 0)) & 255; k < SH * (ST / SB); k += 256) {
+            const int yy = k / (ST / SB), xb = (k % (ST / SB)) * SB;
+            f2 v[SB + 2 * SR];
+            float v2[SB + 2 * SR];
 #pragma unroll
-    for (int o = 0; o < SB; o++) {
-        const int y = y0 + tyb + o;
-        if (x < a.W && y < a.H) {
-            const size_t at = ((size_t)c * a.H + y) * a.W + x;
-            a.grad[at] = a.gscale * (g0[o] + 2.f * a.img1[at] * g1[o] + a.img2[at] * g2[o]);
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { v[tt] = s01[yy][xb + SOFF + tt]; v2[tt] = s2[yy][xb + SOFF + tt]; }
+#pragma unroll
+            for (int o = 0; o < SB; o++) {
+                f2 g = {0.f, 0.f};
+                float g2 = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 2 * SR + 1; tt++) {
+                    const float wt = a.w[tt];
+                    g += wt * v[o + tt]; g2 += wt * v2[o + tt];
+                }
+                h01[yy][xb + o] = g; h2[yy][xb + o] = g2;
+            }
+        }
+        __syncthreads();
+        f2 g01[SB];
+        float g2[SB];
+#pragma unroll
+        for (int o = 0; o < SB; o++) { g01[o] = f2{0.f, 0.f}; g2[o] = 0.f; }
+        {
+            f2 v[SB + 2 * SR];
+            float v2[SB + 2 * SR];
+#pragma unroll
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { v[tt] = h01[tyb + tt][tx]; v2[tt] = h2[tyb + tt][tx]; }
+#pragma unroll
+            for (int o = 0; o < SB; o++)
+#pragma unroll
+                for (int tt = 0; tt < 2 * SR + 1; tt++) {
+                    const float wt = a.w[tt];
+                    g01[o] += wt * v[o + tt]; g2[o] += wt * v2[o + tt];
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < SB; o++) {
+            const int y = y0 + tyb + o;
+            if (x < a.W && y < a.H) {
+                const size_t at = ((size_t)c * a.H + y) * a.W + x;
+                a.grad[at] = a.gscale * (g01[o].x + 2.f * i1[o] * g01[o].y + i2[o] * g2[o]);
+            }
         }
     }
 }
@@ -226,7 +296,14 @@ __global__ void __launch_bounds__(1024) ssim_finish_kernel(Batch<SsimFinishArgs>
     float *out = fa.out;
     __shared__ float red[16];
     float s = 0.f;
-    for (int k = threadIdx.x; k < n; k += 1024) s += partials[k];
+    // (four partials per tile, one per wave: a tile's sum, then the tiles in a fixed order)
+    if ((reinterpret_cast<uintptr_t>(partials) & 15u) == 0u)
+        for (int k = threadIdx.x; k < n / 4; k += 1024) {
+            const float4 p = reinterpret_cast<const float4 *>(partials)[k];
+            s += (p.x + p.y) + (p.z + p.w);
+        }
+    else
+        for (int k = threadIdx.x; k < n / 4; k += 1024) s += (partials[4 * k] + partials[4 * k + 1]) + (partials[4 * k + 2] + partials[4 * k + 3]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -259,8 +336,8 @@ using namespace soar;
 extern "C" int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count)
 {
     if (C <= 0 || H <= 0 || W <= 0 || !count) { set_error("soar_ssim_scratch_floats: bad arguments"); return 1; }
-    const size_t blocks = (size_t)((W + 15) / 16) * ((H + 15) / 16) * C;     // (one partial per 32x32 tile is used; 16x16 tiles of round 1 counted)
-    *count = 3 * (size_t)C * H * W + blocks;
+    const size_t blocks = 4 * (size_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) * C;     // one partial per 32x32 tile and wave
+    *count = ((3 * (size_t)C * H * W + 3) & ~(size_t)3) + blocks;
     return 0;
 }
 
@@ -272,16 +349,30 @@ extern "C" int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, con
     SsimArgs a = {};
     a.C = C; a.H = H; a.W = W; a.img1 = img1; a.img2 = img2;
     a.dmaps = scratch;
-    a.partials = scratch + 3 * (size_t)C * H * W;
+    a.partials = scratch + ((3 * (size_t)C * H * W + 3) & ~(size_t)3);        // (16-byte aligned behind the maps when the scratch is)
     a.grad = dssim_dimg1;
     a.gscale = 1.0f / ((float)C * (float)H * (float)W);
     fill_window(a.w);
-    const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, C);
+    a.tiles_x = (W + ST - 1) / ST;
+    a.tiles = a.tiles_x * ((H + ST - 1) / ST);
+    // one workgroup per tile and channel; the frames of a batch along z (the kernels remap the workgroups XCD by XCD)
+    if (batch_ctx().n) {         // (the grid alone does not tell the launch sites that the frames of a batch agree in size)
+        static thread_local int c0 = 0, h0 = 0, w0 = 0;
+        if (batch_ctx().f == 0) { c0 = C; h0 = H; w0 = W; }
+        else if (C != c0 || H != h0 || W != w0) { set_error("soar_ssim: the frames of a batch must agree in size"); return 1; }
+    }
+    const dim3 grid(a.tiles * C, 1, 1);
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0u; };
+    const bool vec = (W & 3) == 0 && al(img1) && al(img2) && al(scratch);
     StageTimer timer(ST_FRAME_LOSS, stream);
-    SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel, grid, dim3(256), 0, stream, a);
-    const SsimFinishArgs fa = {a.partials, (int)(grid.x * grid.y * grid.z), a.gscale, ssim_out};
+    if (vec) SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel<true>, grid, dim3(256), 0, stream, a);
+    else SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel<false>, grid, dim3(256), 0, stream, a);
+    const SsimFinishArgs fa = {a.partials, 4 * a.tiles * C, a.gscale, ssim_out};
     SOAR_LAUNCH_BATCHED(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, fa);
-    if (dssim_dimg1) SOAR_LAUNCH_BATCHED_Z(ssim_backward_kernel, grid, dim3(256), 0, stream, a);
+    if (dssim_dimg1) {
+        if (vec) SOAR_LAUNCH_BATCHED_Z(ssim_backward_kernel<true>, grid, dim3(256), 0, stream, a);
+        else SOAR_LAUNCH_BATCHED_Z(ssim_backward_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
     SOAR_LAUNCH_OK("ssim", stream, 0);
     return 0;
 }
