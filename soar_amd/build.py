@@ -41,6 +41,7 @@ EXTRA_FLAGS = {
     # the SLP vectoriser pairs neighbouring float operations into v_pk_* and pays for it with register shuffles (v_mov, v_pk_mov);
     # a packed float instruction occupies the SIMD as long as the two plain ones it replaces (32 lanes per cycle either way)
     "rast_render_bwd.hip": ["-fno-slp-vectorize"],
+    "rast_render_fwd.hip": ["-fno-slp-vectorize"],      # (round 4: 275 -> 249 us per 4-frame step of the forward blends)
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_blockmask.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
            "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip", "densify.hip", "optim.hip", "view.hip"]

@@ -120,14 +120,31 @@ __device__ __forceinline__ void fill_tile(const FwdArgs &a, int tile, int tid, i
 // Running products of one pixel's four slots: T is replicated in the quad, m is this lane's factor; lane k returns
 // ((T m_0) m_1 ...) m_k -- every product a plain rounded multiply, in list order.  Pass k makes lane k final (lane 0 is
 // final after the first multiply and is carried through the passes with the factor 1).
-__device__ __forceinline__ float quad_scan_products(float T, float m, bool first_slot)
+__device__ __forceinline__ float quad_scan_products(float T, float m, float m_pass)
 {
-    const float m_pass = first_slot ? 1.0f : m;
     float x = mul_keep(T, m);
     x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
     x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
     x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
     return x;
+}
+
+// the same for two chains at once, their steps side by side
+__device__ __forceinline__ void quad_scan_products2(float T, float m, float m_pass, float U, float n, float n_pass, float &x, float &y)
+{
+    x = mul_keep(T, m);
+    y = mul_keep(U, n);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
+        y = mul_keep(quad_move<DPP_QUAD_SHIFT1>(y), n_pass);
+    }
+}
+
+// the element at byte offset 16 j of an LDS array of 16-byte elements (the ring holds 16 j)
+__device__ __forceinline__ float4 lds_at(const float4 *arr, uint32_t j16)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(arr) + j16);
 }
 
 // OCC = true additionally blends, in the same walk of the list, what a second rasterization with render_front = 1 and
@@ -139,9 +156,9 @@ template <bool LOG, bool OCC>
 __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, const int quad)
 {
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
-    __shared__ float2 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing}
+    __shared__ float4 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing, -, -}: the stride of the others
     __shared__ int wave_alive[2][4];
-    __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: LDS slots of a sub-chunk's relevant entries
+    __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: 16 x LDS slot (= byte offset) of a sub-chunk's relevant entries
     __shared__ unsigned long long wmask[4][CHUNK / WAVE];                                 // per wavefront: phase A's survivor words of a chunk
     unsigned long long t_start = 0, t_ready = 0, t_blended = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
@@ -157,7 +174,11 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     const int pxl = lane >> 2, slot = lane & 3;
     const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
     const bool inside = px < a.W && py < a.H;
-    const float fx = (float)px, fy = (float)py;
+    const float not_first = slot == 0 ? 0.f : 1.f;
+    float fx = (float)px, fy = (float)py;
+    // (opaque to the compiler: it would rather convert the integers again in every step of the blend loop than hold two registers --
+    // a conversion costs a full-rate multiply-add twice over, profiles/r04d_valu_issue_rate.txt)
+    asm volatile("" : "+v"(fx), "+v"(fy));
 
     const uint2 range = make_uint2(orec.y, orec.z);
     set_wave_priority_by_length(range.y - range.x);
@@ -176,7 +197,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         sq0[CHUNK] = z; sq1[CHUNK] = z; sq2[CHUNK] = z; sq3[CHUNK] = z;
-        if (OCC) sq4[CHUNK] = make_float2(0.f, 0.f);
+        if (OCC) sq4[CHUNK] = z;
     }
 
     // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended, and the list ids of
@@ -218,7 +239,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         const int n = min((uint32_t)CHUNK, range.y - base);
         if (tid < n) {
             sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3;
-            if (OCC) sq4[tid] = r4;
+            if (OCC) *reinterpret_cast<float2 *>(&sq4[tid]) = r4;
         }
         emit_masks();                                // (the chunk before)
         emit_base = base;
@@ -261,20 +282,23 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                 // three pad entries behind them point at the zero record, so the last step needs no special case
                 const unsigned long long todo = __ballot(relevant);
                 const int n_todo = (int)__builtin_popcountll(todo);
-                if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(sub + lane);
-                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)CHUNK;
+                if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(16 * (sub + lane));
+                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)(16 * CHUNK);
                 if (lane == 0) wmask[wave][sub / WAVE] = todo;                  // left behind for the backward blend: emit_masks below
                 emit_n = sub / WAVE + 1;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t contrib1 = base - range.x + 1u;                  // list position + 1 of LDS slot 0
+                // 16 x (list position + 1) of LDS slot 0, in a vector register (the positions are kept x 16 -- what the ring holds --
+                // until the epilogue: no shift in the loop; an operand from a scalar register halves the add's rate)
+                uint32_t contrib16 = 16u * (base - range.x + 1u);
+                asm volatile("" : "+v"(contrib16));
 
                 // phase B -- lanes = (pixel, slot): four surviving entries per step, in list order
                 for (int it = 0; it < n_todo; it += 4) {
                     if (LOG) n_iter++;
-                    const int j = todo_ring[wave][it + slot];
-                    const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+                    const uint32_t j16 = todo_ring[wave][it + slot];
+                    const float4 q0 = lds_at(sq0, j16), q1 = lds_at(sq1, j16), q2 = lds_at(sq2, j16), q3 = lds_at(sq3, j16);
                     // x,y,A,B | C,opacity,depth,plane_a | plane_b,r,g,b | nx,ny,nz,-
                     const float dx = q0.x - fx, dy = q0.y - fy;
                     const float power = falloff_power(q0.z, q0.w, q1.x, dx, dy);          // forward.cu:507-508
@@ -287,20 +311,36 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     // running transmittance through the four slots, reference order (:548-553, :602).
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
                     const float om = 1.f - a_eff;
+                    // OCC: the same chain over the camera-facing entries only, with its own transmittance and stop
+                    float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float a_o = 0.f, mo = 1.f;
+                    if (OCC) {
+                        e4 = lds_at(sq4, j16);
+                        a_o = a_live * e4.y * alive_o;                                    // camera-facing flag and liveness are 0 / 1
+                        mo = 1.f - a_o;
+                    }
                     // unclamped running products first: transmittances only shrink, so some slot stops the pixel in
                     // this step iff the last product is below the threshold -- and in most steps no pixel of the
                     // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed.
                     // The products run through the quad as a scan (lane k <- lane k - 1, three fused DPP multiplies): lane k
-                    // ends with ((T om_0) om_1 ...) om_k, the reference's order of roundings
-                    float x = quad_scan_products(T, om, slot == 0);
+                    // ends with ((T om_0) om_1 ...) om_k, the reference's order of roundings.  The two chains' scans are
+                    // issued step by step side by side: a DPP operand written by the instruction in front costs two idle
+                    // cycles, which the other chain's step fills.
+                    float x, y = 1.f;
+                    // (the factor a lane passes the running product on with: 1 in slot 0, its own elsewhere -- 1 - a x {0, 1}: exact)
+                    const float om_pass = __builtin_fmaf(-a_eff, not_first, 1.f);
+                    if (OCC) quad_scan_products2(T, om, om_pass, T_o, mo, __builtin_fmaf(-a_o, not_first, 1.f), x, y);
+                    else x = quad_scan_products(T, om, om_pass);
                     const float p3 = quad_move<DPP_QUAD_BCAST3>(x);
-                    float w;
+                    const float v3 = OCC ? quad_move<DPP_QUAD_BCAST3>(y) : 1.f;
+                    float w, w_o = 0.f;
                     bool some_stop = false;                                               // wave-uniform
                     if (__ballot(p3 < 0.0001f) == 0ull) {
                         const float T_prev = quad_move<DPP_QUAD_SHIFT1>(x);               // the product in front of my entry
                         w = a_eff * (slot == 0 ? T : T_prev);
                         T = p3;
                     } else {
+                        // (the general form: the same products, with the clamping selects)
                         const float om0 = quad_move<DPP_QUAD_BCAST0>(om), om1 = quad_move<DPP_QUAD_BCAST1>(om),
                                     om2 = quad_move<DPP_QUAD_BCAST2>(om), om3 = quad_move<DPP_QUAD_BCAST3>(om);
                         const float t0 = mul_keep(T, om0);
@@ -322,24 +362,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                         alive = s3 ? 0.f : alive;
                         some_stop = true;
                     }
-                    const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
-                    const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
-                    D = __builtin_fmaf(depth, w, D);
-                    C0 = __builtin_fmaf(q2.y, w, C0);
-                    C1 = __builtin_fmaf(q2.z, w, C1);
-                    C2 = __builtin_fmaf(q2.w, w, C2);
-                    N0 = __builtin_fmaf(q3.x, w, N0);
-                    N1 = __builtin_fmaf(q3.y, w, N1);
-                    N2 = __builtin_fmaf(q3.z, w, N2);
-                    last_contributor = blend ? contrib1 + (uint32_t)j : last_contributor;
                     if (OCC) {
-                        // the same chain over the camera-facing entries only, with its own transmittance and stop
-                        const float2 e4 = sq4[j];
-                        const float a_o = a_live * e4.y * alive_o;                        // camera-facing flag and liveness are 0 / 1
-                        const float mo = 1.f - a_o;
-                        float y = quad_scan_products(T_o, mo, slot == 0);
-                        const float v3 = quad_move<DPP_QUAD_BCAST3>(y);
-                        float w_o;
                         if (__ballot(v3 < 0.0001f) == 0ull) {
                             const float U_prev = quad_move<DPP_QUAD_SHIFT1>(y);
                             w_o = a_o * (slot == 0 ? T_o : U_prev);
@@ -365,8 +388,18 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                             alive_o = z3 ? 0.f : alive_o;
                             some_stop = true;
                         }
-                        Co = __builtin_fmaf(e4.x, w_o, Co);
                     }
+                    const bool blend = w != 0.f;          // w == 0 adds exactly nothing to the sums below (records are finite)
+                    const float depth = q1.z - (dx * q1.w + dy * q2.x);                   // depth on the surfel plane
+                    D = __builtin_fmaf(depth, w, D);
+                    C0 = __builtin_fmaf(q2.y, w, C0);
+                    C1 = __builtin_fmaf(q2.z, w, C1);
+                    C2 = __builtin_fmaf(q2.w, w, C2);
+                    N0 = __builtin_fmaf(q3.x, w, N0);
+                    N1 = __builtin_fmaf(q3.y, w, N1);
+                    N2 = __builtin_fmaf(q3.z, w, N2);
+                    last_contributor = blend ? contrib16 + j16 : last_contributor;        // (x 16: see contrib16)
+                    if (OCC) Co = __builtin_fmaf(e4.x, w_o, Co);
                     if (some_stop && __ballot(alive + alive_o != 0.f) == 0ull) { wave_done = true; break; }
                 }
                 if (wave_done) break;
@@ -391,6 +424,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     N2 += quad_move<DPP_QUAD_XOR1>(N2); N2 += quad_move<DPP_QUAD_XOR2>(N2);
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR1>(last_contributor));
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR2>(last_contributor));
+    last_contributor >>= 4;                          // (kept x 16 in the loop)
     if (OCC) { Co += quad_move<DPP_QUAD_XOR1>(Co); Co += quad_move<DPP_QUAD_XOR2>(Co); }
 
     if (inside && slot == 0) {
@@ -508,7 +542,9 @@ __device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int ra
     const int pxl = lane >> 2, slot = lane & 3;
     const int px = bx0 + (pxl & 3), py = by0 + (pxl >> 2);
     const bool inside = px < a.W && py < a.H;
-    const float fx = (float)px, fy = (float)py;
+    const float not_first = slot == 0 ? 0.f : 1.f;
+    float fx = (float)px, fy = (float)py;
+    asm volatile("" : "+v"(fx), "+v"(fy));           // (kept as floats: see blend_quad)
     const uint2 range = a.ranges[tile];
 
     float G = 0.f;
@@ -587,7 +623,7 @@ __device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int ra
                     a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
                     const float a_o = a_live * q1.w * alive_o;                           // (back-facing entries never enter the ring; the
                     const float mo = 1.f - a_o;                                          //  pad record has flag 0)
-                    float y = quad_scan_products(T_o, mo, slot == 0);
+                    float y = quad_scan_products(T_o, mo, __builtin_fmaf(-a_o, not_first, 1.f));
                     const float v3 = quad_move<DPP_QUAD_BCAST3>(y);
                     float w_o;
                     bool some_stop = false;
