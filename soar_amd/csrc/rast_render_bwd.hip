@@ -241,7 +241,7 @@ struct BlockWalk {           // descending walk over the 64-position groups of a
 };
 
 template <bool WIDE>
-__device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[3], uint32_t *ring,
+__device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[4], uint32_t *ring,
                                                float *xpose, uint32_t *xgid)
 {
     const int lane = threadIdx.x & 63;
@@ -273,7 +273,6 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     PixelConsts c;
     PixelState st;
     load_pixel_at_once(a, px, py, inside, c, st);
-    float vT = st.T, vP = 0.f;                   // lane p: transmittance behind / blend of everything behind . upstream gradient, pixel p
     const uint32_t vLast = c.last;
     const uint32_t deepest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vLast));
     if (deepest == 0u) return;
@@ -281,7 +280,11 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     if (lane < 16) {
         pixc[lane][0] = make_float4(c.fx, c.fy, c.dC0, c.dC1);
         pixc[lane][1] = make_float4(c.dC2, c.dN0, c.dN1, c.dN2);
-        pixc[lane][2] = make_float4(c.dD, c.dD_ch, c.norm_depth_k + c.tail, 0.f);
+        pixc[lane][2] = make_float4(c.dD, c.dD_ch, c.norm_depth_k + c.tail, __uint_as_float(vLast));
+        // the pixel's running state: transmittance behind / blend of everything behind . upstream gradient -- read back by every lane
+        // when the pixel's turn comes in a batch, rewritten by lane 63 at the end of it (four register-to-scalar moves, a compare and
+        // two selects per step when it lived in the lanes' registers)
+        pixc[lane][3] = make_float4(st.T, 0.f, 0.f, 0.f);
     }
     const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
@@ -407,9 +410,10 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         while (act) {
             const int p = __builtin_ctz(act);
             act &= act - 1u;
-            const uint32_t last_p = (uint32_t)__builtin_amdgcn_readlane((int)vLast, p);
-            const float T_in = lane_value(vT, p), P_in = lane_value(vP, p);
             const float4 c0 = pixc[p][0], c1 = pixc[p][1], c2 = pixc[p][2];
+            const float2 tp = *reinterpret_cast<const float2 *>(&pixc[p][3]);
+            const uint32_t last_p = __float_as_uint(c2.w);
+            const float T_in = tp.x, P_in = tp.y;
             const float dx = ex - c0.x, dy = ey - c0.y;
             const float power = falloff_power(eA, eB, eC, dx, dy);
             const float Gx = exp_nonpositive(power);
@@ -459,12 +463,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             acc[4] = __builtin_fmaf(dL_ddist, pp.dydy, acc[4]);
             acc[5] = __builtin_fmaf(G, dL_dalpha, acc[5]);                               // :854
             sdD += live ? c2.x : 0.f;                                                    // :839-840: - dL_dpixD plane_(a, b)
-            any_live = fmaxf(any_live, a_eff);
-            float T_out = lane_value(T_mine, 63), P_out = lane_value(P_front, 63);
-            asm volatile("" : "+s"(T_out), "+s"(P_out));
-            const bool mine = lane == p;
-            vT = mine ? T_out : vT;
-            vP = mine ? P_out : vP;
+            any_live += a_eff;                                                           // (a_eff >= 0: > 0 iff some pair was live)
+            if (lane == 63) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
         }
         // the batch's sums -> LDS, [entry][13]; they leave at the start of the next step
         acc[0] = acc[0] * two_ddelx - sdD * epa;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)
 {
-    __shared__ float4 pixc[16][3];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, -}
+    __shared__ float4 pixc[16][4];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last | T, P, -, -}
     __shared__ uint32_t ring[WAVE];
     __shared__ float xpose[WAVE * 13];                   // a batch's sums, [entry][13]
     __shared__ uint32_t xgid[WAVE];
