@@ -37,7 +37,8 @@ extern "C" {
  * the geometry buffer grew (ask soar_rast_geometry_bytes); inside the binning buffer the tiles' lists are no longer in tile order
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
- * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses;
+ * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses, soar_rast_backward_occ (the image
+ * buffer grew by two planes: ask soar_rast_image_bytes);
  * soar_selftest_wave_reduce is gone with the backward form it tested. */
 #define SOAR_HIP_ABI_VERSION 6
 
@@ -198,6 +199,24 @@ int soar_rast_backward(const SoarRastParams *prm,
  * same arithmetic as the forward's occlusion chain.  dL_dout_occ [3,H,W]; dL_docc [P], overwritten. */
 int soar_rast_occ_backward(const SoarRastParams *prm, const void *geom_buffer, const void *binning_buffer,
                            const void *image_buffer, int64_t num_rendered, const float *dL_dout_occ, float *dL_docc,
+                           void *stream);
+/* soar_rast_backward and soar_rast_occ_backward in ONE walk of the lists (round 4): the backward blend also takes the fused
+ * occlusion chain of soar_rast_forward_render_occ back to front -- from the chain's final transmittance and last contributor, which
+ * that forward left in the image buffer -- with T in front of an entry recovered by division like the reference's own backward pass of
+ * its separate occlusion rasterization (backward.cu:683).  dL_dout_occ [3,H,W]; dL_docc [P], overwritten.  For a main pass
+ * (render_front = 0, sort_descending = 0) whose forward was soar_rast_forward_render_occ. */
+int soar_rast_backward_occ(const SoarRastParams *prm,
+                           const float *means3D, const int32_t *radii, const float *shs,
+                           const float *colors_precomp, const float *scales, const float *rotations,
+                           const float *cov3D_precomp,
+                           const void *geom_buffer, const void *binning_buffer, const void *image_buffer,
+                           int64_t num_rendered,
+                           const float *dL_dout_color, const float *dL_dout_normal,
+                           const float *dL_dout_depth, const float *dL_dout_opac, const float *dL_dout_occ,
+                           float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D,
+                           float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                           float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc,
+                           void *workspace, size_t workspace_bytes,
                            void *stream);
 /* Same, with the four image gradients multiplied by the device scalar *grad_scale_dev while they are loaded (the
  * upstream gradient of a scalar image loss whose gradient planes soar_frame_loss wrote): no scaling pass. */

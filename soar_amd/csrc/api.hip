@@ -45,13 +45,14 @@ BatchCtx &batch_ctx()
 }
 
 namespace {
-struct ZeroArgs { uint32_t *ptr[4]; size_t words[4]; size_t first_block[5]; };
+constexpr int ZERO_RANGES = 5;
+struct ZeroArgs { uint32_t *ptr[ZERO_RANGES]; size_t words[ZERO_RANGES]; size_t first_block[ZERO_RANGES + 1]; };
 __global__ void __launch_bounds__(256) zero_ranges_kernel(Batch<ZeroArgs> b)
 {
     const ZeroArgs &z = b.v[blockIdx.y];
-    if (blockIdx.x >= z.first_block[4]) return;
+    if (blockIdx.x >= z.first_block[ZERO_RANGES]) return;
     int r = 0;
-    while (r < 3 && blockIdx.x >= z.first_block[r + 1]) r++;
+    while (r < ZERO_RANGES - 1 && blockIdx.x >= z.first_block[r + 1]) r++;
     const size_t w0 = ((size_t)blockIdx.x - z.first_block[r]) * 1024 + threadIdx.x * 4;
     uint32_t *p = z.ptr[r];
     const size_t n = z.words[r];
@@ -67,13 +68,14 @@ int launch_zero_ranges(const ZeroRange *ranges, int count, hipStream_t stream)
 {
     ZeroArgs z;
     size_t blocks = 0;
-    for (int r = 0; r < 4; r++) {
+    if (count > ZERO_RANGES) { set_error("launch_zero_ranges: at most %d ranges", ZERO_RANGES); return 1; }
+    for (int r = 0; r < ZERO_RANGES; r++) {
         z.first_block[r] = blocks;
         z.ptr[r] = r < count ? static_cast<uint32_t *>(ranges[r].ptr) : nullptr;
         z.words[r] = r < count ? ranges[r].bytes / 4 : 0;
         blocks += (z.words[r] + 1023) / 1024;
     }
-    z.first_block[4] = blocks;
+    z.first_block[ZERO_RANGES] = blocks;
     if (blocks == 0) return 0;
     SOAR_LAUNCH_BATCHED(zero_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z);
     return post_launch("zero_ranges", stream, 0);
@@ -213,6 +215,8 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->tile_count, tiles > 0 ? tiles : 1);
     take(p, out->bg_state, 8);
     take(p, out->bg_tiles, tiles > 0 ? tiles : 1);
+    take(p, out->final_To, pix > 0 ? pix : 1);
+    take(p, out->n_contrib_o, pix > 0 ? pix : 1);
     out->total_bytes = align_up((size_t)(p - static_cast<char *>(base))) + ALIGN;
     return 0;
 }
@@ -636,7 +640,9 @@ int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const in
                                      stream_);
 }
 
-int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
+}  // extern "C"
+
+static int backward_impl(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
                               const float *colors_precomp, const float *scales, const float *rotations,
                               const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
                               const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
@@ -644,11 +650,16 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
                               const float *grad_scale_dev, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                               float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
                               float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, void *workspace,
-                              size_t workspace_bytes, void *stream_)
+                              size_t workspace_bytes, const float *dL_dout_occ, float *dL_docc, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
     if (!dL_dviewmat || !dL_dprojmat || !dL_dcampos) { set_error("camera gradient pointers must not be NULL"); return 1; }
+    if ((dL_dout_occ == nullptr) != (dL_docc == nullptr)) { set_error("soar_rast_backward_occ: dL_dout_occ and dL_docc go together"); return 1; }
+    if (dL_dout_occ && (prm->render_front != 0 || prm->sort_descending != 0)) {
+        set_error("soar_rast_backward_occ: the fused occlusion chain belongs to a main pass (render_front = 0, ascending)");
+        return 1;
+    }
     if (prm->P == 0) {
         SOAR_HIP_OK(hipMemsetAsync(dL_dviewmat, 0, 16 * sizeof(float), stream));
         SOAR_HIP_OK(hipMemsetAsync(dL_dprojmat, 0, 16 * sizeof(float), stream));
@@ -682,13 +693,14 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
                          : nullptr;
     {
         // accumulation rows and the camera gradients (atomic sums of the two backward kernels) in one launch
-        const ZeroRange zr[4] = {{wide ? (void *)acc64 : (void *)acc, (wide ? sizeof(double) : sizeof(float)) * ACC_STRIDE * (size_t)prm->P},
-                                 {dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)}};
-        if (launch_zero_ranges(zr, 4, stream)) return 1;
+        const ZeroRange zr[5] = {{wide ? (void *)acc64 : (void *)acc, (wide ? sizeof(double) : sizeof(float)) * ACC_STRIDE * (size_t)prm->P},
+                                 {dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)},
+                                 {dL_docc, sizeof(float) * (size_t)prm->P}};
+        if (launch_zero_ranges(zr, dL_docc ? 5 : 4, stream)) return 1;
     }
     if (num_rendered > 0 || wide) {
         if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
-                                   acc64, num_rendered > 0, stream))
+                                   acc64, num_rendered > 0, dL_dout_occ, dL_docc, stream))
             return 1;
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
@@ -696,6 +708,42 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
                                  dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/false, stream))
         return 1;
     return 0;
+}
+
+
+extern "C" {
+
+int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
+                              const float *colors_precomp, const float *scales, const float *rotations,
+                              const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
+                              const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
+                              const float *dL_dout_normal, const float *dL_dout_depth, const float *dL_dout_opac,
+                              const float *grad_scale_dev, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                              float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, void *workspace,
+                              size_t workspace_bytes, void *stream_)
+{
+    return backward_impl(prm, means3D, radii, shs, colors_precomp, scales, rotations, cov3D_precomp, geom_buffer, binning_buffer, image_buffer,
+                         num_rendered, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, dL_dmeans2D, dL_dcolors,
+                         dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos, workspace,
+                         workspace_bytes, nullptr, nullptr, stream_);
+}
+
+int soar_rast_backward_occ(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
+                           const float *colors_precomp, const float *scales, const float *rotations,
+                           const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
+                           const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
+                           const float *dL_dout_normal, const float *dL_dout_depth, const float *dL_dout_opac,
+                           const float *dL_dout_occ, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                           float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
+                           float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc, void *workspace,
+                           size_t workspace_bytes, void *stream_)
+{
+    if (!dL_dout_occ || !dL_docc) { set_error("soar_rast_backward_occ: dL_dout_occ / dL_docc must not be NULL"); return 1; }
+    return backward_impl(prm, means3D, radii, shs, colors_precomp, scales, rotations, cov3D_precomp, geom_buffer, binning_buffer, image_buffer,
+                         num_rendered, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, nullptr, dL_dmeans2D, dL_dcolors,
+                         dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos, workspace,
+                         workspace_bytes, dL_dout_occ, dL_docc, stream_);
 }
 
 int soar_rast_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -47,6 +47,13 @@ struct BwdArgs {
     double *acc64;                   // order-insensitive mode: float64 accumulation rows (same layout)
     const uint64_t *masks;           // BinBuf::block_masks (rast_blockmask.hip)
     size_t mask_plane;
+    // the fused occlusion chain walked back to front in the same pass (OCC): upstream gradient of the occlusion image [3,H,W], the
+    // entries' camera-facing flags, what the forward left of the chain per pixel, and the per-Gaussian sums (zeroed by the caller)
+    const float *dL_docc_img;
+    const float *front;
+    const float *final_To;
+    const uint32_t *n_contrib_o;
+    float *g_values;
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
@@ -204,6 +211,41 @@ __device__ __forceinline__ PairProducts affine_scan_with_products(float &m, floa
         : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
     return o;
 }
+// ... and with the running product of a second chain's factors (the occlusion chain: mo) carried through the same six steps
+__device__ __forceinline__ PairProducts affine_scan_with_products_occ(float &m, float &b, float &mo, float dx, float dy, float A, float B, float C)
+{
+    PairProducts o;
+    asm volatile(
+        "v_mul_f32 %2, %9, %9\n\t"
+        "v_mul_f32 %3, %9, %10\n\t"
+        "v_rcp_f32 %7, %1\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %4, %10, %10\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %5, %11, %9\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %6, %13, %10\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32 %5, %12, %10\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_fmac_f32 %6, %12, %9\n\t"
+        "v_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om), "+v"(mo)
+        : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    return o;
+}
 // device self-test of affine_scan (soar_selftest_affine_scan): out[lane] = {m, b} of the scan of known maps
 __global__ void selftest_affine_scan_kernel(const float *m_in, const float *b_in, float *out)
 {
@@ -240,9 +282,9 @@ struct BlockWalk {           // descending walk over the 64-position groups of a
     uint32_t base;           // list position of bit 0 of `rem`
 };
 
-template <bool WIDE>
-__device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[4], uint32_t *ring,
-                                               float *xpose, uint32_t *xgid)
+template <bool WIDE, bool OCC>
+__device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
+                                               float *xpose, uint32_t *xgid, float *xocc, uint32_t *xgid_o)
 {
     const int lane = threadIdx.x & 63;
     // tile and list range in ONE load (ImageBuf::order_rec; ranks below n_work are tiles with work)
@@ -272,19 +314,33 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 
     PixelConsts c;
     PixelState st;
+    // OCC: the occlusion chain of the pixel -- what is left of its transmittance, its last contributor, the upstream gradient of its
+    // three (equal) channels; asked for together with the rest
+    float To_final = 0.f, G_occ = 0.f;
+    uint32_t last_o = 0u;
+    if (OCC) {
+        const size_t hw = (size_t)a.H * a.W, pix = inside ? (size_t)a.W * py + px : 0;
+        const float g0 = a.dL_docc_img[pix], g1 = a.dL_docc_img[hw + pix], g2 = a.dL_docc_img[2 * hw + pix];
+        const float tf = a.final_To[pix];
+        const uint32_t lo = a.n_contrib_o[pix];
+        last_o = inside ? lo : 0u;
+        To_final = tf;
+        G_occ = last_o != 0u ? (g0 + g1) + g2 : 0.f;
+    }
     load_pixel_at_once(a, px, py, inside, c, st);
-    const uint32_t vLast = c.last;
-    const uint32_t deepest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vLast));
+    const uint32_t vLast = OCC ? max(c.last, last_o) : c.last;       // how deep the pixel's walk starts (the occlusion chain skips the
+    const uint32_t deepest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vLast));     // back-facing entries: it may outlive the main one)
     if (deepest == 0u) return;
     set_wave_priority_by_length(deepest);
     if (lane < 16) {
         pixc[lane][0] = make_float4(c.fx, c.fy, c.dC0, c.dC1);
         pixc[lane][1] = make_float4(c.dC2, c.dN0, c.dN1, c.dN2);
-        pixc[lane][2] = make_float4(c.dD, c.dD_ch, c.norm_depth_k + c.tail, __uint_as_float(vLast));
+        pixc[lane][2] = make_float4(c.dD, c.dD_ch, c.norm_depth_k + c.tail, __uint_as_float(c.last));
         // the pixel's running state: transmittance behind / blend of everything behind . upstream gradient -- read back by every lane
         // when the pixel's turn comes in a batch, rewritten by lane 63 at the end of it (four register-to-scalar moves, a compare and
         // two selects per step when it lived in the lanes' registers)
-        pixc[lane][3] = make_float4(st.T, 0.f, 0.f, 0.f);
+        pixc[lane][3] = make_float4(st.T, 0.f, To_final, __uint_as_float(last_o));
+        if (OCC) pixc[lane][4] = make_float4(G_occ, 0.f, 0.f, 0.f);
     }
     const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
@@ -340,6 +396,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     float ex = 0.f, ey = 0.f, eA = 0.f, eB = 0.f, eC = 0.f, eop = 0.f, edepth = 0.f, epa = 0.f, epb = 0.f;
     float er = 0.f, eg = 0.f, eb = 0.f, enx = 0.f, eny = 0.f, enz = 0.f;
     uint32_t egid = 0u, epos = 0xFFFFFFFFu;      // position relative to the start of the list; 0xFFFFFFFF: no entry in this lane
+    float efront = 0.f, rfront = 0.f;            // OCC: 1 = camera-facing (an entry of the occlusion chain)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     uint32_t rgid = 0u, rpos = 0xFFFFFFFFu;
     uint32_t ngid = 0u, npos = 0xFFFFFFFFu;      // ids of the batch after that
@@ -360,6 +417,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         if (rpos != 0xFFFFFFFFu) {
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + rgid);
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+            if (OCC) rfront = a.front[rgid];
         }
     };
     auto flush_atomics = [&]() {
@@ -375,6 +433,10 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 else atomicAdd(a.acc + (size_t)g * ACC_STRIDE + q, v);
             }
         }
+        if (OCC) {
+            const float v = xocc[lane];
+            if (v != 0.f) atomicAdd(a.g_values + xgid_o[lane], v);
+        }
     };
 
     // fill the pipeline: batch 0 in (r), batch 1's ids in (n)
@@ -389,6 +451,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         ex = r0.x; ey = r0.y; eA = r0.z; eB = r0.w; eC = r1.x; eop = r1.y; edepth = r1.z; epa = r1.w;
         epb = r2.x; er = r2.y; eg = r2.z; eb = r2.w; enx = r3.x; eny = r3.y; enz = r3.z;
         egid = rgid; epos = rpos; cnt_e = cnt_r;
+        if (OCC) efront = rfront;
         if (cnt_e == 0) break;
         // the sums of the batch before leave now, in front of this step's gathers
         if (pending) flush_atomics();
@@ -406,12 +469,13 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         for (int q = 0; q < 13; q++) acc[q] = 0.f;
         float sdD = 0.f;
         float any_live = 0.f;                    // > 0: some pair of this lane's entry was live
+        float acc_o = 0.f;                       // OCC: sum over the pixels of weight x upstream gradient of this lane's entry
         const float oh = -0.5f * eop;
         while (act) {
             const int p = __builtin_ctz(act);
             act &= act - 1u;
             const float4 c0 = pixc[p][0], c1 = pixc[p][1], c2 = pixc[p][2];
-            const float2 tp = *reinterpret_cast<const float2 *>(&pixc[p][3]);
+            const float4 tp = pixc[p][3];
             const uint32_t last_p = __float_as_uint(c2.w);
             const float T_in = tp.x, P_in = tp.y;
             const float dx = ex - c0.x, dy = ey - c0.y;
@@ -422,6 +486,12 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             // scalar mask instructions
             float a_eff = (power > 0.0f) ? 0.f : alpha;
             a_eff = (alpha < 1.0f / 255.0f) ? 0.f : a_eff;
+            // OCC: the occlusion chain sees the camera-facing entries in front of ITS last contributor
+            float a_o = 0.f, m_o = 1.f;
+            if (OCC) {
+                a_o = (epos < __float_as_uint(tp.w)) ? a_eff * efront : 0.f;
+                m_o = 1.f - a_o;
+            }
             a_eff = (epos < last_p) ? a_eff : 0.f;
             const bool live = a_eff != 0.f;
             const float G = live ? Gx : 0.f;
@@ -431,7 +501,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #if SOAR_BWD_DIV
             const float om = m;
 #endif
-            const PairProducts pp = affine_scan_with_products(m, b, dx, dy, eA, eB, eC);
+            const PairProducts pp = OCC ? affine_scan_with_products_occ(m, b, m_o, dx, dy, eA, eB, eC) : affine_scan_with_products(m, b, dx, dy, eA, eB, eC);
             const float P_front = __builtin_fmaf(m, P_in, b);
 #if SOAR_BWD_DIV == 2
             // the reference divides (backward.cu:683, :791): IEEE quotients instead of v_rcp_f32 (1 ulp) x multiply
@@ -464,7 +534,14 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             acc[5] = __builtin_fmaf(G, dL_dalpha, acc[5]);                               // :854
             sdD += live ? c2.x : 0.f;                                                    // :839-840: - dL_dpixD plane_(a, b)
             any_live += a_eff;                                                           // (a_eff >= 0: > 0 iff some pair was live)
-            if (lane == 63) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
+            if (OCC) {
+                // transmittance of the occlusion chain in front of my entry: T_in / (the factors behind and at it), like T_mine
+                const float To_mine = tp.z * __builtin_amdgcn_rcpf(m_o);
+                acc_o = __builtin_fmaf(a_o * To_mine, pixc[p][4].x, acc_o);
+                if (lane == 63) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(T_mine, P_front, To_mine, tp.w);
+            } else {
+                if (lane == 63) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
+            }
         }
         // the batch's sums -> LDS, [entry][13]; they leave at the start of the next step
         acc[0] = acc[0] * two_ddelx - sdD * epa;
@@ -473,6 +550,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #pragma unroll
         for (int q = 0; q < 13; q++) xpose[lane * 13 + q] = acc[q];
         xgid[lane] = any_live != 0.f ? egid : 0xFFFFFFFFu;
+        if (OCC) { xocc[lane] = acc_o; xgid_o[lane] = egid; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -489,21 +567,37 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #endif
 // one wavefront per workgroup: a finished block frees its slot at once.  Grid = 16 x ranks; the 16 blocks of a tile are
 // consecutive workgroups of one XCD (its L2 holds the tile's records), ranks dealt round-robin to the XCDs.
-template <bool WIDE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)
+template <bool WIDE, bool OCC>
+__device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
 {
-    __shared__ float4 pixc[16][4];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last | T, P, -, -}
+    __shared__ float4 pixc[16][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
+                                                         //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
     __shared__ float xpose[WAVE * 13];                   // a batch's sums, [entry][13]
     __shared__ uint32_t xgid[WAVE];
-    int frame, bx;
-    batch_interleave(frame, bx);
-    const BwdArgs &a = batch.v[frame];
+    __shared__ float xocc[OCC ? WAVE : 1];               // ... and of the occlusion values' gradient
+    __shared__ uint32_t xgid_o[OCC ? WAVE : 1];
     const int xcd = bx & 7, kth = bx >> 3;
     const int rank0 = (kth >> 4) * 8 + xcd, blk = kth & 15;
     const int stride = (int)(gridDim.x >> 4);                // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
-    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE>(a, rank, blk, pixc, ring, xpose, xgid);
+    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, xpose, xgid, xocc, xgid_o);
+}
+template <bool WIDE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)
+{
+    int frame, bx;
+    batch_interleave(frame, bx);
+    backward_blocks<WIDE, false>(batch.v[frame], bx);
+}
+// ... with the fused occlusion chain walked in the same pass (soar_rast_backward_occ): a few registers more than the 128 that four
+// wavefronts per SIMD allow
+template <bool WIDE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) render_backward_blocks_occ_kernel(Batch<BwdArgs> batch)
+{
+    int frame, bx;
+    batch_interleave(frame, bx);
+    backward_blocks<WIDE, true>(batch.v[frame], bx);
 }
 
 }  // namespace
@@ -521,9 +615,12 @@ __global__ void narrow_rows_kernel(Batch<NarrowArgs> batch)
 
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
-                           const float *grad_scale, float *acc, double *acc64, bool blend, hipStream_t stream)
+                           const float *grad_scale, float *acc, double *acc64, bool blend, const float *dL_dout_occ, float *dL_docc,
+                           hipStream_t stream)
 {
     BwdArgs a;
+    a.dL_docc_img = dL_dout_occ; a.front = g.front; a.final_To = img.final_To; a.n_contrib_o = img.n_contrib_o; a.g_values = dL_docc;
+    const bool occ = dL_dout_occ != nullptr;
     a.grad_scale = grad_scale;
     a.W = prm.W; a.H = prm.H;
     a.gx = (prm.W + TILE - 1) / TILE; a.gy = (prm.H + TILE - 1) / TILE;
@@ -538,14 +635,16 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     a.masks = b.block_masks; a.mask_plane = b.mask_plane;
     const dim3 grid_blocks(16 * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
-        if (blend) SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
+        if (blend && occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
+        else if (blend) SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
         // in a batch this launches with the last frame like the blend in front of it (it used to launch per call, i.e. for
         // the frames 0 .. n-2 BEFORE their rows had been accumulated)
         NarrowArgs na;
         na.n = (size_t)prm.P * ACC_STRIDE; na.wide = acc64; na.narrow = acc;
         SOAR_LAUNCH_BATCHED(narrow_rows_kernel, dim3((unsigned)((na.n + 255) / 256)), dim3(256), 0, stream, na);
     } else {
-        SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<false>), grid_blocks, dim3(64), 0, stream, a);
+        if (occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<false>), grid_blocks, dim3(64), 0, stream, a);
+        else SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<false>), grid_blocks, dim3(64), 0, stream, a);
     }
     SOAR_LAUNCH_OK("render_backward", stream, prm.debug & 1);
     return 0;

@@ -61,6 +61,8 @@ struct FwdArgs {
     uint32_t *bg_tiles;              // ImageBuf::bg_tiles
     const uint32_t *bg_state;        // ImageBuf::bg_state
     int keep_background;             // SoarRastParams.debug bit 2
+    float *final_To;                 // ImageBuf::final_To / n_contrib_o (OCC): what the backward blend needs to walk the occlusion
+    uint32_t *n_contrib_o;           // chain back to front (soar_rast_backward_occ)
     unsigned long long *wave_log;    // diagnostic build only (SOAR_WAVE_LOG): per wave {t_start, t_end, list length, iterations}
     // BinBuf::block_masks (rast_blockmask.hip describes the layout): phase A's survivor word of every 64 list positions a block's
     // wavefront tests is what the backward blend walks -- left behind here instead of being derived again by a pass of its own
@@ -186,6 +188,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     float T = 1.0f;                                  // replicated in the four lanes of a pixel
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;   // per-slot partial sums
     uint32_t last_contributor = 0;                   // per-slot, folded with max at the end
+    uint32_t last_contributor_o = 0;                 // the occlusion chain's
     // 1 while the pixel blends, 0 once it has stopped (replicated in its four lanes).  Kept as a number, not a predicate:
     // a per-lane bool that lives across the loop becomes a 64-bit mask in scalar registers, merged with three scalar
     // instructions at every join -- and one SIMD issues a scalar instruction only every ~4 cycles, half the vector rate
@@ -399,7 +402,10 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     N1 = __builtin_fmaf(q3.y, w, N1);
                     N2 = __builtin_fmaf(q3.z, w, N2);
                     last_contributor = blend ? contrib16 + j16 : last_contributor;        // (x 16: see contrib16)
-                    if (OCC) Co = __builtin_fmaf(e4.x, w_o, Co);
+                    if (OCC) {
+                        Co = __builtin_fmaf(e4.x, w_o, Co);
+                        last_contributor_o = (w_o != 0.f) ? contrib16 + j16 : last_contributor_o;
+                    }
                     if (some_stop && __ballot(alive + alive_o != 0.f) == 0ull) { wave_done = true; break; }
                 }
                 if (wave_done) break;
@@ -425,7 +431,12 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR1>(last_contributor));
     last_contributor = max(last_contributor, quad_move_u<DPP_QUAD_XOR2>(last_contributor));
     last_contributor >>= 4;                          // (kept x 16 in the loop)
-    if (OCC) { Co += quad_move<DPP_QUAD_XOR1>(Co); Co += quad_move<DPP_QUAD_XOR2>(Co); }
+    if (OCC) {
+        Co += quad_move<DPP_QUAD_XOR1>(Co); Co += quad_move<DPP_QUAD_XOR2>(Co);
+        last_contributor_o = max(last_contributor_o, quad_move_u<DPP_QUAD_XOR1>(last_contributor_o));
+        last_contributor_o = max(last_contributor_o, quad_move_u<DPP_QUAD_XOR2>(last_contributor_o));
+        last_contributor_o >>= 4;
+    }
 
     if (inside && slot == 0) {
         // epilogue, forward.cu:618-633
@@ -445,6 +456,8 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         if (a.normalize_depth) a.final_D[pix] = D;
         if (OCC) {
             T_o = fminf((float)(1 - 0.000001), T_o);
+            a.final_To[pix] = T_o;
+            a.n_contrib_o[pix] = last_contributor_o;
             a.out_occ[pix] = Co + T_o * a.bg[0];
             a.out_occ[hw + pix] = Co + T_o * a.bg[1];
             a.out_occ[2 * hw + pix] = Co + T_o * a.bg[2];
@@ -703,6 +716,7 @@ int launch_render_forward(const SoarRastParams &prm, const GeomBuf &g, const Bin
     a.final_T = img.final_T; a.final_D = img.final_D; a.n_contrib = img.n_contrib;
     a.out_color = out_color; a.out_normal = out_normal; a.out_depth = out_depth; a.out_opac = out_opac;
     a.occ_values = occ_values; a.front = g.front; a.out_occ = out_occ;
+    a.final_To = img.final_To; a.n_contrib_o = img.n_contrib_o;
     a.bg_tiles = img.bg_tiles; a.bg_state = img.bg_state; a.keep_background = (prm.debug & 4) ? 1 : 0;
     a.wave_log = nullptr;
     a.masks = reinterpret_cast<unsigned long long *>(b.block_masks); a.mask_plane = b.mask_plane;

@@ -184,6 +184,8 @@ struct ImageBuf {
     uint32_t *bg_tiles;      // [T] 1: every output plane of the tile holds the background values of the last forward blend.
                              // One 32-bit word per tile, written with agent-scope stores: workgroups on different XCDs (one L2
                              // each) update neighbouring tiles in the same launch, and narrower flags sharing a word lost updates
+    float *final_To;         // [pix] the fused occlusion chain's final transmittance and last contributor (list position + 1) -- what
+    uint32_t *n_contrib_o;   // [pix] the occlusion pass's own final_T / n_contrib would hold; written by the forward blend with OCC only
     size_t total_bytes;
 };
 struct BinBuf {
@@ -442,7 +444,8 @@ int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBu
                         float *dL_docc, hipStream_t stream);
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
-                           const float *grad_scale, float *acc, double *acc64, bool blend, hipStream_t stream);
+                           const float *grad_scale, float *acc, double *acc64, bool blend, const float *dL_dout_occ, float *dL_docc,
+                           hipStream_t stream);
 int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, const int32_t *radii, const float *shs,
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,

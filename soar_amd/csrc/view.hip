@@ -264,6 +264,14 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
         live[v] = a.g_render || a.g_normal || a.g_depth || a.g_pred_normal || a.g_mask || a.g_curv;
         n_live += live[v] ? 1 : 0;
     }
+    // a front view's occlusion image came out of its main pass's blend: the backward blend takes that chain along (soar_rast_backward_occ)
+    const bool occ_grad = pose->dL_docc != nullptr;
+    bool fused_occ[MAX_BATCH];
+    int n_fused = 0;
+    for (int v = 0; v < n_views; v++) {
+        fused_occ[v] = occ_grad && views[v].g_occ && !views[v].back && live[v];
+        n_fused += fused_occ[v] ? 1 : 0;
+    }
     auto plane = [](const SoarViewArgs &a, int k) { return a.out + (size_t)k * a.rast.W * a.rast.H; };
     // a view none of whose images was used contributes nothing: its blocks are zeroed instead of computed
     auto zero_view = [&](int v) -> int {
@@ -288,6 +296,12 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
                 if (!g_opac) g_opac = vb[v].zero4 + 3 * pix;
             }
             float *junk = Gjunk + 7 * (size_t)v * P, *cam = Gcam + 35 * (size_t)v;
+            if (fused_occ[v])
+                return soar_rast_backward_occ(&a.rast, xyz_p, a.radii, nullptr, pose->colors, scales3, rot_p, nullptr, vb[v].geom, vb[v].binning,
+                                              vb[v].img, a.capacity, g_color, vb[v].g_nd, vb[v].g_nd + 3 * pix, g_opac, a.g_occ, a.dL_dmeans2D,
+                                              Gc + 3 * (size_t)v * P, junk, Gx + 3 * (size_t)v * P, junk + P, nullptr, Gs + 3 * (size_t)v * P,
+                                              Gr + 4 * (size_t)v * P, cam, cam + 16, cam + 32, Go + (size_t)v * P, vb[v].work,
+                                              vb[v].work_bytes, stream_);
             return soar_rast_backward(&a.rast, xyz_p, a.radii, nullptr, pose->colors, scales3, rot_p, nullptr, vb[v].geom, vb[v].binning,
                                       vb[v].img, a.capacity, g_color, vb[v].g_nd, vb[v].g_nd + 3 * pix, g_opac, a.dL_dmeans2D,
                                       Gc + 3 * (size_t)v * P, junk, Gx + 3 * (size_t)v * P, junk + P, nullptr, Gs + 3 * (size_t)v * P,
@@ -296,7 +310,7 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
         }
     };
     int rc = 0;
-    if (batched && n_live == n_views) {
+    if (batched && n_live == n_views && (n_fused == 0 || n_fused == n_views)) {        // (one kernel per launch site: all or none fused)
         if (soar_batch_begin(n_views)) return 1;
         for (int s = 0; s < 2 && !rc; s++)
             for (int v = 0; v < n_views && !rc; v++) rc = soar_batch_frame(v) || stage(s, v);
@@ -308,10 +322,10 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
         }
     }
     if (rc) return rc;
-    // the occlusion image came out of the main pass's blend: one more walk of its lists for dL/docc (soar_rast_occ_backward)
-    const bool occ_grad = pose->dL_docc != nullptr;
+    // the occlusion gradients the backward blends above did not take along
     for (int v = 0; v < n_views && occ_grad; v++) {
         const SoarViewArgs &a = views[v];
+        if (fused_occ[v]) continue;
         if (a.g_occ && a.back) {
             // that occlusion pass saw detached geometry (:281-291): only its colours = occ.repeat(1, 3) carry gradient.  A full
             // backward of the pass with zero normal / depth / opacity gradients; what it leaves in the colour block [P][3] is summed
@@ -330,7 +344,7 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
             SumColsArgs sc = {P, gc3, Go + (size_t)v * P};
             hipLaunchKernelGGL(sum_cols3_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, sc);
             SOAR_LAUNCH_OK("sum_cols3", stream, 0);
-        } else if (a.g_occ) {
+        } else if (a.g_occ) {                            // (a view whose other images went unused: one walk of its lists for the chain alone)
             if (soar_rast_occ_backward(&a.rast, vb[v].geom, vb[v].binning, vb[v].img, a.capacity, a.g_occ, Go + (size_t)v * P, stream_)) return 1;
         } else {
             SOAR_HIP_OK(hipMemsetAsync(Go + (size_t)v * P, 0, sizeof(float) * P, stream));

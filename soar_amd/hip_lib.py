@@ -89,6 +89,8 @@ SIGNATURES = {
                            + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_backward_scaled": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 5
                                   + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
+    "soar_rast_backward_occ": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 5
+                               + [_vp] * 12 + [_vp, C.c_size_t, _vp]),
     "soar_batch_begin": (C.c_int, [C.c_int32]),
     "soar_batch_frame": (C.c_int, [C.c_int32]),
     "soar_batch_end": (C.c_int, []),

@@ -275,11 +275,6 @@ class FrameStepPlan:
         # the frame's loss value (device side): terms . coef + lambda_occ mean(1 - occ[mask])
         torch.add(torch.dot(v["terms"], up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
 
-    def _f_occ_backward(self, i: int, stream: int) -> None:
-        v = self.views[i]
-        check(self.L.soar_rast_occ_backward(C.byref(self.ctx.params), ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]), self.capacity,
-                                            ptr(v["g_occ_img"]), ptr(self.g_occ_all[i]), stream), "soar_rast_occ_backward")
-
     def _leaf_signature(self):
         s = self.seq
         return tuple((t.data_ptr(), tuple(t.shape)) for t in (s.xyz, s.rot, s.scales, s.colors, s.occ))
@@ -387,6 +382,20 @@ class FrameStepPlan:
                                            ptr(v["work"]), v["work"].numel(), stream), "backward")
         self._call(("backward", i, stream), build)
 
+    def _f_backward_occ(self, i: int, stream: int) -> None:
+        """the rasterizer backward with the fused occlusion chain taken along (soar_rast_backward_occ): dL/docc of the frame without a
+        walk of its own"""
+        def build():
+            L, s, v = self.L, self.seq, self.views[i]
+            return (L.soar_rast_backward_occ, (C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
+                                               ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
+                                               self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_occ_img"]),
+                                               ptr(v["g_means2D"]), ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]),
+                                               ptr(v["g_cov3D"]), None, ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]),
+                                               ptr(v["g_proj"]), ptr(v["g_campos"]), ptr(self.g_occ_all[i]), ptr(v["work"]), v["work"].numel(),
+                                               stream), "backward_occ")
+        self._call(("backward_occ", i, stream), build)
+
     def _frame(self, i: int, stream: int) -> None:
         """forward and backward of frame i: a straight line of launches on one stream"""
         self._stamp(2 + 2 * i, stream)
@@ -394,8 +403,7 @@ class FrameStepPlan:
             self._f_geometry(i, stream)
             self._f_render(i, stream)
             self._f_avatar_loss(i, self._frames_now[i], stream)
-            self._f_backward(i, stream)
-            self._f_occ_backward(i, stream)
+            self._f_backward_occ(i, stream)
             self._stamp(3 + 2 * i, stream)
             return
         for k, stage in enumerate((self._f_geometry, self._f_render, self._f_loss, self._f_backward)):
@@ -424,7 +432,7 @@ class FrameStepPlan:
         if self.loss_kind == "avatar":
             from .losses import _AvatarStageLoss as S
             batch((self._f_geometry, self._f_render) + tuple(getattr(self, name) for name in self.AV_FORWARD + self.AV_BACKWARD) +
-                  (self._av_finish_b, self._f_backward, self._f_occ_backward))
+                  (self._av_finish_b, self._f_backward_occ))
             # the frames' loss values: terms . coef + lambda_occ mean(1 - occ[mask])
             if len(frames) == self.n:
                 torch.addmv(self.av_occ_terms_all[:, 0] * self.av_occ_up[0], self.av_terms_all, self.av_coef, out=self.losses)
