@@ -213,6 +213,7 @@ int soar_rast_backward_occ(const SoarRastParams *prm,
                            int64_t num_rendered,
                            const float *dL_dout_color, const float *dL_dout_normal,
                            const float *dL_dout_depth, const float *dL_dout_opac, const float *dL_dout_occ,
+                           const float *normal_scale_dev,   /* optional device scalar dL_dout_normal is multiplied by on load */
                            float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D,
                            float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
                            float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc,
@@ -400,6 +401,13 @@ typedef struct SoarAvatarLossArgs {
     const float *up_l1, *up_l1m, *up_cos, *up_occ, *up_ssim;
     const float *g_ssim;                         /* [3,H,W] or NULL */
     float *g_render, *g_mask, *g_normal, *g_occ; /* [3,H,W], [1,H,W], [3,H,W], [3,H,W] */
+    /* normal_raw != 0: `normal` still is the plugin's normal' = (n (1,-1,-1) + 1) / 2, but g_normal leaves as the gradient of the
+     * rasterizer's n (x 0.5, signs, zero where mask_img -- the opacity image -- is <= 1e-5: what soar_view_finish_backward makes of
+     * dL/dnormal' alone).  cos_scale_out (mode 3 with counts only): the cosine term's gradient leaves without its factor
+     * upstream / count, which is written here when the pass ends -- for a consumer that multiplies on load
+     * (soar_rast_backward_occ's normal_scale_dev): value and gradient of every term in ONE pass over the images. */
+    int32_t normal_raw, pad_;
+    float *cos_scale_out;
 } SoarAvatarLossArgs;
 int soar_avatar_loss_scratch_floats(size_t *count);
 int soar_avatar_pixel_losses(const SoarAvatarLossArgs *args, int32_t mode, void *stream);

@@ -194,6 +194,13 @@ struct AvatarArgs {
     const float *up_l1, *up_l1m, *up_cos, *up_occ; // device scalars (null: 1)
     const float *g_ssim, *up_ssim;                 // optional
     float *g_render, *g_mask, *g_normal, *g_occ;
+    // normal_raw: g_normal is the gradient of the RASTERIZER's normal image, not of the plugin's normal' = (normal (1,-1,-1) + 1) / 2
+    // inside opacity > 1e-5 (TS/renderer/diff_gaussian_rasterizer.py:292-296; mask_img is that opacity): x 0.5, signs, mask -- exact
+    // factors, the values soar_view_finish_backward would make of it.  cos_scale_out: the cosine term's gradient leaves WITHOUT its
+    // factor upstream / count -- the count is only known when the pass ends -- and the factor is left there for the consumer
+    // (soar_rast_backward_occ multiplies the normal gradient by it on load): value and gradient of all terms in one pass.
+    int normal_raw;
+    float *cos_scale_out;
 };
 
 template <bool VALUES, bool GRADS>
@@ -206,10 +213,10 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
     if (GRADS) {
         auto up = [](const float *p) { return p ? *p : 1.f; };
         const float c_l1 = a.counts ? a.counts[0] : a.stats[1], c_l1m = a.counts ? a.counts[1] : a.stats[3];
-        const float c_cos = a.counts ? a.counts[2] : a.stats[5];
+        const float c_cos = a.cos_scale_out ? 1.f : (a.counts ? a.counts[2] : a.stats[5]);
         sc_l1 = up(a.up_l1) / fmaxf(c_l1 * 3.f, 1.f);
         sc_l1m = up(a.up_l1m) / fmaxf(c_l1m * 1.f, 1.f);
-        sc_cos = up(a.up_cos) / fmaxf(c_cos, 1.f);
+        sc_cos = a.cos_scale_out ? 1.f : up(a.up_cos) / fmaxf(c_cos, 1.f);
         if (a.occ) sc_occ = up(a.up_occ) / fmaxf((a.counts ? a.counts[3] : a.stats_occ[1]) * 3.f, 1.f);
         if (a.g_ssim) k_ssim = up(a.up_ssim);
     }
@@ -241,9 +248,12 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
             if (GRADS) reinterpret_cast<float4 *>(a.g_render + c * n)[p] = pack(g);
         }
         // ---- mask image (every pixel)
+        bool opaque[V];                                // the plugin's mask: opacity > 1e-5
         {
             float x[V], y[V], g[V];
             unpack(reinterpret_cast<const float4 *>(a.mask_img)[p], x);
+#pragma unroll
+            for (int k = 0; k < V; k++) opaque[k] = x[k] > 1e-5f;
             unpack(reinterpret_cast<const float4 *>(a.gt_mask)[p], y);
 #pragma unroll
             for (int k = 0; k < V; k++) {
@@ -277,7 +287,13 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
                 for (int c = 0; c < 3; c++) {
                     float g[V];
 #pragma unroll
-                    for (int k = 0; k < V; k++) g[k] = seln[k] ? -2.f * a.cos_weight * (gt[c][k] * 2.f - 1.f) * sc_cos : 0.f;
+                    for (int k = 0; k < V; k++) {
+                        g[k] = seln[k] ? -2.f * a.cos_weight * (gt[c][k] * 2.f - 1.f) * sc_cos : 0.f;
+                        if (a.normal_raw) {
+                            const float h = g[k] * 0.5f;
+                            g[k] = opaque[k] ? (c == 0 ? h : -h) : 0.f;
+                        }
+                    }
                     reinterpret_cast<float4 *>(a.g_normal + c * n)[p] = pack(g);
                 }
         }
@@ -313,6 +329,8 @@ struct AvatarFinishArgs {
     const float *partials;
     int nblocks;
     float *stats, *stats_occ;
+    const float *up_cos;
+    float *cos_scale_out;
 };
 // {sum / (count * channels), count} of the four terms (an empty selection gives NaN like the reference's mean of an empty tensor)
 __global__ void __launch_bounds__(256) avatar_finish_kernel(Batch<AvatarFinishArgs> batch)
@@ -337,6 +355,7 @@ __global__ void __launch_bounds__(256) avatar_finish_kernel(Batch<AvatarFinishAr
         const float per = (t == 0 || t == 3) ? 3.f : 1.f;
         float *dst = t < 3 ? fa.stats + 2 * t : fa.stats_occ;
         if (dst) { dst[0] = st / (ct * per); dst[1] = ct; }
+        if (t == 2 && fa.cos_scale_out) *fa.cos_scale_out = (fa.up_cos ? *fa.up_cos : 1.f) / fmaxf(ct, 1.f);
     }
 }
 
@@ -443,6 +462,10 @@ extern "C" int soar_avatar_pixel_losses(const SoarAvatarLossArgs *q, int32_t mod
     if ((q->occ == nullptr) != (q->sel_occ == nullptr)) { set_error("soar_avatar_pixel_losses: occ and sel_occ go together"); return 1; }
     if (values && (!q->stats || !q->scratch || (q->occ && !q->stats_occ))) { set_error("soar_avatar_pixel_losses: stats and scratch are needed for the values"); return 1; }
     if (grads && (!q->g_render || !q->g_mask || !q->g_normal || (q->occ && !q->g_occ))) { set_error("soar_avatar_pixel_losses: a gradient plane is NULL"); return 1; }
+    if (q->cos_scale_out && !(values && grads && q->counts)) {
+        set_error("soar_avatar_pixel_losses: cos_scale_out belongs to the one-pass form (mode 3 with counts)");
+        return 1;
+    }
     if (grads && !q->counts && (values || !q->stats || (q->occ && !q->stats_occ))) {
         set_error("soar_avatar_pixel_losses: gradients need the counts -- from a values pass before (stats), or given (counts) for the one-pass form");
         return 1;
@@ -464,13 +487,14 @@ extern "C" int soar_avatar_pixel_losses(const SoarAvatarLossArgs *q, int32_t mod
     a.partials = q->scratch; a.stats = q->stats; a.stats_occ = q->stats_occ; a.counts = q->counts;
     a.up_l1 = q->up_l1; a.up_l1m = q->up_l1m; a.up_cos = q->up_cos; a.up_occ = q->up_occ; a.g_ssim = q->g_ssim; a.up_ssim = q->up_ssim;
     a.g_render = q->g_render; a.g_mask = q->g_mask; a.g_normal = q->g_normal; a.g_occ = q->g_occ;
+    a.normal_raw = q->normal_raw; a.cos_scale_out = q->cos_scale_out;
     const int blocks = min(LOSS_BLOCKS, (a.n / 4 + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
     if (values && grads) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);
     else if (values) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, a);
     else SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, a);
     if (values) {
-        const AvatarFinishArgs fa = {q->scratch, blocks, q->stats, q->stats_occ};
+        const AvatarFinishArgs fa = {q->scratch, blocks, q->stats, q->stats_occ, q->up_cos, q->cos_scale_out};
         SOAR_LAUNCH_BATCHED(avatar_finish_kernel, dim3(1), dim3(256), 0, stream, fa);
     }
     SOAR_LAUNCH_OK("avatar_pixel_losses", stream, 0);

@@ -43,6 +43,7 @@ struct BwdArgs {
     const uint32_t *n_contrib;
     const float *dL_dcolor, *dL_dnormal, *dL_ddepth, *dL_dopac;
     const float *grad_scale;         // optional device scalar the four image gradients are multiplied by
+    const float *normal_scale;       // optional device scalar for the normal image's gradient alone (soar_rast_backward_occ)
     float *acc;
     double *acc64;                   // order-insensitive mode: float64 accumulation rows (same layout)
     const uint64_t *masks;           // BinBuf::block_masks (rast_blockmask.hip)
@@ -100,7 +101,8 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
     const float T_final = inside ? Tf : 0.f;
     const float D_final = inside ? Df : 0.f;
     c.dC0 = on ? gs * g0 : 0.f; c.dC1 = on ? gs * g1 : 0.f; c.dC2 = on ? gs * g2 : 0.f;
-    c.dN0 = on ? gs * n0 : 0.f; c.dN1 = on ? gs * n1 : 0.f; c.dN2 = on ? gs * n2 : 0.f;
+    const float gn = a.normal_scale ? *a.normal_scale : 1.f;
+    c.dN0 = on ? gs * (gn * n0) : 0.f; c.dN1 = on ? gs * (gn * n1) : 0.f; c.dN2 = on ? gs * (gn * n2) : 0.f;
     c.dD = on ? gs * gd : 0.f;
     const float dO = on ? gs * go : 0.f;
     const float bg_dot = a.bg[0] * c.dC0 + a.bg[1] * c.dC1 + a.bg[2] * c.dC2;     // :798-800
@@ -616,9 +618,10 @@ __global__ void narrow_rows_kernel(Batch<NarrowArgs> batch)
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
                            const float *grad_scale, float *acc, double *acc64, bool blend, const float *dL_dout_occ, float *dL_docc,
-                           hipStream_t stream)
+                           const float *normal_scale, hipStream_t stream)
 {
     BwdArgs a;
+    a.normal_scale = normal_scale;
     a.dL_docc_img = dL_dout_occ; a.front = g.front; a.final_To = img.final_To; a.n_contrib_o = img.n_contrib_o; a.g_values = dL_docc;
     const bool occ = dL_dout_occ != nullptr;
     a.grad_scale = grad_scale;

@@ -196,6 +196,12 @@ class FrameStepPlan:
         coef[S.L1M], coef[S.COS] = lam["mask"], 0.2 * lam["normal"]
         self.av_coef = torch.tensor(coef, **f)                         # loss = terms . coef; also the upstream factor of every term
         self.av_occ_up = torch.tensor([lam["occ"]], **f)
+        # the selected pixels of the terms whose selection is a constant of the target (colour L1, mask L1, -, occlusion L1): with them
+        # the per-pixel terms' values AND gradients come out of one pass over the images (soar_avatar_pixel_losses mode 3); the cosine
+        # term's count depends on the render -- its gradient leaves without the factor, which the rasterizer backward applies on load
+        self.av_counts = torch.stack([self.av["sel"].reshape(n_sets, -1).sum(1).float(), torch.full((n_sets,), float(H * W), **f),
+                                      torch.zeros((n_sets,), **f), self.av["sel_occ"].reshape(n_sets, -1).sum(1).float()], dim=1).contiguous()
+        self.av_cos_scale_all = torch.zeros((self.n,), **f)
         check(L.soar_avatar_loss_scratch_floats(C.byref(k)), "soar_avatar_loss_scratch_floats")
         n_pix = int(k.value)
         self._av_args = {}
@@ -206,9 +212,9 @@ class FrameStepPlan:
         self.av_terms_all, self.av_occ_terms_all = torch.zeros((self.n, S.N), **f), torch.zeros((self.n, 2), **f)
         self.av_terms_all[:, S.ONE] = 1.0
         for i, v in enumerate(self.views):
-            g_nd = torch.empty((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] of the rasterizer's outputs
+            g_nd = torch.zeros((4, H, W), **f)                          # dL/dnormal [3] + dL/ddepth [1] (stays zero) of the rasterizer's outputs
             v.update(normal_out=torch.empty((3, H, W), **f), curv=torch.empty((1, H, W), **f), pred=torch.empty((3, H, W), **f),
-                     gC=self.av_gC_all[i], g_ssim=self.av_g_ssim_all[i], g_n=torch.empty((3, H, W), **f), g_nd=g_nd,
+                     gC=self.av_gC_all[i], g_ssim=self.av_g_ssim_all[i], g_nd=g_nd,
                      g_occ_img=torch.empty((3, H, W), **f), terms=self.av_terms_all[i], occ_terms=self.av_occ_terms_all[i],
                      av_scratch=torch.empty((max(n_loss, n_ssim),), **f), av_pix_scratch=torch.empty((n_pix,), **f))
             v["gN"], v["gD"] = g_nd[:3], g_nd[3:]                       # what the rasterizer backward reads
@@ -238,9 +244,9 @@ class FrameStepPlan:
             H=H, W=W, cos_limit=1.0, cos_weight=1.0, render=ptr(v["color"]), gt_rgb=ptr(a["rgb"][k]), mask_img=ptr(v["opac"]),
             gt_mask=ptr(a["mask"][k]), normal=ptr(v["normal_out"]), gt_normal=ptr(a["normal"][k]), occ=ptr(v["occ"]),
             sel=ptr(a["sel"][k]), sel_normal=ptr(a["sel"][k]), sel_occ=ptr(a["sel_occ"][k]), stats=at(t, S.L1), stats_occ=ptr(v["occ_terms"]),
-            scratch=ptr(v["av_pix_scratch"]), counts=None, up_l1=at(up, S.L1), up_l1m=at(up, S.L1M), up_cos=at(up, S.COS),
+            scratch=ptr(v["av_pix_scratch"]), counts=ptr(self.av_counts[k]), up_l1=at(up, S.L1), up_l1m=at(up, S.L1M), up_cos=at(up, S.COS),
             up_occ=ptr(self.av_occ_up), up_ssim=at(up, S.SSIM), g_ssim=ptr(v["g_ssim"]), g_render=ptr(v["gC"]), g_mask=ptr(v["gO"]),
-            g_normal=ptr(v["g_n"]), g_occ=ptr(v["g_occ_img"]))
+            g_normal=ptr(v["gN"]), g_occ=ptr(v["g_occ_img"]), normal_raw=1, cos_scale_out=self.av_cos_scale_all.data_ptr() + 4 * i)
 
     def _av_pixel(self, i, stream, mode):
         key = ("av_pixel", i, self._frames_now[i] % int(self.pool.shape[0]))
@@ -249,21 +255,14 @@ class FrameStepPlan:
             args = self._av_args[key] = self._av_pixel_args(i)
         check(self.L.soar_avatar_pixel_losses(C.byref(args), mode, stream), "soar_avatar_pixel_losses")
 
-    def _av_values(self, i, stream):
-        self._av_pixel(i, stream, 1)
+    def _av_onepass(self, i, stream):
+        # values and gradients of the four per-pixel terms in one pass; the colour gradient takes the SSIM term's on the way
+        # (g_render = L1 part + coef[SSIM] * g_ssim); the normal gradient leaves as the gradient of the RASTERIZER's normal image
+        # (the plugin's normal' = (n (1,-1,-1) + 1) / 2 inside the mask: exact factors -- no post-ops backward pass for it)
+        self._av_pixel(i, stream, 3)
 
-    def _av_grads(self, i, stream):
-        # (the colour gradient takes the SSIM term's on the way: g_render = L1 part + coef[SSIM] * g_ssim)
-        self._av_pixel(i, stream, 2)
-
-    def _av_finish_b(self, i, stream):
-        S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_view_finish_backward(W, H, ptr(v["normal"]), ptr(v["depth"]), ptr(v["opac"]), ptr(self.ctx.keep[3]), self.av_focal[0],
-                                          self.av_focal[1], ptr(v["g_n"]), None, None, None, ptr(v["g_nd"]), stream),
-              "soar_view_finish_backward")
-
-    AV_FORWARD = ("_av_finish", "_av_ssim", "_av_values")
-    AV_BACKWARD = ("_av_grads",)
+    AV_FORWARD = ("_av_finish", "_av_ssim", "_av_onepass")
+    AV_BACKWARD = ()
 
     def _f_avatar_loss(self, i: int, frame: int, stream: int) -> None:
         """post-ops -> SSIM, the per-pixel terms' values (one pass), their gradients (one pass) -> post-ops backward: everything
@@ -271,7 +270,6 @@ class FrameStepPlan:
         v, up = self.views[i], self.av_coef
         for name in self.AV_FORWARD + self.AV_BACKWARD:
             getattr(self, name)(i, stream)
-        self._av_finish_b(i, stream)
         # the frame's loss value (device side): terms . coef + lambda_occ mean(1 - occ[mask])
         torch.add(torch.dot(v["terms"], up), v["occ_terms"][0] * self.av_occ_up[0], out=self.losses[i])
 
@@ -390,7 +388,7 @@ class FrameStepPlan:
             return (L.soar_rast_backward_occ, (C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
                                                ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
                                                self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_occ_img"]),
-                                               ptr(v["g_means2D"]), ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]),
+                                               self.av_cos_scale_all.data_ptr() + 4 * i, ptr(v["g_means2D"]), ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]),
                                                ptr(v["g_cov3D"]), None, ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]),
                                                ptr(v["g_proj"]), ptr(v["g_campos"]), ptr(self.g_occ_all[i]), ptr(v["work"]), v["work"].numel(),
                                                stream), "backward_occ")
@@ -432,7 +430,7 @@ class FrameStepPlan:
         if self.loss_kind == "avatar":
             from .losses import _AvatarStageLoss as S
             batch((self._f_geometry, self._f_render) + tuple(getattr(self, name) for name in self.AV_FORWARD + self.AV_BACKWARD) +
-                  (self._av_finish_b, self._f_backward_occ))
+                  (self._f_backward_occ,))
             # the frames' loss values: terms . coef + lambda_occ mean(1 - occ[mask])
             if len(frames) == self.n:
                 torch.addmv(self.av_occ_terms_all[:, 0] * self.av_occ_up[0], self.av_terms_all, self.av_coef, out=self.losses)

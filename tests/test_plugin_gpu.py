@@ -1044,6 +1044,7 @@ def test_avatar_pixel_losses_in_one_pass_equal_the_separate_kernels(hw, with_occ
     render, gt_rgb, mask_img, normal, gt_normal, occ = rnd(3, H, W), rnd(3, H, W), rnd(1, H, W), rnd(3, H, W), rnd(3, H, W), rnd(3, H, W)
     gt_mask = (rnd(1, H, W) > 0.4).float() * rnd(1, H, W)
     render[:, :4] = gt_rgb[:, :4]                                   # zero differences: the sign's third case
+    mask_img[:, 12:15] = 0.0                                        # outside the plugin's mask (opacity <= 1e-5)
     occ[:, 5:9] = 1.0
     normal[:, 9:12] = gt_normal[:, 9:12] = 1.0                      # cosine 3 > the limit: dropped from the selection
     sel, sel_n, sel_o = (gt_mask[0] > 1e-5).view(torch.uint8), (rnd(H, W) > 0.3).view(torch.uint8), (gt_mask[0] > 0).view(torch.uint8)
@@ -1093,8 +1094,25 @@ def test_avatar_pixel_losses_in_one_pass_equal_the_separate_kernels(hw, with_occ
         for name, g, w in (("render", g_r, w_r), ("mask", g_m, w_m), ("normal", g_n, w_n)) + ((("occ", g_o, w_o),) if with_occ else ()):
             assert (g - w).abs().max().item() <= 1e-6 * w.abs().max().item(), name
         assert torch.equal(g_m, w_m) and torch.equal(g_n, w_n)
+    # ---- the normal gradient as the gradient of the rasterizer's normal image, the cosine term's factor left to the consumer:
+    #      g_raw x factor == what soar_view_finish_backward makes of the plugin-normal gradient above, bit for bit
+    cos_scale = torch.full((1,), float("nan"), device=DEV)
+    g_raw = torch.full_like(normal, float("nan"))
+    keep_counts = want[1::2].contiguous()
+    a.counts, a.normal_raw, a.g_normal, a.cos_scale_out = ptr(keep_counts), 1, ptr(g_raw), ptr(cos_scale)
+    check(L.soar_avatar_pixel_losses(C.byref(a), 3, stream), "one pass, raw normal gradient")
+    assert float(cos_scale) == float(ups[2] / want[5].clamp(min=1.0))
+    prcp = torch.tensor([0.5, 0.5], device=DEV)
+    depth = torch.rand(1, H, W, generator=gen).to(DEV)
+    g_nd = torch.empty(4, H, W, device=DEV)
+    check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(mask_img), ptr(prcp), 100.0, 100.0, ptr(w_n), None, None, None,
+                                      ptr(g_nd), stream), "view_finish_backward")
+    assert torch.equal(g_raw * cos_scale, g_nd[:3]) and not bool(g_nd[3].any())
+    a.normal_raw, a.cos_scale_out, a.g_normal = 0, None, ptr(g_n)
     # ---- refusals: nothing to do, gradients without counts, occ without its selection, a pixel count that is no multiple of 4
-    a.counts = None
+    a.cos_scale_out = ptr(cos_scale)
+    assert L.soar_avatar_pixel_losses(C.byref(a), 2, stream) != 0 and "one-pass" in hip_lib.last_error()
+    a.counts, a.cos_scale_out = None, None
     assert L.soar_avatar_pixel_losses(C.byref(a), 0, stream) != 0
     assert L.soar_avatar_pixel_losses(C.byref(a), 3, stream) != 0 and "counts" in hip_lib.last_error()
     a.sel_occ, a.occ = None, ptr(occ)
