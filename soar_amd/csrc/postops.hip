@@ -232,6 +232,22 @@ __global__ void __launch_bounds__(256) view_finish_kernel(Batch<ViewArgs> batch)
     }
 }
 
+// the backward pass when only the plugin-normal image (and the depth image itself) carry gradient -- the usual case: the curvature
+// and depth-normal images are outputs few losses read -- is point-wise: no stencil, no zero-fill, no atomics.  Same values as the
+// general kernel leaves (0 + x: its sums start from the zero-filled planes).
+__global__ void __launch_bounds__(256) view_finish_backward_pointwise_kernel(Batch<ViewArgs> batch)
+{
+    const ViewArgs &a = batch.v[blockIdx.z];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const size_t hw = (size_t)a.W * a.H, ip = (size_t)y * a.W + x;
+    const bool in = a.g_normal_out && a.opac[ip] > 1e-5f;
+    a.g_normal[ip] = in ? 0.f + a.g_normal_out[ip] * 0.5f : 0.f;
+    a.g_normal[hw + ip] = in ? 0.f + -(a.g_normal_out[hw + ip] * 0.5f) : 0.f;
+    a.g_normal[2 * hw + ip] = in ? 0.f + -(a.g_normal_out[2 * hw + ip] * 0.5f) : 0.f;
+    a.g_depth[ip] = a.g_depth_direct ? 0.f + a.g_depth_direct[ip] : 0.f;
+}
+
 dim3 pix_grid(int W, int H) { return dim3((W + 31) / 32, (H + 7) / 8); }
 
 }  // namespace
@@ -330,8 +346,13 @@ extern "C" int soar_view_finish_backward(int32_t W, int32_t H, const float *norm
     a.normal = normal; a.depth = depth; a.opac = opac;
     a.g_normal_out = dL_dnormal_out; a.g_curv = dL_dcurv; a.g_pred = dL_dpred_normal; a.g_depth_direct = dL_ddepth_direct;
     a.g_normal = dL_dnormal_and_depth; a.g_depth = dL_dnormal_and_depth + 3 * hw;
-    SOAR_HIP_OK(hipMemsetAsync(dL_dnormal_and_depth, 0, sizeof(float) * 4 * hw, stream));
     StageTimer timer(ST_POSTOPS, stream);
+    if (!dL_dcurv && !dL_dpred_normal && batch_ctx().n == 0) {       // (inside a batch every frame must reach the same launch site)
+        SOAR_LAUNCH_BATCHED_Z(view_finish_backward_pointwise_kernel, pix_grid(W, H), dim3(256), 0, stream, a);
+        SOAR_LAUNCH_OK("view_finish_backward", stream, 0);
+        return 0;
+    }
+    SOAR_HIP_OK(hipMemsetAsync(dL_dnormal_and_depth, 0, sizeof(float) * 4 * hw, stream));
     SOAR_LAUNCH_BATCHED_Z(view_finish_kernel<true>, pix_grid(W, H), dim3(256), 0, stream, a);
     SOAR_LAUNCH_OK("view_finish_backward", stream, 0);
     return 0;
