@@ -57,15 +57,18 @@ STAGE_KERNELS = {
     "tile_ranges": ["band_place_kernel", "band_count_kernel"],
     "tile_lists": ["bin_tiles_kernel"],
     "render_forward": ["render_forward_kernel"],
-    "render_backward": ["render_backward_blocks_kernel", "zero_ranges_kernel"],
+    "render_backward": ["render_backward_blocks_kernel", "zero_ranges_kernel",
+                        "(--loss avatar: render_backward_blocks_occ_kernel, the occlusion chain's gradient taken along)"],
     "block_masks": ["tile_order_binned_kernel", "(tile order + cleared mask words; the masks themselves are left behind by render_forward_kernel since "
                     "round 4; block_mask_kernel only behind the key export)"],
     "geometry_backward": ["geometry_backward_kernel"],
     "lbs_knn_weights": ["knn_follow_kernel", "knn_search_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
     "optimizer": ["adam_update_kernel", "adam_tick_kernel"],
-    "lbs_warp_forward": ["warp_forward_kernel"],
-    "lbs_warp_backward": ["warp_backward_kernel"],
-    "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel"],
+    "lbs_warp_forward": ["warp_forward_frames_kernel", "warp_forward_kernel"],
+    "lbs_warp_backward": ["warp_backward_frames_kernel", "warp_backward_kernel"],
+    "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel",
+                   "(--loss avatar: ssim_forward_kernel, ssim_backward_kernel, avatar_pixel_kernel + their finish kernels)"],
+    "postops": ["view_finish_kernel"],
 }
 PMC_JSON = None               # --pmc-json: the counter summary to quote instead of the newest committed one
 

@@ -14,15 +14,16 @@ cp $src/bench_avatar.json profiles/${tag}_bench_avatar_C3.json
 cp $src/bench_C5.json profiles/${tag}_bench_C5.json
 cp $src/bench_C2.json profiles/${tag}_bench_C2.json
 cp $src/plugin_path.txt profiles/${tag}_plugin_path.txt
+[ -f $src/kernel_stats_avatar.csv ] && cp $src/kernel_stats_avatar.csv profiles/${tag}_kernel_stats_avatar_C3.csv
 f=$(find $src/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/${tag}_kernel_stats_C3_plan_mode.csv
 python3 - <<PY
 import json
 p = json.load(open("$src/bench_plain.json")); d = json.load(open("$src/bench_forced_dist.json")); e = json.load(open("$src/bench_forced_dist_1bucket.json"))
 open("profiles/${tag}_forced_dist_vs_plain.txt", "w").write(
     "python bench.py --no-cpu-baseline --no-stage-timers (C3, default form, one GPU): %.3f ms per step, %.0f frames/s\\n"
-    "SOAR_BENCH_FORCE_DIST=1 (the same with a one-rank RCCL group: two asynchronous all-reduce buckets per step, the optimizer inside the "
+    "SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=2 (the same with a one-rank RCCL group: two asynchronous all-reduce buckets per step, the optimizer inside the "
     "plan behind them): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
-    "SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=1 (one collective for the whole buffer): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
+    "SOAR_BENCH_FORCE_DIST=1 (the default: one collective for the whole buffer): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
     % (p["ms_per_step"], p["value"], d["ms_per_step"], d["value"], 100.0 * (d["ms_per_step"] / p["ms_per_step"] - 1.0), json.dumps(d.get("ranks")),
        e["ms_per_step"], e["value"], 100.0 * (e["ms_per_step"] / p["ms_per_step"] - 1.0), json.dumps(e.get("ranks"))))
 PY

@@ -21,14 +21,17 @@ bash scripts/pmc_kernel.sh "render_" > $out/sq_counters.txt 2>&1
 python3 bench.py --pmc-json $out/hbm_traffic.json > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --loss avatar --no-cpu-baseline > $out/bench_avatar.json 2> $out/bench_avatar.err
 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_plain.json 2> $out/bench_plain.err
-SOAR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist.json 2> $out/bench_forced_dist.err
-SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist_1bucket.json 2> $out/bench_forced_dist_1bucket.err
+SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=2 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist.json 2> $out/bench_forced_dist.err
+SOAR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist_1bucket.json 2> $out/bench_forced_dist_1bucket.err
 python3 bench.py --workload C5 --no-cpu-baseline --steps 40 > $out/bench_C5.json 2> $out/bench_C5.err
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/bench_C2.err
 cat $out/batched_launches.txt
 for f in default avatar plain forced_dist forced_dist_1bucket C5 C2; do python3 -c "
 import json,sys
 d=json.load(open('$out/bench_$f.json')); print('$f', d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('frac'), (d.get('roofline') or {}).get('traffic'), d.get('ranks'))"; done
+# 4b. the avatar-loss form's kernels (durations of the batched launches)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_avatar -o t -- python3 bench.py --loss avatar --steps 20 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace_avatar.log 2>&1
+f=$(find $out/trace_avatar -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_avatar.csv
 # 5. the plugin path
 python3 scripts/plugin_time.py 2>&1 | grep -v -E "Warning|amdgpu.ids" > $out/plugin_path.txt
 python3 scripts/plugin_host_split.py 2>&1 | grep -v -E "Warning|amdgpu.ids" >> $out/plugin_path.txt

@@ -1,0 +1,21 @@
+# round 4, GPU box: per-kernel time of the default bench step (rocprofv3 kernel trace), microseconds per step.  usage: bash scripts/r4_trace_default.sh TAG
+tag=${1:-trace}; out=$GRAFT_REPO_ROOT/gpurun_out/r4_$tag; mkdir -p $out
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
+f=$(find $out/trace -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats_C3.csv
+tail -1 $out/trace.log | cut -c1-200
+python3 - $out/kernel_stats_C3.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = 45.0
+tot = 0.0
+for r in rows:
+    us = float(r["TotalDurationNs"]) / 1e3 / steps
+    tot += us
+    if us >= 1.0:
+        name = r["Name"].replace("soar::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+        print("%-62s calls/step %5.1f  avg %7.1f us  per step %7.1f us" % (name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, us))
+print("sum of kernel time per step: %.1f us" % tot)
+PY
+rm -rf $out/trace
