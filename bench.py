@@ -545,20 +545,46 @@ def main():
         stepper = lambda frames: run_step(seq, targets, flat, frames, bg, capacity)
     for s in range(2):                                           # untimed steps in the timed mode
         stepper(frames_of(s))
+    # The interpreter's cyclic collector walks every tracked object of the process when its oldest generation comes due -- 35-70 ms
+    # with torch imported, measured as ONE stall of the host around step 39 of the timed region, long enough for the device to run
+    # dry (0.95 -> 1.0-1.36 ms per step, run to run).  What exists now stays: collected once, then moved out of the collector's sight
+    # (gc.freeze, what a long-running training process does after its set-up); the collector stays on for what the steps allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     flat.wait_all()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    step_marks = [] if os.environ.get("SOAR_BENCH_STEP_TIMES", "0") == "1" else None      # (diagnostic: when the host issued every step)
     t0 = time.perf_counter()
     for s in range(args.steps):
         stepper(frames_of(args.warmup + s))
+        if step_marks is not None:
+            step_marks.append(time.perf_counter() - t0)
+    host_issue = time.perf_counter() - t0                        # the host is done ISSUING the K steps here; the device may still be working
+    if step_marks is not None:
+        per = [1e3 * (b - a) for a, b in zip([0.0] + step_marks[:-1], step_marks)]
+        print("[bench] host issue per step (ms): " + " ".join(f"{v:.2f}" for v in per), file=sys.stderr)
     flat.wait_all()                                              # the last step's gradient buckets
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0                     # this rank's own K steps (before it waits for the others)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # SOAR_BENCH_REPEAT=n (diagnostic): n more timed regions of the same K steps in this process, one line each on stderr -- tells a
+    # per-process spread (placement of the buffers, clocks at start) from a spread in time (other tenants of the node)
+    for rep in range(int(os.environ.get("SOAR_BENCH_REPEAT", "0"))):
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for s in range(args.steps):
+            stepper(frames_of(args.warmup + s))
+        r_issue = time.perf_counter() - r0
+        flat.wait_all()
+        torch.cuda.synchronize()
+        r_all = time.perf_counter() - r0
+        print(f"[bench] repeat {rep}: {1e3 * r_all / args.steps:.3f} ms/step, host issue {1e3 * r_issue / args.steps:.3f} ms/step", file=sys.stderr)
     binning_status = None
     if plan is not None:
         binning_status = plan.check()                            # raises if a binning buffer of ANY timed step was too small (sticky words)
@@ -713,6 +739,9 @@ def main():
                                    "space are neighbours in memory, as in a model initialised from the SMPL-X vertices; "
                                    "SOAR_BENCH_RANDOM_ORDER=1 keeps the generator's random order: -2 % at C3)"),
                    "build_digest": build.source_digest(),
+                   # how long the HOST needed to issue the K timed steps, per step: close to ms_per_step = the run was bound by the
+                   # host's launch rate (a slow or shared CPU), not by the device
+                   "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,
