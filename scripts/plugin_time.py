@@ -88,7 +88,7 @@ if VARIANTS:
     pc._occ.requires_grad_(True)
     opt = torch.optim.Adam([pc._xyz, pc._rot, pc._scale, pc._color, pc._occ], lr=1e-4)
     TRAIN_OCC = True
-    timed("avatar_stage_loss + loss_occ as a masked mean, occlusion parameter trained (soar_rast_occ_backward)", "fused")
+    timed("avatar_stage_loss + loss_occ as a masked mean, occlusion parameter trained (soar_rast_backward_occ: the chain taken along by the backward blend)", "fused")
     TRAIN_OCC = "indexed"
     timed("avatar_stage_loss + loss_occ by boolean indexing as the reference writes it (a host read-back per frame)", "fused")
     TRAIN_OCC = False
