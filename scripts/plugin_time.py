@@ -62,10 +62,14 @@ if os.environ.get("SOAR_PLUGIN_TIME_IMPORT_ONLY") == "1":       # scripts/plugin
 TRAIN_OCC = False
 
 
-def timed(name, wl, n=40):
+def timed(name, wl, n=int(os.environ.get("SOAR_PLUGIN_TIME_FRAMES", "40"))):
     for f in range(F + 4):               # every frame of the sequence once (per-frame caches, allocator) before the clock starts
         step(f, wl)
     torch.cuda.synchronize()
+    if os.environ.get("SOAR_PLUGIN_TIME_GC", "") == "freeze":     # what a long-running training process does after its set-up
+        import gc
+        gc.collect()
+        gc.freeze()
     t0 = time.perf_counter()
     for f in range(n):
         step(f, wl)
