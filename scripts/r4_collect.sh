@@ -21,9 +21,9 @@ import json
 p = json.load(open("$src/bench_plain.json")); d = json.load(open("$src/bench_forced_dist.json")); e = json.load(open("$src/bench_forced_dist_1bucket.json"))
 open("profiles/${tag}_forced_dist_vs_plain.txt", "w").write(
     "python bench.py --no-cpu-baseline --no-stage-timers (C3, default form, one GPU): %.3f ms per step, %.0f frames/s\\n"
-    "SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=2 (the same with a one-rank RCCL group: two asynchronous all-reduce buckets per step, the optimizer inside the "
+    "SOAR_BENCH_FORCE_DIST=1 (the same with a one-rank RCCL group; the default: two asynchronous all-reduce buckets per step, the optimizer inside the "
     "plan behind them): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
-    "SOAR_BENCH_FORCE_DIST=1 (the default: one collective for the whole buffer): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
+    "SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=1 (one collective for the whole buffer): %.3f ms per step, %.0f frames/s (%+.1f %%); ranks: %s\\n"
     % (p["ms_per_step"], p["value"], d["ms_per_step"], d["value"], 100.0 * (d["ms_per_step"] / p["ms_per_step"] - 1.0), json.dumps(d.get("ranks")),
        e["ms_per_step"], e["value"], 100.0 * (e["ms_per_step"] / p["ms_per_step"] - 1.0), json.dumps(e.get("ranks"))))
 PY

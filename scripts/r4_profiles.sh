@@ -21,8 +21,8 @@ bash scripts/pmc_kernel.sh "render_" > $out/sq_counters.txt 2>&1
 python3 bench.py --pmc-json $out/hbm_traffic.json > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --loss avatar --no-cpu-baseline > $out/bench_avatar.json 2> $out/bench_avatar.err
 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_plain.json 2> $out/bench_plain.err
-SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=2 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist.json 2> $out/bench_forced_dist.err
-SOAR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist_1bucket.json 2> $out/bench_forced_dist_1bucket.err
+SOAR_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist.json 2> $out/bench_forced_dist.err
+SOAR_BENCH_FORCE_DIST=1 SOAR_DP_BUCKETS=1 python3 bench.py --no-cpu-baseline --no-stage-timers > $out/bench_forced_dist_1bucket.json 2> $out/bench_forced_dist_1bucket.err
 python3 bench.py --workload C5 --no-cpu-baseline --steps 40 > $out/bench_C5.json 2> $out/bench_C5.err
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/bench_C2.err
 cat $out/batched_launches.txt

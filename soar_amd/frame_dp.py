@@ -75,12 +75,13 @@ class FlatGradBuffer:
                     self.leaves[name] = t
             start += P * width
         self.split = P * LEAVES[0][1]             # end of the xyz slice = boundary between the two buckets
-        # One collective for the whole buffer (default since round 4), or SOAR_DP_BUCKETS=2: the xyz slice first, so that the KNN
-        # refresh (which only needs the positions) hides the flight of the rest.  Every collective is a hand-off to RCCL's stream and
-        # back (~20-30 us each on this stack): with a one-rank group the step pays +4 % for one bucket and +15 % for two
-        # (profiles/r04c_forced_dist_vs_plain.txt); what two buckets hide -- the flight of 4.8 MB over xGMI against an ~80 us
-        # refresh -- is of the same size.  bench.py reports the stalls per bucket and rank (`ranks`): the first multi-GPU run decides.
-        self.n_buckets = 2 if os.environ.get("SOAR_DP_BUCKETS", "1") == "2" else 1
+        # Two collectives per step (the default), the xyz slice first: the KNN refresh only needs the positions and hides the flight
+        # of the rest -- 4.8 of the 6 MB over xGMI against an ~80 us refresh.  SOAR_DP_BUCKETS=1: one collective for the whole buffer.
+        # Every collective is a hand-off to RCCL's stream and back: with a one-rank group the step pays +3.9 % for two buckets and
+        # +4.1 % for one (profiles/r04d_forced_dist_vs_plain.txt; the +15 % for two that made one bucket the default for a while in
+        # round 4 was the interpreter's collector stalling the host in one of the two runs).  bench.py reports the
+        # stalls per bucket and rank (`ranks`).
+        self.n_buckets = 1 if os.environ.get("SOAR_DP_BUCKETS", "2") == "1" else 2
         # diagnostics (bench.py, world > 1): HIP events around every stream-side wait for a bucket -- what the stream stalled for
         self.time_waits = False
         self._wait_events: List = []
