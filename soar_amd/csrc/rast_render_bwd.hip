@@ -127,7 +127,9 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 // Turned around -- lane = entry, the wavefront walks the (up to 16) pixels of its 4x4 block one after the other -- none of that
 // is needed:
 //   * a lane keeps its entry's record in registers for the whole batch of 64 surviving entries (read from LDS once);
-//   * the pixel's constants are wave-uniform (broadcast LDS reads), its state (T, P) lives in lane `pixel` of two registers;
+//   * the pixel's constants AND its running state (T, P; the occlusion chain's T) are wave-uniform broadcast LDS reads; lane 63 writes
+//     the state back at the end of the pixel's turn (round 4; it lived in lane `pixel` of two registers before: five register-to-scalar
+//     moves, a compare and two selects per step);
 //   * the two back-to-front recurrences of a pixel (T = T / (1 - alpha), backward.cu:683; "colour behind me", :701-:766, folded
 //     into the scalar P' = alpha u + (1 - alpha) P as above) become ONE inclusive scan over the lanes of the affine maps
 //     P -> (1 - alpha_i) P + alpha_i u_i (12 DPP-fused instructions): its multiplier IS the product of the (1 - alpha) behind
