@@ -66,7 +66,10 @@ def timed(name, wl, n=int(os.environ.get("SOAR_PLUGIN_TIME_FRAMES", "40"))):
     for f in range(F + 4):               # every frame of the sequence once (per-frame caches, allocator) before the clock starts
         step(f, wl)
     torch.cuda.synchronize()
-    if os.environ.get("SOAR_PLUGIN_TIME_GC", "") == "freeze":     # what a long-running training process does after its set-up
+    # (the interpreter's cyclic collector walks the whole heap of a process with torch imported when its oldest generation comes due:
+    # one 40-70 ms stall somewhere in the run -- 1-2 ms per frame over the 40 timed frames of a variant that happens to catch it.
+    # Collected once and frozen here, what a long-running training process does after its set-up; SOAR_PLUGIN_TIME_GC=keep: not)
+    if os.environ.get("SOAR_PLUGIN_TIME_GC", "freeze") == "freeze":
         import gc
         gc.collect()
         gc.freeze()
