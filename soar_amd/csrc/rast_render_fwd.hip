@@ -119,27 +119,28 @@ __device__ __forceinline__ void fill_tile(const FwdArgs &a, int tile, int tid, i
     }
 }
 
-// Running products of one pixel's four slots: T is replicated in the quad, m is this lane's factor; lane k returns
-// ((T m_0) m_1 ...) m_k -- every product a plain rounded multiply, in list order.  Pass k makes lane k final (lane 0 is
-// final after the first multiply and is carried through the passes with the factor 1).
-__device__ __forceinline__ float quad_scan_products(float T, float m, float m_pass)
+// Running products of one pixel's four slots, EXCLUSIVE: T is replicated in the quad, m_front is the factor of the lane in front of
+// this one (1 in slot 0); lane k returns ((T m_0) m_1 ...) m_{k-1} -- the transmittance in FRONT of its entry, every product a plain
+// rounded multiply in list order.  Pass k makes lane k final (lane 0 keeps T through the passes with the factor 1); lanes behind hold
+// partial values until their pass.  (The inclusive form of rounds 2-4a needed a shifted copy and a select to get at this value.)
+__device__ __forceinline__ float quad_scan_front(float T, float m_front)
 {
-    float x = mul_keep(T, m);
-    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
-    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
-    x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
-    return x;
+    float e = T;
+    e = mul_keep(quad_move<DPP_QUAD_SHIFT1>(e), m_front);
+    e = mul_keep(quad_move<DPP_QUAD_SHIFT1>(e), m_front);
+    e = mul_keep(quad_move<DPP_QUAD_SHIFT1>(e), m_front);
+    return e;
 }
 
-// the same for two chains at once, their steps side by side
-__device__ __forceinline__ void quad_scan_products2(float T, float m, float m_pass, float U, float n, float n_pass, float &x, float &y)
+// the same for two chains at once, their steps side by side (a DPP operand written by the instruction in front costs two idle cycles)
+__device__ __forceinline__ void quad_scan_front2(float T, float m_front, float U, float n_front, float &e, float &f)
 {
-    x = mul_keep(T, m);
-    y = mul_keep(U, n);
+    e = T;
+    f = U;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        x = mul_keep(quad_move<DPP_QUAD_SHIFT1>(x), m_pass);
-        y = mul_keep(quad_move<DPP_QUAD_SHIFT1>(y), n_pass);
+        e = mul_keep(quad_move<DPP_QUAD_SHIFT1>(e), m_front);
+        f = mul_keep(quad_move<DPP_QUAD_SHIFT1>(f), n_front);
     }
 }
 
@@ -326,21 +327,20 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     // this step iff the last product is below the threshold -- and in most steps no pixel of the
                     // wavefront stops: then the clamping selects and the per-slot "stopped" predicate are not needed.
                     // The products run through the quad as a scan (lane k <- lane k - 1, three fused DPP multiplies): lane k
-                    // ends with ((T om_0) om_1 ...) om_k, the reference's order of roundings.  The two chains' scans are
-                    // issued step by step side by side: a DPP operand written by the instruction in front costs two idle
-                    // cycles, which the other chain's step fills.
-                    float x, y = 1.f;
-                    // (the factor a lane passes the running product on with: 1 in slot 0, its own elsewhere -- 1 - a x {0, 1}: exact)
-                    const float om_pass = __builtin_fmaf(-a_eff, not_first, 1.f);
-                    if (OCC) quad_scan_products2(T, om, om_pass, T_o, mo, __builtin_fmaf(-a_o, not_first, 1.f), x, y);
-                    else x = quad_scan_products(T, om, om_pass);
+                    // ends with ((T om_0) om_1 ...) om_{k-1}, the transmittance in front of its entry in the reference's
+                    // order of roundings.  The two chains' scans are issued step by step side by side.
+                    // (the factor of the lane in front: 1 in slot 0, else 1 - its alpha -- 1 - a x {0, 1}: the same rounding as its own om)
+                    const float om_front = __builtin_fmaf(-quad_move<DPP_QUAD_SHIFT1>(a_eff), not_first, 1.f);
+                    float T_front, U_front = 1.f;
+                    if (OCC) quad_scan_front2(T, om_front, T_o, __builtin_fmaf(-quad_move<DPP_QUAD_SHIFT1>(a_o), not_first, 1.f), T_front, U_front);
+                    else T_front = quad_scan_front(T, om_front);
+                    const float x = mul_keep(T_front, om), y = OCC ? mul_keep(U_front, mo) : 1.f;     // the products behind my entry
                     const float p3 = quad_move<DPP_QUAD_BCAST3>(x);
                     const float v3 = OCC ? quad_move<DPP_QUAD_BCAST3>(y) : 1.f;
                     float w, w_o = 0.f;
                     bool some_stop = false;                                               // wave-uniform
                     if (__ballot(p3 < 0.0001f) == 0ull) {
-                        const float T_prev = quad_move<DPP_QUAD_SHIFT1>(x);               // the product in front of my entry
-                        w = a_eff * (slot == 0 ? T : T_prev);
+                        w = a_eff * T_front;
                         T = p3;
                     } else {
                         // (the general form: the same products, with the clamping selects)
@@ -367,8 +367,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     }
                     if (OCC) {
                         if (__ballot(v3 < 0.0001f) == 0ull) {
-                            const float U_prev = quad_move<DPP_QUAD_SHIFT1>(y);
-                            w_o = a_o * (slot == 0 ? T_o : U_prev);
+                            w_o = a_o * U_front;
                             T_o = v3;
                         } else {
                             const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
@@ -636,13 +635,12 @@ __device__ __forceinline__ void occ_grad_quad(const OccGradArgs &a, const int ra
                     a_live = (alpha < 1.0f / 255.0f) ? 0.f : a_live;
                     const float a_o = a_live * q1.w * alive_o;                           // (back-facing entries never enter the ring; the
                     const float mo = 1.f - a_o;                                          //  pad record has flag 0)
-                    float y = quad_scan_products(T_o, mo, __builtin_fmaf(-a_o, not_first, 1.f));
-                    const float v3 = quad_move<DPP_QUAD_BCAST3>(y);
+                    const float U_front = quad_scan_front(T_o, __builtin_fmaf(-quad_move<DPP_QUAD_SHIFT1>(a_o), not_first, 1.f));
+                    const float v3 = quad_move<DPP_QUAD_BCAST3>(mul_keep(U_front, mo));
                     float w_o;
                     bool some_stop = false;
                     if (__ballot(v3 < 0.0001f) == 0ull) {
-                        const float U_prev = quad_move<DPP_QUAD_SHIFT1>(y);
-                        w_o = a_o * (slot == 0 ? T_o : U_prev);
+                        w_o = a_o * U_front;
                         T_o = v3;
                     } else {
                         const float mo0 = quad_move<DPP_QUAD_BCAST0>(mo), mo1 = quad_move<DPP_QUAD_BCAST1>(mo),
