@@ -316,10 +316,10 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     // Invariant: T >= 1e-4 in every lane, so "T*(1-a) < 1e-4" can only fire on a live entry.
                     const float om = 1.f - a_eff;
                     // OCC: the same chain over the camera-facing entries only, with its own transmittance and stop
-                    float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float2 e4 = make_float2(0.f, 0.f);
                     float a_o = 0.f, mo = 1.f;
                     if (OCC) {
-                        e4 = lds_at(sq4, j16);
+                        e4 = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sq4) + j16);      // (8 of the slot's 16 bytes)
                         a_o = a_live * e4.y * alive_o;                                    // camera-facing flag and liveness are 0 / 1
                         mo = 1.f - a_o;
                     }
