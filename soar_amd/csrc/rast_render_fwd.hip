@@ -161,7 +161,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     __shared__ float4 sq0[CHUNK + 1], sq1[CHUNK + 1], sq2[CHUNK + 1], sq3[CHUNK + 1];   // +1: an all-zero record
     __shared__ float4 sq4[OCC ? CHUNK + 1 : 1];                                          // {occ value, camera-facing, -, -}: the stride of the others
     __shared__ int wave_alive[2][4];
-    __shared__ unsigned short todo_ring[4][WAVE + 4];                                     // per wavefront: 16 x LDS slot (= byte offset) of a sub-chunk's relevant entries
+    __shared__ unsigned short todo_ring[4][CHUNK + 4];                                    // per wavefront: 16 x LDS slot (= byte offset) of a chunk's relevant entries
     __shared__ unsigned long long wmask[4][CHUNK / WAVE];                                 // per wavefront: phase A's survivor words of a chunk
     unsigned long long t_start = 0, t_ready = 0, t_blended = 0, n_iter = 0, n_useful = 0;
     if (LOG) t_start = wall_clock64();
@@ -275,21 +275,25 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     rx0 = (float)(bx0 + c0); ry0 = (float)(by0 + r0); rex = (float)(c1 - c0); rey = (float)(r1 - r0);
                 }
             }
+            // phase A -- lanes = entries, 64 at a time over the whole chunk: conservative test against that rectangle.  The relevant
+            // entries' LDS slots are compacted in list order into the wavefront's ring (ballot-prefix ranks) -- ONE ring for the chunk
+            // (round 4: it was one per 64 entries; a block keeps 4-5 of 64 on average, and every ring's last step ran with one to three
+            // of its four slots empty: a fifth of all steps' slots); three pad entries behind the last one point at the zero record
+            int n_todo = 0;
             for (int sub = 0; sub < n; sub += WAVE) {
-                // phase A -- lanes = entries of this 64-entry sub-chunk: conservative test against that rectangle
                 bool relevant = false;
                 if (sub + lane < n) {
                     const float4 e0 = sq0[sub + lane], e1 = sq1[sub + lane];
                     relevant = splat_may_touch_rect(e0.x, e0.y, e0.z, e0.w, e1.x, sq3[sub + lane].w, rx0, ry0, rex, rey);
                 }
-                // the relevant entries' LDS slots, compacted in list order into the wavefront's ring (ballot-prefix ranks);
-                // three pad entries behind them point at the zero record, so the last step needs no special case
                 const unsigned long long todo = __ballot(relevant);
-                const int n_todo = (int)__builtin_popcountll(todo);
-                if (relevant) todo_ring[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(16 * (sub + lane));
-                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)(16 * CHUNK);
+                if (relevant) todo_ring[wave][n_todo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (unsigned short)(16 * (sub + lane));
+                n_todo += (int)__builtin_popcountll(todo);
                 if (lane == 0) wmask[wave][sub / WAVE] = todo;                  // left behind for the backward blend: emit_masks below
-                emit_n = sub / WAVE + 1;
+            }
+            emit_n = (n + WAVE - 1) / WAVE;
+            {
+                if (lane < 3) todo_ring[wave][n_todo + lane] = (unsigned short)(16 * CHUNK);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -407,7 +411,6 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
                     }
                     if (some_stop && __ballot(alive + alive_o != 0.f) == 0ull) { wave_done = true; break; }
                 }
-                if (wave_done) break;
             }
         }
         // "is any wavefront of the workgroup still blending?" -- also the barrier that protects the LDS arrays before
