@@ -745,17 +745,20 @@ __device__ __forceinline__ void blend_rows(uint32_t mask, uint32_t pos, float d2
 {
     if (lane < KNN_KEEP && ((mask >> lane) & 1u)) {
         const int at = __builtin_popcount(mask & ((1u << lane) - 1u));
-        cp[at] = pos;
+        cp[at] = pos * (uint32_t)(KNN_JMAX * sizeof(float));          // the row's BYTE offset (V x 224 bytes stay far below 2^32): a 32-bit add
         cw[at] = 1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f);       // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int jl = min(lane, KNN_JMAX - 1);
+    // (a 64-bit multiply-add per gathered row -- v_mad_u64_u32 -- was a third of this loop's instructions; the base pointer is
+    // wave-uniform: scalar base + 32-bit lane offset)
+    const uint32_t jl4 = (uint32_t)min(lane, KNN_JMAX - 1) * (uint32_t)sizeof(float);
+    const char *rows_bytes = reinterpret_cast<const char *>(rows_padded);
     float accj = 0.f, norm = 0.f;
 #pragma unroll 15
     for (int k = 0; k < KNN_K; k++) {
         const float wk = cw[k];
-        accj = __builtin_fmaf(wk, rows_padded[(size_t)cp[k] * KNN_JMAX + jl], accj);
+        accj = __builtin_fmaf(wk, *reinterpret_cast<const float *>(rows_bytes + (cp[k] + jl4)), accj);
         norm += wk;
     }
     if (lane < J) out_row[lane] = accj / norm;
