@@ -19,8 +19,8 @@ constexpr int SR = 5;                  // window radius
 constexpr int SH = ST + 2 * SR;        // 42: tile + halo
 constexpr int SB = 4;                  // outputs per thread and pass (a sliding window over SB + 10 inputs)
 constexpr int SQ = 12;                 // 16-byte units staged per halo row: columns x0 - 8 .. x0 + 39 (aligned; 42 of the 48 are used)
-constexpr int SOFF = 3;                // the first used column (x0 - 5) inside the staged row
-constexpr int SS = 49;                 // staged row stride (odd: a wave's 8 rows x 8 column groups spread over the banks)
+constexpr int SOFF = 3;                // the first used column (x0 - 5) inside the row of units; only the 42 used columns are staged
+constexpr int SS = SH + 1;             // staged row stride (43, odd: a wave's 8 rows x 8 column groups spread over the banks)
 constexpr int HS = ST + 1;
 
 typedef float f2 __attribute__((ext_vector_type(2)));     // two maps side by side: one v_pk_fma_f32 / v_pk_mul_f32 per pair
@@ -77,15 +77,15 @@ __device__ __forceinline__ float4 keep(float4 v, bool in) { return in ? v : make
 
 // Both passes of the separable window are register-blocked: a thread produces SB consecutive outputs from SB + 10 inputs it
 // reads once.  Every output is accumulated tap by tap in window order with fused multiply-adds, so the values are those of the
-// unblocked loops; the maps travel in pairs -- (mu1, mu2) and (E[x^2], E[y^2]) -- so that a tap costs two packed FMAs and one
-// plain one instead of five (the forward was bound by instruction issue: 340 vector instructions per pixel and channel).
+// unblocked loops; the maps travel in pairs -- (mu1, mu2) and (E[x^2] + E[y^2], E[xy]) -- so that a tap costs two packed FMAs
+// instead of five plain ones (the forward was bound by instruction issue: 340 vector instructions per pixel and channel), and the
+// rows between the passes fit 39 KB of LDS: four workgroups per CU.
 template <bool VEC>
 __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch)
 {
     const SsimArgs &a0 = batch.v[0];
     __shared__ f2 s[SH][SS];                            // (img1, img2)
-    __shared__ f2 h01[SH][HS], h23[SH][HS];             // rows after the horizontal pass: (mu1, mu2), (E11, E22)
-    __shared__ float h4[SH][HS];                        // E12
+    __shared__ f2 h01[SH][HS], h23[SH][HS];             // rows after the horizontal pass: (mu1, mu2), (E11 + E22, E12)
     const int tid = threadIdx.x;
     const TileAt cur = tile_of_block(a0);
     const SsimArgs &a = batch.v[cur.frame];
@@ -105,12 +105,17 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
             for (int i = 0; i < 2; i++) {
                 const int u = tid + 256 * i, yy = u / SQ, xx = 4 * (u % SQ);
                 const float4 p = keep(r1[i], in[i]), q = keep(r2[i], in[i]);
-                if (u < SH * SQ) { s[yy][xx] = f2{p.x, q.x}; s[yy][xx + 1] = f2{p.y, q.y}; s[yy][xx + 2] = f2{p.z, q.z}; s[yy][xx + 3] = f2{p.w, q.w}; }
+                if (u < SH * SQ) {       // (columns -3 .. 44 of the tile's halo arrive; 0 .. 41 are kept)
+                    if (xx >= SOFF) s[yy][xx - SOFF] = f2{p.x, q.x};
+                    if (xx + 1 >= SOFF && xx + 1 - SOFF < SH) s[yy][xx + 1 - SOFF] = f2{p.y, q.y};
+                    if (xx + 2 >= SOFF && xx + 2 - SOFF < SH) s[yy][xx + 2 - SOFF] = f2{p.z, q.z};
+                    if (xx + 3 - SOFF < SH) s[yy][xx + 3 - SOFF] = f2{p.w, q.w};
+                }
             }
         } else {
             for (int k = tid; k < SH * SH; k += 256) {
                 const int yy = k / SH, xx = k % SH;
-                s[yy][xx + SOFF] = f2{load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W), load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
+                s[yy][xx] = f2{load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W), load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
             }
         }
         __syncthreads();
@@ -118,42 +123,41 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
         // trip go to waves 0-1 for even tiles, to waves 2-3 for odd ones -- a workgroup's waves sit on different SIMDs)
         for (int k = (tid + ((cur.tile & 1) ? 128 : 0)) & 255; k < SH * (ST / SB); k += 256) {
             const int yy = k / (ST / SB), xb = (k % (ST / SB)) * SB;
+            // the map only needs sigma1^2 + sigma2^2 (its denominator): E[x^2] and E[y^2] travel as their sum, next to E[xy] -- four
+            // windowed sums instead of the reference's five (TS/utils/loss_utils.py:56-62), two packed FMAs per tap instead of two and
+            // a half; the derivative maps need d/dE[x^2] alone, which the sum gives as well
             f2 v[SB + 2 * SR], sq[SB + 2 * SR];
-            float pq[SB + 2 * SR];
 #pragma unroll
-            for (int tt = 0; tt < SB + 2 * SR; tt++) v[tt] = s[yy][xb + SOFF + tt];
+            for (int tt = 0; tt < SB + 2 * SR; tt++) v[tt] = s[yy][xb + tt];
 #pragma unroll
-            for (int tt = 0; tt < SB + 2 * SR; tt++) { sq[tt] = v[tt] * v[tt]; pq[tt] = v[tt].x * v[tt].y; }
+            for (int tt = 0; tt < SB + 2 * SR; tt++) sq[tt] = f2{v[tt].x * v[tt].x + v[tt].y * v[tt].y, v[tt].x * v[tt].y};
 #pragma unroll
             for (int o = 0; o < SB; o++) {
                 f2 m = {0.f, 0.f}, e = {0.f, 0.f};
-                float e12 = 0.f;
 #pragma unroll
                 for (int tt = 0; tt < 2 * SR + 1; tt++) {
                     const float wt = a.w[tt];
-                    m += wt * v[o + tt]; e += wt * sq[o + tt]; e12 += wt * pq[o + tt];
+                    m += wt * v[o + tt]; e += wt * sq[o + tt];
                 }
-                h01[yy][xb + o] = m; h23[yy][xb + o] = e; h4[yy][xb + o] = e12;
+                h01[yy][xb + o] = m; h23[yy][xb + o] = e;
             }
         }
         __syncthreads();
         // vertical pass: thread = column tx, rows 4 tyb .. 4 tyb + 3
         const int tx = tid & 31, tyb = (tid >> 5) * SB;
         f2 mu[SB], ee[SB];
-        float e12[SB];
 #pragma unroll
-        for (int o = 0; o < SB; o++) { mu[o] = f2{0.f, 0.f}; ee[o] = f2{0.f, 0.f}; e12[o] = 0.f; }
+        for (int o = 0; o < SB; o++) { mu[o] = f2{0.f, 0.f}; ee[o] = f2{0.f, 0.f}; }
         {
             f2 v0[SB + 2 * SR], v1[SB + 2 * SR];
-            float v2[SB + 2 * SR];
 #pragma unroll
-            for (int tt = 0; tt < SB + 2 * SR; tt++) { v0[tt] = h01[tyb + tt][tx]; v1[tt] = h23[tyb + tt][tx]; v2[tt] = h4[tyb + tt][tx]; }
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { v0[tt] = h01[tyb + tt][tx]; v1[tt] = h23[tyb + tt][tx]; }
 #pragma unroll
             for (int o = 0; o < SB; o++)
 #pragma unroll
                 for (int tt = 0; tt < 2 * SR + 1; tt++) {
                     const float wt = a.w[tt];
-                    mu[o] += wt * v0[o + tt]; ee[o] += wt * v1[o + tt]; e12[o] += wt * v2[o + tt];
+                    mu[o] += wt * v0[o + tt]; ee[o] += wt * v1[o + tt];
                 }
         }
         const int x = x0 + tx;
@@ -166,8 +170,8 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
                 const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
                 const float mu1 = mu[o].x, mu2 = mu[o].y;
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s1sq = ee[o].x - mu1_sq, s2sq = ee[o].y - mu2_sq, s12 = e12[o] - mu12;
-                const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1sq + s2sq + C2;
+                const float s_sum = (ee[o].x - mu1_sq) - mu2_sq, s12 = ee[o].y - mu12;          // sigma1^2 + sigma2^2, sigma12
+                const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s_sum + C2;
                 val += (A * B) / (Cc * D);                 // the map: the reference's expression, IEEE division
                 // its derivatives through map(mu1, E11, E12) with sigma1_sq = E11 - mu1^2 and sigma12 = E12 - mu1 mu2; the two
                 // reciprocals (Cc >= 1e-4, D >= 9e-4: 1 ulp each) instead of five divisions
@@ -221,16 +225,18 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batc
                 const int u = tid + 256 * i, yy = u / SQ, xx = 4 * (u % SQ);
                 const float4 d0 = keep(r[0][i], in[i]), d1 = keep(r[1][i], in[i]), d2 = keep(r[2][i], in[i]);
                 if (u < SH * SQ) {
-                    s01[yy][xx] = f2{d0.x, d1.x}; s01[yy][xx + 1] = f2{d0.y, d1.y}; s01[yy][xx + 2] = f2{d0.z, d1.z}; s01[yy][xx + 3] = f2{d0.w, d1.w};
-                    s2[yy][xx] = d2.x; s2[yy][xx + 1] = d2.y; s2[yy][xx + 2] = d2.z; s2[yy][xx + 3] = d2.w;
+                    if (xx >= SOFF) { s01[yy][xx - SOFF] = f2{d0.x, d1.x}; s2[yy][xx - SOFF] = d2.x; }
+                    if (xx + 1 >= SOFF && xx + 1 - SOFF < SH) { s01[yy][xx + 1 - SOFF] = f2{d0.y, d1.y}; s2[yy][xx + 1 - SOFF] = d2.y; }
+                    if (xx + 2 >= SOFF && xx + 2 - SOFF < SH) { s01[yy][xx + 2 - SOFF] = f2{d0.z, d1.z}; s2[yy][xx + 2 - SOFF] = d2.z; }
+                    if (xx + 3 - SOFF < SH) { s01[yy][xx + 3 - SOFF] = f2{d0.w, d1.w}; s2[yy][xx + 3 - SOFF] = d2.w; }
                 }
             }
         } else {
             for (int k = tid; k < SH * SH; k += 256) {
                 const int yy = k / SH, xx = k % SH;
-                s01[yy][xx + SOFF] = f2{load_px(a.dmaps, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W),
+                s01[yy][xx] = f2{load_px(a.dmaps, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W),
                                         load_px(a.dmaps + plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
-                s2[yy][xx + SOFF] = load_px(a.dmaps + 2 * plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W);
+                s2[yy][xx] = load_px(a.dmaps + 2 * plane, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W);
             }
         }
         __syncthreads();
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batc
             f2 v[SB + 2 * SR];
             float v2[SB + 2 * SR];
 #pragma unroll
-            for (int tt = 0; tt < SB + 2 * SR; tt++) { v[tt] = s01[yy][xb + SOFF + tt]; v2[tt] = s2[yy][xb + SOFF + tt]; }
+            for (int tt = 0; tt < SB + 2 * SR; tt++) { v[tt] = s01[yy][xb + tt]; v2[tt] = s2[yy][xb + tt]; }
 #pragma unroll
             for (int o = 0; o < SB; o++) {
                 f2 g = {0.f, 0.f};
