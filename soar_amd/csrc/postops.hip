@@ -36,6 +36,7 @@ struct D2NArgs {
 
 struct Stencil {
     int ip, iu, il, ib, ir;        // pixel indices (replicate padding)
+    int x, y, xl, xr, yu, yb;      // ... and their coordinates (an index taken apart again costs an integer division by a run-time width)
     float mp, mu, ml, mb, mr;
 };
 __device__ __forceinline__ Stencil stencil_of(int x, int y, int W, int H, const uint8_t *mask)
@@ -43,13 +44,13 @@ __device__ __forceinline__ Stencil stencil_of(int x, int y, int W, int H, const 
     Stencil s;
     const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
     s.ip = y * W + x; s.iu = yu * W + x; s.ib = yb * W + x; s.il = y * W + xl; s.ir = y * W + xr;
+    s.x = x; s.y = y; s.xl = xl; s.xr = xr; s.yu = yu; s.yb = yb;
     s.mp = mask[s.ip] ? 1.f : 0.f; s.mu = mask[s.iu] ? 1.f : 0.f; s.ml = mask[s.il] ? 1.f : 0.f;
     s.mb = mask[s.ib] ? 1.f : 0.f; s.mr = mask[s.ir] ? 1.f : 0.f;
     return s;
 }
-__device__ __forceinline__ V3 ray_of(const D2NArgs &a, int idx)
+__device__ __forceinline__ V3 ray_of(const D2NArgs &a, int x, int y)
 {
-    const int x = idx % a.W, y = idx / a.W;
     return {((float)x - a.cxW) * a.inv_k00, ((float)y - a.cyH) * a.inv_k11, 1.f};
 }
 
@@ -59,17 +60,16 @@ __global__ void __launch_bounds__(256) depth2normal_kernel(D2NArgs a)
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= a.W || y >= a.H) return;
     const Stencil s = stencil_of(x, y, a.W, a.H, a.mask);
-    const V3 ap = ray_of(a, s.ip), au = ray_of(a, s.iu), al = ray_of(a, s.il), ab = ray_of(a, s.ib), ar = ray_of(a, s.ir);
+    const V3 ap = ray_of(a, s.x, s.y), au = ray_of(a, s.x, s.yu), al = ray_of(a, s.xl, s.y), ab = ray_of(a, s.x, s.yb), ar = ray_of(a, s.xr, s.y);
     // back-projected points in the reference's order of operations: ((x - cx W) d) / K  (the differences below cancel
     // most of the digits, so the rounding of the points decides the last digits of the normal)
-    auto point = [&](int idx) -> V3 {
+    auto point = [&](int idx, int px, int py) -> V3 {
         const float d = a.depth[idx];
-        const int px = idx % a.W, py = idx / a.W;
         return {(((float)px - a.cxW) * d) * a.inv_k00, (((float)py - a.cyH) * d) * a.inv_k11, d};
     };
-    const V3 c = point(s.ip) * s.mp;
-    const V3 u = (point(s.iu) - c) * s.mu, l = (point(s.il) - c) * s.ml;
-    const V3 b = (point(s.ib) - c) * s.mb, r = (point(s.ir) - c) * s.mr;
+    const V3 c = point(s.ip, s.x, s.y) * s.mp;
+    const V3 u = (point(s.iu, s.x, s.yu) - c) * s.mu, l = (point(s.il, s.xl, s.y) - c) * s.ml;
+    const V3 b = (point(s.ib, s.x, s.yb) - c) * s.mb, r = (point(s.ir, s.xr, s.y) - c) * s.mr;
     const V3 N = cross(u, l) + cross(r, u) + cross(b, r) + cross(l, b);
     const float len = sqrtf(dot(N, N)), inv = 1.f / fmaxf(len, 1e-12f);
     const V3 n = N * inv;
@@ -153,6 +153,7 @@ __device__ __forceinline__ Stencil stencil_of_opac(int x, int y, int W, int H, c
     Stencil s;
     const int yu = max(y - 1, 0), yb = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
     s.ip = y * W + x; s.iu = yu * W + x; s.ib = yb * W + x; s.il = y * W + xl; s.ir = y * W + xr;
+    s.x = x; s.y = y; s.xl = xl; s.xr = xr; s.yu = yu; s.yb = yb;
     s.mp = opac[s.ip] > 1e-5f ? 1.f : 0.f; s.mu = opac[s.iu] > 1e-5f ? 1.f : 0.f; s.ml = opac[s.il] > 1e-5f ? 1.f : 0.f;
     s.mb = opac[s.ib] > 1e-5f ? 1.f : 0.f; s.mr = opac[s.ir] > 1e-5f ? 1.f : 0.f;
     return s;
@@ -173,18 +174,14 @@ __global__ void __launch_bounds__(256) view_finish_kernel(Batch<ViewArgs> batch)
     const V3 nc = nc_raw * s.mp;
     const V3 lap = ((nat(s.iu) - nc) * s.mu + (nat(s.il) - nc) * s.ml + (nat(s.ib) - nc) * s.mb + (nat(s.ir) - nc) * s.mr) * s.mp;
     // ---- normal of the depth image (same order of operations as depth2normal_kernel)
-    auto ray = [&](int idx) -> V3 {
-        const int px = idx % a.W, py = idx / a.W;
-        return {((float)px - cxW) * a.inv_k00, ((float)py - cyH) * a.inv_k11, 1.f};
-    };
-    auto point = [&](int idx) -> V3 {
+    auto ray = [&](int px, int py) -> V3 { return {((float)px - cxW) * a.inv_k00, ((float)py - cyH) * a.inv_k11, 1.f}; };
+    auto point = [&](int idx, int px, int py) -> V3 {
         const float d = a.depth[idx];
-        const int px = idx % a.W, py = idx / a.W;
         return {(((float)px - cxW) * d) * a.inv_k00, (((float)py - cyH) * d) * a.inv_k11, d};
     };
-    const V3 c = point(s.ip) * s.mp;
-    const V3 u = (point(s.iu) - c) * s.mu, l = (point(s.il) - c) * s.ml;
-    const V3 b = (point(s.ib) - c) * s.mb, r = (point(s.ir) - c) * s.mr;
+    const V3 c = point(s.ip, s.x, s.y) * s.mp;
+    const V3 u = (point(s.iu, s.x, s.yu) - c) * s.mu, l = (point(s.il, s.xl, s.y) - c) * s.ml;
+    const V3 b = (point(s.ib, s.x, s.yb) - c) * s.mb, r = (point(s.ir, s.xr, s.y) - c) * s.mr;
     const V3 N = cross(u, l) + cross(r, u) + cross(b, r) + cross(l, b);
     const float len = sqrtf(dot(N, N)), inv = 1.f / fmaxf(len, 1e-12f);
     const V3 n = N * inv;
@@ -224,11 +221,11 @@ __global__ void __launch_bounds__(256) view_finish_kernel(Batch<ViewArgs> batch)
         const V3 gN = (g - n * dot(n, g)) * inv;
         const V3 du = cross(l - r, gN) * s.mu, dl = cross(b - u, gN) * s.ml, db = cross(r - l, gN) * s.mb, dr = cross(u - b, gN) * s.mr;
         const V3 dc = (du + dl + db + dr) * -1.f;
-        atomicAdd(&a.g_depth[s.ip], dot(ray(s.ip), dc) * s.mp);
-        atomicAdd(&a.g_depth[s.iu], dot(ray(s.iu), du));
-        atomicAdd(&a.g_depth[s.il], dot(ray(s.il), dl));
-        atomicAdd(&a.g_depth[s.ib], dot(ray(s.ib), db));
-        atomicAdd(&a.g_depth[s.ir], dot(ray(s.ir), dr));
+        atomicAdd(&a.g_depth[s.ip], dot(ray(s.x, s.y), dc) * s.mp);
+        atomicAdd(&a.g_depth[s.iu], dot(ray(s.x, s.yu), du));
+        atomicAdd(&a.g_depth[s.il], dot(ray(s.xl, s.y), dl));
+        atomicAdd(&a.g_depth[s.ib], dot(ray(s.x, s.yb), db));
+        atomicAdd(&a.g_depth[s.ir], dot(ray(s.xr, s.y), dr));
     }
 }
 
