@@ -38,7 +38,7 @@ extern "C" {
  * (`ranges` says where each list is; soar_rast_export_state re-packs them into the reference's layout).  6 (round 4): the betas and eps
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
  * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses, soar_rast_backward_occ (the image
- * buffer grew by two planes: ask soar_rast_image_bytes);
+ * buffer grew by two planes: ask soar_rast_image_bytes), soar_gather_step_inputs_ids;
  * soar_selftest_wave_reduce is gone with the backward form it tested. */
 #define SOAR_HIP_ABI_VERSION 6
 
@@ -592,6 +592,11 @@ int soar_sum_frames(int32_t n_frames, int64_t count, const float *in_dev, float 
 int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
                             const int32_t *frame_ids_dev, const float *table_dev, float *mats_out_dev,
                             int32_t *set_index_out_dev, void *stream);
+/* ... with the (at most 8) frame ids read from HOST memory at the call and passed in the kernel's arguments: no device copy of
+ * them in front of a step (launches issued directly; a captured graph needs the device form above). */
+int soar_gather_step_inputs_ids(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
+                                const int32_t *frame_ids_host, const float *table_dev, float *mats_out_dev,
+                                int32_t *set_index_out_dev, void *stream);
 
 /* ---- the optimizer step (round 3).  torch.optim.Adam(eps=1e-15) over the parameter groups of the Gaussian model
  * (TS/geometry/surfel_base.py:596-681 training_setup, TS/system/gaussian_surfel_mvdream.py:471-472 optimizer.step()) as ONE launch

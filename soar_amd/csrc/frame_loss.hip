@@ -256,6 +256,17 @@ __global__ void gather_step_inputs_kernel(int n_frames, int num_frames_seq, int 
     for (int k = threadIdx.x; k < floats_per_frame; k += blockDim.x) mats_out[(size_t)f * floats_per_frame + k] = table[(size_t)id * floats_per_frame + k];
     if (threadIdx.x == 0 && set_out) set_out[f] = n_sets > 0 ? id % n_sets : 0;
 }
+// ... with the frame ids in the kernel's arguments (the eager plan: no host -> device copy of n integers in front of every step)
+struct StepFrameIds { int32_t id[MAX_BATCH]; };
+__global__ void gather_step_inputs_ids_kernel(int n_frames, int num_frames_seq, int floats_per_frame, int n_sets, StepFrameIds ids,
+                                              const float *__restrict__ table, float *__restrict__ mats_out, int32_t *__restrict__ set_out)
+{
+    const int f = blockIdx.x;
+    int id = ids.id[f] % num_frames_seq;
+    if (id < 0) id += num_frames_seq;
+    for (int k = threadIdx.x; k < floats_per_frame; k += blockDim.x) mats_out[(size_t)f * floats_per_frame + k] = table[(size_t)id * floats_per_frame + k];
+    if (threadIdx.x == 0 && set_out) set_out[f] = n_sets > 0 ? id % n_sets : 0;
+}
 }  // namespace
 }  // namespace soar
 
@@ -284,6 +295,24 @@ extern "C" int soar_gather_step_inputs(int32_t n_frames, int32_t num_frames_seq,
     }
     hipLaunchKernelGGL(gather_step_inputs_kernel, dim3(n_frames), dim3(256), 0, stream, n_frames, num_frames_seq, floats_per_frame, n_sets,
                        frame_ids_dev, table_dev, mats_out_dev, set_index_out_dev);
+    SOAR_LAUNCH_OK("gather_step_inputs", stream, 0);
+    return 0;
+}
+
+extern "C" int soar_gather_step_inputs_ids(int32_t n_frames, int32_t num_frames_seq, int32_t floats_per_frame, int32_t n_sets,
+                                           const int32_t *frame_ids_host, const float *table_dev, float *mats_out_dev,
+                                           int32_t *set_index_out_dev, void *stream_)
+{
+    using namespace soar;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_frames <= 0 || n_frames > MAX_BATCH || num_frames_seq <= 0 || floats_per_frame <= 0 || !frame_ids_host || !table_dev || !mats_out_dev) {
+        set_error("soar_gather_step_inputs_ids: bad arguments (at most %d frames per step)", MAX_BATCH);
+        return 1;
+    }
+    StepFrameIds ids = {};
+    for (int f = 0; f < n_frames; f++) ids.id[f] = frame_ids_host[f];
+    hipLaunchKernelGGL(gather_step_inputs_ids_kernel, dim3(n_frames), dim3(256), 0, stream, n_frames, num_frames_seq, floats_per_frame, n_sets, ids,
+                       table_dev, mats_out_dev, set_index_out_dev);
     SOAR_LAUNCH_OK("gather_step_inputs", stream, 0);
     return 0;
 }

@@ -149,6 +149,7 @@ SIGNATURES = {
     "soar_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "soar_sum_frames": (C.c_int, [C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "soar_gather_step_inputs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "soar_gather_step_inputs_ids": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "soar_prof_timestamp": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "soar_view_buffer_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_views_grad_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),

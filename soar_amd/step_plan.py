@@ -162,6 +162,7 @@ class FrameStepPlan:
         self.optimizer = None                     # see _run_eager
         self.optimizer_in_two_parts = None        # None: when a gradient reduction is in flight; True / False force it (tests)
         self.graphs = None
+        self._ids_by_value = not use_graphs and self.n <= 8     # launches issued directly: the step's frame ids travel in a kernel's arguments
         if use_graphs:
             if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
                 raise RuntimeError("FrameStepPlan(use_graphs=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment "
@@ -305,8 +306,14 @@ class FrameStepPlan:
         L, s = self.L, self.seq
         self._stamp(0, stream)
         n_sets = int(self.pool.shape[0]) if self.pool is not None else 0
-        check(L.soar_gather_step_inputs(self.n, s.num_frames, 55 * 16, n_sets, ptr(self.frame_ids), ptr(s.cano2live), ptr(self.mats),
-                                        ptr(self.frame_sel), stream), "gather_step_inputs")
+        if self._ids_by_value:
+            # (launched directly: the step's frame ids travel in the kernel's arguments -- no host -> device copy in front of a step)
+            ids = (C.c_int32 * self.n)(*self._frames_now)
+            check(L.soar_gather_step_inputs_ids(self.n, s.num_frames, 55 * 16, n_sets, ids, ptr(s.cano2live), ptr(self.mats),
+                                                ptr(self.frame_sel), stream), "gather_step_inputs")
+        else:
+            check(L.soar_gather_step_inputs(self.n, s.num_frames, 55 * 16, n_sets, ptr(self.frame_ids), ptr(s.cano2live), ptr(self.mats),
+                                            ptr(self.frame_sel), stream), "gather_step_inputs")
         # (the flat gradient buffer is not zeroed here: the epilogue overwrites every registered slice, and the previous
         # step's second all-reduce bucket may still be reading it)
         if resort:
@@ -557,8 +564,11 @@ class FrameStepPlan:
         self._check_fresh()
         dev = self.device
         self._frames_now = [int(f) % self.seq.num_frames for f in frames]
-        # the step's only host -> device traffic: n frame ids, through a ring of pinned slots (the host runs steps ahead of the
-        # device; a slot is reused 64 steps later)
+        if self._ids_by_value:
+            self._run_eager()
+            return self.losses
+        # (graph replay) the step's only host -> device traffic: n frame ids, through a ring of pinned slots (the host runs steps
+        # ahead of the device; a slot is reused 64 steps later)
         k_slot = self.steps % self._ids_pinned.shape[0]
         slot = self._ids_pinned[k_slot]
         if self._ids_copied[k_slot] is not None:
