@@ -214,6 +214,7 @@ int soar_rast_backward_occ(const SoarRastParams *prm,
                            const float *dL_dout_color, const float *dL_dout_normal,
                            const float *dL_dout_depth, const float *dL_dout_opac, const float *dL_dout_occ,
                            const float *normal_scale_dev,   /* optional device scalar dL_dout_normal is multiplied by on load */
+                           int32_t occ_planes,              /* 3: dL_dout_occ is [3,H,W]; 1: [1,H,W], the three channels' gradients already summed */
                            float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D,
                            float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
                            float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc,
@@ -406,7 +407,9 @@ typedef struct SoarAvatarLossArgs {
      * dL/dnormal' alone).  cos_scale_out (mode 3 with counts only): the cosine term's gradient leaves without its factor
      * upstream / count, which is written here when the pass ends -- for a consumer that multiplies on load
      * (soar_rast_backward_occ's normal_scale_dev): value and gradient of every term in ONE pass over the images. */
-    int32_t normal_raw, pad_;
+    int32_t normal_raw;
+    int32_t occ_grad_summed;                     /* != 0: g_occ is ONE plane [1,H,W], the sum (g_0 + g_1) + g_2 of the three channels' gradients
+                                                  * -- all the occlusion chain's backward reads of them (soar_rast_backward_occ, occ_planes = 1) */
     float *cos_scale_out;
 } SoarAvatarLossArgs;
 int soar_avatar_loss_scratch_floats(size_t *count);

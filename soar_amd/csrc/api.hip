@@ -650,7 +650,8 @@ static int backward_impl(const SoarRastParams *prm, const float *means3D, const 
                               const float *grad_scale_dev, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                               float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
                               float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, void *workspace,
-                              size_t workspace_bytes, const float *dL_dout_occ, float *dL_docc, const float *normal_scale_dev, void *stream_)
+                              size_t workspace_bytes, const float *dL_dout_occ, float *dL_docc, const float *normal_scale_dev, int occ_planes,
+                              void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (check_params(prm)) return 1;
@@ -700,7 +701,7 @@ static int backward_impl(const SoarRastParams *prm, const float *means3D, const 
     }
     if (num_rendered > 0 || wide) {
         if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
-                                   acc64, num_rendered > 0, dL_dout_occ, dL_docc, normal_scale_dev, stream))
+                                   acc64, num_rendered > 0, dL_dout_occ, dL_docc, normal_scale_dev, occ_planes, stream))
             return 1;
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
@@ -726,7 +727,7 @@ int soar_rast_backward_scaled(const SoarRastParams *prm, const float *means3D, c
     return backward_impl(prm, means3D, radii, shs, colors_precomp, scales, rotations, cov3D_precomp, geom_buffer, binning_buffer, image_buffer,
                          num_rendered, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, dL_dmeans2D, dL_dcolors,
                          dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos, workspace,
-                         workspace_bytes, nullptr, nullptr, nullptr, stream_);
+                         workspace_bytes, nullptr, nullptr, nullptr, 3, stream_);
 }
 
 int soar_rast_backward_occ(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
@@ -734,16 +735,18 @@ int soar_rast_backward_occ(const SoarRastParams *prm, const float *means3D, cons
                            const float *cov3D_precomp, const void *geom_buffer, const void *binning_buffer,
                            const void *image_buffer, int64_t num_rendered, const float *dL_dout_color,
                            const float *dL_dout_normal, const float *dL_dout_depth, const float *dL_dout_opac,
-                           const float *dL_dout_occ, const float *normal_scale_dev, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                           const float *dL_dout_occ, const float *normal_scale_dev, int32_t occ_planes, float *dL_dmeans2D, float *dL_dcolors,
+                           float *dL_dopacity,
                            float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
                            float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc, void *workspace,
                            size_t workspace_bytes, void *stream_)
 {
     if (!dL_dout_occ || !dL_docc) { set_error("soar_rast_backward_occ: dL_dout_occ / dL_docc must not be NULL"); return 1; }
+    if (occ_planes != 1 && occ_planes != 3) { set_error("soar_rast_backward_occ: occ_planes is 3 or 1, got %d", occ_planes); return 1; }
     return backward_impl(prm, means3D, radii, shs, colors_precomp, scales, rotations, cov3D_precomp, geom_buffer, binning_buffer, image_buffer,
                          num_rendered, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, nullptr, dL_dmeans2D, dL_dcolors,
                          dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat, dL_dprojmat, dL_dcampos, workspace,
-                         workspace_bytes, dL_dout_occ, dL_docc, normal_scale_dev, stream_);
+                         workspace_bytes, dL_dout_occ, dL_docc, normal_scale_dev, occ_planes, stream_);
 }
 
 int soar_rast_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

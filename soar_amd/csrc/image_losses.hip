@@ -201,6 +201,7 @@ struct AvatarArgs {
     // (soar_rast_backward_occ multiplies the normal gradient by it on load): value and gradient of all terms in one pass.
     int normal_raw;
     float *cos_scale_out;
+    int occ_grad_summed;               // g_occ is ONE plane: the sum of the three channels' gradients (all the occlusion chain's backward reads)
 };
 
 template <bool VALUES, bool GRADS>
@@ -298,7 +299,8 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
                 }
         }
         // ---- occlusion image against 1 over its own selection
-        if (a.occ)
+        if (a.occ) {
+            float gsum[3][V];
             for (int c = 0; c < 3; c++) {
                 float x[V], g[V];
                 unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
@@ -306,10 +308,17 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
                 for (int k = 0; k < V; k++) {
                     const float d = x[k] - 1.f;
                     if (VALUES) s[3] += selo[k] ? fabsf(d) : 0.f;
-                    if (GRADS) g[k] = selo[k] ? (d > 0.f ? sc_occ : (d < 0.f ? -sc_occ : 0.f)) : 0.f;
+                    if (GRADS) gsum[c][k] = g[k] = selo[k] ? (d > 0.f ? sc_occ : (d < 0.f ? -sc_occ : 0.f)) : 0.f;
                 }
-                if (GRADS) reinterpret_cast<float4 *>(a.g_occ + c * n)[p] = pack(g);
+                if (GRADS && !a.occ_grad_summed) reinterpret_cast<float4 *>(a.g_occ + c * n)[p] = pack(g);
             }
+            if (GRADS && a.occ_grad_summed) {          // (g_0 + g_1) + g_2: the order the backward blend adds the three planes in
+                float g[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) g[k] = (gsum[0][k] + gsum[1][k]) + gsum[2][k];
+                reinterpret_cast<float4 *>(a.g_occ)[p] = pack(g);
+            }
+        }
     }
     if (VALUES) {
         __shared__ float red[4][8];
@@ -487,7 +496,7 @@ extern "C" int soar_avatar_pixel_losses(const SoarAvatarLossArgs *q, int32_t mod
     a.partials = q->scratch; a.stats = q->stats; a.stats_occ = q->stats_occ; a.counts = q->counts;
     a.up_l1 = q->up_l1; a.up_l1m = q->up_l1m; a.up_cos = q->up_cos; a.up_occ = q->up_occ; a.g_ssim = q->g_ssim; a.up_ssim = q->up_ssim;
     a.g_render = q->g_render; a.g_mask = q->g_mask; a.g_normal = q->g_normal; a.g_occ = q->g_occ;
-    a.normal_raw = q->normal_raw; a.cos_scale_out = q->cos_scale_out;
+    a.normal_raw = q->normal_raw; a.cos_scale_out = q->cos_scale_out; a.occ_grad_summed = q->occ_grad_summed;
     const int blocks = min(LOSS_BLOCKS, (a.n / 4 + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
     if (values && grads) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);

@@ -51,6 +51,7 @@ struct BwdArgs {
     // the fused occlusion chain walked back to front in the same pass (OCC): upstream gradient of the occlusion image [3,H,W], the
     // entries' camera-facing flags, what the forward left of the chain per pixel, and the per-Gaussian sums (zeroed by the caller)
     const float *dL_docc_img;
+    int occ_planes;                  // 3: [3,H,W]; 1: the three channels' gradients already summed, [1,H,W]
     const float *front;
     const float *final_To;
     const uint32_t *n_contrib_o;
@@ -324,12 +325,13 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     uint32_t last_o = 0u;
     if (OCC) {
         const size_t hw = (size_t)a.H * a.W, pix = inside ? (size_t)a.W * py + px : 0;
-        const float g0 = a.dL_docc_img[pix], g1 = a.dL_docc_img[hw + pix], g2 = a.dL_docc_img[2 * hw + pix];
+        const bool three = a.occ_planes != 1;
+        const float g0 = a.dL_docc_img[pix], g1 = three ? a.dL_docc_img[hw + pix] : 0.f, g2 = three ? a.dL_docc_img[2 * hw + pix] : 0.f;
         const float tf = a.final_To[pix];
         const uint32_t lo = a.n_contrib_o[pix];
         last_o = inside ? lo : 0u;
         To_final = tf;
-        G_occ = last_o != 0u ? (g0 + g1) + g2 : 0.f;
+        G_occ = last_o != 0u ? (three ? (g0 + g1) + g2 : g0) : 0.f;
     }
     load_pixel_at_once(a, px, py, inside, c, st);
     const uint32_t vLast = OCC ? max(c.last, last_o) : c.last;       // how deep the pixel's walk starts (the occlusion chain skips the
@@ -620,10 +622,11 @@ __global__ void narrow_rows_kernel(Batch<NarrowArgs> batch)
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
                            const float *grad_scale, float *acc, double *acc64, bool blend, const float *dL_dout_occ, float *dL_docc,
-                           const float *normal_scale, hipStream_t stream)
+                           const float *normal_scale, int occ_planes, hipStream_t stream)
 {
     BwdArgs a;
     a.normal_scale = normal_scale;
+    a.occ_planes = occ_planes;
     a.dL_docc_img = dL_dout_occ; a.front = g.front; a.final_To = img.final_To; a.n_contrib_o = img.n_contrib_o; a.g_values = dL_docc;
     const bool occ = dL_dout_occ != nullptr;
     a.grad_scale = grad_scale;

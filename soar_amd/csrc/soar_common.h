@@ -445,7 +445,7 @@ int launch_occ_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBu
 int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const BinBuf &b, const ImageBuf &img,
                            const float *dL_dcolor, const float *dL_dnormal, const float *dL_ddepth, const float *dL_dopac,
                            const float *grad_scale, float *acc, double *acc64, bool blend, const float *dL_dout_occ, float *dL_docc,
-                           const float *normal_scale, hipStream_t stream);
+                           const float *normal_scale, int occ_planes, hipStream_t stream);
 int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, const int32_t *radii, const float *shs,
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,

@@ -298,7 +298,7 @@ int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarVie
             float *junk = Gjunk + 7 * (size_t)v * P, *cam = Gcam + 35 * (size_t)v;
             if (fused_occ[v])
                 return soar_rast_backward_occ(&a.rast, xyz_p, a.radii, nullptr, pose->colors, scales3, rot_p, nullptr, vb[v].geom, vb[v].binning,
-                                              vb[v].img, a.capacity, g_color, vb[v].g_nd, vb[v].g_nd + 3 * pix, g_opac, a.g_occ, nullptr, a.dL_dmeans2D,
+                                              vb[v].img, a.capacity, g_color, vb[v].g_nd, vb[v].g_nd + 3 * pix, g_opac, a.g_occ, nullptr, 3, a.dL_dmeans2D,
                                               Gc + 3 * (size_t)v * P, junk, Gx + 3 * (size_t)v * P, junk + P, nullptr, Gs + 3 * (size_t)v * P,
                                               Gr + 4 * (size_t)v * P, cam, cam + 16, cam + 32, Go + (size_t)v * P, vb[v].work,
                                               vb[v].work_bytes, stream_);

@@ -66,7 +66,7 @@ class SoarAvatarLossArgs(C.Structure):
                 ("sel", _vp), ("sel_normal", _vp), ("sel_occ", _vp), ("stats", _vp), ("stats_occ", _vp), ("scratch", _vp), ("counts", _vp),
                 ("up_l1", _vp), ("up_l1m", _vp), ("up_cos", _vp), ("up_occ", _vp), ("up_ssim", _vp), ("g_ssim", _vp),
                 ("g_render", _vp), ("g_mask", _vp), ("g_normal", _vp), ("g_occ", _vp),
-                ("normal_raw", C.c_int32), ("pad_", C.c_int32), ("cos_scale_out", _vp)]
+                ("normal_raw", C.c_int32), ("occ_grad_summed", C.c_int32), ("cos_scale_out", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/soar_hip.h declares
@@ -90,7 +90,7 @@ SIGNATURES = {
                            + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
     "soar_rast_backward_scaled": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 5
                                   + [_vp] * 11 + [_vp, C.c_size_t, _vp]),
-    "soar_rast_backward_occ": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 6
+    "soar_rast_backward_occ": (C.c_int, [C.POINTER(SoarRastParams)] + [_vp] * 7 + [_vp, _vp, _vp, C.c_int64] + [_vp] * 6 + [C.c_int32]
                                + [_vp] * 12 + [_vp, C.c_size_t, _vp]),
     "soar_batch_begin": (C.c_int, [C.c_int32]),
     "soar_batch_frame": (C.c_int, [C.c_int32]),

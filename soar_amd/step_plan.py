@@ -247,7 +247,7 @@ class FrameStepPlan:
             sel=ptr(a["sel"][k]), sel_normal=ptr(a["sel"][k]), sel_occ=ptr(a["sel_occ"][k]), stats=at(t, S.L1), stats_occ=ptr(v["occ_terms"]),
             scratch=ptr(v["av_pix_scratch"]), counts=ptr(self.av_counts[k]), up_l1=at(up, S.L1), up_l1m=at(up, S.L1M), up_cos=at(up, S.COS),
             up_occ=ptr(self.av_occ_up), up_ssim=at(up, S.SSIM), g_ssim=ptr(v["g_ssim"]), g_render=ptr(v["gC"]), g_mask=ptr(v["gO"]),
-            g_normal=ptr(v["gN"]), g_occ=ptr(v["g_occ_img"]), normal_raw=1, cos_scale_out=self.av_cos_scale_all.data_ptr() + 4 * i)
+            g_normal=ptr(v["gN"]), g_occ=ptr(v["g_occ_img"]), normal_raw=1, occ_grad_summed=1, cos_scale_out=self.av_cos_scale_all.data_ptr() + 4 * i)
 
     def _av_pixel(self, i, stream, mode):
         key = ("av_pixel", i, self._frames_now[i] % int(self.pool.shape[0]))
@@ -395,7 +395,7 @@ class FrameStepPlan:
             return (L.soar_rast_backward_occ, (C.byref(self.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.colors.detach()),
                                                ptr(s.scales.detach()), ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["binning"]), ptr(v["img"]),
                                                self.capacity, ptr(v["gC"]), ptr(v["gN"]), ptr(v["gD"]), ptr(v["gO"]), ptr(v["g_occ_img"]),
-                                               self.av_cos_scale_all.data_ptr() + 4 * i, ptr(v["g_means2D"]), ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]),
+                                               self.av_cos_scale_all.data_ptr() + 4 * i, 1, ptr(v["g_means2D"]), ptr(self.g_colors[i]), ptr(v["g_opacity"]), ptr(v["g_means3D"]),
                                                ptr(v["g_cov3D"]), None, ptr(self.g_scales[i]), ptr(v["g_rot_p"]), ptr(v["g_view"]),
                                                ptr(v["g_proj"]), ptr(v["g_campos"]), ptr(self.g_occ_all[i]), ptr(v["work"]), v["work"].numel(),
                                                stream), "backward_occ")

@@ -1108,6 +1108,13 @@ def test_avatar_pixel_losses_in_one_pass_equal_the_separate_kernels(hw, with_occ
     check(L.soar_view_finish_backward(W, H, ptr(normal), ptr(depth), ptr(mask_img), ptr(prcp), 100.0, 100.0, ptr(w_n), None, None, None,
                                       ptr(g_nd), stream), "view_finish_backward")
     assert torch.equal(g_raw * cos_scale, g_nd[:3]) and not bool(g_nd[3].any())
+    if with_occ:
+        # ... and the occlusion image's gradient as ONE plane, the three channels' summed in the order the backward blend adds them
+        g_sum = torch.full((1, H, W), float("nan"), device=DEV)
+        a.occ_grad_summed, a.g_occ = 1, ptr(g_sum)
+        check(L.soar_avatar_pixel_losses(C.byref(a), 3, stream), "one pass, summed occlusion gradient")
+        assert torch.equal(g_sum[0], (w_o[0] + w_o[1]) + w_o[2])
+        a.occ_grad_summed, a.g_occ = 0, ptr(g_o)
     a.normal_raw, a.cos_scale_out, a.g_normal = 0, None, ptr(g_n)
     # ---- refusals: nothing to do, gradients without counts, occ without its selection, a pixel count that is no multiple of 4
     a.cos_scale_out = ptr(cos_scale)
