@@ -278,18 +278,9 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 //     the lanes' registers, TWO and ONE batch ahead of the one being worked on;
 //   * the sums of batch n leave through LDS (13 row-contiguous atomic wave-instructions) at the start of batch n + 1, behind the
 //     gathers of that step: every wait for a gather then finds the atomics in front of it a whole pixel loop old.
-struct BlockWalk {           // descending walk over the 64-position groups of a block's mask words
-    uint32_t x0, top;        // first list position of the tile, first position behind the deepest contributor (absolute)
-    uint32_t g_top;          // group of position top - 1: the walk visits g_top, g_top - 1, ... x0 >> 6
-    int n_groups;
-    int s;                   // next group of the sequence
-    unsigned long long rem;  // bits of group s - 1 not yet consumed
-    uint32_t base;           // list position of bit 0 of `rem`
-};
-
 template <bool WIDE, bool OCC>
 __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
-                                               float *xpose, uint32_t *xgid, float *xocc, uint32_t *xgid_o)
+                                               uint32_t *list, float *xpose, uint32_t *xgid, float *xocc, uint32_t *xgid_o)
 {
     const int lane = threadIdx.x & 63;
     // tile and list range in ONE load (ImageBuf::order_rec; ranks below n_work are tiles with work)
@@ -350,51 +341,79 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     }
     const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
-    BlockWalk w;
-    w.x0 = range.x; w.top = range.x + deepest;
-    w.g_top = (w.top - 1u) >> 6;
-    w.n_groups = (int)(w.g_top - (w.x0 >> 6)) + 1;
-    w.s = 0; w.rem = 0ull; w.base = 0u;
-    g_end = w.g_top;
+    // ---- the walk: the set bits of the block's mask words, deepest list position first.  Sixteen groups (1024 positions) are
+    //      compacted at a time by all 64 lanes (four lanes per word, 16 bits each) into `list`; a batch is the next 64 entries of it.
+    //      (Rounds 3-4a walked the words one at a time -- two register-to-scalar moves, a ballot, two prefix counts and a dozen scalar
+    //      instructions per 64 positions, of which a block keeps seven: a quarter of the launch's instructions made batches.)
+    const uint32_t x0 = range.x, top = range.x + deepest;       // positions at and behind `top` are not walked (nothing was blended there
+    const uint32_t g_top = (top - 1u) >> 6;                      // for this block's pixels); positions in front of x0 belong to the tile before
+    g_end = g_top;
     if (!early) {                                // a long list: the window hangs from the deepest contributor's group
-        wb = w.g_top - g_lo >= (uint32_t)WAVE ? w.g_top - (uint32_t)(WAVE - 1) : g_lo;
+        wb = g_top - g_lo >= (uint32_t)WAVE ? g_top - (uint32_t)(WAVE - 1) : g_lo;
         load_window();
     }
-
-    // next batch of up to 64 list positions, deepest first -> ring[0 .. count)
-    auto assemble = [&]() -> int {
-        int cnt = 0;
-        for (;;) {
-            if (w.rem == 0ull) {
-                if (w.s >= w.n_groups) break;
-                const uint32_t g = w.g_top - (uint32_t)w.s;               // >= g_lo
-                if (g < wb) { wb = g - g_lo >= (uint32_t)WAVE ? g - (uint32_t)(WAVE - 1) : g_lo; load_window(); }
-                const int j = (int)(g - wb);
-                unsigned long long word = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)w_lo, j) |
-                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)w_hi, j) << 32);
-                w.base = (w.g_top - (uint32_t)w.s) << 6;
-                // positions at and behind `top` are not walked (nothing was blended there for this block's pixels); positions in
-                // front of x0 belong to the tile before
-                const uint32_t nvalid = w.top - w.base;                  // > 0
-                if (nvalid < 64u) word &= (1ull << nvalid) - 1ull;
-                if (w.x0 > w.base) word &= ~0ull << (w.x0 - w.base);     // (only in the last group of the walk: x0 - base < 64)
-                w.rem = word;
-                w.s++;
-                continue;
-            }
-            const int pop = (int)__builtin_popcountll(w.rem);
-            const int room = WAVE - cnt;
-            const bool set = (w.rem >> lane) & 1ull;
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w.rem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w.rem, 0u));
-            const int above = pop - 1 - below;                           // set bits above mine: they go first
-            if (set && above < room) ring[cnt + above] = w.base + (uint32_t)lane;
-            if (pop <= room) { cnt += pop; w.rem = 0ull; }
-            else { cnt = WAVE; w.rem = __ballot(set && above >= room); }
-            if (cnt == WAVE) break;
-        }
+    int g_next = (int)g_top;                     // highest group not compacted yet; the walk ends below g_lo
+    int n_list = 0, l_pos = 0;                   // list[l_pos .. n_list): positions not handed out yet (wave-uniform)
+    auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto compact_unit = [&]() {                  // groups g_next, g_next - 1, ... g_next - 15 (those at or above g_lo) -> list[n_list ..)
+        const int g_hi = g_next, g_low = max(g_hi - 15, (int)g_lo);
+        if ((uint32_t)g_low < wb) { wb = (uint32_t)g_hi - g_lo >= (uint32_t)WAVE ? (uint32_t)g_hi - (uint32_t)(WAVE - 1) : g_lo; load_window(); }
+        // lane = (word: 0 = the highest group, quarter: highest bits first)
+        const int g = g_hi - (lane >> 2), q = 3 - (lane & 3);
+        const int src = (g - (int)wb) & 63;                      // the window's lane that holds the word
+        const uint32_t word_lo = (uint32_t)__shfl((int)w_lo, src), word_hi = (uint32_t)__shfl((int)w_hi, src);
+        const uint32_t base = ((uint32_t)g << 6) + 16u * (uint32_t)q;      // list position of bit 0 of this lane's 16 bits
+        uint32_t bits = 0u;
+        if (g >= g_low) {
+            bits = ((q >= 2 ? word_hi : word_lo) >> (16 * (q & 1))) & 0xFFFFu;
+            if (base + 16u > top) bits &= base >= top ? 0u : (1u << (top - base)) - 1u;
+            if (base < x0) bits &= x0 - base >= 16u ? 0u : (0xFFFFu << (x0 - base)) & 0xFFFFu;
+        }
+        const int cnt = __builtin_popcount(bits);
+        // inclusive sum over the lanes, lane 0 first (DPP: a lane without a source lane adds 0)
+        int incl = cnt;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);      // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);      // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);      // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);      // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+        const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+        int off = n_list + incl - cnt;
+        while (__ballot(bits != 0u)) {           // highest bit first: at most 16 trips, usually two or three
+            if (bits) {
+                const int b = 31 - __builtin_clz(bits);
+                list[off++] = base + (uint32_t)b;
+                bits &= ~(1u << b);
+            }
+        }
+        n_list += total;
+        g_next = g_low - 1;
+    };
+
+    // next batch of up to 64 list positions, deepest first -> ring[0 .. count)
+    auto assemble = [&]() -> int {
+        while (n_list - l_pos < WAVE && g_next >= (int)g_lo) {
+            if (l_pos > 0) {                     // what has not been handed out (fewer than 64 entries) moves to the front
+                const int left = n_list - l_pos;
+                uint32_t v = 0u;
+                if (lane < left) v = list[l_pos + lane];
+                wave_sync();
+                if (lane < left) list[lane] = v;
+                n_list = left; l_pos = 0;
+            }
+            wave_sync();
+            compact_unit();
+            wave_sync();
+        }
+        const int cnt = min(WAVE, n_list - l_pos);
+        if (lane < cnt) ring[lane] = list[l_pos + lane];
+        l_pos += cnt;
+        wave_sync();
         return cnt;
     };
 
@@ -413,7 +432,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         if (lane < cnt) {
             const uint32_t at = ring[lane];
             gid = a.point_list[at];
-            pos = at - w.x0;
+            pos = at - x0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the ring is refilled by the next assemble
         __builtin_amdgcn_wave_barrier();
@@ -579,6 +598,7 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
     __shared__ float4 pixc[16][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
                                                          //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
+    __shared__ uint32_t list[16 * WAVE + WAVE];          // compacted list positions of up to sixteen mask words + a batch's worth carried over
     __shared__ float xpose[WAVE * 13];                   // a batch's sums, [entry][13]
     __shared__ uint32_t xgid[WAVE];
     __shared__ float xocc[OCC ? WAVE : 1];               // ... and of the occlusion values' gradient
@@ -587,7 +607,7 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
     const int rank0 = (kth >> 4) * 8 + xcd, blk = kth & 15;
     const int stride = (int)(gridDim.x >> 4);                // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
-    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, xpose, xgid, xocc, xgid_o);
+    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, list, xpose, xgid, xocc, xgid_o);
 }
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)
