@@ -391,8 +391,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 bits &= ~(1u << b);
             }
         }
-        n_list += total;
-        g_next = g_low - 1;
+        n_list = __builtin_amdgcn_readfirstlane(n_list + total);       // (wave-uniform by construction: kept in scalar registers)
+        g_next = __builtin_amdgcn_readfirstlane(g_low - 1);
     };
 
     // next batch of up to 64 list positions, deepest first -> ring[0 .. count)
@@ -404,15 +404,15 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 if (lane < left) v = list[l_pos + lane];
                 wave_sync();
                 if (lane < left) list[lane] = v;
-                n_list = left; l_pos = 0;
+                n_list = __builtin_amdgcn_readfirstlane(left); l_pos = 0;
             }
             wave_sync();
             compact_unit();
             wave_sync();
         }
-        const int cnt = min(WAVE, n_list - l_pos);
+        const int cnt = __builtin_amdgcn_readfirstlane(min(WAVE, n_list - l_pos));
         if (lane < cnt) ring[lane] = list[l_pos + lane];
-        l_pos += cnt;
+        l_pos = __builtin_amdgcn_readfirstlane(l_pos + cnt);
         wave_sync();
         return cnt;
     };
