@@ -167,6 +167,21 @@ __global__ void __launch_bounds__(256) view_finish_kernel(Batch<ViewArgs> batch)
     if (x >= a.W || y >= a.H) return;
     const Stencil s = stencil_of_opac(x, y, a.W, a.H, a.opac);
     const size_t hw = (size_t)a.W * a.H;
+    // A pixel whose whole stencil lies outside the mask (opacity <= 1e-5 at all five points: most of a frame of one person): every
+    // masked difference below is (finite) x 0, the curvature 0, the depth normal the zero vector -- the images' background constants,
+    // written without reading the twenty normal / depth values of the stencil (the rasterizer's images are finite everywhere)
+    if ((s.mp + s.mu) + (s.ml + s.mb) + s.mr == 0.f) {
+        if (!BACKWARD) {
+            a.normal_out[s.ip] = (a.normal[s.ip] + 1.f) * 0.5f;
+            a.normal_out[hw + s.ip] = (-a.normal[hw + s.ip] + 1.f) * 0.5f;
+            a.normal_out[2 * hw + s.ip] = (-a.normal[2 * hw + s.ip] + 1.f) * 0.5f;
+            a.curv_out[s.ip] = 0.f;
+            a.pred_out[s.ip] = 0.5f; a.pred_out[hw + s.ip] = 0.5f; a.pred_out[2 * hw + s.ip] = 0.5f;
+        } else if (a.g_depth_direct) {
+            atomicAdd(&a.g_depth[s.ip], a.g_depth_direct[s.ip]);
+        }
+        return;
+    }
     const float cxW = a.prcp[0] * a.W, cyH = a.prcp[1] * a.H;
     // ---- curvature of the normal image
     auto nat = [&](int i) -> V3 { return {a.normal[i], a.normal[hw + i], a.normal[2 * hw + i]}; };
