@@ -231,11 +231,16 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
         if (VALUES)
 #pragma unroll
             for (int k = 0; k < V; k++) { cnt[0] += sel[k] ? 1.f : 0.f; cnt[1] += 1.f; if (a.occ) cnt[3] += selo[k] ? 1.f : 0.f; }
+        // (four pixels outside a selection -- most of a frame of one person -- never use the images the selection guards: not read)
+        const bool any_sel = sel[0] | sel[1] | sel[2] | sel[3], any_seln = seln[0] | seln[1] | seln[2] | seln[3];
+        const bool any_selo = a.occ && (selo[0] | selo[1] | selo[2] | selo[3]);
         // ---- colours
         for (int c = 0; c < 3; c++) {
-            float x[V], y[V], g[V], gs[V];
-            unpack(reinterpret_cast<const float4 *>(a.render + c * n)[p], x);
-            unpack(reinterpret_cast<const float4 *>(a.gt_rgb + c * n)[p], y);
+            float x[V] = {0.f, 0.f, 0.f, 0.f}, y[V] = {0.f, 0.f, 0.f, 0.f}, g[V], gs[V];
+            if (any_sel) {
+                unpack(reinterpret_cast<const float4 *>(a.render + c * n)[p], x);
+                unpack(reinterpret_cast<const float4 *>(a.gt_rgb + c * n)[p], y);
+            }
             if (GRADS && a.g_ssim) unpack(reinterpret_cast<const float4 *>(a.g_ssim + c * n)[p], gs);
 #pragma unroll
             for (int k = 0; k < V; k++) {
@@ -270,9 +275,11 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
 #pragma unroll
             for (int k = 0; k < V; k++) cs[k] = 0.f;
             for (int c = 0; c < 3; c++) {
-                float x[V], y[V];
-                unpack(reinterpret_cast<const float4 *>(a.normal + c * n)[p], x);
-                unpack(reinterpret_cast<const float4 *>(a.gt_normal + c * n)[p], y);
+                float x[V] = {0.f, 0.f, 0.f, 0.f}, y[V] = {0.f, 0.f, 0.f, 0.f};
+                if (any_seln) {
+                    unpack(reinterpret_cast<const float4 *>(a.normal + c * n)[p], x);
+                    unpack(reinterpret_cast<const float4 *>(a.gt_normal + c * n)[p], y);
+                }
 #pragma unroll
                 for (int k = 0; k < V; k++) {
                     cs[k] += (x[k] * 2.f - 1.f) * (y[k] * 2.f - 1.f) * a.cos_weight;
@@ -302,8 +309,8 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
         if (a.occ) {
             float gsum[3][V];
             for (int c = 0; c < 3; c++) {
-                float x[V], g[V];
-                unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
+                float x[V] = {1.f, 1.f, 1.f, 1.f}, g[V];
+                if (any_selo) unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
 #pragma unroll
                 for (int k = 0; k < V; k++) {
                     const float d = x[k] - 1.f;
