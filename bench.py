@@ -62,7 +62,7 @@ STAGE_KERNELS = {
     "block_masks": ["tile_order_binned_kernel", "(tile order + cleared mask words; the masks themselves are left behind by render_forward_kernel since "
                     "round 4; block_mask_kernel only behind the key export)"],
     "geometry_backward": ["geometry_backward_kernel"],
-    "lbs_knn_weights": ["knn_follow_kernel", "knn_search_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
+    "lbs_knn_weights": ["knn_blend_search_kernel", "knn_certify_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
     "optimizer": ["adam_update_kernel", "adam_tick_kernel"],
     "lbs_warp_forward": ["warp_forward_frames_kernel", "warp_forward_kernel"],
     "lbs_warp_backward": ["warp_backward_frames_kernel", "warp_backward_kernel"],

@@ -289,6 +289,7 @@ struct KnnStatePtrs {        // (every array in the queries' sorted order: entry
     float4 *ref30, *ref32;   // [P] {position the 30-subset / the 32-set was determined at, half the gap behind it (0: unknown)}
     uint32_t *in30;          // [P] which of the 32 are the K = 30 nearest
     uint32_t *work;          // [2 + 2 P] {entries, wavefronts done, {query, bits of its search radius squared} ...}
+    float *d2;               // [P][32] squared distances to the 32 stored vertices at this refresh's positions (< 0: the query is on the work list)
 };
 
 // First wavefront of the workgroup: list the contiguous sorted-vertex ranges covered by the box of radius r around
@@ -708,6 +709,9 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
 // the grid cells that ball touches are scanned.
 // Whatever the tier, the K distances, the inverse-distance weights and the blend of the K skinning rows are then recomputed with the
 // expressions and in the (vertex-grid) order of knn_cell_kernel: the weights are the full search's bit for bit.
+#ifndef SOAR_KNN_SLOT_UNROLL
+#define SOAR_KNN_SLOT_UNROLL 5
+#endif
 constexpr int KNN_KEEP = KNN_STATE_STRIDE;   // neighbours kept per query
 constexpr int RF_CAP = 192;              // candidates the seeded search holds between two selections (KNN_KEEP + a chunk of 64 fit)
 
@@ -766,16 +770,71 @@ __device__ __forceinline__ void blend_rows(uint32_t mask, uint32_t pos, float d2
     __builtin_amdgcn_wave_barrier();
 }
 
+// The follower's form of the same blend: FOUR queries per trip.  One query's blend is a chain of 30 (LDS read, row load, multiply-add)
+// steps that keeps 55 lanes busy with one float each -- the kernel is bound by the number of instructions it issues, not by the
+// rows' bytes (profiles/README.md, round 4).  Here a slot holds a query's list {row byte offset, weight} x 30; sixteen lanes take a
+// slot, lane t of them the joints 4t .. 4t+3 as ONE 16-byte load per row (rows are 224 bytes: 14 lanes of the sixteen), so a
+// trip issues a quarter of the loads and LDS reads per query and no more multiply-adds.  Every (query, joint) sum is the same chain of
+// fused multiply-adds over the neighbours in ascending grid position, the norm the same chain of additions: bit for bit blend_rows.
+constexpr int KNN_FSLOTS = 4;
+struct KnnSlots { uint2 list[KNN_FSLOTS][KNN_KEEP]; int p[KNN_FSLOTS]; };
+// lanes 0..31 / 32..63 hold (pos ascending, d2) of the 32 stored vertices of the queries of slot_lo / slot_lo + 1 (p < 0: no query)
+__device__ __forceinline__ void slots_fill_pair(KnnSlots &sl, int slot_lo, int p, uint32_t mask, uint32_t pos, float d2, int lane)
+{
+    const int slot = slot_lo + (lane >> 5), l5 = lane & (KNN_KEEP - 1);
+    if (p >= 0 && ((mask >> l5) & 1u)) {
+        const int at = __builtin_popcount(mask & ((1u << l5) - 1u));
+        // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634); the row's BYTE offset (V x 224 bytes stay far below 2^32)
+        sl.list[slot][at] = make_uint2(pos * (uint32_t)(KNN_JMAX * sizeof(float)), __float_as_uint(1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f)));
+    }
+    if (l5 == 0) sl.p[slot] = p;
+}
+__device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float *__restrict__ rows_padded, int J,
+                                            float *__restrict__ weights_out)
+{
+    static_assert(KNN_K % 2 == 0 && KNN_JMAX % 4 == 0 && KNN_JMAX / 4 <= 16 && KNN_FSLOTS * 16 == WAVE && KNN_KEEP * 2 == WAVE, "slot layout");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int g = lane >> 4, t = lane & 15;
+    const int p = sl.p[g];
+    if (p >= 0) {
+        const uint32_t t16 = (uint32_t)min(t, KNN_JMAX / 4 - 1) * 16u;
+        const char *rows_bytes = reinterpret_cast<const char *>(rows_padded);
+        const uint4 *mine = reinterpret_cast<const uint4 *>(sl.list[g]);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float norm = 0.f;
+#pragma unroll SOAR_KNN_SLOT_UNROLL
+        for (int k2 = 0; k2 < KNN_K / 2; k2++) {
+            const uint4 e = mine[k2];
+            const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (e.x + t16));
+            const float4 r1 = *reinterpret_cast<const float4 *>(rows_bytes + (e.z + t16));
+            const float w0 = __uint_as_float(e.y), w1 = __uint_as_float(e.w);
+            acc.x = __builtin_fmaf(w0, r0.x, acc.x); acc.y = __builtin_fmaf(w0, r0.y, acc.y);
+            acc.z = __builtin_fmaf(w0, r0.z, acc.z); acc.w = __builtin_fmaf(w0, r0.w, acc.w);
+            norm += w0;
+            acc.x = __builtin_fmaf(w1, r1.x, acc.x); acc.y = __builtin_fmaf(w1, r1.y, acc.y);
+            acc.z = __builtin_fmaf(w1, r1.z, acc.z); acc.w = __builtin_fmaf(w1, r1.w, acc.w);
+            norm += w1;
+        }
+        float *out = weights_out + (size_t)p * J + 4 * t;
+        if (4 * t + 0 < J) out[0] = acc.x / norm;
+        if (4 * t + 1 < J) out[1] = acc.y / norm;
+        if (4 * t + 2 < J) out[2] = acc.z / norm;
+        if (4 * t + 3 < J) out[3] = acc.w / norm;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // tiers 1 and 2: one wavefront per query, consecutive queries of the (cell-sorted) order per wavefront -- queries of one cell share
 // most neighbours, so the skinning rows mostly come from the CU's L1.  A query is a chain of dependent reads (its id -> its position;
 // its neighbour list -> their coordinates -> their skinning rows) around very little arithmetic: the wavefront keeps three queries in
 // flight, one per level of the chain.
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
-knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded,
-                  int J, const uint32_t *__restrict__ order, KnnStatePtrs st, float *__restrict__ weights_out)
+knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict__ sorted_verts, const uint32_t *__restrict__ order,
+                   KnnStatePtrs st)
 {
-    __shared__ uint32_t c_pos[KNN_WAVES][KNN_KEEP];
-    __shared__ float c_w[KNN_WAVES][KNN_KEEP];
     // (wave-uniform index: what is the same for all lanes -- id, position, reference points, mask -- travels through scalar loads;
     // as vector loads of one address the kernel measured 65 us against 57)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -799,10 +858,8 @@ knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict
     if (q_begin < q_end) { level1(q_begin); level2(); }
     if (q_begin + 1 < q_end) level1(q_begin + 1);
     for (int q = q_begin; q < q_end; q++) {
-        const int p = p1;
         const float x = x1, y = y1, z = z1;
         const float4 ra = a1, rb = b1;
-        const uint32_t pos = nbr1;
         uint32_t mask = mask1;
         const float d2 = dist2_exact(x, y, z, v1);                   // (lanes 32..63 repeat lanes 0..31)
         if (q + 1 < q_end) level2();
@@ -812,7 +869,7 @@ knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict
         const float moved_b = sqrtf((bx * bx + by * by) + bz * bz) * 1.0001f + 1.0e-12f;
         if (!(ra.w > 0.f && moved_a < ra.w)) {                        // (wave-uniform)
             if (!(rb.w > 0.f && moved_b < rb.w)) {
-                // neither certificate holds: the seeded search (knn_search_kernel) takes the query
+                // neither certificate holds: the seeded search (knn_blend_search_kernel) takes the query
                 // (with the largest new distance to a stored neighbour: the radius of its search)
                 float far = d2;
 #pragma unroll
@@ -822,6 +879,7 @@ knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict
                     st.work[2u + 2u * at] = (uint32_t)q;
                     st.work[3u + 2u * at] = __float_as_uint(far);
                 }
+                if (lane < KNN_KEEP) st.d2[(size_t)q * KNN_STATE_STRIDE + lane] = -1.f;
                 continue;
             }
             // the 32 stored vertices still are the 32 nearest: the K nearest among them, and the gap behind the K-th, from here
@@ -829,26 +887,53 @@ knn_follow_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict
             mask = rank_32(d2, lane, h30);
             if (lane == 0) { st.ref30[q] = make_float4(x, y, z, h30); st.in30[q] = mask; }
         }
-        blend_rows(mask, pos, d2, lane, c_pos[wave], c_w[wave], rows_padded, J, weights_out + (size_t)p * J);
+        if (lane < KNN_KEEP) st.d2[(size_t)q * KNN_STATE_STRIDE + lane] = d2;
     }
 }
 
-// tier 3: one wavefront per query of the work list
+// The second launch of a refresh.  Its first `search_blocks` workgroups take the work list (tier 3: one wavefront per query; a seeded
+// search is ~20 us of dependent steps whatever the list's length), the others blend the certified queries, four per wavefront, from
+// what knn_certify_kernel left (distances, in-set masks): the searches run UNDER the blends instead of behind them.
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
-knn_search_kernel(const float *__restrict__ xyz, const GridMeta *__restrict__ meta, const uint2 *__restrict__ cell_range,
-                  const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded, int J, const uint32_t *__restrict__ order,
-                  KnnStatePtrs st, float *__restrict__ weights_out, uint32_t *__restrict__ counters)
+knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks, const GridMeta *__restrict__ meta,
+                        const uint2 *__restrict__ cell_range, const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded,
+                        int J, const uint32_t *__restrict__ order, KnnStatePtrs st, float *__restrict__ weights_out,
+                        uint32_t *__restrict__ counters)
 {
     constexpr int KEEP = KNN_KEEP;
     __shared__ uint32_t c_pos[KNN_WAVES][RF_CAP];
     __shared__ float c_d[KNN_WAVES][RF_CAP];
     __shared__ uint32_t row_first[KNN_WAVES][WAVE], row_end[KNN_WAVES][WAVE];
+    __shared__ __attribute__((aligned(16))) KnnSlots slots[KNN_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= search_blocks) {
+        // ---- certified queries: consecutive ones of the (cell-sorted) order share most neighbours -- the rows mostly come from the CU's L1
+        const int q0 = (((int)blockIdx.x - search_blocks) * KNN_WAVES + wave) * KNN_FSLOTS;
+        if (q0 >= P) return;
+        const int l5 = lane & (KNN_KEEP - 1);
+        float dd[2];
+        uint32_t pp[2], mm[2];
+        int pq[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int q = q0 + 2 * r + (lane >> 5);
+            const size_t at = (size_t)min(q, P - 1) * KNN_STATE_STRIDE + l5;
+            dd[r] = st.d2[at];
+            pp[r] = st.nbr[at];
+            mm[r] = st.in30[min(q, P - 1)];
+            pq[r] = order ? (int)order[min(q, P - 1)] : min(q, P - 1);
+            if (q >= P) dd[r] = -1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) slots_fill_pair(slots[wave], 2 * r, dd[r] >= 0.f ? pq[r] : -1, mm[r], pp[r], dd[r], lane);
+        slots_blend(slots[wave], lane, rows_padded, J, weights_out);
+        return;
+    }
     uint32_t *cp = c_pos[wave];
     float *cd = c_d[wave];
     const GridMeta m = *meta;
     const uint32_t n_work = st.work[0];
-    for (uint32_t w = blockIdx.x * KNN_WAVES + wave; w < n_work; w += gridDim.x * KNN_WAVES) {
+    for (uint32_t w = blockIdx.x * KNN_WAVES + wave; w < n_work; w += (uint32_t)search_blocks * KNN_WAVES) {
         const size_t q = st.work[2u + 2u * w];
         // everything within the largest new distance to an old neighbour (there are at least K vertices that close) ...
         const float tau_ub = __uint_as_float(st.work[3u + 2u * w]);
@@ -1125,7 +1210,7 @@ int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
     return 0;
 }
 
-// neighbour state of soar_lbs_knn_refresh: [P][32] grid positions | [P] ref30 | [P] ref32 | [P] in30 | [2 + P] work list
+// neighbour state of soar_lbs_knn_refresh: [P][32] grid positions | [P] ref30 | [P] ref32 | [P] in30 | [2 + 2 P] work list | [P][32] distances
 struct KnnState { KnnStatePtrs p; size_t total; };
 int carve_knn_state(void *base, int32_t P, KnnState *out)
 {
@@ -1138,6 +1223,7 @@ int carve_knn_state(void *base, int32_t P, KnnState *out)
     out->p.ref32 = reinterpret_cast<float4 *>(carve(sizeof(float4) * n));
     out->p.in30 = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * n));
     out->p.work = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * (2 * n + 2)));
+    out->p.d2 = reinterpret_cast<float *>(carve(sizeof(float) * KNN_STATE_STRIDE * n));
     out->total = off;
     return 0;
 }
@@ -1147,7 +1233,7 @@ int knn_query(const KnnGrid &g, int32_t V, const float *vert_weights, int32_t J,
               hipStream_t stream, const KnnState *state = nullptr)
 {
     const bool fast = (K == KNN_K) && (J <= KNN_JMAX);
-    KnnStatePtrs st_none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    KnnStatePtrs st_none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const KnnStatePtrs st = state ? state->p : st_none;
     if (!fast && state) { set_error("soar_lbs_knn: the neighbour state needs K = %d and J <= %d", KNN_K, KNN_JMAX); return 1; }
     if (!fast) {
@@ -1335,10 +1421,10 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     // (the work list starts empty: a memset node -- letting the last wavefront of the search kernel reset it meant one atomic per
     // wavefront on one address, 50 us for 2048 of them)
     SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(knn_follow_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, g.rows, J, order,
-                       st.p, weights_out);
-    hipLaunchKernelGGL(knn_search_kernel, dim3(512), dim3(KNN_WAVES * WAVE), 0, stream, xyz, g.meta, g.cell_range, g.sorted_verts,
-                       g.rows, J, order, st.p, weights_out, searched_counter_dev);
+    hipLaunchKernelGGL(knn_certify_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, order, st.p);
+    const int search_blocks = 512, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
+    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks + blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
+                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
     SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
     return 0;
 }
