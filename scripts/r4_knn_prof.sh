@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "knn_follow" in k or "knn_search" in k: acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "knn_certify" in k or "knn_blend" in k: acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k, {c: round(sum(v[-4:]) / len(v[-4:]) / 1e6, 3) for c, v in d.items()}, "(millions per launch)")
 PY

@@ -18,4 +18,14 @@ for r in rows:
         print("%-62s calls/step %5.1f  avg %7.1f us  per step %7.1f us" % (name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, us))
 print("sum of kernel time per step: %.1f us" % tot)
 PY
+python3 - $out/trace <<'PY'
+import csv, glob, sys, statistics, collections
+d = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        d[r["Kernel_Name"] + ("" if "knn" not in r["Kernel_Name"] else " grid " + str(r.get("Grid_Size_X", r.get("Grid_Size", "?"))))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("medians (us) of the launches of a kernel:")
+for k, v in sorted(d.items(), key=lambda kv: -statistics.median(kv[1]) * len(kv[1])):
+    if len(v) >= 20: print("  %-60s n %4d  median %7.1f  min %7.1f" % (k.replace("soar::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:42] + k[k.rfind(" grid"):] if " grid" in k else k.replace("soar::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], len(v), statistics.median(v), min(v)))
+PY
 rm -rf $out/trace

@@ -743,39 +743,13 @@ __device__ __forceinline__ uint32_t rank_32(float d2, int lane, float &h30)
     return (uint32_t)__ballot(in);
 }
 
-// the blend of the K in-set neighbours, ascending grid position (lanes = joints); cp / cw: 32 words of LDS of this wavefront
-__device__ __forceinline__ void blend_rows(uint32_t mask, uint32_t pos, float d2, int lane, uint32_t *cp, float *cw,
-                                           const float *__restrict__ rows_padded, int J, float *__restrict__ out_row)
-{
-    if (lane < KNN_KEEP && ((mask >> lane) & 1u)) {
-        const int at = __builtin_popcount(mask & ((1u << lane) - 1u));
-        cp[at] = pos * (uint32_t)(KNN_JMAX * sizeof(float));          // the row's BYTE offset (V x 224 bytes stay far below 2^32): a 32-bit add
-        cw[at] = 1.0f / fminf(fmaxf(sqrtf(d2), 0.0001f), 1.0f);       // ws = (1/d) / sum(1/d), d = clamp(sqrt(d2), 1e-4, 1) (smpl.py:630-634)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // (a 64-bit multiply-add per gathered row -- v_mad_u64_u32 -- was a third of this loop's instructions; the base pointer is
-    // wave-uniform: scalar base + 32-bit lane offset)
-    const uint32_t jl4 = (uint32_t)min(lane, KNN_JMAX - 1) * (uint32_t)sizeof(float);
-    const char *rows_bytes = reinterpret_cast<const char *>(rows_padded);
-    float accj = 0.f, norm = 0.f;
-#pragma unroll 15
-    for (int k = 0; k < KNN_K; k++) {
-        const float wk = cw[k];
-        accj = __builtin_fmaf(wk, *reinterpret_cast<const float *>(rows_bytes + (cp[k] + jl4)), accj);
-        norm += wk;
-    }
-    if (lane < J) out_row[lane] = accj / norm;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// The follower's form of the same blend: FOUR queries per trip.  One query's blend is a chain of 30 (LDS read, row load, multiply-add)
-// steps that keeps 55 lanes busy with one float each -- the kernel is bound by the number of instructions it issues, not by the
+// The blend of the K in-set neighbours' skinning rows, ascending grid position, FOUR queries per trip.  One query's blend with lanes =
+// joints is a chain of 30 (LDS read, row load, multiply-add) steps that keeps 55 lanes busy with one float each -- the kernel is bound by the number of instructions it issues, not by the
 // rows' bytes (profiles/README.md, round 4).  Here a slot holds a query's list {row byte offset, weight} x 30; sixteen lanes take a
 // slot, lane t of them the joints 4t .. 4t+3 as ONE 16-byte load per row (rows are 224 bytes: 14 lanes of the sixteen), so a
 // trip issues a quarter of the loads and LDS reads per query and no more multiply-adds.  Every (query, joint) sum is the same chain of
-// fused multiply-adds over the neighbours in ascending grid position, the norm the same chain of additions: bit for bit blend_rows.
+// fused multiply-adds over the neighbours in ascending grid position, the norm the same chain of additions as in knn_cell_kernel's
+// blend: bit for bit the full search's weights.
 constexpr int KNN_FSLOTS = 4;
 struct KnnSlots { uint2 list[KNN_FSLOTS][KNN_KEEP]; int p[KNN_FSLOTS]; };
 // lanes 0..31 / 32..63 hold (pos ascending, d2) of the 32 stored vertices of the queries of slot_lo / slot_lo + 1 (p < 0: no query)
@@ -827,74 +801,98 @@ __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float 
     __builtin_amdgcn_wave_barrier();
 }
 
-// tiers 1 and 2: one wavefront per query, consecutive queries of the (cell-sorted) order per wavefront -- queries of one cell share
-// most neighbours, so the skinning rows mostly come from the CU's L1.  A query is a chain of dependent reads (its id -> its position;
-// its neighbour list -> their coordinates -> their skinning rows) around very little arithmetic: the wavefront keeps three queries in
-// flight, one per level of the chain.
+// the same for TWO queries at once: lanes 0..31 hold the 32 stored vertices of one query, lanes 32..63 those of another; each half
+// gets its own mask and gap (the distances of a half travel by ds_bpermute instead of v_readlane)
+__device__ __forceinline__ uint32_t rank_32_halves(float d2, int lane, float &h30)
+{
+    const int l5 = lane & (KNN_KEEP - 1), base = lane & KNN_KEEP;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < KNN_KEEP; j++) {
+        const float dj = __shfl(d2, base + j);
+        rank += (dj < d2 || (dj == d2 && j < l5)) ? 1 : 0;
+    }
+    const bool in = rank < KNN_K;
+    float d_in = in ? d2 : 0.f, d_out = in ? 3.0e38f : d2;
+#pragma unroll
+    for (int off = KNN_KEEP / 2; off > 0; off >>= 1) {
+        d_in = fmaxf(d_in, __shfl_xor(d_in, off));
+        d_out = fminf(d_out, __shfl_xor(d_out, off));
+    }
+    h30 = half_gap(d_in, d_out);
+    const unsigned long long b = __ballot(in);
+    return (uint32_t)(base ? (b >> 32) : b);
+}
+
+// First launch of a refresh -- tiers 1 and 2: which queries keep their neighbour sets.  Half a wavefront per query (lane = stored
+// vertex; what belongs to the query itself -- id, position, reference points -- is loaded by all 32 lanes from one address: one
+// request), four pairs of queries per wavefront with every load of the four in flight before the first is used: a query is a chain
+// of two dependent reads (its id -> its position; its neighbour list -> their coordinates) around very little arithmetic.  Leaves the
+// 32 distances of a certified query for the blend (st.d2), -1 for a query that goes on the work list.
+constexpr int KNN_CERT_PAIRS = 4;
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
 knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict__ sorted_verts, const uint32_t *__restrict__ order,
                    KnnStatePtrs st)
 {
-    // (wave-uniform index: what is the same for all lanes -- id, position, reference points, mask -- travels through scalar loads;
-    // as vector loads of one address the kernel measured 65 us against 57)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int per_wave = (P + (int)gridDim.x * KNN_WAVES - 1) / ((int)gridDim.x * KNN_WAVES);
-    const int q_begin = ((int)blockIdx.x * KNN_WAVES + wave) * per_wave, q_end = min(P, q_begin + per_wave);
-    // level 1 (two queries ahead): id, neighbour list, reference points, mask; level 2 (one ahead): position, neighbour coordinates
-    int p2 = 0, p1 = 0;
-    uint32_t nbr2 = 0u, nbr1 = 0u, mask2 = 0u, mask1 = 0u;
-    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2, a1 = a2, b1 = a2, v1 = a2;
-    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-    auto level1 = [&](int q) {
-        p2 = order ? (int)order[q] : q;
-        nbr2 = st.nbr[(size_t)q * KNN_STATE_STRIDE + (lane & (KNN_KEEP - 1))];
-        a2 = st.ref30[q]; b2 = st.ref32[q]; mask2 = st.in30[q];
-    };
-    auto level2 = [&]() {                                            // of the query level 1 last fetched
-        p1 = p2; nbr1 = nbr2; a1 = a2; b1 = b2; mask1 = mask2;
-        x1 = xyz[3 * p1]; y1 = xyz[3 * p1 + 1]; z1 = xyz[3 * p1 + 2];
-        v1 = sorted_verts[nbr1];
-    };
-    if (q_begin < q_end) { level1(q_begin); level2(); }
-    if (q_begin + 1 < q_end) level1(q_begin + 1);
-    for (int q = q_begin; q < q_end; q++) {
-        const float x = x1, y = y1, z = z1;
-        const float4 ra = a1, rb = b1;
-        uint32_t mask = mask1;
-        const float d2 = dist2_exact(x, y, z, v1);                   // (lanes 32..63 repeat lanes 0..31)
-        if (q + 1 < q_end) level2();
-        if (q + 2 < q_end) level1(q + 2);
-        const float ax = x - ra.x, ay = y - ra.y, az = z - ra.z, bx = x - rb.x, by = y - rb.y, bz = z - rb.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l5 = lane & (KNN_KEEP - 1);
+    const int q_base = ((int)blockIdx.x * KNN_WAVES + wave) * (2 * KNN_CERT_PAIRS) + (lane >> 5);
+    if (q_base - (lane >> 5) >= P) return;
+    int qs[KNN_CERT_PAIRS];
+    float4 ra[KNN_CERT_PAIRS], rb[KNN_CERT_PAIRS], vv[KNN_CERT_PAIRS];
+    float xs[KNN_CERT_PAIRS], ys[KNN_CERT_PAIRS], zs[KNN_CERT_PAIRS];
+#pragma unroll
+    for (int i = 0; i < KNN_CERT_PAIRS; i++) {
+        qs[i] = q_base + 2 * i;
+        const int qc = min(qs[i], P - 1);
+        const int p = order ? (int)order[qc] : qc;
+        const uint32_t pos = st.nbr[(size_t)qc * KNN_STATE_STRIDE + l5];
+        ra[i] = st.ref30[qc]; rb[i] = st.ref32[qc];
+        xs[i] = xyz[3 * p]; ys[i] = xyz[3 * p + 1]; zs[i] = xyz[3 * p + 2];
+        vv[i] = sorted_verts[pos];
+    }
+#pragma unroll
+    for (int i = 0; i < KNN_CERT_PAIRS; i++) {
+        const int q = qs[i];
+        const bool valid = q < P;
+        const float x = xs[i], y = ys[i], z = zs[i];
+        const float d2 = dist2_exact(x, y, z, vv[i]);
+        const float ax = x - ra[i].x, ay = y - ra[i].y, az = z - ra[i].z, bx = x - rb[i].x, by = y - rb[i].y, bz = z - rb[i].z;
         const float moved_a = sqrtf((ax * ax + ay * ay) + az * az) * 1.0001f + 1.0e-12f;
         const float moved_b = sqrtf((bx * bx + by * by) + bz * bz) * 1.0001f + 1.0e-12f;
-        if (!(ra.w > 0.f && moved_a < ra.w)) {                        // (wave-uniform)
-            if (!(rb.w > 0.f && moved_b < rb.w)) {
-                // neither certificate holds: the seeded search (knn_blend_search_kernel) takes the query
-                // (with the largest new distance to a stored neighbour: the radius of its search)
-                float far = d2;
+        const bool ok_a = ra[i].w > 0.f && moved_a < ra[i].w, ok_b = rb[i].w > 0.f && moved_b < rb[i].w;
+        const bool tier3 = valid && !ok_a && !ok_b, tier2 = valid && !ok_a && ok_b;
+        if (__ballot(tier3)) {
+            // neither certificate holds: the seeded search (knn_blend_search_kernel) takes the query, with the largest new distance to a
+            // stored neighbour -- the radius of its search
+            float far = d2;
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
-                if (lane == 0) {
-                    const uint32_t at = atomicAdd(st.work, 1u);
-                    st.work[2u + 2u * at] = (uint32_t)q;
-                    st.work[3u + 2u * at] = __float_as_uint(far);
-                }
-                if (lane < KNN_KEEP) st.d2[(size_t)q * KNN_STATE_STRIDE + lane] = -1.f;
-                continue;
+            for (int off = KNN_KEEP / 2; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
+            if (tier3 && l5 == 0) {
+                const uint32_t at = atomicAdd(st.work, 1u);
+                st.work[2u + 2u * at] = (uint32_t)q;
+                st.work[3u + 2u * at] = __float_as_uint(far);
             }
+        }
+        if (__ballot(tier2)) {
             // the 32 stored vertices still are the 32 nearest: the K nearest among them, and the gap behind the K-th, from here
             float h30;
-            mask = rank_32(d2, lane, h30);
-            if (lane == 0) { st.ref30[q] = make_float4(x, y, z, h30); st.in30[q] = mask; }
+            const uint32_t mask = rank_32_halves(d2, lane, h30);
+            if (tier2 && l5 == 0) { st.ref30[q] = make_float4(x, y, z, h30); st.in30[q] = mask; }
         }
-        if (lane < KNN_KEEP) st.d2[(size_t)q * KNN_STATE_STRIDE + lane] = d2;
+        if (valid) st.d2[(size_t)q * KNN_STATE_STRIDE + l5] = tier3 ? -1.f : d2;
     }
 }
 
 // The second launch of a refresh.  Its first `search_blocks` workgroups take the work list (tier 3: one wavefront per query; a seeded
 // search is ~20 us of dependent steps whatever the list's length), the others blend the certified queries, four per wavefront, from
 // what knn_certify_kernel left (distances, in-set masks): the searches run UNDER the blends instead of behind them.
-__global__ void __launch_bounds__(KNN_WAVES *WAVE)
+#ifndef SOAR_KNN_SEARCH_BLOCKS
+#define SOAR_KNN_SEARCH_BLOCKS 512
+#endif
+#ifndef SOAR_KNN_BS_WPE
+#define SOAR_KNN_BS_WPE 4
+#endif
+__global__ void __launch_bounds__(KNN_WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(SOAR_KNN_BS_WPE, 8)))
 knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks, const GridMeta *__restrict__ meta,
                         const uint2 *__restrict__ cell_range, const float4 *__restrict__ sorted_verts, const float *__restrict__ rows_padded,
                         int J, const uint32_t *__restrict__ order, KnnStatePtrs st, float *__restrict__ weights_out,
@@ -910,6 +908,9 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         // ---- certified queries: consecutive ones of the (cell-sorted) order share most neighbours -- the rows mostly come from the CU's L1
         const int q0 = (((int)blockIdx.x - search_blocks) * KNN_WAVES + wave) * KNN_FSLOTS;
         if (q0 >= P) return;
+#ifdef SOAR_KNN_EXP
+        if (SOAR_KNN_EXP & 1) return;
+#endif
         const int l5 = lane & (KNN_KEEP - 1);
         float dd[2];
         uint32_t pp[2], mm[2];
@@ -932,9 +933,18 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
     uint32_t *cp = c_pos[wave];
     float *cd = c_d[wave];
     const GridMeta m = *meta;
-    const uint32_t n_work = st.work[0];
+    uint32_t n_work = st.work[0];
+#ifdef SOAR_KNN_EXP
+    if (SOAR_KNN_EXP & 2) n_work = 0;
+    if (SOAR_KNN_EXP & 4) n_work = min(n_work, 64u);
+#endif
     for (uint32_t w = blockIdx.x * KNN_WAVES + wave; w < n_work; w += (uint32_t)search_blocks * KNN_WAVES) {
         const size_t q = st.work[2u + 2u * w];
+#ifdef SOAR_KNN_SEARCH_LOG
+        const unsigned long long lt0 = wall_clock64();
+        unsigned long long lt1 = lt0, lt2 = lt0;
+        int l_sel = 0, l_cand = 0, l_rows = 0, l_nin = 0;
+#endif
         // everything within the largest new distance to an old neighbour (there are at least K vertices that close) ...
         const float tau_ub = __uint_as_float(st.work[3u + 2u * w]);
         const int p = order ? (int)order[q] : (int)q;
@@ -965,6 +975,9 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
             next_d2 = 3.0e38f;
             // keep the KEEP best of the n_in held candidates (ties in list = grid order), remember the best one dropped
             auto select_keep = [&]() {
+#ifdef SOAR_KNN_SEARCH_LOG
+                l_sel++;
+#endif
                 uint32_t e_pos[RF_CAP / WAVE];
                 float e_d[RF_CAP / WAVE];
                 int rank[RF_CAP / WAVE];
@@ -1029,6 +1042,9 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
                     if (lane >= d) incl += up;
                 }
                 const int n_cand = (int)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+#ifdef SOAR_KNN_SEARCH_LOG
+                l_cand += n_cand; l_rows = n_rows;
+#endif
                 row_first[wave][lane] = rs;
                 row_end[wave][lane] = incl;                           // candidates of the rows 0 .. lane
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1088,6 +1104,9 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // row_first / row_end are rewritten by the next 64 rows
                 __builtin_amdgcn_wave_barrier();
             }
+#ifdef SOAR_KNN_SEARCH_LOG
+            lt1 = wall_clock64(); l_nin = n_in;
+#endif
             if (n_in >= KEEP) { select_keep(); break; }               // n_in == KEEP now
         }
         if (!sane) {                                                  // (wave-uniform)
@@ -1099,6 +1118,9 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
             }
             continue;
         }
+#ifdef SOAR_KNN_SEARCH_LOG
+        lt2 = wall_clock64();
+#endif
         const uint32_t pos = lane < KEEP ? cp[lane] : 0u;
         const float d2 = lane < KEEP ? cd[lane] : 3.0e38f;
         float far = lane < KEEP ? d2 : 0.f;
@@ -1116,7 +1138,23 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        blend_rows(mask, pos, d2, lane, cp, cd, rows_padded, J, weights_out + (size_t)p * J);
+#ifdef SOAR_KNN_SEARCH_LOG
+        const unsigned long long lt3 = wall_clock64();
+#endif
+        // (as one slot of the four-query blend: its row loads travel ten at a time -- the one-query chain of 30 (LDS read, row load,
+        // multiply-add) steps came out of the compiler as 30 round trips one after the other here, 11 of a search's 26 us)
+        slots_fill_pair(slots[wave], 0, lane < KNN_KEEP ? p : -1, mask, pos, d2, lane);
+        if (lane == 0) { slots[wave].p[2] = -1; slots[wave].p[3] = -1; }
+        slots_blend(slots[wave], lane, rows_padded, J, weights_out);
+#ifdef SOAR_KNN_SEARCH_LOG
+        if (lane == 0) {
+            const unsigned long long lt4 = wall_clock64();
+            float *lg = st.d2 + q * KNN_STATE_STRIDE;
+            auto put = [&](int k, float v) { lg[k] = -(1.f + v); };
+            put(0, (float)(lt4 - lt0)); put(1, (float)(lt1 - lt0)); put(2, (float)(lt2 - lt1)); put(3, (float)(lt3 - lt2)); put(4, (float)(lt4 - lt3));
+            put(5, (float)growths); put(6, (float)l_sel); put(7, (float)l_cand); put(8, (float)l_rows); put(9, (float)l_nin);
+        }
+#endif
     }
     if (counters && blockIdx.x == 0 && threadIdx.x == 0 && n_work) atomicAdd(counters, n_work);
 }
@@ -1417,14 +1455,21 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     KnnState st;
     carve_knn_state(state_buffer, P, &st);
     StageTimer timer(ST_LBS_KNN, stream);
-    const int nblocks = min((P + KNN_WAVES - 1) / KNN_WAVES, 8192);
+    const int per_block = KNN_WAVES * 2 * KNN_CERT_PAIRS, nblocks = (P + per_block - 1) / per_block;
     // (the work list starts empty: a memset node -- letting the last wavefront of the search kernel reset it meant one atomic per
     // wavefront on one address, 50 us for 2048 of them)
     SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(knn_certify_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, order, st.p);
-    const int search_blocks = 512, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
+    const int search_blocks = SOAR_KNN_SEARCH_BLOCKS, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
+#if defined(SOAR_KNN_EXP) && (SOAR_KNN_EXP & 8)
+    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, 0,
+                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, 0, search_blocks,
+                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+#else
     hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks + blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
                        g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+#endif
     SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
     return 0;
 }
