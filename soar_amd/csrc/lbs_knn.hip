@@ -288,9 +288,22 @@ struct KnnStatePtrs {        // (every array in the queries' sorted order: entry
     uint32_t *nbr;           // [P][32] the 32 nearest vertices, ascending grid position
     float4 *ref30, *ref32;   // [P] {position the 30-subset / the 32-set was determined at, half the gap behind it (0: unknown)}
     uint32_t *in30;          // [P] which of the 32 are the K = 30 nearest
-    uint32_t *work;          // [2 + 2 P] {entries, wavefronts done, {query, bits of its search radius squared} ...}
+    uint32_t *work;          // the work lists of the seeded search (layout: knn_work_* below)
     float *d2;               // [P][32] squared distances to the 32 stored vertices at this refresh's positions (< 0: the query is on the work list)
 };
+
+// Work lists: KNN_WORK_LISTS of them, each with its own counter in its own 256-byte line -- every query that fails its certificates
+// takes a slot with a returning atomic, and ~3000 of those on ONE address cost the certificate launch 11 of its 22 us (they are
+// served one after the other); 32 consecutive queries share a list, the lists' counters sit in different memory channels.
+// Layout in words: [KNN_WORK_LISTS][64] counters (first word of each line) | [KNN_WORK_LISTS][cap] {query, bits of its search radius squared}
+constexpr int KNN_WORK_LISTS = 64, KNN_WORK_LINE = 64;
+__host__ __device__ __forceinline__ uint32_t knn_work_cap(int P) { return (uint32_t)(P > 0 ? P : 1) / KNN_WORK_LISTS + 64u; }   // >= 32 ceil(ceil(P / 32) / 64)
+__host__ __device__ __forceinline__ size_t knn_work_words(int P) { return (size_t)KNN_WORK_LISTS * KNN_WORK_LINE + 2 * (size_t)KNN_WORK_LISTS * knn_work_cap(P); }
+__device__ __forceinline__ uint32_t knn_work_list_of(uint32_t q) { return (q >> 5) & (KNN_WORK_LISTS - 1); }
+__device__ __forceinline__ uint32_t *knn_work_item(uint32_t *work, int P, uint32_t list, uint32_t at)
+{
+    return work + KNN_WORK_LISTS * KNN_WORK_LINE + 2 * ((size_t)list * knn_work_cap(P) + at);
+}
 
 // First wavefront of the workgroup: list the contiguous sorted-vertex ranges covered by the box of radius r around
 // (cx,cy,cz) (the cells of one grid row are adjacent keys) as prefix offsets; info[0] = number of candidates,
@@ -781,8 +794,13 @@ __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float 
 #pragma unroll SOAR_KNN_SLOT_UNROLL
         for (int k2 = 0; k2 < KNN_K / 2; k2++) {
             const uint4 e = mine[k2];
+#ifdef SOAR_KNN_EXP_FEWQUADS
+            const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (t < SOAR_KNN_EXP_FEWQUADS ? e.x + t16 : 0u));
+            const float4 r1 = *reinterpret_cast<const float4 *>(rows_bytes + (t < SOAR_KNN_EXP_FEWQUADS ? e.z + t16 : 0u));
+#else
             const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (e.x + t16));
             const float4 r1 = *reinterpret_cast<const float4 *>(rows_bytes + (e.z + t16));
+#endif
             const float w0 = __uint_as_float(e.y), w1 = __uint_as_float(e.w);
             acc.x = __builtin_fmaf(w0, r0.x, acc.x); acc.y = __builtin_fmaf(w0, r0.y, acc.y);
             acc.z = __builtin_fmaf(w0, r0.z, acc.z); acc.w = __builtin_fmaf(w0, r0.w, acc.w);
@@ -868,9 +886,10 @@ knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restric
 #pragma unroll
             for (int off = KNN_KEEP / 2; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
             if (tier3 && l5 == 0) {
-                const uint32_t at = atomicAdd(st.work, 1u);
-                st.work[2u + 2u * at] = (uint32_t)q;
-                st.work[3u + 2u * at] = __float_as_uint(far);
+                const uint32_t list = knn_work_list_of((uint32_t)q);
+                uint32_t *item = knn_work_item(st.work, P, list, atomicAdd(st.work + list * KNN_WORK_LINE, 1u));
+                item[0] = (uint32_t)q;
+                item[1] = __float_as_uint(far);
             }
         }
         if (__ballot(tier2)) {
@@ -887,7 +906,7 @@ knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restric
 // search is ~20 us of dependent steps whatever the list's length), the others blend the certified queries, four per wavefront, from
 // what knn_certify_kernel left (distances, in-set masks): the searches run UNDER the blends instead of behind them.
 #ifndef SOAR_KNN_SEARCH_BLOCKS
-#define SOAR_KNN_SEARCH_BLOCKS 512
+#define SOAR_KNN_SEARCH_BLOCKS 1024
 #endif
 #ifndef SOAR_KNN_BS_WPE
 #define SOAR_KNN_BS_WPE 4
@@ -908,9 +927,6 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         // ---- certified queries: consecutive ones of the (cell-sorted) order share most neighbours -- the rows mostly come from the CU's L1
         const int q0 = (((int)blockIdx.x - search_blocks) * KNN_WAVES + wave) * KNN_FSLOTS;
         if (q0 >= P) return;
-#ifdef SOAR_KNN_EXP
-        if (SOAR_KNN_EXP & 1) return;
-#endif
         const int l5 = lane & (KNN_KEEP - 1);
         float dd[2];
         uint32_t pp[2], mm[2];
@@ -933,20 +949,19 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
     uint32_t *cp = c_pos[wave];
     float *cd = c_d[wave];
     const GridMeta m = *meta;
-    uint32_t n_work = st.work[0];
-#ifdef SOAR_KNN_EXP
-    if (SOAR_KNN_EXP & 2) n_work = 0;
-    if (SOAR_KNN_EXP & 4) n_work = min(n_work, 64u);
-#endif
-    for (uint32_t w = blockIdx.x * KNN_WAVES + wave; w < n_work; w += (uint32_t)search_blocks * KNN_WAVES) {
-        const size_t q = st.work[2u + 2u * w];
+    // wavefront g of the searchers takes list g % 64 (the four of a workgroup different ones), items g / 64, g / 64 + searchers / 64, ...
+    const uint32_t searcher = blockIdx.x * KNN_WAVES + wave, my_list = searcher % KNN_WORK_LISTS;
+    const uint32_t n_mine = min(st.work[my_list * KNN_WORK_LINE], knn_work_cap(P));
+    for (uint32_t w = searcher / KNN_WORK_LISTS; w < n_mine; w += (uint32_t)search_blocks * KNN_WAVES / KNN_WORK_LISTS) {
+        const uint32_t *item = knn_work_item(st.work, P, my_list, w);
+        const size_t q = item[0];
 #ifdef SOAR_KNN_SEARCH_LOG
         const unsigned long long lt0 = wall_clock64();
         unsigned long long lt1 = lt0, lt2 = lt0;
         int l_sel = 0, l_cand = 0, l_rows = 0, l_nin = 0;
 #endif
         // everything within the largest new distance to an old neighbour (there are at least K vertices that close) ...
-        const float tau_ub = __uint_as_float(st.work[3u + 2u * w]);
+        const float tau_ub = __uint_as_float(item[1]);
         const int p = order ? (int)order[q] : (int)q;
         const float x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
         int n_in = 0;                                                 // candidates held in (cp, cd), ascending grid position
@@ -1156,7 +1171,13 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         }
 #endif
     }
-    if (counters && blockIdx.x == 0 && threadIdx.x == 0 && n_work) atomicAdd(counters, n_work);
+    if (counters && blockIdx.x == 0 && wave == 0) {                   // statistics: the queries searched by this launch
+        static_assert(KNN_WORK_LISTS == WAVE, "one list per lane");
+        uint32_t n = st.work[lane * KNN_WORK_LINE];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n += (uint32_t)__shfl_xor((int)n, off);
+        if (lane == 0 && n) atomicAdd(counters, n);
+    }
 }
 
 }  // namespace
@@ -1248,7 +1269,7 @@ int carve_query_ws(void *base, int32_t P, QueryWs *out, hipStream_t stream)
     return 0;
 }
 
-// neighbour state of soar_lbs_knn_refresh: [P][32] grid positions | [P] ref30 | [P] ref32 | [P] in30 | [2 + 2 P] work list | [P][32] distances
+// neighbour state of soar_lbs_knn_refresh: [P][32] grid positions | [P] ref30 | [P] ref32 | [P] in30 | work lists | [P][32] distances
 struct KnnState { KnnStatePtrs p; size_t total; };
 int carve_knn_state(void *base, int32_t P, KnnState *out)
 {
@@ -1260,7 +1281,7 @@ int carve_knn_state(void *base, int32_t P, KnnState *out)
     out->p.ref30 = reinterpret_cast<float4 *>(carve(sizeof(float4) * n));
     out->p.ref32 = reinterpret_cast<float4 *>(carve(sizeof(float4) * n));
     out->p.in30 = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * n));
-    out->p.work = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * (2 * n + 2)));
+    out->p.work = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t) * knn_work_words(P)));
     out->p.d2 = reinterpret_cast<float *>(carve(sizeof(float) * KNN_STATE_STRIDE * n));
     out->total = off;
     return 0;
@@ -1435,7 +1456,7 @@ extern "C" int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, cons
     KnnState st;
     carve_knn_state(state_buffer, P, &st);
     StageTimer timer(ST_LBS_KNN, stream);
-    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
+    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, KNN_WORK_LISTS * KNN_WORK_LINE * sizeof(uint32_t), stream));
     return knn_query(g, V, vert_weights, J, xyz, P, KNN_K, weights_out, nullptr, order, resort, query_workspace, query_workspace_bytes,
                      stream, &st);
 }
@@ -1458,18 +1479,11 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     const int per_block = KNN_WAVES * 2 * KNN_CERT_PAIRS, nblocks = (P + per_block - 1) / per_block;
     // (the work list starts empty: a memset node -- letting the last wavefront of the search kernel reset it meant one atomic per
     // wavefront on one address, 50 us for 2048 of them)
-    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, 2 * sizeof(uint32_t), stream));
+    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, KNN_WORK_LISTS * KNN_WORK_LINE * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(knn_certify_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, order, st.p);
     const int search_blocks = SOAR_KNN_SEARCH_BLOCKS, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
-#if defined(SOAR_KNN_EXP) && (SOAR_KNN_EXP & 8)
-    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, 0,
-                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
-    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, 0, search_blocks,
-                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
-#else
     hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks + blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
                        g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
-#endif
     SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
     return 0;
 }
