@@ -295,7 +295,7 @@ struct KnnStatePtrs {        // (every array in the queries' sorted order: entry
 // Work lists: KNN_WORK_LISTS of them, each with its own counter in its own 256-byte line -- every query that fails its certificates
 // takes a slot with a returning atomic, and ~3000 of those on ONE address cost the certificate launch 11 of its 22 us (they are
 // served one after the other); 32 consecutive queries share a list, the lists' counters sit in different memory channels.
-// Layout in words: [KNN_WORK_LISTS][64] counters (first word of each line) | [KNN_WORK_LISTS][cap] {query, bits of its search radius squared}
+// Layout in words: [KNN_WORK_LISTS][64] {entries, searchers done, ...} (one line each) | [KNN_WORK_LISTS][cap] {query, bits of its search radius squared}
 constexpr int KNN_WORK_LISTS = 64, KNN_WORK_LINE = 64;
 __host__ __device__ __forceinline__ uint32_t knn_work_cap(int P) { return (uint32_t)(P > 0 ? P : 1) / KNN_WORK_LISTS + 64u; }   // >= 32 ceil(ceil(P / 32) / 64)
 __host__ __device__ __forceinline__ size_t knn_work_words(int P) { return (size_t)KNN_WORK_LISTS * KNN_WORK_LINE + 2 * (size_t)KNN_WORK_LISTS * knn_work_cap(P); }
@@ -779,7 +779,8 @@ __device__ __forceinline__ void slots_fill_pair(KnnSlots &sl, int slot_lo, int p
 __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float *__restrict__ rows_padded, int J,
                                             float *__restrict__ weights_out)
 {
-    static_assert(KNN_K % 2 == 0 && KNN_JMAX % 4 == 0 && KNN_JMAX / 4 <= 16 && KNN_FSLOTS * 16 == WAVE && KNN_KEEP * 2 == WAVE, "slot layout");
+    static_assert(KNN_K % 2 == 0 && KNN_JMAX % 4 == 0 && KNN_JMAX / 4 <= 16 && KNN_FSLOTS * 16 == WAVE && KNN_KEEP * 2 == WAVE &&
+                  KNN_JMAX * sizeof(float) <= KNN_KEEP * sizeof(uint2) && KNN_JMAX <= WAVE, "slot layout");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -794,13 +795,8 @@ __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float 
 #pragma unroll SOAR_KNN_SLOT_UNROLL
         for (int k2 = 0; k2 < KNN_K / 2; k2++) {
             const uint4 e = mine[k2];
-#ifdef SOAR_KNN_EXP_FEWQUADS
-            const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (t < SOAR_KNN_EXP_FEWQUADS ? e.x + t16 : 0u));
-            const float4 r1 = *reinterpret_cast<const float4 *>(rows_bytes + (t < SOAR_KNN_EXP_FEWQUADS ? e.z + t16 : 0u));
-#else
             const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (e.x + t16));
             const float4 r1 = *reinterpret_cast<const float4 *>(rows_bytes + (e.z + t16));
-#endif
             const float w0 = __uint_as_float(e.y), w1 = __uint_as_float(e.w);
             acc.x = __builtin_fmaf(w0, r0.x, acc.x); acc.y = __builtin_fmaf(w0, r0.y, acc.y);
             acc.z = __builtin_fmaf(w0, r0.z, acc.z); acc.w = __builtin_fmaf(w0, r0.w, acc.w);
@@ -809,11 +805,19 @@ __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float 
             acc.z = __builtin_fmaf(w1, r1.z, acc.z); acc.w = __builtin_fmaf(w1, r1.w, acc.w);
             norm += w1;
         }
-        float *out = weights_out + (size_t)p * J + 4 * t;
-        if (4 * t + 0 < J) out[0] = acc.x / norm;
-        if (4 * t + 1 < J) out[1] = acc.y / norm;
-        if (4 * t + 2 < J) out[2] = acc.z / norm;
-        if (4 * t + 3 < J) out[3] = acc.w / norm;
+        // (the lists are read: the slot's row of results goes where its list was -- [KNN_JMAX] floats fit in [KNN_KEEP] pairs)
+        float4 *mine_out = reinterpret_cast<float4 *>(sl.list[g]);
+        if (t < KNN_JMAX / 4) mine_out[t] = make_float4(acc.x / norm, acc.y / norm, acc.z / norm, acc.w / norm);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // one row per store: lane j writes joint j (220 contiguous bytes; with lanes = (slot, four joints) a store touched all four rows
+    // in 4-byte pieces 16 bytes apart)
+#pragma unroll
+    for (int r = 0; r < KNN_FSLOTS; r++) {
+        const int pr = sl.p[r];                                        // (wave-uniform)
+        if (pr >= 0 && lane < J) weights_out[(size_t)pr * J + lane] = reinterpret_cast<const float *>(sl.list[r])[lane];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -847,7 +851,10 @@ __device__ __forceinline__ uint32_t rank_32_halves(float d2, int lane, float &h3
 // request), four pairs of queries per wavefront with every load of the four in flight before the first is used: a query is a chain
 // of two dependent reads (its id -> its position; its neighbour list -> their coordinates) around very little arithmetic.  Leaves the
 // 32 distances of a certified query for the blend (st.d2), -1 for a query that goes on the work list.
-constexpr int KNN_CERT_PAIRS = 4;
+#ifndef SOAR_KNN_CERT_PAIRS
+#define SOAR_KNN_CERT_PAIRS 4
+#endif
+constexpr int KNN_CERT_PAIRS = SOAR_KNN_CERT_PAIRS;
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
 knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restrict__ sorted_verts, const uint32_t *__restrict__ order,
                    KnnStatePtrs st)
@@ -1171,12 +1178,16 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         }
 #endif
     }
-    if (counters && blockIdx.x == 0 && wave == 0) {                   // statistics: the queries searched by this launch
-        static_assert(KNN_WORK_LISTS == WAVE, "one list per lane");
-        uint32_t n = st.work[lane * KNN_WORK_LINE];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) n += (uint32_t)__shfl_xor((int)n, off);
-        if (lane == 0 && n) atomicAdd(counters, n);
+    // The last of a list's searchers to get here empties the list for the next refresh (a memset launch in front of the certificate
+    // kernel was 4.7 us of a 64 us refresh) and adds its length to the statistics: every searcher has read the length by then.
+    if (lane == 0) {
+        uint32_t *line = st.work + my_list * KNN_WORK_LINE;
+        if (atomicAdd(line + 1, 1u) == (uint32_t)search_blocks * KNN_WAVES / KNN_WORK_LISTS - 1u) {
+            const uint32_t n = line[0];
+            if (counters && n) atomicAdd(counters, n);
+            line[0] = 0u;
+            line[1] = 0u;
+        }
     }
 }
 
@@ -1477,9 +1488,8 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     carve_knn_state(state_buffer, P, &st);
     StageTimer timer(ST_LBS_KNN, stream);
     const int per_block = KNN_WAVES * 2 * KNN_CERT_PAIRS, nblocks = (P + per_block - 1) / per_block;
-    // (the work list starts empty: a memset node -- letting the last wavefront of the search kernel reset it meant one atomic per
-    // wavefront on one address, 50 us for 2048 of them)
-    SOAR_HIP_OK(hipMemsetAsync(st.p.work, 0, KNN_WORK_LISTS * KNN_WORK_LINE * sizeof(uint32_t), stream));
+    // (the work lists are empty: soar_lbs_knn_query_state cleared them, every refresh leaves them empty again)
+    static_assert(SOAR_KNN_SEARCH_BLOCKS * KNN_WAVES % KNN_WORK_LISTS == 0, "searchers per list");
     hipLaunchKernelGGL(knn_certify_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, order, st.p);
     const int search_blocks = SOAR_KNN_SEARCH_BLOCKS, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
     hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks + blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
