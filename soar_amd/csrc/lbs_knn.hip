@@ -776,6 +776,7 @@ __device__ __forceinline__ void slots_fill_pair(KnnSlots &sl, int slot_lo, int p
     }
     if (l5 == 0) sl.p[slot] = p;
 }
+template <int UNROLL>
 __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float *__restrict__ rows_padded, int J,
                                             float *__restrict__ weights_out)
 {
@@ -792,7 +793,7 @@ __device__ __forceinline__ void slots_blend(KnnSlots &sl, int lane, const float 
         const uint4 *mine = reinterpret_cast<const uint4 *>(sl.list[g]);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float norm = 0.f;
-#pragma unroll SOAR_KNN_SLOT_UNROLL
+#pragma unroll UNROLL
         for (int k2 = 0; k2 < KNN_K / 2; k2++) {
             const uint4 e = mine[k2];
             const float4 r0 = *reinterpret_cast<const float4 *>(rows_bytes + (e.x + t16));
@@ -852,7 +853,7 @@ __device__ __forceinline__ uint32_t rank_32_halves(float d2, int lane, float &h3
 // of two dependent reads (its id -> its position; its neighbour list -> their coordinates) around very little arithmetic.  Leaves the
 // 32 distances of a certified query for the blend (st.d2), -1 for a query that goes on the work list.
 #ifndef SOAR_KNN_CERT_PAIRS
-#define SOAR_KNN_CERT_PAIRS 4
+#define SOAR_KNN_CERT_PAIRS 2
 #endif
 constexpr int KNN_CERT_PAIRS = SOAR_KNN_CERT_PAIRS;
 __global__ void __launch_bounds__(KNN_WAVES *WAVE)
@@ -913,7 +914,7 @@ knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restric
 // search is ~20 us of dependent steps whatever the list's length), the others blend the certified queries, four per wavefront, from
 // what knn_certify_kernel left (distances, in-set masks): the searches run UNDER the blends instead of behind them.
 #ifndef SOAR_KNN_SEARCH_BLOCKS
-#define SOAR_KNN_SEARCH_BLOCKS 1024
+#define SOAR_KNN_SEARCH_BLOCKS 768
 #endif
 #ifndef SOAR_KNN_BS_WPE
 #define SOAR_KNN_BS_WPE 4
@@ -950,7 +951,7 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         }
 #pragma unroll
         for (int r = 0; r < 2; r++) slots_fill_pair(slots[wave], 2 * r, dd[r] >= 0.f ? pq[r] : -1, mm[r], pp[r], dd[r], lane);
-        slots_blend(slots[wave], lane, rows_padded, J, weights_out);
+        slots_blend<SOAR_KNN_SLOT_UNROLL>(slots[wave], lane, rows_padded, J, weights_out);
         return;
     }
     uint32_t *cp = c_pos[wave];
@@ -1167,7 +1168,7 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         // multiply-add) steps came out of the compiler as 30 round trips one after the other here, 11 of a search's 26 us)
         slots_fill_pair(slots[wave], 0, lane < KNN_KEEP ? p : -1, mask, pos, d2, lane);
         if (lane == 0) { slots[wave].p[2] = -1; slots[wave].p[3] = -1; }
-        slots_blend(slots[wave], lane, rows_padded, J, weights_out);
+        slots_blend<SOAR_KNN_SLOT_UNROLL>(slots[wave], lane, rows_padded, J, weights_out);
 #ifdef SOAR_KNN_SEARCH_LOG
         if (lane == 0) {
             const unsigned long long lt4 = wall_clock64();
@@ -1492,8 +1493,15 @@ extern "C" int soar_lbs_knn_refresh(const void *grid_buffer, int32_t V, int32_t 
     static_assert(SOAR_KNN_SEARCH_BLOCKS * KNN_WAVES % KNN_WORK_LISTS == 0, "searchers per list");
     hipLaunchKernelGGL(knn_certify_kernel, dim3(nblocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, g.sorted_verts, order, st.p);
     const int search_blocks = SOAR_KNN_SEARCH_BLOCKS, blend_blocks = (P + KNN_WAVES * KNN_FSLOTS - 1) / (KNN_WAVES * KNN_FSLOTS);
+#ifdef SOAR_KNN_SPLIT_LAUNCH      // diagnostic build: the two halves of the second launch one after the other (what each takes alone)
+    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, 0,
+                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+    hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
+                       g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+#else
     hipLaunchKernelGGL(knn_blend_search_kernel, dim3(search_blocks + blend_blocks), dim3(KNN_WAVES * WAVE), 0, stream, xyz, P, search_blocks,
                        g.meta, g.cell_range, g.sorted_verts, g.rows, J, order, st.p, weights_out, searched_counter_dev);
+#endif
     SOAR_LAUNCH_OK("lbs_knn_refresh", stream, 0);
     return 0;
 }
