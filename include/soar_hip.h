@@ -305,7 +305,10 @@ int soar_lbs_knn_query_ordered(const void *grid_buffer, int32_t V, const float *
  * exactly, seeded by its old set, and gets a new set and new gaps.
  * Either way the weights are those of soar_lbs_knn_query_ordered at the same positions, bit for bit.  `order`: the
  * query order soar_lbs_knn_query_state stored -- the state is kept in that order.  searched_counter_dev (nullable): device uint32 that the number of queries that
- * needed the search is added to.  The state is tied to (grid, P): after densification start again with soar_lbs_knn_query_state. */
+ * needed the search is added to.  The state is tied to (grid, P): after densification start again with soar_lbs_knn_query_state.
+ * Round 4: a refresh is two launches -- the certificates, then the blends of the certified queries with the seeded searches running
+ * under them -- and the state also holds the refresh's 32 distances per query and the searches' work lists (about 306 bytes per
+ * query; ask soar_lbs_knn_state_bytes).  The lists are left empty by every refresh: one refresh of a state at a time (one stream). */
 int soar_lbs_knn_state_bytes(int32_t P, size_t *bytes);
 int soar_lbs_knn_query_state(const void *grid_buffer, int32_t V, const float *vert_weights, int32_t J, const float *xyz, int32_t P,
                              uint32_t *order, int32_t resort, float *weights_out, void *state_buffer, void *query_workspace,
