@@ -241,6 +241,32 @@ def test_knn_follower_is_the_full_search_bit_for_bit_under_motion():
     assert fractions[1] == 1.0 and fractions[2] < 0.3 and fractions[3] < 0.4 and fractions[4] > 0.9 and fractions[7] < 0.01, fractions
 
 
+@pytest.mark.parametrize("P", [1, 5, 33, 1999, 6007])
+def test_knn_follower_ragged_query_counts(P):
+    """Query counts that fill neither a pair of the certificate launch, nor the four slots of a blend wavefront, nor a work list's group
+    of 32: the follower still equals the full search bit for bit over refreshes of every tier, and leaves its work lists empty (the
+    searched counts of later refreshes would be off otherwise)."""
+    from soar_amd import lbs
+    bm = syn.make_body_model(0)
+    v, w = bm.v_template.to(DEV), bm.lbs_weights.to(DEV)
+    grid = lbs.KnnGrid(v, w)
+    x = syn.make_surfels(max(P, 64), 9).xyz[:P].contiguous().to(DEV)
+    fol = lbs.KnnFollower(grid, P)
+    g = torch.Generator().manual_seed(17)
+    before = 0
+    for step, sigma in enumerate([0.0, 1e-5, 2e-5, 4e-3, 1e-5, 0.0, 1e-4]):
+        x = x + sigma * torch.randn(x.shape, generator=g).to(DEV)
+        got = fol(x).clone()
+        assert torch.equal(got, grid.query(x)), (P, step, sigma)
+        n = int(fol.searched.item())
+        assert 0 <= n - before <= P, (P, step, n, before)
+        if step == 1:
+            assert n - before == P          # the first refresh after a full search measures every gap
+        if step == 5:
+            assert n - before <= P // 50    # nothing moved: certified (but for near-ties at the K-th place), and no stale entry left on a list
+        before = n
+
+
 def test_knn_follower_with_ties_and_dense_clusters():
     """Duplicated vertices (exact distance ties at the K-th place, thousands of candidates in one cell): the follower still equals
     the full search bit for bit -- ties are never certified and the seeded search applies the full search's tie rule (grid order)."""
