@@ -725,6 +725,9 @@ knn_cell_kernel(const float *__restrict__ xyz, int P, int V, const GridMeta *__r
 #ifndef SOAR_KNN_SLOT_UNROLL
 #define SOAR_KNN_SLOT_UNROLL 5
 #endif
+#ifndef SOAR_KNN_SEARCH_UNROLL
+#define SOAR_KNN_SEARCH_UNROLL 8
+#endif
 constexpr int KNN_KEEP = KNN_STATE_STRIDE;   // neighbours kept per query
 constexpr int RF_CAP = 192;              // candidates the seeded search holds between two selections (KNN_KEEP + a chunk of 64 fit)
 
@@ -883,8 +886,11 @@ knn_certify_kernel(const float *__restrict__ xyz, int P, const float4 *__restric
         const float x = xs[i], y = ys[i], z = zs[i];
         const float d2 = dist2_exact(x, y, z, vv[i]);
         const float ax = x - ra[i].x, ay = y - ra[i].y, az = z - ra[i].z, bx = x - rb[i].x, by = y - rb[i].y, bz = z - rb[i].z;
-        const float moved_a = sqrtf((ax * ax + ay * ay) + az * az) * 1.0001f + 1.0e-12f;
-        const float moved_b = sqrtf((bx * bx + by * by) + bz * bz) * 1.0001f + 1.0e-12f;
+        // (an upper bound of the displacement is all a certificate needs -- v_sqrt_f32 is within one ulp, the factor covers 1e-4 --;
+        // the correctly rounded square roots were a sixth of this launch's instructions.  Which tier a query takes may differ by
+        // that; its weights never do)
+        const float moved_a = __builtin_amdgcn_sqrtf((ax * ax + ay * ay) + az * az) * 1.0001f + 1.0e-12f;
+        const float moved_b = __builtin_amdgcn_sqrtf((bx * bx + by * by) + bz * bz) * 1.0001f + 1.0e-12f;
         const bool ok_a = ra[i].w > 0.f && moved_a < ra[i].w, ok_b = rb[i].w > 0.f && moved_b < rb[i].w;
         const bool tier3 = valid && !ok_a && !ok_b, tier2 = valid && !ok_a && ok_b;
         if (__ballot(tier3)) {
@@ -1001,6 +1007,33 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
 #ifdef SOAR_KNN_SEARCH_LOG
                 l_sel++;
 #endif
+                if (n_in <= WAVE) {
+                    // the usual case (a ball seeded by the old set holds ~38 vertices): one candidate per lane, the others' distances by
+                    // v_readlane instead of an LDS read per candidate and three slots of bookkeeping
+                    const bool have = lane < n_in;
+                    const uint32_t pos0 = have ? cp[lane] : 0u;
+                    const float d0 = have ? cd[lane] : 3.0e38f;
+                    int rk = 0;
+                    for (int j = 0; j < n_in; j++) {
+                        const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), j));
+                        rk += (dj < d0 || (dj == d0 && j < lane)) ? 1 : 0;
+                    }
+                    const bool keep = have && rk < KEEP;
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                        cp[at] = pos0;
+                        cd[at] = d0;
+                    }
+                    float dropped = (have && !keep) ? d0 : 3.0e38f;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) dropped = fminf(dropped, __shfl_xor(dropped, off));
+                    next_d2 = fminf(next_d2, dropped);
+                    n_in = (int)__builtin_popcountll(km);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    return;
+                }
                 uint32_t e_pos[RF_CAP / WAVE];
                 float e_d[RF_CAP / WAVE];
                 int rank[RF_CAP / WAVE];
@@ -1168,7 +1201,7 @@ knn_blend_search_kernel(const float *__restrict__ xyz, int P, int search_blocks,
         // multiply-add) steps came out of the compiler as 30 round trips one after the other here, 11 of a search's 26 us)
         slots_fill_pair(slots[wave], 0, lane < KNN_KEEP ? p : -1, mask, pos, d2, lane);
         if (lane == 0) { slots[wave].p[2] = -1; slots[wave].p[3] = -1; }
-        slots_blend<SOAR_KNN_SLOT_UNROLL>(slots[wave], lane, rows_padded, J, weights_out);
+        slots_blend<SOAR_KNN_SEARCH_UNROLL>(slots[wave], lane, rows_padded, J, weights_out);
 #ifdef SOAR_KNN_SEARCH_LOG
         if (lane == 0) {
             const unsigned long long lt4 = wall_clock64();
