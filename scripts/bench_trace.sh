@@ -3,7 +3,7 @@ tag=${1:-trace}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stage-timers > $out/run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stage-timers > $out/run.log 2>&1
 tail -1 $out/run.log | cut -c1-200
 python3 scripts/trace_busy.py $out
 python3 - <<PY

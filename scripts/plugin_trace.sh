@@ -2,7 +2,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/plugin_trace
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 scripts/plugin_time.py > $out/log.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 scripts/plugin_time.py > $out/log.txt 2>&1
 tail -2 $out/log.txt
 python3 scripts/trace_busy.py $out
 f=$(find $out -name "*kernel_stats.csv" | head -1)

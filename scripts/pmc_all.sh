@@ -1,6 +1,6 @@
 # instruction mix of every kernel of a serialized (plan-eager) step: VALU / SALU / LDS / VMEM / SMEM instructions and wave-cycles per launch
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d gpurun_out/pmca -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage-timers --mode plan-eager > gpurun_out/pmca.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d gpurun_out/pmca -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage-timers --mode plan-eager > gpurun_out/pmca.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 for f in glob.glob("gpurun_out/pmca/**/*counter_collection.csv", recursive=True):

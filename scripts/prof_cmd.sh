@@ -3,7 +3,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 "$@" > $out/run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 "$@" > $out/run.log 2>&1
 tail -2 $out/run.log
 python3 - <<PY
 import csv, glob

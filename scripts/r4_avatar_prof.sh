@@ -10,14 +10,14 @@ d = json.load(open(sys.argv[1]))
 print("avatar C3: %.1f frames/s  %.3f ms/step" % (d["value"], d["ms_per_step"]))
 print({k: round(v, 1) for k, v in d["roofline"]["stage_us_per_step"].items()})
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --loss avatar --steps 20 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --loss avatar --steps 20 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats_avatar_C3.csv
 head -28 $out/kernel_stats_avatar_C3.csv | cut -c1-150
 re='ssim|masked_l1|cos_loss|view_finish|frame_loss|mean_finish|avatar_'
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-include-regex "$re" --output-format csv -d $out/pmc1 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc1.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --kernel-include-regex "$re" --output-format csv -d $out/pmc2 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$re" --output-format csv -d $out/pmc3 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$re" --output-format csv -d $out/pmc4 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc4.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-include-regex "$re" --output-format csv -d $out/pmc1 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc1.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --kernel-include-regex "$re" --output-format csv -d $out/pmc2 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc2.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$re" --output-format csv -d $out/pmc3 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc3.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$re" --output-format csv -d $out/pmc4 -- python3 bench.py --loss avatar --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timers > $out/pmc4.log 2>&1
 python3 - $out > $out/counters_loss_kernels.txt <<'PY'
 import csv, glob, collections, sys
 out = sys.argv[1]

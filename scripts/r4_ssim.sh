@@ -11,7 +11,7 @@ d = json.load(open(sys.argv[1]))
 print("avatar C3: %.1f frames/s  %.3f ms/step" % (d["value"], d["ms_per_step"]))
 print({k: round(v, 1) for k, v in d["roofline"]["stage_us_per_step"].items()})
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --loss avatar --steps 20 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --loss avatar --steps 20 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats_avatar_C3.csv
 grep -E "ssim|avatar_pixel|view_finish|occ_backward" $out/kernel_stats_avatar_C3.csv | cut -d, -f1-4 | sed 's/soar::(anonymous namespace):://g' | cut -c1-120
 rm -rf $out/trace

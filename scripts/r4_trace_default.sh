@@ -2,7 +2,7 @@
 tag=${1:-trace}; out=$GRAFT_REPO_ROOT/gpurun_out/r4_$tag; mkdir -p $out
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-stage-timers > $out/trace.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats_C3.csv
 tail -1 $out/trace.log | cut -c1-200
 python3 - $out/kernel_stats_C3.csv <<'PY'

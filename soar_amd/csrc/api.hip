@@ -581,11 +581,16 @@ int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *ra
     if (num_rendered > 0) {
         if (launch_tile_binning(*prm, g, b, img, num_rendered, stream)) return 1;
         if (status_pinned) {
+            // (pinned word, device header) pairs of the frames of the OPEN batch: a batch that ended early (an error between its
+            // frames) must not leave pairs behind for the next, unrelated call -- they belong to the batch whose serial made them
             static thread_local std::vector<std::pair<uint32_t *, const uint32_t *>> pending;
+            static thread_local unsigned pending_serial = 0u;
+            const soar::BatchCtx &bc = soar::batch_ctx();
+            if (!bc.n || pending_serial != bc.serial) pending.clear();
+            pending_serial = bc.serial;
             status_pinned[0] = 0xFFFFFFFFu;          // "not there yet": neither word can be this (counts of 32-bit list positions)
             status_pinned[1] = 0xFFFFFFFFu;
             pending.push_back({status_pinned, g.header + H_TOTAL});
-            const soar::BatchCtx &bc = soar::batch_ctx();
             if (!bc.n || bc.f == bc.n - 1) {
                 for (const auto &c : pending)
                     SOAR_HIP_OK(hipMemcpyAsync(c.first, c.second, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

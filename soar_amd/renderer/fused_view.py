@@ -259,34 +259,63 @@ class CapacityBook:
 
 capacity_book = CapacityBook()
 _pinned_free = []
+_pinned_limbo = []          # words whose device-to-host copy may still be in flight and that nobody waits for any more
 _pinned_lock = threading.Lock()
 _buffer_bytes = {}
 POLL_TIMEOUT_S = 20.0
 
 
+def _landed(words) -> bool:
+    w = words.numpy()
+    return not (w[0] == -1 or w[1] == -1 or w[2] == -1 or w[3] == -1)
+
+
 def _status_words():
+    """Four page-locked words for a view's {instances, overflow} pairs (main pass, then a back view's occlusion pass).  The copy into
+    them is issued by the C library: torch's host allocator has no event for it, so a block must never go back to that allocator
+    (or to another view) while a copy may still land in it -- words nobody waited for stay in `_pinned_limbo`, referenced, until
+    their sentinels are gone."""
     with _pinned_lock:
+        if _pinned_limbo:
+            still = []
+            for w in _pinned_limbo:
+                if not _landed(w):
+                    still.append(w)
+                elif len(_pinned_free) < 64:
+                    _pinned_free.append(w)           # (a landed block beyond the free list's size goes back to torch's allocator)
+            _pinned_limbo[:] = still
         if _pinned_free:
             return _pinned_free.pop()
-    return torch.zeros(4, dtype=torch.int32).pin_memory()      # {instances, overflow} of the main pass, then of a back view's occlusion pass
+    return torch.zeros(4, dtype=torch.int32).pin_memory()
 
 
 def _release_words(words):
+    """Words the host has SEEN land (a finished poll) go back to the free list; anything else is parked in the limbo list."""
     with _pinned_lock:
-        if len(_pinned_free) < 64:
-            _pinned_free.extend(words)
+        for w in words:
+            if any(w is k for k in _pinned_free) or any(w is k for k in _pinned_limbo):
+                continue                             # (released before: an error path may come by twice)
+            if _landed(w):
+                if len(_pinned_free) < 64:
+                    _pinned_free.append(w)
+            else:
+                _pinned_limbo.append(w)
 
 
 def _wait_words(words, device, stream):
     """The two status words of a view (instances found, 0 or what was needed), waited for WITHOUT draining the device: they were
     copied out behind the binning chain, in front of the blend.  Bounded: after POLL_TIMEOUT_S the stream the copy sits on is
-    synchronised once, and a copy that still has not landed is an error."""
+    synchronised once, and a copy that still has not landed is an error.  The poll yields the interpreter lock between looks (other
+    threads of a training process -- data loader, logger -- run while this one waits)."""
     w = words.numpy()
     pending = lambda: w[0] == -1 or w[1] == -1 or w[2] == -1 or w[3] == -1
     if pending():
         t_end = time.perf_counter() + POLL_TIMEOUT_S
+        spins = 0
         while pending() and time.perf_counter() < t_end:
-            pass
+            spins += 1
+            if spins > 64:
+                time.sleep(0 if spins < 4096 else 2e-5)
         if pending():
             stream.synchronize()
             if pending():
@@ -308,6 +337,13 @@ class _PendingStatus:
         words, self.words = self.words, None
         if words is None:
             return None
+        try:
+            return self._resolve(words, block)
+        except BaseException:
+            _release_words(words)                    # (a poll that timed out: the blocks stay referenced until their copies land)
+            raise
+
+    def _resolve(self, words, block: bool):
         worst = None
         for (rs, _f, cap, key, _back), wd in zip(self.specs, words):
             if block:
@@ -321,8 +357,7 @@ class _PendingStatus:
             rasterizer.note_num_rendered(total)
             if over and (worst is None or over > worst[0]):
                 worst = (over, cap, rs, bound)
-        if block:
-            _release_words(words)                    # (words that may still be written to are not handed out again)
+        _release_words(words)                        # (sorted there: seen to have landed -> free list, anything else -> limbo)
         return worst
 
     def __del__(self):
@@ -384,8 +419,12 @@ class _PoseViews(torch.autograd.Function):
             a.focal_k00, a.focal_k11, a.capacity, a.back = focal[0], focal[1], int(cap), int(bool(back))
             a.buffer, a.buffer_bytes, a.out, a.radii, a.status_pinned = buf.data_ptr(), nbytes, out.data_ptr(), radii.data_ptr(), words.data_ptr()
             per_view.append((c, buf, out, radii, words))
-        with torch.cuda.device(dev):
-            check(L.soar_views_forward(C.byref(pose), n, views, stream), "soar_views_forward")
+        try:
+            with torch.cuda.device(dev):
+                check(L.soar_views_forward(C.byref(pose), n, views, stream), "soar_views_forward")
+        except BaseException:
+            _release_words([pv[4] for pv in per_view])   # (copies of the views in front of the failing one may be on their way)
+            raise
         return views, per_view
 
     @staticmethod
@@ -415,6 +454,17 @@ class _PoseViews(torch.autograd.Function):
         stream = cur.cuda_stream
         keep = [x, q, w, A, off, T, cols, ssrc, occ_v]
         views, per_view = _PoseViews._launch(L, dev, stream, pose, specs, P, keep)
+        try:
+            return _PoseViews._finish_forward(ctx, L, dev, cur, stream, pose, specs, P, J, keep, views, per_view, grad_mode, x, q, w, A,
+                                              off, T, cols, ssrc, occ_v, occ3, posed, scale_src, occ, offsets)
+        except BaseException:
+            if getattr(ctx, "pending", None) is None:    # nobody owns the words yet: park them until their copies have landed
+                _release_words([pv[4] for pv in per_view if pv[4] is not None])
+            raise
+
+    @staticmethod
+    def _finish_forward(ctx, L, dev, cur, stream, pose, specs, P, J, keep, views, per_view, grad_mode, x, q, w, A, off, T, cols, ssrc,
+                        occ_v, occ3, posed, scale_src, occ, offsets):
         # can a backward pass come?  (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off,
         # and needs_input_grad only says which inputs require gradients)
         training = bool(grad_mode) and any(ctx.needs_input_grad)

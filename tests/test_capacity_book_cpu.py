@@ -61,3 +61,32 @@ def test_frames_rendered_with_gradients_but_never_differentiated_still_teach_the
     finally:
         fv.capacity_book.bound.clear()
         fv.capacity_book.bound.update(book_before)
+
+
+def test_status_words_whose_copy_may_still_land_are_never_handed_out_again():
+    """The device-to-host copy into a view's status words is issued by the C library: torch's host allocator knows nothing of it.
+    Words nobody waited for (outputs rendered with gradients and dropped) must stay referenced -- and out of the free list -- until
+    their sentinels are gone; releasing a block twice (error paths come by twice) must not put it on a list twice."""
+    free_before, limbo_before = list(fv._pinned_free), list(fv._pinned_limbo)
+    try:
+        fv._pinned_free.clear(); fv._pinned_limbo.clear()
+        mk = lambda v: torch.tensor(v, dtype=torch.int32)
+        landed, flying = mk([5, 0, 0, 0]), mk([-1, -1, 0, 0])
+        rs = types.SimpleNamespace(image_width=64, image_height=48)
+        k = ("cpu", 64, 48, 11, 0, 0)
+        p = fv._PendingStatus([(rs, None, 1 << 20, k, False), (rs, None, 1 << 20, k, False)], [landed, flying], "cpu", None)
+        del p                                                         # end of life without a backward pass
+        assert any(w is landed for w in fv._pinned_free) and not any(w is flying for w in fv._pinned_free)
+        assert any(w is flying for w in fv._pinned_limbo)             # still referenced: its block cannot be recycled
+        fv._release_words([landed, flying])                           # a second release changes nothing
+        assert len(fv._pinned_free) == 1 and len(fv._pinned_limbo) == 1
+        got = fv._status_words()                                      # the copy has not landed: the flying words are not handed out
+        assert got is landed and len(fv._pinned_limbo) == 1
+        flying[:2] = 3                                                # ... now it has
+        fv._release_words([got])
+        a, b = fv._status_words(), fv._status_words()
+        assert {id(a), id(b)} == {id(landed), id(flying)} and not fv._pinned_limbo
+    finally:
+        fv.capacity_book.bound.pop(("cpu", 64, 48, 11, 0, 0), None)
+        fv._pinned_free[:] = free_before
+        fv._pinned_limbo[:] = limbo_before

@@ -122,6 +122,81 @@ def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
         np.testing.assert_array_equal(r["rad"], np.arange(P, dtype=np.float32))
 
 
+def _worker8(rank, world, port, P, steps, buckets, out_dir):
+    """What bench.py --gpus 8 does per rank, on CPU tensors: every step the rank renders ITS frames of the global batch (unequal
+    cost: the ranks reach the collectives at different times and in a different order every step), issues the asynchronous bucket
+    reductions, waits for the xyz bucket, 'updates' xyz, waits for the rest, updates the rest -- the order FrameStepPlan._run_eager
+    keeps -- and sums the densifier's statistics at the end."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        leaves = _make_leaves(P)
+        buf = frame_dp.FlatGradBuffer(leaves)
+        buf.n_buckets = buckets
+        acc5, rad = torch.zeros(5, P), torch.zeros(P)
+        seen = []
+        for step in range(steps):
+            batch = frame_dp.global_batch(step, 3, world, num_frames=50)            # 24 frames per step over a 50-frame video: wraps
+            mine = frame_dp.shard_frames(batch, rank, world)
+            seen.append(mine)
+            buf.zero()
+            for f in mine:
+                time.sleep(0.001 * ((f * 7 + rank) % 5))                            # frames of unequal cost
+                _frame_loss(leaves, f).backward()
+                acc5[:, f % P] += 1.0 + f
+                rad[f % P] = max(float(rad[f % P]), float(f))
+            buf.all_reduce_buckets()
+            buf.wait_bucket(0)
+            with torch.no_grad():
+                leaves["xyz"] -= 1e-3 * buf.views["xyz"]                            # positions behind the first bucket ...
+            buf.wait_all()
+            with torch.no_grad():
+                for n in ("rot", "scales", "colors"):
+                    leaves[n] -= 1e-3 * buf.views[n]                                # ... the rest behind the second
+        frame_dp.all_reduce_densifier_stats(acc5, rad)                                # (what SurfelDensifier.sync_stats does before it plans)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), acc5=acc5.numpy(), rad=rad.numpy(), seen=np.array(seen),
+                 **{n: t.detach().numpy() for n, t in leaves.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("buckets", [2, 1])
+def test_eight_rank_gloo_training_steps_equal_single_process(tmp_path, buckets):
+    """world_size 8 (BASELINE configs C4 / C5: 8 x MI355X frame-DP) on CPU: partition of every global batch, both gradient buckets,
+    parameter updates applied behind each bucket, densifier statistics -- so that the first real `bench.py --gpus 8` run cannot
+    fail on partition or hand-over logic.  Three steps; every rank must end with the single-process parameters."""
+    P, world, steps = 19, 8, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker8, args=(world, port, P, steps, buckets, str(tmp_path)), nprocs=world, join=True)
+    leaves = _make_leaves(P)
+    buf = frame_dp.FlatGradBuffer(leaves)
+    acc5, rad = torch.zeros(5, P), torch.zeros(P)
+    for step in range(steps):
+        buf.zero()
+        for f in frame_dp.global_batch(step, 3, world, num_frames=50):
+            _frame_loss(leaves, f).backward()
+            acc5[:, f % P] += 1.0 + f
+            rad[f % P] = max(float(rad[f % P]), float(f))
+        with torch.no_grad():
+            for n in leaves:
+                leaves[n] -= 1e-3 * buf.views[n]
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for step in range(steps):                                                       # every frame of every batch exactly once
+        got = sorted(int(f) for r in ranks for f in r["seen"][step])
+        assert got == sorted(frame_dp.global_batch(step, 3, world, num_frames=50))
+    for r in ranks:
+        for n in leaves:
+            np.testing.assert_array_equal(r[n], ranks[0][n])                        # replicas stay bit-identical ...
+            np.testing.assert_allclose(r[n], leaves[n].detach().numpy(), rtol=2e-5, atol=2e-6)     # ... and follow the one-process run
+    for r in ranks:                                                                 # densifier statistics: sum and max over the ranks
+        np.testing.assert_allclose(r["acc5"], acc5.numpy(), rtol=1e-6)
+        np.testing.assert_array_equal(r["rad"], rad.numpy())
+
+
 def test_flat_buffer_refuses_stale_views():
     P = 5
     leaves = {n: torch.randn(P, w, requires_grad=True) for n, w in frame_dp.LEAVES[:4]}
