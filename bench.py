@@ -98,6 +98,36 @@ def measured_traffic(stage):
     return d["kernels"][k]["traffic_bytes"], rel
 
 
+# kernels of the plan's timed step (default loss) by how often they run: once per FRAME of the step, or once per STEP
+STEP_KERNELS_PER_FRAME = ["preprocess_kernel", "zero_ranges_kernel", "bucket_count_kernel", "bucket_scan_kernel", "bucket_scatter_kernel",
+                          "bucket_sort_kernel", "band_count_kernel", "band_place_kernel", "bin_tiles_kernel", "tile_order_binned_kernel",
+                          "render_forward_kernel", "frame_loss_kernel", "frame_loss_finish_kernel", "render_backward_blocks_kernel",
+                          "geometry_backward_kernel"]
+STEP_KERNELS_PER_STEP = ["adam_update_kernel", "knn_certify_kernel", "knn_blend_search_kernel", "gather_step_inputs_ids_kernel",
+                         "warp_forward_frames_kernel", "warp_backward_frames_kernel"]
+
+
+def measured_step_traffic(frames_per_step):
+    """HBM bytes one timed step moves by the same counter summary `measured_traffic` quotes (FETCH_SIZE + WRITE_SIZE per launch of
+    every kernel of the step, the per-frame ones x frames_per_step; zero_ranges runs twice per frame) -> (bytes, kernels missing)."""
+    import glob
+    from soar_amd import build
+    files = [PMC_JSON] if PMC_JSON else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    if d.get("build_digest") != build.source_digest():
+        return None, None
+    k = d.get("kernels", {})
+    missing = [n for n in STEP_KERNELS_PER_FRAME + STEP_KERNELS_PER_STEP if n not in k]
+    per_frame = sum(k[n]["traffic_bytes"] * (2 if n == "zero_ranges_kernel" else 1) for n in STEP_KERNELS_PER_FRAME if n in k)
+    per_step = sum(k[n]["traffic_bytes"] for n in STEP_KERNELS_PER_STEP if n in k)
+    return per_frame * frames_per_step + per_step, missing
+
+
 def algorithmic_bytes(P, R, W, H, R_occ=None):
     """compulsory bytes per launch of every stage.  The reference's `sort` (24 * passes * R) and
     `emit_keys` rows have no counterpart any more: tile binning orders the P Gaussians by depth (depth_order: keys + pairs +
@@ -550,14 +580,19 @@ def main():
     # dry (0.95 -> 1.0-1.36 ms per step, run to run).  What exists now stays: collected once, then moved out of the collector's sight
     # (gc.freeze, what a long-running training process does after its set-up); the collector stays on for what the steps allocate.
     import gc
-    gc.collect()
-    gc.freeze()
+    if os.environ.get("SOAR_BENCH_NO_GC_FREEZE", "0") != "1":
+        gc.collect()
+        gc.freeze()
     flat.wait_all()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     step_marks = [] if os.environ.get("SOAR_BENCH_STEP_TIMES", "0") == "1" else None      # (diagnostic: when the host issued every step)
+    # the same region on the device's clock: a HIP event pair on the stream the steps are issued on (every step of the plan ends on
+    # it) -- `value` stays the host's wall clock between the synchronisations, as the contract says; both are in the line
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_begin.record()
     t0 = time.perf_counter()
     for s in range(args.steps):
         stepper(frames_of(args.warmup + s))
@@ -568,8 +603,10 @@ def main():
         per = [1e3 * (b - a) for a, b in zip([0.0] + step_marks[:-1], step_marks)]
         print("[bench] host issue per step (ms): " + " ".join(f"{v:.2f}" for v in per), file=sys.stderr)
     flat.wait_all()                                              # the last step's gradient buckets
+    ev_end.record()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0                     # this rank's own K steps (before it waits for the others)
+    device_ms_per_step = ev_begin.elapsed_time(ev_end) / args.steps
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -693,9 +730,15 @@ def main():
                     how = (f"HIP events around every stage on its launch stream, {args.steps} more steps of the same "
                            f"workload right after the timed region with the views of a step serialised on one stream "
                            f"(the timed region overlaps them on {rasterizer.NUM_STREAMS} streams)")
+                step_traffic, step_missing = measured_step_traffic(fps_per_rank) if (args.workload == "C3" and args.loss == "synthetic" and plan is not None) else (None, None)
+                counter_GBs = round(traffic / avg_s / 1e9, 2) if traffic is not None else None
                 roof = {"bound": "hbm", "kernel": dom, "frames_per_launch": frames_per_launch,
                         "measured": how, "stage_total_ms": {k: round(v[0], 3) for k, v in stages.items()}, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        # the same launch by the bytes it MOVED (the counters' FETCH_SIZE + WRITE_SIZE / the same duration): `achieved` /
+                        # `frac` price the launch with SURVEY 8(d)'s algorithmic bytes, which charge every pixel of the frame -- the
+                        # kernels never fetch the background's pixels, so the counter rate is the lower of the two
+                        "counter_GBs": counter_GBs, "counter_frac": round(counter_GBs / HBM_PEAK_GBS, 5) if counter_GBs is not None else None,
                         "traffic_source": (f"not measured in this run: FETCH_SIZE + WRITE_SIZE per launch of "
                                            f"{STAGE_KERNELS[dom][0]} from the rocprofv3 --pmc summary {traffic_src} (same build digest)")
                         if traffic is not None else traffic_src,
@@ -704,7 +747,12 @@ def main():
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "whole_frame": {"algorithmic_bytes_per_frame": int(frame_bytes(P, R_main, R_occ, W, H)),
                                         "achieved_GBs": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9, 2),
-                                        "frac": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+                                        "frac": round(frame_bytes(P, R_main, R_occ, W, H) * value / world / 1e9 / HBM_PEAK_GBS, 5),
+                                        # the whole step by the counters: bytes every kernel of a step moved / the step's duration
+                                        "counter_bytes_per_step": step_traffic,
+                                        "counter_GBs": round(step_traffic / (ms_per_step * 1e-3) / 1e9, 2) if step_traffic else None,
+                                        "counter_frac": round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_traffic else None,
+                                        "counter_kernels_missing": step_missing},
                         "stage_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in stages.items()},
                         # a stage may be several timed scopes per step (depth_order: the bucket kernels of the geometry call and the
                         # per-bucket sort of the render call): the totals per step add up to the step
@@ -742,6 +790,14 @@ def main():
                    # how long the HOST needed to issue the K timed steps, per step: close to ms_per_step = the run was bound by the
                    # host's launch rate (a slow or shared CPU), not by the device
                    "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
+                   # the timed region by a HIP event pair on the issuing stream (ms_per_step is the host's clock between the two
+                   # synchronisations; the two differ by the first launch's latency and the last synchronisation's return)
+                   "device_events_ms_per_step": round(device_ms_per_step, 4),
+                   # the library the numbers come from (SOAR_HIP_LIB swaps it for development A/B runs: then this is not the in-tree build)
+                   "library": os.path.relpath(hip_lib.LIB_PATH, ROOT) + (" (SOAR_HIP_LIB override)" if os.environ.get("SOAR_HIP_LIB") or
+                                                                        os.path.abspath(hip_lib.LIB_PATH) != os.path.abspath(build.LIB_PATH) else ""),
+                   "host_gc": "gc.collect() + gc.freeze() in front of the timed region (README: what a training loop should do after its set-up); "
+                              "SOAR_BENCH_NO_GC_FREEZE=1 times the steps without it",
                    "num_rendered_main": int(rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1)),
                    "num_rendered_occ": int(occ_ratio * rasterizer.stats["num_rendered"] / max(rasterizer.stats["forward_calls"], 1))},
         "roofline": roof,

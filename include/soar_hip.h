@@ -39,8 +39,9 @@ extern "C" {
  * of soar_adam_step / _at / _rows are doubles; soar_views_forward / _backward (+ soar_view_buffer_bytes, soar_views_grad_scratch_floats),
  * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses, soar_rast_backward_occ (the image
  * buffer grew by two planes: ask soar_rast_image_bytes), soar_gather_step_inputs_ids;
- * soar_selftest_wave_reduce is gone with the backward form it tested. */
-#define SOAR_HIP_ABI_VERSION 6
+ * soar_selftest_wave_reduce is gone with the backward form it tested.  7 (round 5): soar_step_views_forward / _backward (several poses
+ * behind one call each way), soar_cameras_from_c2w. */
+#define SOAR_HIP_ABI_VERSION 7
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */
@@ -567,6 +568,26 @@ int soar_view_buffer_bytes(int32_t P, int32_t W, int32_t H, int64_t capacity, in
 int soar_views_grad_scratch_floats(int32_t P, int32_t n_views, size_t *floats);
 int soar_views_forward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);
 int soar_views_backward(const SoarPoseArgs *pose, int32_t n_views, const SoarViewArgs *views, void *stream);
+/* ---- the views of a whole optimizer step behind ONE call each way (round 5, ABI 7) ----
+ * One step of the reference's training loop renders the 4 SDS views of the canonical (zeroed-root) pose and the 3 views of the video
+ * frame's pose (TS/system/gaussian_surfel_mvdream.py:79-92 -> TS/renderer/gaussian_batch_renderer.py:243-398 and :10-241): 2 poses, 7
+ * views.  soar_step_views_forward / _backward take n_poses poses with views_per_pose[p] views each (`views`: pose after pose, at most
+ * 8 in all): every pose is warped once each way; front views of one size and capacity -- of ANY pose -- share their launches, one per
+ * stage; the groups (another size, a back view) are issued on streams of the library's own beside each other, forked from `stream`
+ * behind the warps and joined into it before the call returns (SOAR_STEP_STREAMS=0: all on `stream`).  Every pose carries its own
+ * gradient outputs: the caller adds the poses' contributions to a shared model.  soar_views_forward / _backward are the n_poses = 1 forms. */
+int soar_step_views_forward(int32_t n_poses, const SoarPoseArgs *poses, const int32_t *views_per_pose, const SoarViewArgs *views, void *stream);
+int soar_step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_t *views_per_pose, const SoarViewArgs *views, void *stream);
+/* The cameras of a step in one launch: get_cam_info_gaussian_cxcy (TS/renderer/gaussian_batch_renderer.py:401-471) for n <= 8
+ * camera-to-world matrices [n][16] (row-major; in device memory, or on the host: then they travel in the kernel's arguments -- no
+ * copy, no synchronisation either way).  out_dev [n][48]: world_view_transform 16 | full_proj_transform 16 | camera_center 3 | 13 unused (every block 16-byte aligned), the
+ * transposed (row-vector) convention of the reference's Camera. */
+typedef struct SoarCameraSpec {
+    double fovx, fovy, znear, zfar;
+    double cx, cy, img_w, img_h;  /* principal point and image size: used when has_cxcy != 0 (:425-432) */
+    int32_t has_cxcy, pad_;
+} SoarCameraSpec;
+int soar_cameras_from_c2w(int32_t n, const float *c2w_dev, const float *c2w_host, const SoarCameraSpec *specs, float *out_dev, void *stream);
 /* soar_rast_forward_render_occ with the status words of soar_rast_binning_status_async copied out right behind the binning chain,
  * in front of the blend (status_pinned may be NULL). */
 int soar_rast_forward_render_status(const SoarRastParams *prm, const int32_t *radii, void *geom_buffer, void *binning_buffer,

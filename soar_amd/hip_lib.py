@@ -11,9 +11,12 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SOAR_HIP_LIB: another build of the same library (development A/B runs: scripts/variant.py); still no fallback of any kind
 LIB_PATH = os.environ.get("SOAR_HIP_LIB") or os.path.join(_HERE, "_lib", "libsoar_hip.so")
+if os.environ.get("SOAR_HIP_LIB"):
+    import sys as _sys
+    print(f"[soar_amd] SOAR_HIP_LIB is set: loading {LIB_PATH} instead of the in-tree build (development A/B runs only)", file=_sys.stderr)
 
 FRAME_LOSS_SCRATCH_FLOATS = 4 * 2048   # SOAR_FRAME_LOSS_SCRATCH_FLOATS: the scratch argument of soar_frame_loss[_pooled]
-ABI_VERSION = 6          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
+ABI_VERSION = 7          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 
@@ -48,6 +51,12 @@ class SoarPoseArgs(C.Structure):
                 ("xyz", _vp), ("rot", _vp), ("weights", _vp), ("joint_mats", _vp), ("offsets", _vp), ("axis_perm", _vp),
                 ("colors", _vp), ("scale_src", _vp), ("occ", _vp), ("occ3", _vp), ("posed", _vp),
                 ("grad_scratch", _vp), ("dL_dxyz", _vp), ("dL_drot", _vp), ("dL_dcolors", _vp), ("dL_dscale", _vp), ("dL_docc", _vp)]
+
+
+class SoarCameraSpec(C.Structure):
+    """Mirror of ``struct SoarCameraSpec`` (include/soar_hip.h)."""
+    _fields_ = [("fovx", C.c_double), ("fovy", C.c_double), ("znear", C.c_double), ("zfar", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("img_w", C.c_double), ("img_h", C.c_double), ("has_cxcy", C.c_int32), ("pad_", C.c_int32)]
 
 
 class SoarViewArgs(C.Structure):
@@ -155,6 +164,9 @@ SIGNATURES = {
     "soar_views_grad_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_views_forward": (C.c_int, [C.POINTER(SoarPoseArgs), C.c_int32, C.POINTER(SoarViewArgs), _vp]),
     "soar_views_backward": (C.c_int, [C.POINTER(SoarPoseArgs), C.c_int32, C.POINTER(SoarViewArgs), _vp]),
+    "soar_step_views_forward": (C.c_int, [C.c_int32, C.POINTER(SoarPoseArgs), C.POINTER(C.c_int32), C.POINTER(SoarViewArgs), _vp]),
+    "soar_step_views_backward": (C.c_int, [C.c_int32, C.POINTER(SoarPoseArgs), C.POINTER(C.c_int32), C.POINTER(SoarViewArgs), _vp]),
+    "soar_cameras_from_c2w": (C.c_int, [C.c_int32, _vp, C.POINTER(C.c_float), C.POINTER(SoarCameraSpec), _vp, _vp]),
     "soar_rast_forward_render_status": (C.c_int, [C.POINTER(SoarRastParams), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                                   _vp, _vp, _vp, _vp]),
     "soar_lbs_warp_backward_views": (C.c_int, [_vp] * 5 + [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp, _vp, _vp, _vp]),

@@ -56,6 +56,39 @@ def get_cam_info_gaussian_cxcy(c2w, fovx, fovy, znear, zfar, cxcy=None, img_wh=N
     return wv.to(device), full.to(device), center.to(device)
 
 
+def get_cams_info_gaussian_cxcy(c2ws, specs, device="cuda"):
+    """``get_cam_info_gaussian_cxcy`` for the n <= 8 cameras of a step in ONE launch (soar_cameras_from_c2w): c2ws = list of [4,4]
+    camera-to-world matrices (all on the host, or all on `device`), specs[i] = (fovx, fovy, znear, zfar, cxcy or None, img_wh or None).
+    -> list of (world_view_transform, full_proj_transform, camera_center) on `device`.  No device-to-host copy, no pageable
+    host-to-device copy: host matrices travel in the kernel's arguments."""
+    import ctypes as C
+    from .. import hip_lib
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return [get_cam_info_gaussian_cxcy(c, sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], device=device) for c, sp in zip(c2ws, specs)]
+    n = len(c2ws)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    arr = (hip_lib.SoarCameraSpec * n)()
+    for a, (fovx, fovy, znear, zfar, cxcy, img_wh) in zip(arr, specs):
+        a.fovx, a.fovy, a.znear, a.zfar = float(fovx), float(fovy), float(znear), float(zfar)
+        a.has_cxcy = int(cxcy is not None and img_wh is not None)
+        if a.has_cxcy:
+            a.cx, a.cy, a.img_w, a.img_h = float(cxcy[0]), float(cxcy[1]), float(img_wh[0]), float(img_wh[1])
+    out = torch.empty((n, 48), dtype=torch.float32, device=dev)
+    on_dev = [c.is_cuda for c in c2ws]
+    host, c2w_dev = None, None
+    if all(on_dev):
+        c2w_dev = torch.cat([c.detach().reshape(1, 16).to(device=dev, dtype=torch.float32) for c in c2ws], dim=0)
+    else:
+        flat = torch.cat([c.detach().reshape(16).to(device="cpu", dtype=torch.float32) for c in c2ws])     # (device ones among them are read back)
+        host = (C.c_float * (16 * n))(*flat.tolist())
+    with torch.cuda.device(dev):
+        hip_lib.check(hip_lib.lib().soar_cameras_from_c2w(n, hip_lib.ptr(c2w_dev), host, arr, out.data_ptr(),
+                                                          torch.cuda.current_stream(dev).cuda_stream), "soar_cameras_from_c2w")
+    return [(out[i, 0:16].view(4, 4), out[i, 16:32].view(4, 4), out[i, 32:35]) for i in range(n)]
+
+
 def sample_camera(global_step=1, n_view=4, real_batch_size=1, random_azimuth_range=(-180.0, 180.0),
                   random_elevation_range=(0.0, 30.0), eval_elevation_deg=15, camera_distance_range=(0.8, 1.0),
                   fovy_range=(15, 60), zoom_range=(1.0, 1.0), progressive_until=0, relative_radius=True):

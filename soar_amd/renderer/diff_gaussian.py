@@ -27,7 +27,7 @@ from ..rasterizer import AUTO, GaussianRasterizationSettings, GaussianRasterizer
 from . import registry
 from .batch import GaussianBatchRenderer
 from .cameras import device_constant
-from .fused_view import render_view, render_views
+from .fused_view import render_step_views, render_view, render_views
 from .postops import depth2normal, normal2curv
 
 # SOAR_FUSED_VIEW=0: always take the composed path (separate autograd ops), e.g. to compare the two
@@ -139,26 +139,20 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
         }
 
-    def forward_views(self, views, gt=True, **kwargs):
-        """Several full-patch views of ONE pose -- `views` = [{"camera", "bg_color", "render_front"}], e.g. the three of
-        ``gt_forward`` -- as one autograd node: the surfels are warped once each way and the views' geometry stages are enqueued in
-        front of the first read-back.  Same per-view dicts as ``forward``; falls back to one ``forward`` call per view when the
-        one-node form does not apply (camera leaves, reference-style guidance, ``SOAR_FUSED_VIEW=0``)."""
-        pc = self.geometry
-        guide = pc.smpl_guidance
-        cams = [v["camera"] for v in views]
+    def _one_node_ok(self, cams):
+        guide = self.geometry.smpl_guidance
         cam_leaf = any(getattr(t, "requires_grad", False) for c in cams
                        for t in (c.world_view_transform, c.full_proj_transform, c.camera_center))
-        if not (FUSED_VIEW and not cam_leaf and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights")):
-            return [self.forward(v["camera"], v["bg_color"], gt=gt, render_front=v.get("render_front", True), **kwargs) for v in views]
-        points, rot = pc.get_xyz, pc.get_rotation
+        return FUSED_VIEW and not cam_leaf and hasattr(guide, "joint_mats") and hasattr(guide, "blend_weights")
+
+    def _pose_views(self, views, gt, points, w, kwargs):
+        """what ``fused_view.render_views`` / ``render_step_views`` need of the views of one pose (``forward``'s per-view set-up)"""
+        pc = self.geometry
+        guide = pc.smpl_guidance
         fields = pc.attribute_field(points.detach()) if not gt else pc.attribute_field(points.detach(), z=None)
-        offsets = fields["offsets"] if self.cfg.offset else None
-        axis_perm = None if gt else axis_permutation("+z,+x,+y", points.device)
         idx, a_smpl = kwargs.get("gt_index"), kwargs.get("gt_a_smpl")
         with torch.no_grad():
             mats = guide.joint_mats(smpl_parms_in=a_smpl, idx=None if a_smpl is not None else idx, zero_out=not gt)
-            w = guide.blend_weights(points)
         settings, carriers = [], []
         for v in views:
             cam, bg_color = v["camera"], v["bg_color"]
@@ -172,12 +166,49 @@ class DiffGaussian(_RendererBase, GaussianBatchRenderer):
                 patch_bbox=cam.random_patch(float("inf"), float("inf")), prcppoint=cam.prcppoint, sh_degree=pc.active_sh_degree,
                 campos=cam.camera_center, prefiltered=False, render_front=False, sort_descending=False, debug=False,
                 config=pc.config))
-        outs = render_views(points, rot, pc.get_colors if self.cfg.use_explicit else fields["shs"],
-                            pc.get_scaling if self.cfg.use_explicit else fields["scales"], carriers, pc.get_occ, w, mats, offsets,
-                            axis_perm, settings, cams, [not v.get("render_front", True) for v in views],
-                            capacity=self._binning_capacity())
+        return {"weights": w, "joint_mats": mats, "offsets": fields["offsets"] if self.cfg.offset else None,
+                "axis_perm": None if gt else axis_permutation("+z,+x,+y", points.device), "settings": settings,
+                "cameras": [v["camera"] for v in views], "backs": [not v.get("render_front", True) for v in views], "means2D": carriers,
+                "fields": fields}
+
+    @staticmethod
+    def _pkgs(outs, carriers):
         return [{"render": o[0], "normal": o[1], "depth": o[2], "pred_normal": o[3], "mask": o[4], "occ": o[5], "curv": o[6],
                  "viewspace_points": c, "visibility_filter": o[7] > 0, "radii": o[7]} for o, c in zip(outs, carriers)]
+
+    def forward_views(self, views, gt=True, **kwargs):
+        """Several full-patch views of ONE pose -- `views` = [{"camera", "bg_color", "render_front"}], e.g. the three of
+        ``gt_forward`` -- as one autograd node: the surfels are warped once each way and the views' geometry stages are enqueued in
+        front of the first read-back.  Same per-view dicts as ``forward``; falls back to one ``forward`` call per view when the
+        one-node form does not apply (camera leaves, reference-style guidance, ``SOAR_FUSED_VIEW=0``)."""
+        pc = self.geometry
+        if not self._one_node_ok([v["camera"] for v in views]):
+            return [self.forward(v["camera"], v["bg_color"], gt=gt, render_front=v.get("render_front", True), **kwargs) for v in views]
+        points, rot = pc.get_xyz, pc.get_rotation
+        with torch.no_grad():
+            w = pc.smpl_guidance.blend_weights(points)
+        p = self._pose_views(views, gt, points, w, kwargs)
+        outs = render_views(points, rot, pc.get_colors if self.cfg.use_explicit else p["fields"]["shs"],
+                            pc.get_scaling if self.cfg.use_explicit else p["fields"]["scales"], p["means2D"], pc.get_occ, w, p["joint_mats"],
+                            p["offsets"], p["axis_perm"], p["settings"], p["cameras"], p["backs"], capacity=self._binning_capacity())
+        return self._pkgs(outs, p["means2D"])
+
+    def forward_step_views(self, groups, **kwargs):
+        """The views of a whole optimizer step -- `groups` = [(views, gt)], e.g. [(the SDS views, False), (the video frame's three,
+        True)] (TS/system/gaussian_surfel_mvdream.py:79-92: batch_forward, then gt_forward) -- as ONE autograd node: one KNN query, one
+        warp per pose each way, one C call each way (``fused_view.render_step_views``).  -> per group the list of per-view dicts of
+        ``forward``.  Falls back to one ``forward_views`` call per group when the one-node form does not apply (attribute fields
+        instead of explicit colours and scales: they differ from pose to pose)."""
+        pc = self.geometry
+        cams = [v["camera"] for views, _gt in groups for v in views]
+        if not (self.cfg.use_explicit and len(groups) > 1 and self._one_node_ok(cams)):
+            return [self.forward_views(views, gt=gt, **kwargs) for views, gt in groups]
+        points, rot = pc.get_xyz, pc.get_rotation
+        with torch.no_grad():
+            w = pc.smpl_guidance.blend_weights(points)
+        poses = [self._pose_views(views, gt, points, w, kwargs) for views, gt in groups]
+        outs = render_step_views(points, rot, pc.get_colors, pc.get_scaling, pc.get_occ, poses, capacity=self._binning_capacity())
+        return [self._pkgs(o, p["means2D"]) for o, p in zip(outs, poses)]
 
     def forward(self, viewpoint_camera, bg_color: torch.Tensor, patch_size: list = [float("inf"), float("inf")],
                 scaling_modifier=1.0, override_color=None, gt=False, render_front=True, stage=0, **kwargs):

@@ -233,12 +233,22 @@ class CapacityBook:
     """Instances of (tile, Gaussian) pairs a view of a kind needs, learnt from the frames before it.  A kind = (device, image size,
     number of Gaussians, field of view to within 2^(1/4)): what scales the count.  The first frame of a kind goes through the
     per-stage path with the reference's blocking read-back and teaches the book; later ones get MARGIN times the largest count seen,
-    and the book grows whenever more than half of a bound was used."""
+    and the book grows whenever more than half of a bound was used.
+
+    What the key cannot see is the camera's distance to the model (its matrices live on the device).  The book therefore also keeps
+    the counts of a kind's last frames: while a kind is YOUNG (fewer than SETTLE frames seen), while its counts MOVE (two consecutive
+    frames differ by more than 1.5x: a camera walking in or out) or while the HEADROOM is short (the last frame used more than a
+    third of the bound), `check_early()` says so and the forward call looks at the status words itself, right behind the binning chain
+    -- a wait for the binning only, not for the blend -- and renders a view that did not fit again before anybody has seen it, like
+    the reference's resize (rasterizer_impl.cu:250-257).  Only a kind whose counts have been steady is left to the late check in
+    `backward()`, where a frame that needs more than MARGIN times anything seen before raises `BinningOverflow`."""
     MARGIN = 8
     FLOOR = 1 << 20
+    SETTLE = 4
 
     def __init__(self):
         self.bound = {}
+        self.history = {}                   # key -> the last SETTLE instance counts, oldest first
         self.lock = threading.Lock()
 
     @staticmethod
@@ -249,12 +259,30 @@ class CapacityBook:
     def get(self, key):
         return self.bound.get(key)
 
+    def reset(self):
+        with self.lock:
+            self.bound.clear()
+            self.history.clear()
+
     def learn(self, key, need):
         with self.lock:
+            h = self.history.setdefault(key, [])
+            h.append(max(int(need), 1))
+            del h[:-self.SETTLE]
             have = self.bound.get(key, 0)
-            if need * 2 > have:
+            if need * 2 > have or key not in self.bound:
                 self.bound[key] = max(have, self.MARGIN * int(need), self.FLOOR)
             return self.bound[key]
+
+    def check_early(self, key) -> bool:
+        """Should the forward call of the next frame of this kind wait for its status words itself?  (see the class docstring)"""
+        with self.lock:
+            h = self.history.get(key, [])
+            if len(h) < self.SETTLE:
+                return True
+            if any(max(a, b) > 1.5 * min(a, b) for a, b in zip(h, h[1:])):
+                return True
+            return 3 * h[-1] > self.bound.get(key, 0)
 
 
 capacity_book = CapacityBook()
@@ -392,25 +420,40 @@ def _view_bytes(P, W, H, cap, back):
     return n
 
 
-class _PoseViews(torch.autograd.Function):
-    """n views of one pose, one C call each way.  Per view 8 outputs like `_RenderViews`.  specs[i] = (settings, (focal_k00,
-    focal_k11), capacity, book key, back): `settings` of a back view (the plugin's render_front = False) carry sort_descending."""
+class _StepViews(torch.autograd.Function):
+    """The views of one or several POSES of the same model, one C call each way (soar_step_views_forward / _backward).  The reference's
+    training step renders 4 SDS views of the zeroed-root pose and 3 views of the video frame's pose (TS/system/gaussian_surfel_mvdream.py:
+    79-92 over TS/renderer/gaussian_batch_renderer.py:243-398 and :10-241): with both poses in `poses` that is ONE autograd node.
+
+    apply(xyz, rot, colors, scale_src, occ, meta, grad_mode, *tensors): meta[p] = {"specs": [...], "axis_perm": T or None};
+    tensors = (weights_p, joint_mats_p, offsets_p or None) per pose, then one screen-space gradient carrier per view (pose after pose).
+    specs[i] = (settings, (focal_k00, focal_k11), capacity, book key, back): `settings` of a back view (the plugin's render_front =
+    False) carry sort_descending.  Per view 8 outputs: render, normal, depth, pred_normal, mask, occ, curv, radii -- the images of
+    views of one size lie in ONE allocation, view after view with a fixed stride (`stack_views` below stacks them without a copy)."""
     N_OUT = 8
     PLANES = 18
 
     @staticmethod
-    def _launch(L, dev, stream, pose, specs, P, keep):
-        """Allocate the views' buffers for the capacities in `specs` and issue the forward call -> (views array, per-view tensors)."""
-        n = len(specs)
+    def _launch(L, dev, stream, pose_args, vpp, flat_specs, P, warp):
+        """Allocate the views' buffers for the capacities in `flat_specs` and issue the forward call -> (views array, per-view tensors)."""
+        n = len(flat_specs)
         views = (SoarViewArgs * n)()
+        # the images of the views of one size in one allocation (view index inside it: the order of appearance)
+        sizes = {}
+        for (rs, _f, _cap, _key, _back) in flat_specs:
+            k = (int(rs.image_height), int(rs.image_width))
+            sizes[k] = sizes.get(k, 0) + 1
+        blocks = {k: torch.empty((cnt, _StepViews.PLANES * k[0] * k[1]), dtype=torch.float32, device=dev) for k, cnt in sizes.items()}
+        used = {k: 0 for k in sizes}
         per_view = []
-        for v, (rs, focal, cap, _key, back) in enumerate(specs):
+        for v, (rs, focal, cap, _key, back) in enumerate(flat_specs):
             H, W = int(rs.image_height), int(rs.image_width)
             c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, bool(back), rs.debug, rs.bg,
                      rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
             nbytes = _view_bytes(P, W, H, int(cap), bool(back))
             buf = _scratch(nbytes, dev)
-            out = torch.empty((_PoseViews.PLANES * H * W,), dtype=torch.float32, device=dev)
+            out = blocks[(H, W)][used[(H, W)]]
+            used[(H, W)] += 1
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             words = _status_words()
             words.numpy()[2:] = 0                       # (only a back view's occlusion pass writes the second pair)
@@ -419,62 +462,86 @@ class _PoseViews(torch.autograd.Function):
             a.focal_k00, a.focal_k11, a.capacity, a.back = focal[0], focal[1], int(cap), int(bool(back))
             a.buffer, a.buffer_bytes, a.out, a.radii, a.status_pinned = buf.data_ptr(), nbytes, out.data_ptr(), radii.data_ptr(), words.data_ptr()
             per_view.append((c, buf, out, radii, words))
+        for pa in pose_args:
+            pa.warp = 1 if warp else 0
         try:
             with torch.cuda.device(dev):
-                check(L.soar_views_forward(C.byref(pose), n, views, stream), "soar_views_forward")
+                if len(pose_args) == 1:
+                    check(L.soar_views_forward(C.byref(pose_args[0]), n, views, stream), "soar_views_forward")
+                else:
+                    check(L.soar_step_views_forward(len(pose_args), pose_args, vpp, views, stream), "soar_step_views_forward")
         except BaseException:
             _release_words([pv[4] for pv in per_view])   # (copies of the views in front of the failing one may be on their way)
             raise
         return views, per_view
 
     @staticmethod
-    def forward(ctx, xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, grad_mode, *means2D):
+    def forward(ctx, xyz, rot, colors, scale_src, occ, meta, grad_mode, *tensors):
         L = hip_lib.lib()
         dev = xyz.device
-        x, q, w, A = _f32(xyz), _f32(rot), _f32(weights), _f32(joint_mats).reshape(-1, 16)
-        off = _f32(offsets) if offsets is not None else None
-        T = _f32(axis_perm.to(dev)) if axis_perm is not None else None
+        n_poses = len(meta)
+        x, q = _f32(xyz), _f32(rot)
         cols, ssrc, occ_v = _f32(colors), _f32(scale_src), _f32(occ).reshape(-1)
-        P, J = x.shape[0], A.shape[0]
-        if w.shape != (P, J):
-            raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
-        if len(means2D) != len(specs):
-            raise ValueError("one screen-space gradient carrier per view")
+        P = x.shape[0]
         if ssrc.shape != (P, 1) or occ_v.shape[0] != P or cols.shape != (P, 3):
             raise ValueError("colors [P,3], scale_src [P,1] and occ [P] / [P,1] expected")
-        posed = torch.empty((11 * P,), dtype=torch.float32, device=dev)
-        pose = SoarPoseArgs()
-        pose.P, pose.J, pose.scale_width, pose.warp = P, J, 1, 1
-        pose.xyz, pose.rot, pose.weights, pose.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
-        pose.offsets, pose.axis_perm = ptr(off), ptr(T)
-        pose.colors, pose.scale_src, pose.occ, pose.posed = cols.data_ptr(), ssrc.data_ptr(), occ_v.data_ptr(), posed.data_ptr()
-        occ3 = torch.empty((P, 3), dtype=torch.float32, device=dev) if any(sp[4] for sp in specs) else None
-        pose.occ3 = ptr(occ3)
+        flat_specs = [sp for m in meta for sp in m["specs"]]
+        n_views = len(flat_specs)
+        means2D = tensors[3 * n_poses:]
+        if len(means2D) != n_views:
+            raise ValueError("one screen-space gradient carrier per view")
+        if n_views > 8:
+            raise ValueError("at most 8 views per call")
+        PoseArr = SoarPoseArgs * n_poses
+        pose_args = PoseArr()
+        vpp = (C.c_int32 * n_poses)(*[len(m["specs"]) for m in meta])
+        per_pose = []
+        for p, m in enumerate(meta):
+            w, A, off = tensors[3 * p], tensors[3 * p + 1], tensors[3 * p + 2]
+            w, A = _f32(w), _f32(A).reshape(-1, 16)
+            off = _f32(off) if off is not None else None
+            T = _f32(m["axis_perm"].to(dev)) if m.get("axis_perm") is not None else None
+            J = A.shape[0]
+            if w.shape != (P, J):
+                raise ValueError(f"weights must be [{P},{J}], got {tuple(w.shape)}")
+            posed = torch.empty((11 * P,), dtype=torch.float32, device=dev)
+            occ3 = torch.empty((P, 3), dtype=torch.float32, device=dev) if any(sp[4] for sp in m["specs"]) else None
+            pa = pose_args[p]
+            pa.P, pa.J, pa.scale_width, pa.warp = P, J, 1, 1
+            pa.xyz, pa.rot, pa.weights, pa.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
+            pa.offsets, pa.axis_perm = ptr(off), ptr(T)
+            pa.colors, pa.scale_src, pa.occ, pa.posed = cols.data_ptr(), ssrc.data_ptr(), occ_v.data_ptr(), posed.data_ptr()
+            pa.occ3 = ptr(occ3)
+            per_pose.append((w, A, off, T, posed, occ3, J))
         cur = torch.cuda.current_stream(dev)
         stream = cur.cuda_stream
-        keep = [x, q, w, A, off, T, cols, ssrc, occ_v]
-        views, per_view = _PoseViews._launch(L, dev, stream, pose, specs, P, keep)
+        views, per_view = _StepViews._launch(L, dev, stream, pose_args, vpp, flat_specs, P, True)
         try:
-            return _PoseViews._finish_forward(ctx, L, dev, cur, stream, pose, specs, P, J, keep, views, per_view, grad_mode, x, q, w, A,
-                                              off, T, cols, ssrc, occ_v, occ3, posed, scale_src, occ, offsets)
+            return _StepViews._finish_forward(ctx, L, dev, cur, stream, pose_args, vpp, meta, flat_specs, P, views, per_view, grad_mode,
+                                              x, q, cols, ssrc, occ_v, per_pose, tensors, scale_src, occ)
         except BaseException:
             if getattr(ctx, "pending", None) is None:    # nobody owns the words yet: park them until their copies have landed
                 _release_words([pv[4] for pv in per_view if pv[4] is not None])
             raise
 
     @staticmethod
-    def _finish_forward(ctx, L, dev, cur, stream, pose, specs, P, J, keep, views, per_view, grad_mode, x, q, w, A, off, T, cols, ssrc,
-                        occ_v, occ3, posed, scale_src, occ, offsets):
+    def _finish_forward(ctx, L, dev, cur, stream, pose_args, vpp, meta, flat_specs, P, views, per_view, grad_mode, x, q, cols, ssrc,
+                        occ_v, per_pose, tensors, scale_src, occ):
+        n_poses = len(meta)
         # can a backward pass come?  (grad_mode: torch.is_grad_enabled() of the CALLER -- inside a Function's forward it is always off,
         # and needs_input_grad only says which inputs require gradients)
         training = bool(grad_mode) and any(ctx.needs_input_grad)
-        if not training:
-            # nobody will come back for a backward pass: look at the status words now and render a view that did not fit again,
-            # transparently (the reference resizes its binning buffer and never drops a frame, rasterizer_impl.cu:250-257)
+        early = any(capacity_book.check_early(sp[3]) for sp in flat_specs)
+        if not training or early:
+            # nobody will come back for a backward pass -- or the counts of a kind are young, moving or close to their bound: look at
+            # the status words now (they sit right behind the binning chain: the blend runs on while the host looks) and render a view
+            # that did not fit again, transparently (the reference resizes its binning buffer and never drops a frame,
+            # rasterizer_impl.cu:250-257)
+            training = False                                       # (the words are resolved here: nothing is left for backward())
             for _attempt in range(6):
                 again = False
                 new_specs = []
-                for (rs, focal, cap, key, back), (_c, _b, _o, _r, words) in zip(specs, per_view):
+                for (rs, focal, cap, key, back), (_c, _b, _o, _r, words) in zip(flat_specs, per_view):
                     total, over = _wait_words(words, dev, cur)
                     bound = capacity_book.learn(key, max(total, over))
                     rasterizer.note_num_rendered(total)
@@ -485,14 +552,22 @@ class _PoseViews(torch.autograd.Function):
                 _release_words([pv[4] for pv in per_view])
                 if not again:
                     break
-                specs = new_specs
-                pose.warp = 0
-                views, per_view = _PoseViews._launch(L, dev, stream, pose, specs, P, keep)
+                # (views that share their launches share a capacity: the largest among the front views of a size)
+                size_of = lambda rs: (int(rs.image_width), int(rs.image_height))
+                caps = {}
+                for (rs, _focal2, cap, _key2, back) in new_specs:
+                    if not back:
+                        caps[size_of(rs)] = max(caps.get(size_of(rs), 0), cap)
+                flat_specs = [(rs, focal, cap if back else caps[size_of(rs)], key, back) for (rs, focal, cap, key, back) in new_specs]
+                views, per_view = _StepViews._launch(L, dev, stream, pose_args, vpp, flat_specs, P, False)
             else:
                 raise BinningOverflow("a view did not fit its binning buffer after six enlargements")
         occ_grad = bool(ctx.needs_input_grad[4])
-        outs, nondiff, saved = [], [], [x, q, w, A, cols, ssrc, posed]
-        for (rs, _f, _cap, _k, _back), (_c, buf, out, radii, _words) in zip(specs, per_view):
+        outs, nondiff, saved = [], [], [x, q, cols, ssrc]
+        for (w, A, _off, _T, posed, _occ3, _J) in per_pose:
+            saved += [w, A, posed]
+        n_fixed = len(saved)
+        for (rs, _f, _cap, _k, _back), (_c, buf, out, radii, _words) in zip(flat_specs, per_view):
             H, W = int(rs.image_height), int(rs.image_width)
             hw = H * W
             render, normal, depth = _carve(out, 0, (3, H, W)), _carve(out, 3 * hw, (3, H, W)), _carve(out, 6 * hw, (1, H, W))
@@ -503,12 +578,14 @@ class _PoseViews(torch.autograd.Function):
             if not occ_grad:
                 nondiff.append(occ_img)
             saved += [depth, mask, raw_normal, buf, radii]       # what the backward reads of a view (depth and mask are outputs:
-        ctx.pose_keep = (off, T, occ_v, occ3)                    # modifying them in place is caught by autograd's version check)
+        ctx.n_fixed = n_fixed                                    # modifying them in place is caught by autograd's version check)
+        ctx.pose_keep = [(off, T, occ3, J) for (_w, _A, off, T, _posed, occ3, J) in per_pose]
+        ctx.occ_keep = occ_v
         ctx.view_ctx = [(pv[0], pv[2]) for pv in per_view]       # parameter blocks (camera tensors kept alive) and the image blocks
-        ctx.pending = _PendingStatus(specs, [pv[4] for pv in per_view], dev, cur) if training else None
-        ctx.specs, ctx.J, ctx.occ_grad, ctx.stream = specs, J, occ_grad, cur
+        ctx.pending = _PendingStatus(flat_specs, [pv[4] for pv in per_view], dev, cur) if training else None
+        ctx.meta, ctx.flat_specs, ctx.occ_grad, ctx.stream = meta, flat_specs, occ_grad, cur
         ctx.scale_shape, ctx.occ_shape = tuple(scale_src.shape), tuple(occ.shape)
-        ctx.off_grad = offsets is not None and offsets.requires_grad
+        ctx.off_grad = [tensors[3 * p + 2] is not None and tensors[3 * p + 2].requires_grad for p in range(n_poses)]
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)
@@ -518,10 +595,11 @@ class _PoseViews(torch.autograd.Function):
     def backward(ctx, *gouts):
         L = hip_lib.lib()
         saved = ctx.saved_tensors
-        x, q, w, A, cols, ssrc, posed = saved[:7]
-        off, T, occ_v, occ3 = ctx.pose_keep
+        x, q, cols, ssrc = saved[:4]
+        meta, flat_specs = ctx.meta, ctx.flat_specs
+        n_poses, n = len(meta), len(flat_specs)
         dev = x.device
-        P, n = x.shape[0], len(ctx.specs)
+        P = x.shape[0]
         # FIRST: did every view fit its binning buffer?  The words landed while the blend and the loss ran.
         if ctx.pending is not None:
             pending, ctx.pending = ctx.pending, None
@@ -535,28 +613,36 @@ class _PoseViews(torch.autograd.Function):
                     "frame again (or set Config.binning_capacity = 0 for the reference's blocking read-back in every call)")
         f = dict(dtype=torch.float32, device=dev)
         k = C.c_size_t(0)
-        check(L.soar_views_grad_scratch_floats(P, n, C.byref(k)), "soar_views_grad_scratch_floats")
-        scratch = torch.empty((int(k.value),), **f)
-        g_leaf = torch.empty((P * 11 + (P if ctx.occ_grad else 0),), **f)
-        g_xyz, g_rot, g_colors, g_scale = (_carve(g_leaf, 0, (P, 3)), _carve(g_leaf, 3 * P, (P, 4)), _carve(g_leaf, 7 * P, (P, 3)),
-                                           _carve(g_leaf, 10 * P, (P, 1)))
-        g_occ = _carve(g_leaf, 11 * P, (P,)) if ctx.occ_grad else None
+        width = P * 11 + (P if ctx.occ_grad else 0)
+        g_leaf = torch.empty((n_poses, width), **f)              # per pose: xyz 3 | rot 4 | colours 3 | scale 1 (| occ 1)
         g2d = torch.empty((n, P, 3), **f)
-        pose = SoarPoseArgs()
-        pose.P, pose.J, pose.scale_width, pose.warp = P, ctx.J, 1, 0
-        pose.xyz, pose.rot, pose.weights, pose.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
-        pose.offsets, pose.axis_perm = ptr(off), ptr(T)
-        pose.colors, pose.scale_src, pose.occ, pose.posed = cols.data_ptr(), ssrc.data_ptr(), occ_v.data_ptr(), posed.data_ptr()
-        pose.occ3 = ptr(occ3)
-        pose.grad_scratch = scratch.data_ptr()
-        pose.dL_dxyz, pose.dL_drot, pose.dL_dcolors, pose.dL_dscale = g_xyz.data_ptr(), g_rot.data_ptr(), g_colors.data_ptr(), g_scale.data_ptr()
-        pose.dL_docc = g_occ.data_ptr() if g_occ is not None else None
+        PoseArr = SoarPoseArgs * n_poses
+        pose_args = PoseArr()
+        vpp = (C.c_int32 * n_poses)(*[len(m["specs"]) for m in meta])
+        scratches = []
+        for p, m in enumerate(meta):
+            w, A, posed = saved[4 + 3 * p:7 + 3 * p]
+            off, T, occ3, J = ctx.pose_keep[p]
+            nv = len(m["specs"])
+            check(L.soar_views_grad_scratch_floats(P, nv, C.byref(k)), "soar_views_grad_scratch_floats")
+            scratch = torch.empty((int(k.value),), **f)
+            scratches.append(scratch)
+            base = g_leaf[p].data_ptr()
+            pa = pose_args[p]
+            pa.P, pa.J, pa.scale_width, pa.warp = P, J, 1, 0
+            pa.xyz, pa.rot, pa.weights, pa.joint_mats = x.data_ptr(), q.data_ptr(), w.data_ptr(), A.data_ptr()
+            pa.offsets, pa.axis_perm = ptr(off), ptr(T)
+            pa.colors, pa.scale_src, pa.occ, pa.posed = cols.data_ptr(), ssrc.data_ptr(), ctx.occ_keep.data_ptr(), posed.data_ptr()
+            pa.occ3 = ptr(occ3)
+            pa.grad_scratch = scratch.data_ptr()
+            pa.dL_dxyz, pa.dL_drot, pa.dL_dcolors, pa.dL_dscale = base, base + 4 * 3 * P, base + 4 * 7 * P, base + 4 * 10 * P
+            pa.dL_docc = base + 4 * 11 * P if ctx.occ_grad else None
         views = (SoarViewArgs * n)()
         keep = []
-        NO = _PoseViews.N_OUT
+        NO = _StepViews.N_OUT
         any_live = False
-        for v, ((rs, focal, cap, _key, back), (c, out)) in enumerate(zip(ctx.specs, ctx.view_ctx)):
-            depth, mask, raw_normal, buf, radii = saved[7 + 5 * v:12 + 5 * v]
+        for v, ((rs, focal, cap, _key, back), (c, out)) in enumerate(zip(flat_specs, ctx.view_ctx)):
+            depth, mask, raw_normal, buf, radii = saved[ctx.n_fixed + 5 * v:ctx.n_fixed + 5 * v + 5]
             g_color, g_normal, g_depth, g_pred, g_mask, g_occ_img, g_curv, _gr = gouts[v * NO:(v + 1) * NO]
             opt = lambda g: _dev_f32(g, dev, "gradient") if g is not None else None
             gs = [opt(g) for g in (g_color, g_normal, g_depth, g_pred, g_mask, g_occ_img if ctx.occ_grad else None, g_curv)]
@@ -568,16 +654,62 @@ class _PoseViews(torch.autograd.Function):
             a.buffer, a.buffer_bytes, a.out, a.radii = buf.data_ptr(), buf.numel(), out.data_ptr(), radii.data_ptr()
             (a.g_render, a.g_normal, a.g_depth, a.g_pred_normal, a.g_mask, a.g_occ, a.g_curv) = [ptr(g) for g in gs]
             a.dL_dmeans2D = g2d[v].data_ptr()
+        n_in = 7 + 3 * n_poses + n
         if not any_live:
-            return (None,) * (11 + n)
+            return (None,) * n_in
         with torch.cuda.device(dev):
-            check(L.soar_views_backward(C.byref(pose), n, views, torch.cuda.current_stream(dev).cuda_stream), "soar_views_backward")
-        g_off = None
-        if ctx.off_grad:
-            g_means3D = scratch[:3 * n * P].reshape(n, P, 3).sum(0)
-            g_off = g_means3D if T is None else g_means3D @ T.t()                  # p'' = (p' + offsets) T
+            if n_poses == 1:
+                check(L.soar_views_backward(C.byref(pose_args[0]), n, views, torch.cuda.current_stream(dev).cuda_stream), "soar_views_backward")
+            else:
+                check(L.soar_step_views_backward(n_poses, pose_args, vpp, views, torch.cuda.current_stream(dev).cuda_stream),
+                      "soar_step_views_backward")
+        tot = g_leaf[0] if n_poses == 1 else g_leaf.sum(0)       # the poses' contributions to the shared model, in pose order
+        g_xyz, g_rot, g_colors, g_scale = (_carve(tot, 0, (P, 3)), _carve(tot, 3 * P, (P, 4)), _carve(tot, 7 * P, (P, 3)),
+                                           _carve(tot, 10 * P, (P, 1)))
+        g_occ = _carve(tot, 11 * P, (P,)) if ctx.occ_grad else None
+        per_pose_grads = []
+        for p, m in enumerate(meta):
+            g_off = None
+            if ctx.off_grad[p]:
+                nv = len(m["specs"])
+                T = ctx.pose_keep[p][1]
+                g_means3D = scratches[p][:3 * nv * P].reshape(nv, P, 3).sum(0)
+                g_off = g_means3D if T is None else g_means3D @ T.t()              # p'' = (p' + offsets) T
+            per_pose_grads += [None, None, g_off]
         return (g_xyz, g_rot, g_colors, g_scale.reshape(ctx.scale_shape), g_occ.reshape(ctx.occ_shape) if g_occ is not None else None,
-                None, None, g_off, None, None, None, *[g2d[v] for v in range(n)])
+                None, None, *per_pose_grads, *[g2d[v] for v in range(n)])
+
+
+class _StackViews(torch.autograd.Function):
+    """torch.stack(xs, 0) of per-view images that already lie in one allocation, one behind the other with a fixed stride (what
+    `_StepViews` leaves behind for the views of one size): the stacked tensor is that memory, no copy each way."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        x0 = xs[0]
+        step = (xs[1].data_ptr() - x0.data_ptr()) // x0.element_size()
+        t = torch.empty(0, dtype=x0.dtype, device=x0.device)
+        t.set_(x0.untyped_storage(), x0.storage_offset(), (len(xs),) + tuple(x0.shape), (step,) + tuple(x0.stride()))
+        ctx.n = len(xs)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[i] for i in range(ctx.n))
+
+
+def stack_views(xs):
+    """torch.stack(xs, dim=0) -- without the copy when the tensors are equally shaped slices of one allocation at a fixed stride."""
+    xs = list(xs)
+    if len(xs) > 1 and all(torch.is_tensor(x) and x.is_cuda for x in xs):
+        x0 = xs[0]
+        d = xs[1].data_ptr() - x0.data_ptr()
+        same = all(x.shape == x0.shape and x.stride() == x0.stride() and x.dtype == x0.dtype and
+                   x.untyped_storage().data_ptr() == x0.untyped_storage().data_ptr() and x.data_ptr() - x0.data_ptr() == i * d
+                   for i, x in enumerate(xs))
+        if same and d > 0 and d % x0.element_size() == 0 and d >= x0.numel() * x0.element_size() and x0.is_contiguous():
+            return _StackViews.apply(*xs)
+    return torch.stack(xs, dim=0)
 
 
 def _focal(camera):
@@ -618,8 +750,8 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
             size = (int(settings_list[i].image_width), int(settings_list[i].image_height))
             caps[i] = max(caps[j] for j in one_call if (int(settings_list[j].image_width), int(settings_list[j].image_height)) == size)
         specs = [(settings_list[i]._replace(sort_descending=bool(backs[i])), _focal(cameras[i]), caps[i], keys[i], bool(backs[i])) for i in one_call]
-        outs = _PoseViews.apply(xyz, rot, colors, scale_src, occ, weights, joint_mats, offsets, axis_perm, specs, torch.is_grad_enabled(),
-                                *[means2D_list[i] for i in one_call])
+        outs = _StepViews.apply(xyz, rot, colors, scale_src, occ, [{"specs": specs, "axis_perm": axis_perm}], torch.is_grad_enabled(),
+                                weights, joint_mats, offsets, *[means2D_list[i] for i in one_call])
         result = {i: tuple(outs[j * n:(j + 1) * n]) for j, i in enumerate(one_call)}
         rest = [i for i in range(len(backs)) if i not in result]
     else:
@@ -634,3 +766,43 @@ def render_views(xyz, rot, colors, scale_src, means2D_list, occ, weights, joint_
             if capacity == AUTO:
                 capacity_book.learn(CapacityBook.key(dev, settings_list[i], P), _RenderViews.last_num_rendered[j])
     return [result[i] for i in range(len(backs))]
+
+
+def render_step_views(xyz, rot, colors, scale_src, occ, poses, capacity: Optional[int] = None):
+    """The views of SEVERAL poses of one model -- the reference's training step renders 4 SDS views of the zeroed-root pose and 3 views
+    of the video frame's pose (TS/system/gaussian_surfel_mvdream.py:79-92) -- as ONE autograd node, one C call each way
+    (soar_step_views_forward / _backward): every pose warped once, the front views of one size -- of any pose -- in one batch of
+    launches, the groups beside each other on the library's side streams.
+    poses[p] = {"weights", "joint_mats", "offsets", "axis_perm", "settings", "cameras", "backs", "means2D"} (lists per view).
+    -> per pose the list of per-view 8-tuples of ``render_view``.  Falls back to one ``render_views`` call per pose whenever a view
+    cannot take the one-call path yet (the first frame of a kind reads its instance count back and teaches the capacity book)."""
+    n = _StepViews.N_OUT
+    dev, P = xyz.device, int(xyz.shape[0])
+    total = sum(len(p["backs"]) for p in poses)
+    ok = bool(capacity) and P > 0 and tuple(scale_src.shape) == (P, 1) and total <= 8 and len(poses) > 1
+    meta, tensors, carriers = [], [], []
+    if ok:
+        flat = [(p_i, i) for p_i, p in enumerate(poses) for i in range(len(p["backs"]))]
+        keys = {pi: CapacityBook.key(dev, poses[pi[0]]["settings"][pi[1]], P) for pi in flat}
+        caps = {pi: (capacity_book.get(keys[pi]) if capacity == AUTO else int(capacity)) for pi in flat}
+        ok = all(caps[pi] for pi in flat)
+    if not ok:
+        return [render_views(xyz, rot, colors, scale_src, p["means2D"], occ, p["weights"], p["joint_mats"], p["offsets"], p["axis_perm"],
+                             p["settings"], p["cameras"], p["backs"], capacity=capacity) for p in poses]
+    size = lambda pi: (int(poses[pi[0]]["settings"][pi[1]].image_width), int(poses[pi[0]]["settings"][pi[1]].image_height))
+    for pi in flat:                                  # front views of one size share the largest bound among them: one batch of launches
+        if not poses[pi[0]]["backs"][pi[1]]:
+            caps[pi] = max(caps[qj] for qj in flat if size(qj) == size(pi) and not poses[qj[0]]["backs"][qj[1]])
+    for p_i, p in enumerate(poses):
+        specs = [(p["settings"][i]._replace(sort_descending=bool(p["backs"][i])), _focal(p["cameras"][i]), caps[(p_i, i)], keys[(p_i, i)],
+                  bool(p["backs"][i])) for i in range(len(p["backs"]))]
+        meta.append({"specs": specs, "axis_perm": p["axis_perm"]})
+        tensors += [p["weights"], p["joint_mats"], p["offsets"]]
+        carriers += list(p["means2D"])
+    outs = _StepViews.apply(xyz, rot, colors, scale_src, occ, meta, torch.is_grad_enabled(), *tensors, *carriers)
+    result, j = [], 0
+    for p in poses:
+        k = len(p["backs"])
+        result.append([tuple(outs[(j + i) * n:(j + i + 1) * n]) for i in range(k)])
+        j += k
+    return result

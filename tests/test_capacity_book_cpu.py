@@ -34,8 +34,35 @@ def test_bounds_grow_before_they_are_used_up_and_never_shrink():
     assert book.learn(k, 3) == book.get(k)
 
 
+def test_young_moving_or_nearly_full_kinds_are_checked_in_the_forward_call():
+    """What the key of a kind cannot see is the camera's distance.  While a kind is young, while its counts move by more than 1.5x
+    between frames, or while the last frame used more than a third of the bound, the forward call looks at the status words itself
+    (and renders again what did not fit); only steady kinds are left to the late check in backward()."""
+    book = fv.CapacityBook()
+    k = ("cuda:0", 512, 512, 100_000, 0, 0)
+    assert book.check_early(k)                                                               # never seen
+    for i in range(fv.CapacityBook.SETTLE - 1):
+        book.learn(k, 500_000)
+        assert book.check_early(k)                                                           # young
+    book.learn(k, 510_000)
+    assert not book.check_early(k)                                                           # four steady frames, 8x headroom
+    book.learn(k, 900_000)                                                                   # the camera walks in: 1.76x in one frame
+    assert book.check_early(k)
+    for _ in range(fv.CapacityBook.SETTLE):
+        book.learn(k, 900_000)
+    assert not book.check_early(k)                                                           # steady again
+    for n in (1_200_000, 1_500_000, 1_900_000, 2_400_000):                                   # a slow walk: < 1.5x per frame ...
+        book.learn(k, n)
+    assert 3 * 2_400_000 > book.get(k) or not book.check_early(k)
+    assert book.get(k) >= fv.CapacityBook.MARGIN * 900_000
+    book.bound[k] = 3 * 2_400_000 - 1                                                        # ... but the headroom is short: checked
+    assert book.check_early(k)
+    book.reset()
+    assert book.get(k) is None and book.check_early(k)
+
+
 def test_frames_rendered_with_gradients_but_never_differentiated_still_teach_the_book():
-    book_before = dict(fv.capacity_book.bound)
+    book_before, hist_before = dict(fv.capacity_book.bound), dict(fv.capacity_book.history)
     try:
         k = ("cpu", 64, 48, 10, 0, 0)
         fv.capacity_book.bound[k] = 1 << 20
@@ -59,8 +86,9 @@ def test_frames_rendered_with_gradients_but_never_differentiated_still_teach_the
             warnings.simplefilter("error")
             del p
     finally:
-        fv.capacity_book.bound.clear()
+        fv.capacity_book.reset()
         fv.capacity_book.bound.update(book_before)
+        fv.capacity_book.history.update(hist_before)
 
 
 def test_status_words_whose_copy_may_still_land_are_never_handed_out_again():
@@ -88,5 +116,6 @@ def test_status_words_whose_copy_may_still_land_are_never_handed_out_again():
         assert {id(a), id(b)} == {id(landed), id(flying)} and not fv._pinned_limbo
     finally:
         fv.capacity_book.bound.pop(("cpu", 64, 48, 11, 0, 0), None)
+        fv.capacity_book.history.pop(("cpu", 64, 48, 11, 0, 0), None)
         fv._pinned_free[:] = free_before
         fv._pinned_limbo[:] = limbo_before

@@ -250,7 +250,7 @@ def test_plugin_default_sizes_binning_buffers_from_earlier_frames(world):
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     blocking = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=w.pc)
     auto = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=w.pc)
-    fused_view.capacity_book.bound.clear()
+    fused_view.capacity_book.reset()
     for f in (2, 3, 4):                                      # frame 2 learns the bound, 3 and 4 run without a read-back
         want = blocking(w.cam, bg, gt=True, gt_index=f)
         n = rasterizer.last_num_rendered
@@ -287,7 +287,7 @@ def test_a_frame_that_does_not_fit_never_reaches_the_optimizer(world):
     bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
     blocking = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=w.pc)
     auto = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=w.pc)
-    fused_view.capacity_book.bound.clear()
+    fused_view.capacity_book.reset()
     want = blocking(w.cam, bg, gt=True, gt_index=4)
     n = rasterizer.last_num_rendered
     auto(w.cam, bg, gt=True, gt_index=4)                     # teaches the book
@@ -295,8 +295,11 @@ def test_a_frame_that_does_not_fit_never_reaches_the_optimizer(world):
     params = [w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color]
     opt = torch.optim.Adam(params, lr=1e-3)
     before = [p.detach().clone() for p in params]
-    # (a) training step on a frame that does not fit
+    # (a) training step on a frame that does not fit -- of a kind whose counts had been steady and far below its bound (the only
+    # kind the forward call does not check itself: CapacityBook.check_early): a jump of 40x between two frames
     fused_view.capacity_book.bound[key] = n // 3
+    fused_view.capacity_book.history[key] = [n // 40] * fused_view.CapacityBook.SETTLE
+    assert not fused_view.capacity_book.check_early(key)
     opt.zero_grad(set_to_none=True)
     out = auto(w.cam, bg, gt=True, gt_index=4)
     loss = out["render"].mean() + out["mask"].mean()
@@ -327,6 +330,60 @@ def test_a_frame_that_does_not_fit_never_reaches_the_optimizer(world):
     for k in ("render", "normal", "depth", "pred_normal", "mask", "occ", "curv", "radii"):
         assert torch.equal(out[k], want[k]), k
     assert fused_view.capacity_book.bound[key] >= n
+    # (c) training on a kind that is young, whose counts move or whose bound is nearly used: the forward call checks the words
+    # itself and renders the view again before anybody has seen it -- no exception, the right image, gradients
+    for history in ([n // 5], [n // 9, n // 6, n // 4, n // 2], [n // 4] * 4):
+        fused_view.capacity_book.bound[key] = n // 3
+        fused_view.capacity_book.history[key] = list(history)
+        assert fused_view.capacity_book.check_early(key)
+        out = auto(w.cam, bg, gt=True, gt_index=4)
+        for k in ("render", "normal", "depth", "pred_normal", "mask", "occ", "curv", "radii"):
+            assert torch.equal(out[k], want[k]), (history, k)
+        (out["render"].mean() + out["mask"].mean()).backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        for p in params:
+            p.grad = None
+        assert fused_view.capacity_book.bound[key] >= n
+
+
+def test_a_camera_walking_in_never_meets_an_exception_or_a_background_frame(world):
+    """the reference reads num_rendered and resizes (rasterizer_impl.cu:250-257) -- a training loop written for
+    it has no handler for an overflow.  The default configuration, a camera that walks from far away to a close-up (the instance
+    count grows by more than 10x along the way, with frames rendered for a log -- gradients enabled, never differentiated --
+    in between), then jumps back out and in again: no exception, and every frame is the blocking form's image."""
+    from soar_amd import rasterizer
+    from soar_amd.renderer import cameras, fused_view, registry
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    blocking = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True, "binning_capacity": 0}, geometry=w.pc)
+    auto = registry.find("gaussiansurfel-rasterizer")({"use_explicit": True}, geometry=w.pc)
+    fused_view.capacity_book.reset()
+    params = [w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color]
+
+    W2, H2 = 1920, 1440                                                     # (room for the count to grow: 10800 tiles)
+
+    def cam_at(distance):
+        spec = syn.make_camera(W2, H2, distance=distance, elevation=0.1, azimuth=0.4)
+        return cameras.Camera(FoVx=spec.fovx, FoVy=spec.fovy, camera_center=spec.camera_center.to(DEV), image_width=W2, image_height=H2,
+                              world_view_transform=spec.world_view_transform.to(DEV), full_proj_transform=spec.full_proj_transform.to(DEV),
+                              prcppoint=spec.prcppoint.to(DEV))
+    counts = []
+    walk = [40.0, 30.0, 22.0, 16.0, 12.0, 9.0, 7.0, 5.5, 4.4, 3.6, 3.0, 2.5, 2.1, 1.8, 1.6, 1.6, 1.6, 1.6, 1.6, 30.0, 1.7, 1.7]
+    for step, d in enumerate(walk):
+        cam = cam_at(d)
+        want = blocking(cam, bg, gt=True, gt_index=step % FRAMES)
+        counts.append(rasterizer.last_num_rendered)
+        got = auto(cam, bg, gt=True, gt_index=step % FRAMES)
+        for k in ("render", "normal", "depth", "pred_normal", "mask", "occ", "curv", "radii"):
+            assert torch.equal(got[k], want[k]), (step, d, k)
+        if step % 3 != 2:
+            (got["render"].mean() + got["mask"].mean()).backward()          # a training frame
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+            for p in params:
+                p.grad = None
+        del got                                                             # (every third frame: rendered for a log, never differentiated)
+    assert max(counts) > 10 * min(counts), counts
+    assert len(fused_view.capacity_book.bound) == 1                         # one kind all along: the key cannot see the distance
 
 
 def test_plugin_occlusion_image_carries_gradient_to_the_occ_parameter(world):
@@ -447,8 +504,12 @@ def test_gt_forward_renders_the_three_views_of_a_video_frame(world):
     assert out["comp_normal"].shape == (2, res, res, 3) and out["comp_pred_normal"].shape == (2, res, res, 3)
     assert out["comp_normal_mask"].shape == (2, res, res, 1) and out["comp_depth"].shape == (1, H, W, 1)
     assert len(out["viewspace_points"]) == 3 and len(out["radii"]) == 3
-    # the RGB view is the plugin's own render of that frame through the same camera
-    one = w.renderer(w.cam, bg, gt=True, gt_index=3)
+    # the RGB view is the plugin's own render of that frame through the same camera (the batch renderer's cameras come out of
+    # soar_cameras_from_c2w, double arithmetic: the last bit of a matrix entry may differ from the host function's float32 inverse)
+    from soar_amd.renderer import cameras
+    (wv, full, center), = cameras.get_cams_info_gaussian_cxcy([batch["gt_c2w"][0]], [(w.spec.fovx, w.spec.fovy, 0.1, 100, None, None)], device=DEV)
+    np.testing.assert_allclose(wv.cpu().numpy(), w.cam.world_view_transform.cpu().numpy(), atol=2e-6)
+    one = w.renderer(w.cam._replace(world_view_transform=wv, full_proj_transform=full, camera_center=center), bg, gt=True, gt_index=3)
     assert torch.equal(out["comp_rgb"][0].permute(2, 0, 1), one["render"]) and torch.equal(out["comp_mask"][0].permute(2, 0, 1), one["mask"])
     # front and back normal views see the body from the same camera: same silhouette, different surfaces
     m_front, m_back = out["comp_normal_mask"][0] > 0.5, out["comp_normal_mask"][1] > 0.5
@@ -505,6 +566,95 @@ def test_batch_forward_renders_the_sds_views_as_one_node(world):
     assert (fo["comp_mask"] > 0.5).float().mean() > 0.01
     for a, b in zip(fg, cg):
         assert b.abs().max() > 0 and (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+
+
+def _ref_step_batch(bs=4, res=96):
+    nf = 2 * math.atan(0.5 / 1.2)
+    spec = syn.make_camera(W, H)
+    c2w = torch.stack([syn.make_c2w(2.5, 0.1 * i, 1.5 * i, target=(0.0, 0.0, 0.0)) for i in range(bs)])
+    return dict(c2w=c2w, fovy=torch.full((bs,), 0.8), width=res, height=res, rays_d=torch.zeros(bs + 1, res, res, 3, device=DEV),
+                gt_fovx=spec.fovx, gt_fovy=spec.fovy, gt_c2w=syn.make_c2w(3.0, 0.1, 0.4)[None], gt_normal_fovx=nf, gt_normal_fovy=nf,
+                gt_normal_res=res, gt_normal_cx=torch.tensor([res / 2.0 + 1.5]), gt_normal_cy=torch.tensor([res / 2.0 - 2.0]),
+                gt_cx=torch.tensor([W / 2.0]), gt_cy=torch.tensor([H / 2.0]), gt_width=W, gt_height=H,
+                gt_rgb=torch.zeros(1, 1, 1, 3, device=DEV), gt_index=3)
+
+
+def test_the_seven_views_of_a_step_as_one_node_equal_the_per_pose_nodes(world, monkeypatch):
+    """VERDICT r4 item 3.  One optimizer step of the reference renders the 4 SDS views of the zeroed-root pose and the 3 views of the
+    video frame's pose (TS/system/gaussian_surfel_mvdream.py:79-92 -> TS/renderer/gaussian_batch_renderer.py:243-398, :10-241).
+    `batch_forward` hands both poses to ONE autograd node / one C call each way (DiffGaussian.forward_step_views ->
+    soar_step_views_forward / _backward: front views of one size of BOTH poses in one batch of launches, the groups on side streams).
+    Against one node per pose (round 4) and against one forward() call per view: same stacked outputs bit for bit, same gradients."""
+    import random
+    from soar_amd.renderer import diff_gaussian as dg, fused_view
+    w = world
+    w.renderer.background = lambda dirs: torch.full(dirs.shape, 0.3, device=DEV)
+    leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color)
+    poses_seen = []
+    launch = fused_view._StepViews._launch
+    monkeypatch.setattr(fused_view._StepViews, "_launch", staticmethod(lambda L, dev, st, pa, *a: (poses_seen.append(len(pa)), launch(L, dev, st, pa, *a))[1]))
+
+    def run():
+        for t in leaves:
+            t.grad = None
+        torch.manual_seed(5); random.seed(5)
+        out, gt_out = w.renderer.batch_forward(_ref_step_batch())
+        loss = out["comp_rgb"].square().mean() + out["comp_normal"].mean() + out["comp_depth"].mean() + out["comp_curv"].abs().mean()
+        loss = loss + gt_out["comp_rgb"].square().mean() + gt_out["comp_normal"].square().mean() + gt_out["comp_mask"].mean() + \
+            gt_out["comp_normal_mask"].mean() + gt_out["comp_pred_normal"].mean() + gt_out["comp_depth"].mean()
+        loss.backward()
+        outs = {("sds", k): v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}
+        outs.update({("gt", k): v.detach().clone() for k, v in gt_out.items() if torch.is_tensor(v)})
+        return outs, [t.grad.clone() for t in leaves]
+
+    fused_view.capacity_book.reset()
+    for _ in range(fused_view.CapacityBook.SETTLE + 1):       # the first frames of the kinds read back / are checked early
+        run()
+    poses_seen.clear()
+    one = run()
+    assert poses_seen == [2], poses_seen                      # both poses in ONE forward call
+    assert one[0][("sds", "comp_rgb")].shape == (4, 96, 96, 3) and one[0][("gt", "comp_rgb")].shape == (1, H, W, 3)
+    assert one[0][("gt", "comp_normal")].shape == (2, 96, 96, 3)
+    monkeypatch.delattr(dg.DiffGaussian, "forward_step_views")
+    poses_seen.clear()
+    per_pose = run()
+    assert poses_seen == [1, 1]
+    monkeypatch.setattr(dg, "FUSED_VIEW", False)
+    per_view = run()
+    for other in (per_pose, per_view):
+        for k in one[0]:
+            assert torch.equal(one[0][k], other[0][k]), k
+        for a, b in zip(one[1], other[1]):
+            assert b.abs().max() > 0 and (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+    assert (one[0][("gt", "comp_mask")] > 0.5).float().mean() > 0.01
+
+
+def test_cameras_of_a_step_in_one_launch_match_the_host_function():
+    """soar_cameras_from_c2w (one thread per camera, double arithmetic) == get_cam_info_gaussian_cxcy per camera (the restatement pinned
+    on the reference's outputs, tests/test_golden_cpu.py), for host and for device matrices, with and without a principal point."""
+    from soar_amd.renderer import cameras
+    g = torch.Generator().manual_seed(3)
+    c2ws = [syn.make_c2w(1.0 + 2.5 * float(torch.rand(1, generator=g)), 0.3 * k - 0.5, 1.1 * k, target=(0.1 * k, -0.1, 0.05)) for k in range(6)]
+    specs = [(0.5 + 0.1 * k, 0.4 + 0.07 * k, 0.1, 100, None if k % 2 else (300.0 + k, 250.0 - k), None if k % 2 else (640, 480)) for k in range(6)]
+    want = [cameras.get_cam_info_gaussian_cxcy(c, sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], device="cpu") for c, sp in zip(c2ws, specs)]
+    for on_device in (False, True):
+        got = cameras.get_cams_info_gaussian_cxcy([c.to(DEV) if on_device else c for c in c2ws], specs, device=DEV)
+        for (wv, full, center), (wv0, full0, center0) in zip(got, want):
+            assert wv.shape == (4, 4) and wv.is_contiguous() and wv.data_ptr() % 16 == 0 and full.data_ptr() % 16 == 0
+            np.testing.assert_allclose(wv.cpu().numpy(), wv0.numpy(), atol=2e-6)
+            np.testing.assert_allclose(full.cpu().numpy(), full0.numpy(), atol=1e-5)
+            np.testing.assert_allclose(center.cpu().numpy(), center0.numpy(), atol=2e-6)
+    # ... and the reference's own outputs (tests/golden/reference_functions.npz)
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_functions.npz"))
+    fx, fy = [float(v) for v in gold["cam_fov"]]
+    cx, cy, Wg, Hg = [float(v) for v in gold["cam_cxcy"]]
+    c2w = torch.from_numpy(gold["cam_c2w"])
+    (wv, fp, cc), (_wv2, fp2, _cc2) = cameras.get_cams_info_gaussian_cxcy([c2w, c2w], [(fx, fy, 0.1, 100, None, None), (fx, fy, 0.1, 100, (cx, cy), (Wg, Hg))], device=DEV)
+    np.testing.assert_allclose(wv.cpu().numpy(), gold["cam_wv"], atol=1e-6)
+    np.testing.assert_allclose(fp.cpu().numpy(), gold["cam_fullproj"], atol=1e-5)
+    np.testing.assert_allclose(cc.cpu().numpy(), gold["cam_center"], atol=1e-6)
+    np.testing.assert_allclose(fp2.cpu().numpy(), gold["cam_fullproj_cxcy"], atol=1e-5)
 
 
 def test_reference_style_guidance_gives_same_frame(world):
