@@ -40,7 +40,7 @@ extern "C" {
  * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses, soar_rast_backward_occ (the image
  * buffer grew by two planes: ask soar_rast_image_bytes), soar_gather_step_inputs_ids;
  * soar_selftest_wave_reduce is gone with the backward form it tested.  7 (round 5): soar_step_views_forward / _backward (several poses
- * behind one call each way), soar_cameras_from_c2w. */
+ * behind one call each way), soar_cameras_from_c2w, soar_ssim_rendered, SoarAvatarLossArgs::background. */
 #define SOAR_HIP_ABI_VERSION 7
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
@@ -415,6 +415,12 @@ typedef struct SoarAvatarLossArgs {
     int32_t occ_grad_summed;                     /* != 0: g_occ is ONE plane [1,H,W], the sum (g_0 + g_1) + g_2 of the three channels' gradients
                                                   * -- all the occlusion chain's backward reads of them (soar_rast_backward_occ, occ_planes = 1) */
     float *cos_scale_out;
+    /* (ABI 7) background != NULL -- [3] floats in device memory -- is a promise of the caller's: the images are the rasterizer's blend
+     * over this background colour followed by the plugin's post-ops, and the gradients of pixels nothing contributed to (mask_img <=
+     * 1e-5) are never read (the backward blend's walk of a pixel starts at its contributor count).  Groups of four such pixels -- 85 %
+     * of a frame of one person -- are answered from the blend's constants (render = occ = (1 - 1e-6) background, normal' = 0.5): their
+     * images and g_ssim are not read, their gradient planes not written.  The values are the same bit for bit. */
+    const float *background;
 } SoarAvatarLossArgs;
 int soar_avatar_loss_scratch_floats(size_t *count);
 int soar_avatar_pixel_losses(const SoarAvatarLossArgs *args, int32_t mode, void *stream);
@@ -426,6 +432,11 @@ int soar_avatar_pixel_losses(const SoarAvatarLossArgs *args, int32_t mode, void 
 int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t *count);
 int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
               float *dssim_dimg1, void *stream);
+/* (ABI 7) the same with `rendered` [H,W]: the opacity image of the rasterization that produced img1.  The gradient is only WRITTEN for
+ * the 32x32 tiles that hold a pixel with rendered > 1e-5 -- the gradient of a pixel nothing contributed to is never read by the
+ * backward blend -- and the forward only leaves its derivative maps where such a tile can want them; the mean is everybody's. */
+int soar_ssim_rendered(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
+                       float *dssim_dimg1, const float *rendered, void *stream);
 
 /* ---- densification / pruning state machine (TS/geometry/surfel_base.py:850-1136,1198-1230).
  * soar_densify_stats: update_states' per-view body + add_densification_stats (:1102-1128,1208-1216) in one pass.

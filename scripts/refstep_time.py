@@ -37,7 +37,7 @@ gt_normal_F = torch.rand(3, RES, RES, generator=g).to(DEV)
 gt_normal_B = torch.rand(3, RES, RES, generator=g).to(DEV)
 gt_normal_mask = (torch.rand(1, RES, RES, generator=g) > 0.5).float().to(DEV)
 normal_sel = gt_normal_mask[0] > 1e-5
-ZERO_N = torch.zeros(3, H, W, device=DEV)
+ZERO_N = torch.full((3, H, W), 0.5, device=DEV)      # (normal' of nothing)
 
 
 def losses(out, gt_out, f):
@@ -46,22 +46,24 @@ def losses(out, gt_out, f):
             sum(v.mean() for k, v in gt_out.items() if torch.is_tensor(v) and v.requires_grad)
     t = syn.pool_targets(PT.pool, f)
     mask = t["mask"][0] > 1e-5
-    chw = lambda x: x.permute(2, 0, 1)
+    # channel-first views of the stacked outputs, permuted as a batch like the reference does for its SSIM term (:315-318) and THEN
+    # indexed: the gradient of `x.permute(0, 3, 1, 2)[k]` comes back planar, the layout the rasterizer's backward reads -- no copies
+    G = {k: v.permute(0, 3, 1, 2) for k, v in gt_out.items() if torch.is_tensor(v) and v.dim() == 4}
+    S = {k: v.permute(0, 3, 1, 2) for k, v in out.items() if torch.is_tensor(v) and v.dim() == 4}
     # (the video frame's view contributes colour, mask, depth, occlusion, curvature; the normal terms come from the 512^2 normal views)
-    frame = {"render": chw(gt_out["comp_rgb"][0]), "mask": chw(gt_out["comp_mask"][0]), "normal": ZERO_N,
-             "depth": chw(gt_out["comp_depth"][0]), "curv": chw(gt_out["comp_curv"][0])}
+    frame = {"render": G["comp_rgb"][0], "mask": G["comp_mask"][0], "normal": ZERO_N, "depth": G["comp_depth"][0], "curv": G["comp_curv"][0]}
     blended = t["color"] * t["mask"] + gt_out["rand_bg_chw"] * (1 - t["mask"])
-    loss = avatar_stage_loss(frame, t["color"], t["mask"], t["normal"], mask, gt_rgb_blended=blended, lambda_normal=0.0)
-    nF, nB = chw(gt_out["comp_normal"][0]), chw(gt_out["comp_normal"][1])
-    loss = loss + 0.2 * cos_loss(nF, gt_normal_F, normal_sel) + 0.2 * cos_loss(nB, gt_normal_B, normal_sel)              # :329-376
-    loss = loss + masked_l1(chw(gt_out["comp_normal_mask"][0]), gt_normal_mask)                                            # :378-382
+    loss = avatar_stage_loss(frame, t["color"], t["mask"], t["normal"], mask, gt_rgb_blended=blended, lambda_normal=0.0,
+                             background=gt_out["rand_bg_chw"].reshape(3) if os.environ.get("SOAR_REFSTEP_BG_PROMISE", "1") == "1" else None)
+    loss = loss + 0.2 * cos_loss(G["comp_normal"][0], gt_normal_F, normal_sel) + 0.2 * cos_loss(G["comp_normal"][1], gt_normal_B, normal_sel)   # :329-376
+    loss = loss + masked_l1(G["comp_normal_mask"][0], gt_normal_mask)                                                       # :378-382
     m3 = (t["mask"] > 0).expand(3, -1, -1)
-    loss = loss + 0.1 * ((1 - chw(gt_out["comp_occ"][0])) * m3).sum() / m3.sum()                                            # :395-400 (masked mean: no host read-back)
+    loss = loss + 0.1 * ((1 - G["comp_occ"][0]) * m3).sum() / m3.sum()                                                      # :395-400 (masked mean: no host read-back)
     pn = 0.0
     for k in range(2):                                                                                                     # :412-424
-        pn = pn + cos_loss(chw(gt_out["comp_pred_normal"][k]), chw(gt_out["comp_normal"][k]).detach(), None, thrsh=math.pi / 10000)
+        pn = pn + cos_loss(G["comp_pred_normal"][k], G["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
     for k in range(BS):                                                                                                    # :425-432
-        pn = pn + cos_loss(chw(out["comp_pred_normal"][k]), chw(out["comp_normal"][k]).detach(), None, thrsh=math.pi / 10000)
+        pn = pn + cos_loss(S["comp_pred_normal"][k], S["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
     loss = loss + 0.05 * pn
     loss = loss + 0.01 * out["comp_curv"].abs().mean()                                                                     # :439-444
     loss_sds = (out["comp_rgb"] * G_sds).sum()
@@ -101,9 +103,10 @@ def timed(label, renderer, n=30):
     t0 = time.perf_counter()
     for f in range(n):
         step(renderer, opt, f)
+    issue = (time.perf_counter() - t0) / n
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"reference step through the plugin ({label}): {dt * 1e3:.2f} ms per step (4 SDS views 512^2 + video frame {H}x{W} + 2 normal views 512^2, "
+    print(f"reference step through the plugin ({label}): {dt * 1e3:.2f} ms per step, the host needs {issue * 1e3:.2f} ms to issue one (4 SDS views 512^2 + video frame {H}x{W} + 2 normal views 512^2, "
           f"avatar-stage losses, backward, torch.optim.Adam; P = {PT.P})", flush=True)
     return dt
 

@@ -202,6 +202,11 @@ struct AvatarArgs {
     int normal_raw;
     float *cos_scale_out;
     int occ_grad_summed;               // g_occ is ONE plane: the sum of the three channels' gradients (all the occlusion chain's backward reads)
+    // != null: the images are the rasterizer's (blend over this background colour [3], then the plugin's post-ops), and nobody reads
+    // the gradient of a pixel nothing contributed to (mask_img <= 1e-5: the backward blend's walk starts at the pixel's contributor
+    // count).  Four such pixels in a row -- 85 % of a frame of one person -- are answered from the blend's constants: render = occ =
+    // (1 - 1e-6) bg, normal' = 0.5; their images and g_ssim are not read, their gradients not written.  Same VALUES bit for bit.
+    const float *background;
 };
 
 template <bool VALUES, bool GRADS>
@@ -223,6 +228,10 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
     }
     const int nv = a.n / V;
     const size_t n = (size_t)a.n;
+    // what the blend leaves where nothing contributed (T = 1 clamped: forward.cu:618-633, the expressions of its epilogue)
+    const float Tc = (float)(1 - 0.000001);
+    float bgc[3] = {0.f, 0.f, 0.f};
+    if (a.background) { bgc[0] = 0.f + Tc * a.background[0]; bgc[1] = 0.f + Tc * a.background[1]; bgc[2] = 0.f + Tc * a.background[2]; }
     for (int p = blockIdx.x * 256 + threadIdx.x; p < nv; p += gridDim.x * 256) {
         bool sel[V], seln[V], selo[V];
         unpack(reinterpret_cast<const uchar4 *>(a.sel)[p], sel);
@@ -234,32 +243,15 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
         // (four pixels outside a selection -- most of a frame of one person -- never use the images the selection guards: not read)
         const bool any_sel = sel[0] | sel[1] | sel[2] | sel[3], any_seln = seln[0] | seln[1] | seln[2] | seln[3];
         const bool any_selo = a.occ && (selo[0] | selo[1] | selo[2] | selo[3]);
-        // ---- colours
-        for (int c = 0; c < 3; c++) {
-            float x[V] = {0.f, 0.f, 0.f, 0.f}, y[V] = {0.f, 0.f, 0.f, 0.f}, g[V], gs[V];
-            if (any_sel) {
-                unpack(reinterpret_cast<const float4 *>(a.render + c * n)[p], x);
-                unpack(reinterpret_cast<const float4 *>(a.gt_rgb + c * n)[p], y);
-            }
-            if (GRADS && a.g_ssim) unpack(reinterpret_cast<const float4 *>(a.g_ssim + c * n)[p], gs);
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                const float d = x[k] - y[k];
-                if (VALUES) s[0] += sel[k] ? fabsf(d) : 0.f;
-                if (GRADS) {
-                    g[k] = sel[k] ? (d > 0.f ? sc_l1 : (d < 0.f ? -sc_l1 : 0.f)) : 0.f;
-                    if (a.g_ssim) g[k] = g[k] + gs[k] * k_ssim;
-                }
-            }
-            if (GRADS) reinterpret_cast<float4 *>(a.g_render + c * n)[p] = pack(g);
-        }
-        // ---- mask image (every pixel)
+        // ---- mask image (every pixel; first: it also says whether anything was rendered here)
         bool opaque[V];                                // the plugin's mask: opacity > 1e-5
+        bool none;                                     // nothing contributed to any of the four pixels, and the caller vouches for what they hold
         {
             float x[V], y[V], g[V];
             unpack(reinterpret_cast<const float4 *>(a.mask_img)[p], x);
 #pragma unroll
             for (int k = 0; k < V; k++) opaque[k] = x[k] > 1e-5f;
+            none = a.background && !(opaque[0] | opaque[1] | opaque[2] | opaque[3]);
             unpack(reinterpret_cast<const float4 *>(a.gt_mask)[p], y);
 #pragma unroll
             for (int k = 0; k < V; k++) {
@@ -267,7 +259,27 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
                 if (VALUES) s[1] += fabsf(d);
                 if (GRADS) g[k] = d > 0.f ? sc_l1m : (d < 0.f ? -sc_l1m : 0.f);
             }
-            if (GRADS) reinterpret_cast<float4 *>(a.g_mask)[p] = pack(g);
+            if (GRADS && !none) reinterpret_cast<float4 *>(a.g_mask)[p] = pack(g);
+        }
+        // ---- colours
+        for (int c = 0; c < 3; c++) {
+            float x[V] = {0.f, 0.f, 0.f, 0.f}, y[V] = {0.f, 0.f, 0.f, 0.f}, g[V], gs[V];
+            if (any_sel) {
+                if (none) { x[0] = x[1] = x[2] = x[3] = bgc[c]; }
+                else unpack(reinterpret_cast<const float4 *>(a.render + c * n)[p], x);
+                unpack(reinterpret_cast<const float4 *>(a.gt_rgb + c * n)[p], y);
+            }
+            if (GRADS && a.g_ssim && !none) unpack(reinterpret_cast<const float4 *>(a.g_ssim + c * n)[p], gs);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const float d = x[k] - y[k];
+                if (VALUES) s[0] += sel[k] ? fabsf(d) : 0.f;
+                if (GRADS && !none) {
+                    g[k] = sel[k] ? (d > 0.f ? sc_l1 : (d < 0.f ? -sc_l1 : 0.f)) : 0.f;
+                    if (a.g_ssim) g[k] = g[k] + gs[k] * k_ssim;
+                }
+            }
+            if (GRADS && !none) reinterpret_cast<float4 *>(a.g_render + c * n)[p] = pack(g);
         }
         // ---- normals: cosine loss
         {
@@ -276,7 +288,8 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
             for (int k = 0; k < V; k++) cs[k] = 0.f;
             for (int c = 0; c < 3; c++) {
                 float x[V] = {0.f, 0.f, 0.f, 0.f}, y[V] = {0.f, 0.f, 0.f, 0.f};
-                if (any_seln) {
+                if (any_seln && none) { x[0] = x[1] = x[2] = x[3] = 0.5f; }      // (normal' = (0 + 1) / 2: the cosine is 0 whatever the target)
+                else if (any_seln) {
                     unpack(reinterpret_cast<const float4 *>(a.normal + c * n)[p], x);
                     unpack(reinterpret_cast<const float4 *>(a.gt_normal + c * n)[p], y);
                 }
@@ -291,7 +304,7 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
             if (VALUES)
 #pragma unroll
                 for (int k = 0; k < V; k++) { s[2] += seln[k] ? 1.f - cs[k] : 0.f; cnt[2] += seln[k] ? 1.f : 0.f; }
-            if (GRADS)
+            if (GRADS && !none)
                 for (int c = 0; c < 3; c++) {
                     float g[V];
 #pragma unroll
@@ -310,16 +323,17 @@ __global__ void __launch_bounds__(256) avatar_pixel_kernel(Batch<AvatarArgs> bat
             float gsum[3][V];
             for (int c = 0; c < 3; c++) {
                 float x[V] = {1.f, 1.f, 1.f, 1.f}, g[V];
-                if (any_selo) unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
+                if (any_selo && none) { x[0] = x[1] = x[2] = x[3] = bgc[c]; }
+                else if (any_selo) unpack(reinterpret_cast<const float4 *>(a.occ + c * n)[p], x);
 #pragma unroll
                 for (int k = 0; k < V; k++) {
                     const float d = x[k] - 1.f;
                     if (VALUES) s[3] += selo[k] ? fabsf(d) : 0.f;
                     if (GRADS) gsum[c][k] = g[k] = selo[k] ? (d > 0.f ? sc_occ : (d < 0.f ? -sc_occ : 0.f)) : 0.f;
                 }
-                if (GRADS && !a.occ_grad_summed) reinterpret_cast<float4 *>(a.g_occ + c * n)[p] = pack(g);
+                if (GRADS && !a.occ_grad_summed && !none) reinterpret_cast<float4 *>(a.g_occ + c * n)[p] = pack(g);
             }
-            if (GRADS && a.occ_grad_summed) {          // (g_0 + g_1) + g_2: the order the backward blend adds the three planes in
+            if (GRADS && a.occ_grad_summed && !none) {          // (g_0 + g_1) + g_2: the order the backward blend adds the three planes in
                 float g[V];
 #pragma unroll
                 for (int k = 0; k < V; k++) g[k] = (gsum[0][k] + gsum[1][k]) + gsum[2][k];
@@ -504,6 +518,7 @@ extern "C" int soar_avatar_pixel_losses(const SoarAvatarLossArgs *q, int32_t mod
     a.up_l1 = q->up_l1; a.up_l1m = q->up_l1m; a.up_cos = q->up_cos; a.up_occ = q->up_occ; a.g_ssim = q->g_ssim; a.up_ssim = q->up_ssim;
     a.g_render = q->g_render; a.g_mask = q->g_mask; a.g_normal = q->g_normal; a.g_occ = q->g_occ;
     a.normal_raw = q->normal_raw; a.cos_scale_out = q->cos_scale_out; a.occ_grad_summed = q->occ_grad_summed;
+    a.background = q->background;
     const int blocks = min(LOSS_BLOCKS, (a.n / 4 + 255) / 256);
     StageTimer timer(ST_FRAME_LOSS, stream);
     if (values && grads) SOAR_LAUNCH_BATCHED((avatar_pixel_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);

@@ -34,6 +34,11 @@ struct SsimArgs {
     float *grad;                       // backward out [C][H][W]
     float gscale;                      // 1 / (C H W)
     float w[2 * SR + 1];               // the normalised 1-D window (float32, as the reference builds it)
+    // optional [H][W]: the opacity image of the rasterization that produced img1.  The gradient of a pixel nothing contributed to
+    // (opacity <= 1e-5) is never read by the backward blend: the backward only works on the tiles that hold a rendered pixel, the
+    // forward only leaves derivative maps where such a tile reads them (its own 42 x 42 halo holds a rendered pixel) -- on a frame of
+    // one person four tiles in five drop out of the backward launch and their maps' twelve bytes per pixel and channel are not written
+    const float *rendered;
 };
 
 __device__ __forceinline__ float load_px(const float *img, int c, int x, int y, int H, int W)
@@ -118,7 +123,22 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
                 s[yy][xx] = f2{load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W), load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
             }
         }
-        __syncthreads();
+        // does any tile that reads this tile's derivative maps hold a rendered pixel?  (its halo: rows y0 - 5 .. y0 + 36, the staged
+        // columns x0 - 8 .. x0 + 39 -- a little wider than needed)
+        int wanted = 1;
+        if (a.rendered) {
+            wanted = 0;
+            for (int u = tid; u < SH * SQ; u += 256) {
+                const int yy = u / SQ, gx = x0 - 8 + 4 * (u % SQ), gy = y0 - SR + yy;
+                if (gy >= 0 && gy < a.H && gx < a.W && gx + 3 >= 0) {
+                    const float *row = a.rendered + (size_t)gy * a.W;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (gx + k >= 0 && gx + k < a.W && row[gx + k] > 1e-5f) wanted = 1;
+                }
+            }
+        }
+        const bool write_maps = __syncthreads_or(wanted) != 0;
         // horizontal pass: 42 rows x 32 columns, a task = SB consecutive columns of one row (336 tasks: the 80 of the second
         // trip go to waves 0-1 for even tiles, to waves 2-3 for odd ones -- a workgroup's waves sit on different SIMDs)
         for (int k = (tid + ((cur.tile & 1) ? 128 : 0)) & 255; k < SH * (ST / SB); k += 256) {
@@ -181,7 +201,7 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
                 const float dE12 = 2.f * A * rCD;
                 const float dmu1 = 2.f * mu2 * B * rCD - 2.f * mu1 * map * rC - 2.f * mu1 * dE11 - mu2 * dE12;
                 const size_t at = ((size_t)c * a.H + y) * a.W + x;
-                a.dmaps[at] = dmu1; a.dmaps[plane + at] = dE11; a.dmaps[2 * plane + at] = dE12;
+                if (write_maps) { a.dmaps[at] = dmu1; a.dmaps[plane + at] = dE11; a.dmaps[2 * plane + at] = dE12; }
             }
         }
 #pragma unroll
@@ -204,6 +224,16 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batc
     const SsimArgs &a = batch.v[cur.frame];
     const int x0 = cur.x0, y0 = cur.y0, c = cur.c, x = x0 + tx;
     const size_t plane = (size_t)a.C * a.H * a.W;
+    if (a.rendered) {
+        // nobody reads the gradient of a pixel nothing contributed to: a tile without a rendered pixel leaves at once
+        int wanted = 0;
+#pragma unroll
+        for (int o = 0; o < SB; o++) {
+            const int y = y0 + tyb + o;
+            if (x < a.W && y < a.H && a.rendered[(size_t)y * a.W + x] > 1e-5f) wanted = 1;
+        }
+        if (!__syncthreads_or(wanted)) return;
+    }
     {
         // the centre pixels of the two images (clamped addresses: no branch around the loads), in flight across both passes
         float i1[SB], i2[SB];
@@ -350,6 +380,12 @@ extern "C" int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t 
 extern "C" int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
                          float *dssim_dimg1, void *stream_)
 {
+    return soar_ssim_rendered(C, H, W, img1, img2, ssim_out, scratch, dssim_dimg1, nullptr, stream_);
+}
+
+extern "C" int soar_ssim_rendered(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_out, float *scratch,
+                                  float *dssim_dimg1, const float *rendered, void *stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_out || !scratch) { set_error("soar_ssim: bad arguments"); return 1; }
     SsimArgs a = {};
@@ -357,6 +393,7 @@ extern "C" int soar_ssim(int32_t C, int32_t H, int32_t W, const float *img1, con
     a.dmaps = scratch;
     a.partials = scratch + ((3 * (size_t)C * H * W + 3) & ~(size_t)3);        // (16-byte aligned behind the maps when the scratch is)
     a.grad = dssim_dimg1;
+    a.rendered = rendered;
     a.gscale = 1.0f / ((float)C * (float)H * (float)W);
     fill_window(a.w);
     a.tiles_x = (W + ST - 1) / ST;

@@ -75,7 +75,7 @@ class SoarAvatarLossArgs(C.Structure):
                 ("sel", _vp), ("sel_normal", _vp), ("sel_occ", _vp), ("stats", _vp), ("stats_occ", _vp), ("scratch", _vp), ("counts", _vp),
                 ("up_l1", _vp), ("up_l1m", _vp), ("up_cos", _vp), ("up_occ", _vp), ("up_ssim", _vp), ("g_ssim", _vp),
                 ("g_render", _vp), ("g_mask", _vp), ("g_normal", _vp), ("g_occ", _vp),
-                ("normal_raw", C.c_int32), ("occ_grad_summed", C.c_int32), ("cos_scale_out", _vp)]
+                ("normal_raw", C.c_int32), ("occ_grad_summed", C.c_int32), ("cos_scale_out", _vp), ("background", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/soar_hip.h declares
@@ -133,6 +133,7 @@ SIGNATURES = {
                                             _vp, _vp]),
     "soar_ssim_scratch_floats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_ssim": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "soar_ssim_rendered": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_densify_stats": (C.c_int, [C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "soar_densify_plan_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "soar_densify_plan": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -217,7 +217,7 @@ class _AvatarStageLoss(torch.autograd.Function):
     L1, L1M, COS, SSIM, DEPTH, CURV, ONE, N = 0, 2, 4, 6, 7, 8, 9, 10
 
     @staticmethod
-    def forward(ctx, render, mask_out, normal, depth, curv, gt_rgb, gt_blended, gt_mask, gt_normal, sel, normal_sel, lam):
+    def forward(ctx, render, mask_out, normal, depth, curv, gt_rgb, gt_blended, gt_mask, gt_normal, sel, normal_sel, lam, background=None):
         import ctypes as C
         S = _AvatarStageLoss
         L = hip_lib.lib()
@@ -247,12 +247,21 @@ class _AvatarStageLoss(torch.autograd.Function):
         fused = Cn == 3 and m_sel is not None and m_nrm is not None and (H * W) % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (r, mo, n, tr, tm, tn)) and \
             all(t.data_ptr() % 4 == 0 for t in (m_sel, m_nrm))
         args = None
+        # background (opt-in, the one-pass form only): `render` / `mask_out` / `normal` are the plugin's images of a rasterization over
+        # this background colour; the gradients of pixels nothing contributed to (mask <= 1e-5) -- which the rasterizer's backward never
+        # reads -- are then not computed: the SSIM gradient only on the tiles with a rendered pixel, the per-pixel terms without reading
+        # the images or writing gradients there.  Same loss value; what such a pixel's gradient holds afterwards is unspecified.
+        bg = _as_f32(background, dev).reshape(-1) if (background is not None and fused) else None
+        if bg is not None and bg.numel() != 3:
+            raise ValueError("avatar_stage_loss: background must hold 3 values")
+        ctx.bg_keep = bg
         with torch.cuda.device(dev):
-            check(L.soar_ssim(Cn, H, W, ptr(r), ptr(tb), at(S.SSIM), scratch.data_ptr() + 4 * n_pix, ptr(g_ssim), stream), "soar_ssim")
+            check(L.soar_ssim_rendered(Cn, H, W, ptr(r), ptr(tb), at(S.SSIM), scratch.data_ptr() + 4 * n_pix, ptr(g_ssim),
+                                       ptr(mo) if bg is not None else None, stream), "soar_ssim")
             if fused:
                 args = hip_lib.SoarAvatarLossArgs(H=H, W=W, cos_limit=1.0, cos_weight=1.0, render=ptr(r), gt_rgb=ptr(tr), mask_img=ptr(mo),
                                                   gt_mask=ptr(tm), normal=ptr(n), gt_normal=ptr(tn), sel=ptr(m_sel), sel_normal=ptr(m_nrm),
-                                                  stats=at(S.L1), scratch=ptr(scratch), g_ssim=ptr(g_ssim))
+                                                  stats=at(S.L1), scratch=ptr(scratch), g_ssim=ptr(g_ssim), background=ptr(bg))
                 check(L.soar_avatar_pixel_losses(C.byref(args), 1, stream), "soar_avatar_pixel_losses")
             else:
                 check(L.soar_masked_l1(Cn, H, W, ptr(r), ptr(tr), ptr(m_sel), at(S.L1), ptr(scratch), stream), "soar_masked_l1")
@@ -280,7 +289,7 @@ class _AvatarStageLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_terms):
         if g is None:
-            return (None,) * 12
+            return (None,) * 13
         import ctypes as C
         S = _AvatarStageLoss
         L = hip_lib.lib()
@@ -310,7 +319,7 @@ class _AvatarStageLoss(torch.autograd.Function):
         sr, sm, sn, sd, sc = ctx.shapes
         g_d = None if sd is None or back[S.DEPTH] == 0.0 else up[S.DEPTH].expand(sd)
         g_c = None if sc is None or back[S.CURV] == 0.0 else up[S.CURV].expand(sc)
-        return (g_r.view(sr), g_mo.view(sm), g_n.view(sn), g_d, g_c) + (None,) * 7
+        return (g_r.view(sr), g_mo.view(sm), g_n.view(sn), g_d, g_c) + (None,) * 8
 
 
 _unit = {}
@@ -341,7 +350,7 @@ def _coef_tensor(coef, dev) -> torch.Tensor:
 def avatar_stage_loss(out: Dict[str, torch.Tensor], gt_rgb: torch.Tensor, gt_mask: torch.Tensor, gt_normal: torch.Tensor,
                       mask: torch.Tensor, normal_mask: Optional[torch.Tensor] = None, gt_rgb_blended: Optional[torch.Tensor] = None,
                       lambda_recon: float = 1.0, lambda_mask: float = 1.0, lambda_normal: float = 1.0, lambda_depth: float = 0.0,
-                      lambda_curv: float = 0.0, return_terms: bool = False):
+                      lambda_curv: float = 0.0, return_terms: bool = False, background: Optional[torch.Tensor] = None):
     """The image losses of the avatar stage on one rendered frame ``out`` (the renderer plugin's dict, channel-first images):
 
         lambda_recon  * (0.8 l1_loss_w(render[mask], gt_rgb[mask]) + 0.2 (1 - ssim(render, gt_rgb_blended)))     (:311-320)
@@ -351,10 +360,13 @@ def avatar_stage_loss(out: Dict[str, torch.Tensor], gt_rgb: torch.Tensor, gt_mas
 
     -- the value ``recon_loss`` / ``masked_l1`` / ``cos_loss`` give when composed by hand, as one autograd node.  (The LPIPS terms
     of :339-352 need the external VGG network and stay with the caller.)  ``return_terms``: also the detached term vector for
-    logging (slots ``_AvatarStageLoss.L1 / L1M / COS`` = {value, selected pixels}, ``SSIM``, ``DEPTH``, ``CURV``)."""
+    logging (slots ``_AvatarStageLoss.L1 / L1M / COS`` = {value, selected pixels}, ``SSIM``, ``DEPTH``, ``CURV``).
+    ``background`` (opt-in): the [3] background colour ``out`` was rendered over -- the gradients of pixels nothing contributed to
+    (``out["mask"] <= 1e-5``), which the rasterizer's backward never reads, are then not computed (same loss value; ~40 % of the
+    block's time on a 1080p frame of one person).  Do not pass it when something else reads ``render.grad`` at background pixels."""
     lam = {"recon": float(lambda_recon), "mask": float(lambda_mask), "normal": float(lambda_normal), "depth": float(lambda_depth),
            "curv": float(lambda_curv)}
     loss, terms = _AvatarStageLoss.apply(out["render"], out["mask"], out["normal"], out.get("depth"), out.get("curv"), gt_rgb,
                                          gt_rgb if gt_rgb_blended is None else gt_rgb_blended, gt_mask, gt_normal, mask,
-                                         mask if normal_mask is None else normal_mask, lam)
+                                         mask if normal_mask is None else normal_mask, lam, background)
     return (loss, terms.detach()) if return_terms else loss

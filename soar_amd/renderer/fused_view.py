@@ -446,15 +446,22 @@ class _StepViews(torch.autograd.Function):
         blocks = {k: torch.empty((cnt, _StepViews.PLANES * k[0] * k[1]), dtype=torch.float32, device=dev) for k, cnt in sizes.items()}
         used = {k: 0 for k in sizes}
         per_view = []
+        # the views' scratch buffers in one allocation, their radii in another (a dozen allocator calls less per step)
+        need = [(_view_bytes(P, int(rs.image_width), int(rs.image_height), int(cap), bool(back)) + 255) // 256 * 256
+                for (rs, _f, cap, _key, back) in flat_specs]
+        pool = _scratch(sum(need), dev)
+        radii_all = torch.empty((n, P), dtype=torch.int32, device=dev)
+        at = 0
         for v, (rs, focal, cap, _key, back) in enumerate(flat_specs):
             H, W = int(rs.image_height), int(rs.image_width)
             c = _Ctx(P, 0, H, W, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree, False, False, bool(back), rs.debug, rs.bg,
                      rs.viewmatrix, rs.projmatrix, rs.prcppoint, rs.patch_bbox, rs.campos, rs.config, dev)
-            nbytes = _view_bytes(P, W, H, int(cap), bool(back))
-            buf = _scratch(nbytes, dev)
+            nbytes = need[v]
+            buf = _carve(pool, at, (nbytes,))
+            at += nbytes
             out = blocks[(H, W)][used[(H, W)]]
             used[(H, W)] += 1
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            radii = radii_all[v]
             words = _status_words()
             words.numpy()[2:] = 0                       # (only a back view's occlusion pass writes the second pair)
             a = views[v]
@@ -700,15 +707,22 @@ class _StackViews(torch.autograd.Function):
 
 def stack_views(xs):
     """torch.stack(xs, dim=0) -- without the copy when the tensors are equally shaped slices of one allocation at a fixed stride."""
-    xs = list(xs)
-    if len(xs) > 1 and all(torch.is_tensor(x) and x.is_cuda for x in xs):
+    n = len(xs)
+    if n > 1:
         x0 = xs[0]
-        d = xs[1].data_ptr() - x0.data_ptr()
-        same = all(x.shape == x0.shape and x.stride() == x0.stride() and x.dtype == x0.dtype and
-                   x.untyped_storage().data_ptr() == x0.untyped_storage().data_ptr() and x.data_ptr() - x0.data_ptr() == i * d
-                   for i, x in enumerate(xs))
-        if same and d > 0 and d % x0.element_size() == 0 and d >= x0.numel() * x0.element_size() and x0.is_contiguous():
-            return _StackViews.apply(*xs)
+        if torch.is_tensor(x0) and x0.is_cuda and x0.is_contiguous():
+            p0, shape, nbytes = x0.data_ptr(), x0.shape, x0.numel() * x0.element_size()
+            d = xs[1].data_ptr() - p0
+            if d >= nbytes and d % x0.element_size() == 0:
+                base = x0.untyped_storage().data_ptr()
+                k = 0
+                for x in xs:
+                    if x.data_ptr() != p0 + k * d or x.shape != shape or x.dtype != x0.dtype or not x.is_contiguous() or \
+                            x.untyped_storage().data_ptr() != base:
+                        break
+                    k += 1
+                if k == n:
+                    return _StackViews.apply(*xs)
     return torch.stack(xs, dim=0)
 
 

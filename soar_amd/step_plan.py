@@ -235,7 +235,9 @@ class FrameStepPlan:
 
     def _av_ssim(self, i, stream):
         S, L, v, W, H, a, k, at, sc, t, up = self._av(i)
-        check(L.soar_ssim(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), stream), "soar_ssim")
+        # (the gradient of a pixel nothing contributed to is never read by the backward blend: only the tiles with a rendered pixel)
+        check(L.soar_ssim_rendered(3, H, W, ptr(v["color"]), ptr(a["blended"][k]), at(t, S.SSIM), sc, ptr(v["g_ssim"]), ptr(v["opac"]), stream),
+              "soar_ssim_rendered")
 
     def _av_pixel_args(self, i):
         """the frame's SoarAvatarLossArgs: colour L1 over gt_mask > 1e-5, mask L1, cosine loss over the same selection, occlusion
@@ -247,7 +249,8 @@ class FrameStepPlan:
             sel=ptr(a["sel"][k]), sel_normal=ptr(a["sel"][k]), sel_occ=ptr(a["sel_occ"][k]), stats=at(t, S.L1), stats_occ=ptr(v["occ_terms"]),
             scratch=ptr(v["av_pix_scratch"]), counts=ptr(self.av_counts[k]), up_l1=at(up, S.L1), up_l1m=at(up, S.L1M), up_cos=at(up, S.COS),
             up_occ=ptr(self.av_occ_up), up_ssim=at(up, S.SSIM), g_ssim=ptr(v["g_ssim"]), g_render=ptr(v["gC"]), g_mask=ptr(v["gO"]),
-            g_normal=ptr(v["gN"]), g_occ=ptr(v["g_occ_img"]), normal_raw=1, occ_grad_summed=1, cos_scale_out=self.av_cos_scale_all.data_ptr() + 4 * i)
+            g_normal=ptr(v["gN"]), g_occ=ptr(v["g_occ_img"]), normal_raw=1, occ_grad_summed=1, cos_scale_out=self.av_cos_scale_all.data_ptr() + 4 * i,
+            background=self.ctx.params.bg_dev)
 
     def _av_pixel(self, i, stream, mode):
         key = ("av_pixel", i, self._frames_now[i] % int(self.pool.shape[0]))

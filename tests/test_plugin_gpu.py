@@ -1142,6 +1142,40 @@ def test_sum_frames_adds_in_frame_order(n, count):
     assert L.soar_sum_frames(0, count, hip_lib.ptr(x), hip_lib.ptr(out), None) != 0
 
 
+def test_avatar_stage_loss_with_the_background_promise_gives_the_same_step(world):
+    """losses.avatar_stage_loss(background=bg): the gradients of pixels nothing contributed to -- which the rasterizer's backward never
+    reads -- are not computed (SSIM gradient only on tiles with a rendered pixel: soar_ssim_rendered; the per-pixel terms answered from
+    the blend's constants: SoarAvatarLossArgs::background).  Same loss value bit for bit, same image gradients wherever something was
+    rendered, same gradients of the model."""
+    from soar_amd.losses import avatar_stage_loss
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    g = torch.Generator().manual_seed(4)
+    gt_rgb, gt_normal = torch.rand(3, H, W, generator=g).to(DEV), torch.rand(3, H, W, generator=g).to(DEV)
+    gt_mask = (torch.rand(1, H, W, generator=g) > 0.4).float().to(DEV)
+    blended = gt_rgb * gt_mask + bg[:, None, None] * (1 - gt_mask)
+    leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color)
+    res = []
+    for promise in (None, bg):
+        for t in leaves:
+            t.grad = None
+        out = w.renderer(w.cam, bg, gt=True, gt_index=2)
+        for k in ("render", "mask", "normal"):
+            out[k].retain_grad()
+        loss = avatar_stage_loss(out, gt_rgb, gt_mask, gt_normal, gt_mask[0] > 1e-5, gt_rgb_blended=blended, background=promise)
+        loss.backward()
+        res.append((loss.detach().clone(), {k: out[k].grad.clone() for k in ("render", "mask", "normal")}, out["mask"].detach() > 1e-5,
+                    [t.grad.clone() for t in leaves]))
+    (l0, g0, m0, p0), (l1, g1, m1, p1) = res
+    assert torch.equal(l0, l1) and torch.equal(m0, m1)
+    assert 0.02 < float(m0.float().mean()) < 0.6                 # a person in front of a background
+    for k in g0:
+        sel = m0.expand_as(g0[k])
+        assert torch.equal(g0[k][sel], g1[k][sel]), k           # wherever something was rendered: the same gradient
+    for a, b in zip(p0, p1):
+        assert b.abs().max() > 0 and (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()     # (float atomics of the backward blend)
+
+
 @pytest.mark.parametrize("hw", [(37, 53), (128, 200)])
 def test_avatar_stage_loss_is_the_composed_losses_in_one_node(hw):
     """losses.avatar_stage_loss against recon_loss + masked_l1 + cos_loss + means composed by hand (the reference's way)."""
