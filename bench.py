@@ -773,7 +773,8 @@ def main():
                             "through the occlusion image's backward; Adam also on the occlusion values"),
                    "plan_form": (("batched" if plan.batched else "streams") + (", graphs" if plan.graphs is not None else ", eager")
                                  if plan is not None else None),
-                   "collectives": ((f"rccl: {flat.n_buckets} asynchronous all-reduce bucket(s) per step" + (" (xyz, rest)" if flat.n_buckets == 2 else ""))
+                   "collectives": (("rccl: one all-reduce per step issued on the step's own stream (SOAR_DP_BUCKETS=0)" if flat.n_buckets == 0 else
+                                    f"rccl: {flat.n_buckets} asynchronous all-reduce bucket(s) per step" + (" (xyz, rest)" if flat.n_buckets == 2 else ""))
                                    if plan is not None else "rccl")
                    if use_dist else "none",
                    "optimizer": ("Adam (eps 1e-15), one launch over all leaves, the reference's learning rates on the activated leaves "

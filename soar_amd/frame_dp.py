@@ -75,13 +75,16 @@ class FlatGradBuffer:
                     self.leaves[name] = t
             start += P * width
         self.split = P * LEAVES[0][1]             # end of the xyz slice = boundary between the two buckets
-        # Two collectives per step (the default), the xyz slice first: the KNN refresh only needs the positions and hides the flight
-        # of the rest -- 4.8 of the 6 MB over xGMI against an ~80 us refresh.  SOAR_DP_BUCKETS=1: one collective for the whole buffer.
-        # Every collective is a hand-off to RCCL's stream and back: with a one-rank group the step pays +3.9 % for two buckets and
-        # +4.1 % for one (profiles/r04d_forced_dist_vs_plain.txt; the +15 % for two that made one bucket the default for a while in
-        # round 4 was the interpreter's collector stalling the host in one of the two runs).  bench.py reports the
-        # stalls per bucket and rank (`ranks`).
-        self.n_buckets = 1 if os.environ.get("SOAR_DP_BUCKETS", "2") == "1" else 2
+        # ONE collective for the whole buffer is the default (round 5): with a one-rank RCCL group -- the only thing this project could
+        # ever measure -- it costs the step +3.9 % against +4.8 % for two (profiles/r05_forced_dist_vs_plain.txt, three rounds on one box,
+        # the same order in rounds 4d / 4f); every collective is a hand-off to RCCL's stream and back.  SOAR_DP_BUCKETS=2: two
+        # collectives, the xyz slice first -- the KNN refresh only needs the positions and would hide the flight of the other 4.8 of the
+        # 6 MB over xGMI under its ~60 us: whether that pays for the second hand-off can only be seen with N > 1 ranks; bench.py
+        # reports the stalls per bucket and rank (`ranks`) so that the first real run can decide.
+        # SOAR_DP_BUCKETS=0: ONE collective issued as a synchronous op -- c10d then runs it on the CURRENT stream (no hand-off to the
+        # communicator's stream and back, no overlap either): the step's own stream order carries it.
+        env = os.environ.get("SOAR_DP_BUCKETS", "1")
+        self.n_buckets = 0 if env == "0" else (2 if env == "2" else 1)
         # diagnostics (bench.py, world > 1): HIP events around every stream-side wait for a bucket -- what the stream stalled for
         self.time_waits = False
         self._wait_events: List = []
@@ -126,7 +129,10 @@ class FlatGradBuffer:
         self.check_views()
         self.wait_all()
         if self._collectives_on():
-            if self.n_buckets == 1:
+            if self.n_buckets == 0:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=False)
+                self.pending = []
+            elif self.n_buckets == 1:
                 self.pending = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)]
             else:
                 self.pending = [dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM, async_op=True),

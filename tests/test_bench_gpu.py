@@ -67,14 +67,16 @@ def test_bench_forced_dist_path_runs_rccl():
     # what makes a first multi-rank run explain itself: per-rank step time, instances per rank, the stall per gradient bucket
     rk = d["ranks"]
     assert len(rk["per_rank_ms_per_step"]) == 1 and rk["per_rank_ms_per_step"][0] > 0 and rk["imbalance_max_over_mean"] == 1.0
-    # (two buckets by default: the positions first, the rest behind the KNN refresh)
-    assert rk["max_num_rendered_per_rank"][0] > 0 and rk["buckets"] == 2 and len(rk["bucket_wait_us_per_rank"][0]) == 2
-    # one collective for the whole buffer (SOAR_DP_BUCKETS=1): same line, same shape
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "4", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, SOAR_DP_BUCKETS="1"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    d1 = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
-    assert d1["ranks"]["buckets"] == 1 and d1["value"] > 0
+    # (one collective for the whole buffer by default: what measured faster next to a one-rank communicator, round 5)
+    assert rk["max_num_rendered_per_rank"][0] > 0 and rk["buckets"] == 1 and len(rk["bucket_wait_us_per_rank"][0]) == 2
+    # two buckets -- the positions first, the rest behind the KNN refresh (SOAR_DP_BUCKETS=2) -- and the collective on the step's own
+    # stream (SOAR_DP_BUCKETS=0): same line, same shape
+    for buckets in ("2", "0"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "4", "--warmup", "1",
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, SOAR_DP_BUCKETS=buckets))
+        assert r.returncode == 0, r.stderr[-2000:]
+        d1 = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+        assert d1["ranks"]["buckets"] == int(buckets) and d1["value"] > 0
 
 
 def test_bench_gpus_flag_must_match_the_job():

@@ -117,7 +117,8 @@ def check_forward(scene, hip, fw, exact_state=True):
     H, W = scene.H, scene.W
     nc = hip["n_contrib"].reshape(H, W)
     mism = float((nc != fw.n_contrib).mean())
-    assert mism <= 1e-3, f"n_contrib differs on {mism:.2%} of the pixels"
+    assert mism <= 1e-3, (f"n_contrib differs from the C oracle's on {mism:.2%} of the pixels (the oracle's host expf against the device's: "
+                          "tests against oracle/_ref hold the product to zero differing pixels)")
     same = nc == fw.n_contrib                   # pixels where an exp() rounding flipped a threshold are excluded
     for name, ref in (("color", fw.out_color), ("normal", fw.out_normal), ("depth", fw.out_depth), ("opac", fw.out_opac)):
         got = hip[name]
@@ -208,6 +209,15 @@ def test_forward_and_backward_parity(mk):
     hip = run_hip(scene, grads)
     check_forward(scene, hip, fw)
     check_backward(scene, hip, bw)
+    # check_forward lets n_contrib differ from the C oracle's on <= 0.1 % of the pixels: that slack is the ORACLE's -- its exponential
+    # is the host's libm expf, the product's is the device's (the one the reference's kernels call on this GPU), and the two round
+    # differently for some arguments next to the 1/255 and 1e-4 thresholds.  Against the reference's own kernels there is no slack:
+    from oracle import ref_rasterizer as rr
+    if rr.available() and scene.rotations is not None:        # (the reference's preprocess reads rotations[idx] unconditionally: forward.cu:273)
+        ref = rr.RefRasterizer().run(scene)
+        for k in ("n_contrib", "final_T", "point_list", "radii"):
+            np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
+        np.testing.assert_array_equal(hip["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
 
 
 @pytest.mark.parametrize("mk", [S.depth_plane_scene, S.big_splats_scene], ids=["depth_plane", "big_splats"])

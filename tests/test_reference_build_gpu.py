@@ -204,25 +204,34 @@ def test_surfel_scenes_meet_the_strict_gradient_bar(name):
 
 def test_c5_frame_matches_the_reference_kernels():
     """BASELINE config C5 size (300k densified surfels, 3840x2160): the product against the reference's kernels -- binning
-    state, per-pixel contributor counts and final transmittance bit-exact, images within 1e-5, gradients within the bars of the
-    scale check (tests/tools/big_scene.py: at 4K hundreds of surfels are wider than the 48 px the small-scene bars call giant,
-    so the cancellation-prone tensors are held to a tensor-level L2 bar, the accumulator-level ones to 1e-4 max-norm)."""
+    state, per-pixel contributor counts and final transmittance bit-exact, images within 1e-5, the four accumulator-level gradient tensors
+    within the strict 1e-4.  On the three cancellation-prone tensors the reference does not reproduce ITSELF to 1e-4 at this size (two runs
+    of its kernels on the same inputs: 1.2e-4 / 1.2e-4 / 1.7e-4 in the max norm, profiles/r05_c5_reference_spread.txt -- hundreds of
+    surfels wider than 48 px, thousands of float atomics each): the test measures that spread and holds the product to max(8e-4, 6 x it)
+    in the max norm and max(2e-4, 4 x it) in L2 (measured: 2.5-3.8 x and 1.6-3.0 x, 6.4e-4 and 1.4e-4 at worst; the float64 rows do not
+    change it: it is not the order of the sums).  Before round 5: L2 <= 3e-4 only."""
     ref_r = _ref()
     scene = S.person_scene(P=300_000, W=3840, H=2160, seed=4, config=(1, 1, 1, 0), opacity=None, distance=2.2)
     grads = S.upstream_grads(scene)
     hip = run_hip(scene, grads=grads)
     ref = ref_r.run(scene, grads=grads)
+    ref2 = ref_r.run(scene, grads=grads, state=False)
     assert hip["R"] == ref["R"] and ref["R"] > 3_000_000
     for k in ("radii", "tiles_touched", "point_offsets", "keys_sorted", "point_list", "n_contrib", "final_T"):
         np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(hip["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
     for name in ("color", "normal", "depth", "opac"):
         assert rel_err(hip[name], ref[name]) <= 1e-5, name
-    worst = {}
+    worst, spread = {}, {}
     for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
-        a, b = hip[k].reshape(ref[k].shape), ref[k]
+        a, b, b2 = hip[k].reshape(ref[k].shape), ref[k], ref2[k].reshape(ref[k].shape)
         assert np.isfinite(a).all(), k
         worst[k] = (rel_err(a, b), l2_err(a, b))
-    print("C5", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
-    assert all(v[1] <= 3e-4 for v in worst.values()), worst
-    assert all(worst[k][0] <= 1e-4 for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity")), worst
+        spread[k] = (rel_err(b2, b), l2_err(b2, b))
+    print("C5 product vs reference", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
+    print("C5 reference vs itself ", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in spread.items()})
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D"):
+        assert worst[k][0] <= 1e-4 and worst[k][1] <= 1e-4, (k, worst[k])
+    for k in ("dL_dcov3D", "dL_dscales", "dL_drotations"):
+        # (the spread of two runs is itself a noisy number: floors at the levels measured over the rounds, a quarter above the worst seen)
+        assert worst[k][0] <= max(8e-4, 6 * spread[k][0]) and worst[k][1] <= max(2e-4, 4 * spread[k][1]), (k, worst[k], spread[k])
