@@ -502,8 +502,17 @@ def main():
     bg = torch.tensor([0.2, 0.5, 0.7], device=device)
     fps_per_rank = args.frames_per_step
 
+    # The frames of a step are consecutive frames of the video (step s: frames 4 s .. 4 s + 3 per rank).  The frames of the synthetic
+    # sequence differ in cost with the pose -- 0.86 to 0.95 ms per step between contiguous 80-frame stretches -- so a short run times the
+    # stretch it happens to cover: the driver's --steps 20 --warmup 5 covers frames 20-99, the heaviest one, and reads 6 % below a
+    # 100-step run of the same build on the same box (profiles/r05_bench_spread_20steps.txt; round 4's "driver 4173 against the builder's
+    # 4421").  SOAR_BENCH_FRAME_STRIDE=97 walks the video in strides (a permutation of the 400 frames, like the reference's random frame
+    # per step): every window then costs the same, 0.95 ms -- consecutive steps no longer show nearly the same silhouette, and the
+    # empty tiles kept from the step before (SoarRastParams.debug bit 2) are fewer.
+    frame_stride = int(os.environ.get("SOAR_BENCH_FRAME_STRIDE", "1"))
+
     def frames_of(step):
-        return shard_frames(global_batch(step, fps_per_rank, world, seq.num_frames), rank, world)
+        return shard_frames(global_batch(step, fps_per_rank, world, seq.num_frames, frame_stride), rank, world)
 
     # instances the occlusion pass renders (camera-facing surfels only): measured once with the unfused two-call form,
     # outside the timed region, to price B_occ of SURVEY 8(d) with the real R
@@ -581,8 +590,15 @@ def main():
     # (gc.freeze, what a long-running training process does after its set-up); the collector stays on for what the steps allocate.
     import gc
     if os.environ.get("SOAR_BENCH_NO_GC_FREEZE", "0") != "1":
+        torch.cuda.synchronize()
         gc.collect()
         gc.freeze()
+    # ... and the collection itself leaves the device idle for those tens of milliseconds: its clocks fall back, and the first timed
+    # steps ran ~6 % slow until they had ramped up again -- 1.2 ms of a 19 ms region with the driver's --steps 20 (0.965 against 0.907
+    # ms per step with --steps 100 on the same box, by the host's clock and by the HIP event pair alike:
+    # profiles/r05_bench_spread_20steps.txt).  The untimed steps that precede the timed region are issued HERE, right in front of it.
+    for s in range(max(args.warmup, 2)):
+        stepper(frames_of(s))
     flat.wait_all()
     torch.cuda.synchronize()
     if use_dist:
@@ -787,6 +803,8 @@ def main():
                                    "Morton order of the canonical positions (synthetic.sort_surfels_spatially: the same surfels, neighbours in "
                                    "space are neighbours in memory, as in a model initialised from the SMPL-X vertices; "
                                    "SOAR_BENCH_RANDOM_ORDER=1 keeps the generator's random order: -2 % at C3)"),
+                   "frame_order": (f"frame ids walk the {seq.num_frames}-frame sequence in strides of {frame_stride} (a permutation: every frame once per "
+                                   f"epoch; SOAR_BENCH_FRAME_STRIDE=1: consecutive frames)" if frame_stride > 1 else "consecutive frames"),
                    "build_digest": build.source_digest(),
                    # how long the HOST needed to issue the K timed steps, per step: close to ms_per_step = the run was bound by the
                    # host's launch rate (a slow or shared CPU), not by the device

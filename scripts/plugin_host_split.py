@@ -24,7 +24,7 @@ def timed(cls, meth, name, static=True):
 
 from soar_amd import losses as LS, rasterizer as RZ
 from soar_amd.renderer import fused_view as FV
-for cls, nm in ((FV._RenderViews, "RenderView"), (FV._PoseViews, "PoseViews (one C call)"), (LS._AvatarStageLoss, "AvatarStageLoss")):
+for cls, nm in ((FV._RenderViews, "RenderView"), (FV._StepViews, "StepViews (one C call)"), (LS._AvatarStageLoss, "AvatarStageLoss")):
     timed(cls, "backward", f"  [{nm}.backward]")
     timed(cls, "forward", f"  [{nm}.forward]")
 timed(RZ._NativeOps, "_geometry_stage", "    [geometry_stage]")

@@ -21,6 +21,10 @@ import plugin_time as PT            # the scene: 100k surfels on the canonical b
 from soar_amd import synthetic as syn
 from soar_amd.losses import avatar_stage_loss, cos_loss, masked_l1
 from soar_amd.renderer import diff_gaussian as dg, registry
+import soar_amd.losses as _losses
+import inspect
+BATCHED_COS = hasattr(_losses, "_CosLossViews")                      # (the script also runs on the round-4 tree, for the baseline)
+BG_PROMISE = "background" in inspect.signature(avatar_stage_loss).parameters
 
 DEV, W, H, F, pc = PT.DEV, PT.W, PT.H, PT.F, PT.pc
 BS, RES = 4, 512
@@ -53,17 +57,22 @@ def losses(out, gt_out, f):
     # (the video frame's view contributes colour, mask, depth, occlusion, curvature; the normal terms come from the 512^2 normal views)
     frame = {"render": G["comp_rgb"][0], "mask": G["comp_mask"][0], "normal": ZERO_N, "depth": G["comp_depth"][0], "curv": G["comp_curv"][0]}
     blended = t["color"] * t["mask"] + gt_out["rand_bg_chw"] * (1 - t["mask"])
-    loss = avatar_stage_loss(frame, t["color"], t["mask"], t["normal"], mask, gt_rgb_blended=blended, lambda_normal=0.0,
-                             background=gt_out["rand_bg_chw"].reshape(3) if os.environ.get("SOAR_REFSTEP_BG_PROMISE", "1") == "1" else None)
+    extra = {"background": gt_out["rand_bg_chw"].reshape(3)} if (BG_PROMISE and os.environ.get("SOAR_REFSTEP_BG_PROMISE", "1") == "1") else {}
+    loss = avatar_stage_loss(frame, t["color"], t["mask"], t["normal"], mask, gt_rgb_blended=blended, lambda_normal=0.0, **extra)
     loss = loss + 0.2 * cos_loss(G["comp_normal"][0], gt_normal_F, normal_sel) + 0.2 * cos_loss(G["comp_normal"][1], gt_normal_B, normal_sel)   # :329-376
     loss = loss + masked_l1(G["comp_normal_mask"][0], gt_normal_mask)                                                       # :378-382
     m3 = (t["mask"] > 0).expand(3, -1, -1)
     loss = loss + 0.1 * ((1 - G["comp_occ"][0]) * m3).sum() / m3.sum()                                                      # :395-400 (masked mean: no host read-back)
-    pn = 0.0
-    for k in range(2):                                                                                                     # :412-424
-        pn = pn + cos_loss(G["comp_pred_normal"][k], G["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
-    for k in range(BS):                                                                                                    # :425-432
-        pn = pn + cos_loss(S["comp_pred_normal"][k], S["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
+    # predicted-normal consistency: the reference's two calls, each on a stacked batch of views (:412-432)
+    if BATCHED_COS:
+        pn = cos_loss(G["comp_pred_normal"], G["comp_normal"].detach(), None, thrsh=math.pi / 10000) + \
+            cos_loss(S["comp_pred_normal"], S["comp_normal"].detach(), None, thrsh=math.pi / 10000)
+    else:                        # (round 4's cos_loss takes one [3,H,W] view at a time)
+        pn = 0.0
+        for k in range(2):
+            pn = pn + cos_loss(G["comp_pred_normal"][k], G["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
+        for k in range(BS):
+            pn = pn + cos_loss(S["comp_pred_normal"][k], S["comp_normal"][k].detach(), None, thrsh=math.pi / 10000)
     loss = loss + 0.05 * pn
     loss = loss + 0.01 * out["comp_curv"].abs().mean()                                                                     # :439-444
     loss_sds = (out["comp_rgb"] * G_sds).sum()

@@ -29,10 +29,16 @@ def shard_frames(frame_ids: Sequence[int], rank: int, world_size: int) -> List[i
     return [f for k, f in enumerate(frame_ids) if k % world_size == rank]
 
 
-def global_batch(step: int, frames_per_rank: int, world_size: int, num_frames: int) -> List[int]:
-    """Frame ids of optimizer step `step` for a job with `world_size` ranks (weak scaling: frames_per_rank each)."""
+def global_batch(step: int, frames_per_rank: int, world_size: int, num_frames: int, stride: int = 1) -> List[int]:
+    """Frame ids of optimizer step `step` for a job with `world_size` ranks (weak scaling: frames_per_rank each).
+    stride > 1 (coprime with num_frames: else ignored) walks the video in steps of `stride` frames -- a fixed permutation, every
+    frame once per epoch -- so that a short run of steps samples the whole sequence instead of one contiguous stretch of poses (the
+    reference draws a random frame per step, TS/data/uncond_multiview.py)."""
+    import math
     n = frames_per_rank * world_size
-    return [(step * n + k) % num_frames for k in range(n)]
+    if stride <= 1 or num_frames <= 1 or math.gcd(stride, num_frames) != 1:
+        stride = 1
+    return [((step * n + k) * stride) % num_frames for k in range(n)]
 
 
 # set by bench.py under SOAR_BENCH_FORCE_DIST=1: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)

@@ -172,6 +172,80 @@ class _CosLoss(torch.autograd.Function):
         return grad, None, None, None, None
 
 
+class _CosLossViews(torch.autograd.Function):
+    """cos_loss over a BATCH of views [B,3,H,W] as the reference calls it (one mean over the selected pixels of all views,
+    TS/system/gaussian_surfel_mvdream.py:412-432): the B views go through the cosine kernel as ONE launch each way (soar_batch_*),
+    their {sum, count} pairs are folded on the device."""
+
+    @staticmethod
+    def forward(ctx, output, gt, mask, thrsh, weight):
+        import ctypes as C
+        import math
+        if not output.is_cuda:
+            raise RuntimeError("cos_loss runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
+        dev = output.device
+        B, Cn, H, W = output.shape
+        if B > 8:
+            raise ValueError("cos_loss: at most 8 views per call")
+        inner = lambda t: t.stride()[1:] == (H * W, W, 1) and t.dtype == torch.float32 and t.stride(0) >= Cn * H * W
+        a = output.detach()
+        a = a if inner(a) else a.to(torch.float32).contiguous()
+        b = gt.detach().to(device=dev)
+        b = b if (b.shape == a.shape and inner(b)) else b.to(torch.float32).expand(B, Cn, H, W).contiguous()
+        m = None
+        if mask is not None:
+            m = mask.detach().to(device=dev)
+            m = (m if m.dtype == torch.bool else m != 0).reshape(-1, H, W).expand(B, H, W).contiguous().view(torch.uint8)
+        L = hip_lib.lib()
+        n = C.c_size_t(0)
+        check(L.soar_image_loss_scratch_floats(C.byref(n)), "soar_image_loss_scratch_floats")
+        k = int(n.value)
+        scratch = torch.empty((B, k), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        ct, wt = float(math.cos(thrsh)), float(weight)
+        es = a.element_size()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(L.soar_batch_begin(B), "soar_batch_begin")
+            try:
+                for v in range(B):
+                    check(L.soar_batch_frame(v), "soar_batch_frame")
+                    check(L.soar_cos_loss(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
+                                          None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
+                                          scratch.data_ptr() + 4 * k * v, stream), "soar_cos_loss")
+            finally:
+                L.soar_batch_end()
+        cnt = stats[:, 1]
+        total = cnt.sum()
+        ctx.saved = (a, b, m, stats, ct, wt, total)
+        # (a view without a selected pixel holds NaN = 0 / 0 like the reference's mean of an empty tensor: its sum is 0)
+        return (torch.nan_to_num(stats[:, 0]) * cnt).sum() / total
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        a, b, m, stats, ct, wt, total = ctx.saved
+        dev = a.device
+        B, Cn, H, W = a.shape
+        L = hip_lib.lib()
+        grad = torch.empty((B, Cn, H, W), dtype=torch.float32, device=dev)
+        # the kernel scales a view's gradient by upstream / count(view): upstream_v = g count_v / total gives g / total everywhere
+        up = (g.detach().to(device=dev, dtype=torch.float32).reshape(1) * stats[:, 1] / total).contiguous()
+        es = a.element_size()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(L.soar_batch_begin(B), "soar_batch_begin")
+            try:
+                for v in range(B):
+                    check(L.soar_batch_frame(v), "soar_batch_frame")
+                    check(L.soar_cos_loss_backward(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
+                                                   None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
+                                                   up.data_ptr() + 4 * v, grad.data_ptr() + 4 * v * Cn * H * W, stream), "soar_cos_loss_backward")
+            finally:
+                L.soar_batch_end()
+        return grad, None, None, None, None
+
+
 def masked_l1(img: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``l1_loss_w(img[mask], gt[mask])`` for channel-first images: img, gt [C,H,W], mask [H,W] / [1,H,W] (bool) or None.
     (The reference indexes [H,W,3] images with the [H,W] mask, TS/system/gaussian_surfel_mvdream.py:311-314.)"""
@@ -181,7 +255,11 @@ def masked_l1(img: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] 
 def cos_loss(output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None, thrsh: float = 0.0,
              weight: float = 1.0) -> torch.Tensor:
     """``cos_loss`` of the reference (TS/system/gaussian_surfel_mvdream.py:622-630) for channel-first [3,H,W] normal images
-    in [0,1]: mean of 1 - cos over the masked pixels whose cosine is below cos(thrsh)."""
+    in [0,1]: mean of 1 - cos over the masked pixels whose cosine is below cos(thrsh).  A batch [B,3,H,W] (B <= 8; the views may be
+    slices of a larger allocation at a fixed stride) gives the reference's single mean over the selected pixels of all views, as
+    one launch each way."""
+    if output.dim() == 4:
+        return _CosLossViews.apply(output, gt, mask, thrsh, weight)
     return _CosLoss.apply(output, gt, mask, thrsh, weight)
 
 

@@ -1071,6 +1071,34 @@ def test_ssim_kernel_matches_oracle_and_reference_goldens(shape):
         ssim(a, b)
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_cos_loss_over_a_batch_of_views_is_the_references_single_mean(masked):
+    """cos_loss on [B,3,H,W] (how the reference calls it on its stacked normal images, TS/system/gaussian_surfel_mvdream.py:412-432):
+    one mean over the selected pixels of all views == oracle/loss_oracle.py's cos_loss on the [B,H,W,3] batch, value and gradient;
+    the views may be slices of a larger allocation (what the one-node step leaves behind: no copy)."""
+    from oracle import loss_oracle as lo
+    from soar_amd.losses import cos_loss
+    B, H, W = 3, 40, 52
+    g = torch.Generator().manual_seed(17)
+    t = torch.nn.functional.normalize(torch.randn(B, H, W, 3, generator=g), dim=-1) * 0.5 + 0.5
+    o = (0.5 * torch.rand(B, H, W, 3, generator=g) + 0.5 * t).clamp(0, 1)
+    m = (torch.rand(B, H, W, generator=g) > 0.4) if masked else None
+    if masked:
+        m[1] = False                                             # a view without a selected pixel counts for nothing
+    for thr, wt in ((0.0, 1.0), (0.6, 0.5)):
+        o_ref = o.clone().requires_grad_(True)
+        v_ref = lo.cos_loss(o_ref, t, m, thrsh=thr, weight=wt)
+        (2.0 * v_ref).backward()
+        big = torch.zeros(B, 7, H, W, device=DEV)                # views at a stride of 7 planes: planes 2..4 of each hold the image
+        big[:, 2:5] = o.permute(0, 3, 1, 2).to(DEV)
+        big.requires_grad_(True)
+        v = cos_loss(big[:, 2:5], t.permute(0, 3, 1, 2).contiguous().to(DEV), None if m is None else m.to(DEV), thrsh=thr, weight=wt)
+        (2.0 * v).backward()
+        assert abs(float(v) - float(v_ref)) < 1e-5 * max(1.0, abs(float(v_ref)))
+        assert _rel(big.grad[:, 2:5].permute(0, 2, 3, 1).cpu().numpy(), o_ref.grad.numpy()) < 1e-4
+        assert float(big.grad[:, :2].abs().max()) == 0.0 and float(big.grad[:, 5:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(24, 40), (37, 53), (540, 960)])
 def test_masked_l1_and_cos_loss_kernels(shape):
     """soar_masked_l1 / soar_cos_loss (value + gradient) == oracle/loss_oracle.py (pinned on the reference's functions) and,
