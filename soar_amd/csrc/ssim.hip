@@ -39,6 +39,7 @@ struct SsimArgs {
     // forward only leaves derivative maps where such a tile reads them (its own 42 x 42 halo holds a rendered pixel) -- on a frame of
     // one person four tiles in five drop out of the backward launch and their maps' twelve bytes per pixel and channel are not written
     const float *rendered;
+    uint32_t *tile_flags;              // [tiles]: != 0 where the 32 x 32 tile holds a rendered pixel (ssim_rendered_tiles_kernel, one pass over `rendered`)
 };
 
 __device__ __forceinline__ float load_px(const float *img, int c, int x, int y, int H, int W)
@@ -123,19 +124,14 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(Batch<SsimArgs> batch
                 s[yy][xx] = f2{load_px(a.img1, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W), load_px(a.img2, c, x0 + xx - SR, y0 + yy - SR, a.H, a.W)};
             }
         }
-        // does any tile that reads this tile's derivative maps hold a rendered pixel?  (its halo: rows y0 - 5 .. y0 + 36, the staged
-        // columns x0 - 8 .. x0 + 39 -- a little wider than needed)
+        // does any tile that reads this tile's derivative maps hold a rendered pixel?  (the 3 x 3 tiles around it: a superset of the
+        // tiles its 42 x 42 halo touches; their flags come from one pass over `rendered`, ssim_rendered_tiles_kernel)
         int wanted = 1;
         if (a.rendered) {
             wanted = 0;
-            for (int u = tid; u < SH * SQ; u += 256) {
-                const int yy = u / SQ, gx = x0 - 8 + 4 * (u % SQ), gy = y0 - SR + yy;
-                if (gy >= 0 && gy < a.H && gx < a.W && gx + 3 >= 0) {
-                    const float *row = a.rendered + (size_t)gy * a.W;
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (gx + k >= 0 && gx + k < a.W && row[gx + k] > 1e-5f) wanted = 1;
-                }
+            if (tid < 9) {
+                const int tx = cur.tile % a.tiles_x + tid % 3 - 1, ty = cur.tile / a.tiles_x + tid / 3 - 1;
+                if (tx >= 0 && tx < a.tiles_x && ty >= 0 && ty * a.tiles_x < a.tiles) wanted = a.tile_flags[ty * a.tiles_x + tx] != 0u;
             }
         }
         const bool write_maps = __syncthreads_or(wanted) != 0;
@@ -224,16 +220,8 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batc
     const SsimArgs &a = batch.v[cur.frame];
     const int x0 = cur.x0, y0 = cur.y0, c = cur.c, x = x0 + tx;
     const size_t plane = (size_t)a.C * a.H * a.W;
-    if (a.rendered) {
-        // nobody reads the gradient of a pixel nothing contributed to: a tile without a rendered pixel leaves at once
-        int wanted = 0;
-#pragma unroll
-        for (int o = 0; o < SB; o++) {
-            const int y = y0 + tyb + o;
-            if (x < a.W && y < a.H && a.rendered[(size_t)y * a.W + x] > 1e-5f) wanted = 1;
-        }
-        if (!__syncthreads_or(wanted)) return;
-    }
+    // nobody reads the gradient of a pixel nothing contributed to: a tile without a rendered pixel leaves at once (wave-uniform load)
+    if (a.rendered && a.tile_flags[cur.tile] == 0u) return;
     {
         // the centre pixels of the two images (clamped addresses: no branch around the loads), in flight across both passes
         float i1[SB], i2[SB];
@@ -317,6 +305,28 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(Batch<SsimArgs> batc
     }
 }
 
+// one pass over the opacity image: which 32 x 32 tiles hold a rendered pixel (opacity > 1e-5)
+struct SsimFlagArgs { int H, W, tiles_x; const float *rendered; uint32_t *tile_flags; };
+__global__ void __launch_bounds__(256) ssim_rendered_tiles_kernel(Batch<SsimFlagArgs> batch)
+{
+    const SsimFlagArgs &a = batch.v[blockIdx.y];
+    const int tile = (int)blockIdx.x, x0 = (tile % a.tiles_x) * ST, y0 = (tile / a.tiles_x) * ST;
+    const int tid = threadIdx.x, y = y0 + tid / 8, x = x0 + 4 * (tid % 8);
+    int any = 0;
+    if (y < a.H) {
+        const float *row = a.rendered + (size_t)y * a.W;
+        if ((a.W & 3) == 0 && x + 3 < a.W && (reinterpret_cast<uintptr_t>(a.rendered) & 15u) == 0u) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + x);
+            any = v.x > 1e-5f || v.y > 1e-5f || v.z > 1e-5f || v.w > 1e-5f;
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (x + k < a.W && row[x + k] > 1e-5f) any = 1;
+        }
+    }
+    const int got = __syncthreads_or(any);
+    if (tid == 0) a.tile_flags[tile] = got ? 1u : 0u;
+}
+
 struct SsimFinishArgs {
     const float *partials;
     int n;
@@ -373,7 +383,7 @@ extern "C" int soar_ssim_scratch_floats(int32_t C, int32_t H, int32_t W, size_t 
 {
     if (C <= 0 || H <= 0 || W <= 0 || !count) { set_error("soar_ssim_scratch_floats: bad arguments"); return 1; }
     const size_t blocks = 4 * (size_t)((W + ST - 1) / ST) * ((H + ST - 1) / ST) * C;     // one partial per 32x32 tile and wave
-    *count = ((3 * (size_t)C * H * W + 3) & ~(size_t)3) + blocks;
+    *count = ((3 * (size_t)C * H * W + 3) & ~(size_t)3) + blocks + blocks / (4 * (size_t)C);      // maps | partials | one flag per tile
     return 0;
 }
 
@@ -398,6 +408,7 @@ extern "C" int soar_ssim_rendered(int32_t C, int32_t H, int32_t W, const float *
     fill_window(a.w);
     a.tiles_x = (W + ST - 1) / ST;
     a.tiles = a.tiles_x * ((H + ST - 1) / ST);
+    a.tile_flags = reinterpret_cast<uint32_t *>(a.partials + 4 * (size_t)a.tiles * C);
     // one workgroup per tile and channel; the frames of a batch along z (the kernels remap the workgroups XCD by XCD)
     if (batch_ctx().n) {         // (the grid alone does not tell the launch sites that the frames of a batch agree in size)
         static thread_local int c0 = 0, h0 = 0, w0 = 0;
@@ -408,6 +419,10 @@ extern "C" int soar_ssim_rendered(int32_t C, int32_t H, int32_t W, const float *
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0u; };
     const bool vec = (W & 3) == 0 && al(img1) && al(img2) && al(scratch);
     StageTimer timer(ST_FRAME_LOSS, stream);
+    if (rendered) {
+        const SsimFlagArgs fl = {H, W, a.tiles_x, rendered, a.tile_flags};
+        SOAR_LAUNCH_BATCHED(ssim_rendered_tiles_kernel, dim3(a.tiles), dim3(256), 0, stream, fl);
+    }
     if (vec) SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel<true>, grid, dim3(256), 0, stream, a);
     else SOAR_LAUNCH_BATCHED_Z(ssim_forward_kernel<false>, grid, dim3(256), 0, stream, a);
     const SsimFinishArgs fa = {a.partials, 4 * a.tiles * C, a.gscale, ssim_out};
