@@ -22,6 +22,10 @@ What follows which reference lines (relative to /root/reference/soar/threestudio
   (golden script executes the reference function); the rest is a restatement.
 * ``dist2_knn3``: simple-knn distCUDA2 (submodule empty, no SHA: PARITY UNPINNED), published semantics: mean of the
   three smallest squared distances to OTHER points.
+
+The three UNPINNED restatements (knn_brute / query_weights, matrix_to_quaternion, dist2_knn3) have a second opinion since round 5:
+tests/test_golden_cpu.py cross-checks them against scipy's k-d tree and scipy's Rotation -- an independent implementation of the
+same published semantics, not a pin on the absent dependency's version.
 """
 from __future__ import annotations
 
