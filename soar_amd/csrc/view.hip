@@ -404,7 +404,7 @@ int step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_poses < 1 || n_poses > MAX_BATCH || !poses || !views_per_pose) { set_error("%s: 1 <= n_poses <= %d", who, MAX_BATCH); return 1; }
     int n_views = 0;
-    int pose_of[MAX_BATCH], local_of[MAX_BATCH], first_of[MAX_BATCH];
+    int pose_of[MAX_BATCH], local_of[MAX_BATCH];
     for (int p = 0; p < n_poses; p++) {
         const SoarPoseArgs *pose = &poses[p];
         if (check_pose(pose, who)) return 1;
@@ -415,7 +415,6 @@ int step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_
             set_error("%s: the gradient pointers of every pose must be given", who);
             return 1;
         }
-        first_of[p] = n_views;
         for (int k = 0; k < views_per_pose[p]; k++) { pose_of[n_views] = p; local_of[n_views] = k; n_views++; }
     }
     // grad_scratch of a pose, per view v of ITS n: blocks [n][P][3] xyz', [n][P][4] rot', [n][P][3] colours, [n][P][3] scales3, [n][P] occ,
@@ -558,7 +557,6 @@ int step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_
         hipLaunchKernelGGL(fold_scale_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, f);
         SOAR_LAUNCH_OK("fold_scale", stream, 0);
     }
-    (void)first_of;
     return 0;
 }
 

@@ -706,7 +706,9 @@ class _StackViews(torch.autograd.Function):
 
 
 def stack_views(xs):
-    """torch.stack(xs, dim=0) -- without the copy when the tensors are equally shaped slices of one allocation at a fixed stride."""
+    """torch.stack(xs, dim=0) -- without the copy when the tensors are equally shaped slices of one allocation at a fixed stride.
+    The result then ALIASES its inputs (it is their memory, not a copy): treat it as read-only, as every consumer of the plugin's
+    stacked outputs does -- an in-place operation on it would change the per-view tensors behind autograd's back."""
     n = len(xs)
     if n > 1:
         x0 = xs[0]
