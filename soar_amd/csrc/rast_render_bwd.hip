@@ -274,10 +274,11 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 //   * the block masks (rast_blockmask.hip) already say which entries of the list concern this block: no staging of the tile's
 //     whole list, no test, no barrier; a wavefront that has nothing to do leaves without waiting for its neighbours;
 //   * the mask words of the block (64 groups = 4096 list positions per load) are asked for together with the pixel's planes; the
-//     set bits are compacted, deepest first, into batches of 64 list positions; lists ids and then records are gathered straight into
-//     the lanes' registers, TWO and ONE batch ahead of the one being worked on;
-//   * the sums of batch n leave through LDS (13 row-contiguous atomic wave-instructions) at the start of batch n + 1, behind the
-//     gathers of that step: every wait for a gather then finds the atomics in front of it a whole pixel loop old.
+//     set bits are compacted, deepest first, into batches of 64 list positions; list ids are gathered straight into the lanes'
+//     registers one batch ahead, the records at the top of the batch's own turn (round 5: holding the next batch's records across the
+//     pixel loop cost sixteen registers and with them 36 bytes of scratch per lane -- more than the hidden round trip was worth);
+//   * the sums of batch n leave through LDS (13 row-contiguous atomic wave-instructions) at the start of batch n + 1, BEHIND that
+//     batch's gather: the wait for the gather of batch n + 2 then finds the atomics in front of it a whole pixel loop old.
 template <bool WIDE, bool OCC>
 __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
                                                uint32_t *list, float *xpose, uint32_t *xgid, float *xocc, uint32_t *xgid_o)
@@ -417,15 +418,14 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         return cnt;
     };
 
-    // this lane's entry of the batch being worked on (lane 0 = deepest), and of the batch after it
+    // this lane's entry of the batch being worked on (lane 0 = deepest), and the list id of its entry in the batch after it
     float ex = 0.f, ey = 0.f, eA = 0.f, eB = 0.f, eC = 0.f, eop = 0.f, edepth = 0.f, epa = 0.f, epb = 0.f;
     float er = 0.f, eg = 0.f, eb = 0.f, enx = 0.f, eny = 0.f, enz = 0.f;
     uint32_t egid = 0u, epos = 0xFFFFFFFFu;      // position relative to the start of the list; 0xFFFFFFFF: no entry in this lane
     float efront = 0.f, rfront = 0.f;            // OCC: 1 = camera-facing (an entry of the occlusion chain)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     uint32_t rgid = 0u, rpos = 0xFFFFFFFFu;
-    uint32_t ngid = 0u, npos = 0xFFFFFFFFu;      // ids of the batch after that
-    int cnt_e = 0, cnt_r = 0, cnt_n = 0;
+    int cnt_e = 0, cnt_r = 0;
 
     auto fetch_ids = [&](int cnt, uint32_t &gid, uint32_t &pos) {
         pos = 0xFFFFFFFFu;
@@ -464,27 +464,25 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         }
     };
 
-    // fill the pipeline: batch 0 in (r), batch 1's ids in (n)
+    // fill the pipeline: batch 0's ids in (r)
     cnt_r = assemble();
     fetch_ids(cnt_r, rgid, rpos);
-    gather();
-    cnt_n = assemble();
-    fetch_ids(cnt_n, ngid, npos);
     bool pending = false;
     for (;;) {
+        gather();
         // (r) -> (e): the batch to work on
         ex = r0.x; ey = r0.y; eA = r0.z; eB = r0.w; eC = r1.x; eop = r1.y; edepth = r1.z; epa = r1.w;
         epb = r2.x; er = r2.y; eg = r2.z; eb = r2.w; enx = r3.x; eny = r3.y; enz = r3.z;
         egid = rgid; epos = rpos; cnt_e = cnt_r;
         if (OCC) efront = rfront;
         if (cnt_e == 0) break;
-        // the sums of the batch before leave now, in front of this step's gathers
+        // the sums of the batch before leave now
         if (pending) flush_atomics();
-        // (n) -> (r): its records are asked for now, the ids of the batch behind it next
-        rgid = ngid; rpos = npos; cnt_r = cnt_n;
-        gather();
-        cnt_n = assemble();
-        fetch_ids(cnt_n, ngid, npos);
+        // the ids of the batch behind this one are asked for now; ITS records only at the top of its own turn (rounds 3-4 kept them in
+        // sixteen registers across this batch's pixel loop: 137 registers wanted, 128 allowed at four waves per SIMD, 36 bytes of
+        // scratch per lane.  Without them the kernel needs 120 and no scratch: 297-305 -> 290 us per 4-frame launch, round 5)
+        cnt_r = assemble();
+        fetch_ids(cnt_r, rgid, rpos);
 
         // ---- one batch: cnt_e entries x the pixels that reach it
         const uint32_t nearest = (uint32_t)__builtin_amdgcn_readlane((int)epos, cnt_e - 1);

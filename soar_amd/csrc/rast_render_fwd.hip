@@ -204,19 +204,13 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         if (OCC) sq4[CHUNK] = z;
     }
 
-    // software pipeline over chunks: the records of chunk k+1 are requested before chunk k is blended, and the list ids of
-    // chunk k+2 before that (the record gather of a chunk then never waits for its own id load: one global round trip per
-    // chunk off the critical path of the long tiles)
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    float2 r4 = make_float2(0.f, 0.f);
-    uint32_t id_next = 0;                            // list id of this thread's entry in the chunk after the prefetched one
-    if (range.x + tid < range.y) {
-        const uint32_t id = a.point_list[range.x + tid];
-        const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
-        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-        if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
-    }
-    if (range.x + CHUNK + tid < range.y) id_next = a.point_list[range.x + CHUNK + tid];
+    // The list ids travel one chunk ahead; a chunk's RECORDS are gathered at the top of its iteration and staged at once.  (Rounds 1-4
+    // kept the next chunk's records in 18 registers across the blend of this one -- the gather's round trip off the critical path of
+    // the long tiles.  Those registers were the difference between 95 and 71: at the 80 that six waves per SIMD allow the kernel
+    // spilled 24 bytes per lane, and without them it runs SEVEN waves per SIMD with no scratch at all -- the other wavefronts cover the
+    // gather better than the prefetch did: 244 -> 221 us per 4-frame launch, round 5.)
+    uint32_t id_next = 0;                            // list id of this thread's entry in the next chunk
+    if (range.x + tid < range.y) id_next = a.point_list[range.x + tid];
     int parity = 0;
     // Phase A's survivor word of every 64 list positions this wavefront tests IS the block mask the backward blend walks
     // (BinBuf::block_masks: bit l of word g of plane `block` = list position 64 g + l; a superset of what the backward needs: an
@@ -241,20 +235,16 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     };
     for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
         const int n = min((uint32_t)CHUNK, range.y - base);
-        if (tid < n) {
-            sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2; sq3[tid] = r3;
-            if (OCC) *reinterpret_cast<float2 *>(&sq4[tid]) = r4;
-        }
         emit_masks();                                // (the chunk before)
         emit_base = base;
-        if (base + CHUNK + tid < range.y) {
+        if (tid < n) {
             const uint32_t id = id_next;
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
-            r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
-            if (OCC) r4 = make_float2(a.occ_values[id], a.front[id]);
+            sq0[tid] = src[0]; sq1[tid] = src[1]; sq2[tid] = src[2]; sq3[tid] = src[3];
+            if (OCC) *reinterpret_cast<float2 *>(&sq4[tid]) = make_float2(a.occ_values[id], a.front[id]);
         }
-        if (base + 2 * CHUNK + tid < range.y) id_next = a.point_list[base + 2 * CHUNK + tid];
-        lds_barrier();           // LDS only: the gathers of the next chunk stay in flight while this one is blended
+        if (base + CHUNK + tid < range.y) id_next = a.point_list[base + CHUNK + tid];
+        lds_barrier();
         if (LOG && base == range.x) t_ready = wall_clock64();
 
         if (!wave_done) {
@@ -482,7 +472,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
 // Gaussian touches sit behind the first n_work ranks and are filled with their background values, whole tiles, by all
 // workgroups once their blending is done.
 #ifndef SOAR_FWD_WPE
-#define SOAR_FWD_WPE 6
+#define SOAR_FWD_WPE 7       // (71 VGPRs, 22.8 KB of LDS per workgroup: seven workgroups per CU)
 #endif
 template <bool LOG, bool OCC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOAR_FWD_WPE, 8))) render_forward_kernel(Batch<FwdArgs> batch)
