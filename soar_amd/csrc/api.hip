@@ -47,19 +47,25 @@ BatchCtx &batch_ctx()
 namespace {
 constexpr int ZERO_RANGES = 5;
 struct ZeroArgs { uint32_t *ptr[ZERO_RANGES]; size_t words[ZERO_RANGES]; size_t first_block[ZERO_RANGES + 1]; };
+// (a workgroup clears 32 KB: with 4 KB each the launch was bound by the rate workgroups are dispatched at -- 25 600 of them for the
+// accumulation rows of four frames, 24 us for 25.6 MB)
+constexpr int ZERO_UNROLL = 8;
+constexpr size_t ZERO_BLOCK_WORDS = 256 * 4 * ZERO_UNROLL;
 __global__ void __launch_bounds__(256) zero_ranges_kernel(Batch<ZeroArgs> b)
 {
     const ZeroArgs &z = b.v[blockIdx.y];
     if (blockIdx.x >= z.first_block[ZERO_RANGES]) return;
     int r = 0;
     while (r < ZERO_RANGES - 1 && blockIdx.x >= z.first_block[r + 1]) r++;
-    const size_t w0 = ((size_t)blockIdx.x - z.first_block[r]) * 1024 + threadIdx.x * 4;
+    const size_t b0 = ((size_t)blockIdx.x - z.first_block[r]) * ZERO_BLOCK_WORDS;
     uint32_t *p = z.ptr[r];
     const size_t n = z.words[r];
-    if (w0 + 3 < n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        *reinterpret_cast<uint4 *>(p + w0) = make_uint4(0u, 0u, 0u, 0u);
+    if (b0 + ZERO_BLOCK_WORDS <= n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+        for (int u = 0; u < ZERO_UNROLL; u++)
+            *reinterpret_cast<uint4 *>(p + b0 + (size_t)u * 1024 + threadIdx.x * 4) = make_uint4(0u, 0u, 0u, 0u);
     } else {
-        for (int k = 0; k < 4; k++) if (w0 + k < n) p[w0 + k] = 0u;
+        for (size_t w = b0 + threadIdx.x; w < n && w < b0 + ZERO_BLOCK_WORDS; w += 256) p[w] = 0u;
     }
 }
 }  // namespace
@@ -73,7 +79,7 @@ int launch_zero_ranges(const ZeroRange *ranges, int count, hipStream_t stream)
         z.first_block[r] = blocks;
         z.ptr[r] = r < count ? static_cast<uint32_t *>(ranges[r].ptr) : nullptr;
         z.words[r] = r < count ? ranges[r].bytes / 4 : 0;
-        blocks += (z.words[r] + 1023) / 1024;
+        blocks += (z.words[r] + ZERO_BLOCK_WORDS - 1) / ZERO_BLOCK_WORDS;
     }
     z.first_block[ZERO_RANGES] = blocks;
     if (blocks == 0) return 0;
