@@ -146,6 +146,10 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 // reciprocal instead of a chain of divisions -- inside the gradient tolerance like the shared reciprocal of the other form
 // (the forward's T, n_contrib and final_T are not touched by any of this).
 constexpr int DPP_WAVE_SHR1 = 0x138;
+#ifndef SOAR_BWD_UNIT_GROUPS
+#define SOAR_BWD_UNIT_GROUPS 8     // (16: 4.3 KB of list per wavefront, 17 wavefronts per CU by LDS; 8: 22 -- the registers allow 20)
+#endif
+constexpr int UNIT_GROUPS = SOAR_BWD_UNIT_GROUPS;    // mask words (64 list positions each) the block walk compacts at a time
 
 // v of the lane the DPP control names; `otherwise` where that lane does not exist or the row is masked out
 template <int CTRL, int ROW_MASK>
@@ -342,8 +346,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     }
     const float two_ddelx = 2.f * c.ddelx_dx, two_ddely = 2.f * c.ddely_dy;
 
-    // ---- the walk: the set bits of the block's mask words, deepest list position first.  Sixteen groups (1024 positions) are
-    //      compacted at a time by all 64 lanes (four lanes per word, 16 bits each) into `list`; a batch is the next 64 entries of it.
+    // ---- the walk: the set bits of the block's mask words, deepest list position first.  UNIT_GROUPS groups (512 positions) are
+    //      compacted at a time by all 64 lanes (eight lanes per word, 8 bits each) into `list`; a batch is the next 64 entries of it.
     //      (Rounds 3-4a walked the words one at a time -- two register-to-scalar moves, a ballot, two prefix counts and a dozen scalar
     //      instructions per 64 positions, of which a block keeps seven: a quarter of the launch's instructions made batches.)
     const uint32_t x0 = range.x, top = range.x + deepest;       // positions at and behind `top` are not walked (nothing was blended there
@@ -360,19 +364,21 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto compact_unit = [&]() {                  // groups g_next, g_next - 1, ... g_next - 15 (those at or above g_lo) -> list[n_list ..)
-        const int g_hi = g_next, g_low = max(g_hi - 15, (int)g_lo);
+    auto compact_unit = [&]() {                  // groups g_next, g_next - 1, ... g_next - (UNIT_GROUPS - 1) (those at or above g_lo) -> list[n_list ..)
+        constexpr int LPW = WAVE / UNIT_GROUPS, BITS = 64 / LPW;           // lanes per mask word, bits per lane
+        const int g_hi = g_next, g_low = max(g_hi - (UNIT_GROUPS - 1), (int)g_lo);
         if ((uint32_t)g_low < wb) { wb = (uint32_t)g_hi - g_lo >= (uint32_t)WAVE ? (uint32_t)g_hi - (uint32_t)(WAVE - 1) : g_lo; load_window(); }
         // lane = (word: 0 = the highest group, quarter: highest bits first)
-        const int g = g_hi - (lane >> 2), q = 3 - (lane & 3);
+        const int g = g_hi - lane / LPW, q = LPW - 1 - (lane % LPW);
         const int src = (g - (int)wb) & 63;                      // the window's lane that holds the word
         const uint32_t word_lo = (uint32_t)__shfl((int)w_lo, src), word_hi = (uint32_t)__shfl((int)w_hi, src);
-        const uint32_t base = ((uint32_t)g << 6) + 16u * (uint32_t)q;      // list position of bit 0 of this lane's 16 bits
+        const uint32_t base = ((uint32_t)g << 6) + (uint32_t)(BITS * q);   // list position of bit 0 of this lane's bits
         uint32_t bits = 0u;
         if (g >= g_low) {
-            bits = ((q >= 2 ? word_hi : word_lo) >> (16 * (q & 1))) & 0xFFFFu;
-            if (base + 16u > top) bits &= base >= top ? 0u : (1u << (top - base)) - 1u;
-            if (base < x0) bits &= x0 - base >= 16u ? 0u : (0xFFFFu << (x0 - base)) & 0xFFFFu;
+            constexpr uint32_t FULL = (1u << BITS) - 1u;
+            bits = ((BITS * q >= 32 ? word_hi : word_lo) >> ((BITS * q) & 31)) & FULL;
+            if (base + (uint32_t)BITS > top) bits &= base >= top ? 0u : (1u << (top - base)) - 1u;
+            if (base < x0) bits &= x0 - base >= (uint32_t)BITS ? 0u : (FULL << (x0 - base)) & FULL;
         }
         const int cnt = __builtin_popcount(bits);
         // inclusive sum over the lanes, lane 0 first (DPP: a lane without a source lane adds 0)
@@ -385,7 +391,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
         const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
         int off = n_list + incl - cnt;
-        while (__ballot(bits != 0u)) {           // highest bit first: at most 16 trips, usually two or three
+        while (__ballot(bits != 0u)) {           // highest bit first: at most BITS trips, usually two or three
             if (bits) {
                 const int b = 31 - __builtin_clz(bits);
                 list[off++] = base + (uint32_t)b;
@@ -446,21 +452,34 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         }
     };
     auto flush_atomics = [&]() {
+        // (the lane's (entry, component) of every one of the 13 instructions is worked out HERE, every time: left to the compiler
+        // the 13 LDS addresses and 13 64-bit offsets were loop-invariant values held in 39 registers for the whole kernel, and
+        // each instruction's two LDS reads and its reload of the pointer were waited for one after the other.  Now: all 26 reads,
+        // one wait, 13 atomics)
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        uint32_t g[13];
+        float v[13];
 #pragma unroll
         for (int k = 0; k < 13; k++) {
-            const int f = k * WAVE + lane;
+            const int f = k * WAVE + lv;
             const int e = (f * 20165) >> 18;                 // f / 13 for f < 832
+            g[k] = xgid[e];
+            v[k] = xpose[f];
+        }
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const int f = k * WAVE + lv;
+            const int e = (f * 20165) >> 18;
             const int q = f - 13 * e;
-            const uint32_t g = xgid[e];
-            const float v = xpose[f];
-            if (g != 0xFFFFFFFFu) {
-                if (WIDE) atomicAdd(a.acc64 + (size_t)g * ACC_STRIDE + q, (double)v);
-                else atomicAdd(a.acc + (size_t)g * ACC_STRIDE + q, v);
+            if (g[k] != 0xFFFFFFFFu) {
+                if (WIDE) atomicAdd(a.acc64 + (size_t)g[k] * ACC_STRIDE + q, (double)v[k]);
+                else atomicAdd(a.acc + (size_t)g[k] * ACC_STRIDE + q, v[k]);
             }
         }
         if (OCC) {
-            const float v = xocc[lane];
-            if (v != 0.f) atomicAdd(a.g_values + xgid_o[lane], v);
+            const float vo = xocc[lane];
+            if (vo != 0.f) atomicAdd(a.g_values + xgid_o[lane], vo);
         }
     };
 
@@ -586,7 +605,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 }
 
 #ifndef SOAR_BWD_BLK_WPE
-#define SOAR_BWD_BLK_WPE 4
+#define SOAR_BWD_BLK_WPE 5     // (88 / 96 VGPRs since the sums' hand-over works out its indices in place: round 5)
 #endif
 // one wavefront per workgroup: a finished block frees its slot at once.  Grid = 16 x ranks; the 16 blocks of a tile are
 // consecutive workgroups of one XCD (its L2 holds the tile's records), ranks dealt round-robin to the XCDs.
@@ -596,7 +615,7 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
     __shared__ float4 pixc[16][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
                                                          //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
-    __shared__ uint32_t list[16 * WAVE + WAVE];          // compacted list positions of up to sixteen mask words + a batch's worth carried over
+    __shared__ uint32_t list[UNIT_GROUPS * WAVE + WAVE]; // compacted list positions of up to UNIT_GROUPS mask words + a batch's worth carried over
     __shared__ float xpose[WAVE * 13];                   // a batch's sums, [entry][13]
     __shared__ uint32_t xgid[WAVE];
     __shared__ float xocc[OCC ? WAVE : 1];               // ... and of the occlusion values' gradient
