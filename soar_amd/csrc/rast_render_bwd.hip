@@ -446,35 +446,43 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     };
     auto gather = [&]() {                                             // records of (rgid, rpos)
         if (rpos != 0xFFFFFFFFu) {
+#ifdef SOAR_EXP_HOT_GATHER
+            const float4 *src = reinterpret_cast<const float4 *>(a.rec + (rgid & 1023u));       // (development: the records from 64 KB that stay in the caches)
+#else
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + rgid);
+#endif
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
             if (OCC) rfront = a.front[rgid];
         }
     };
     auto flush_atomics = [&]() {
-        // (the lane's (entry, component) of every one of the 13 instructions is worked out HERE, every time: left to the compiler
-        // the 13 LDS addresses and 13 64-bit offsets were loop-invariant values held in 39 registers for the whole kernel, and
-        // each instruction's two LDS reads and its reload of the pointer were waited for one after the other.  Now: all 26 reads,
-        // one wait, 13 atomics)
-        int lv = lane;
-        asm volatile("" : "+v"(lv));
-        uint32_t g[13];
-        float v[13];
+        // Every instruction adds WHOLE rows: lane = (one of the four rows of the instruction, component), 13 of 16 lanes at work,
+        // 16 instructions for the 64 entries.  (Until late in round 5: 13 instructions over the 832 floats as they lie -- a row that
+        // straddled two instructions was two requests at the L2, 1.2 per row, and the device-wide float atomics of this path are
+        // not combined there: the L2 counters show every one of them forwarded to the memory side (TCC_EA0_ATOMIC = TCC_ATOMIC =
+        // TCC_PROBE = 3.9 M per 4-frame launch), which is what the launch waits for.  The lane's (row, component) also is two
+        // lane constants now instead of 13 (entry, component) pairs.)
+        static_assert(ACC_STRIDE == 16 && WAVE == 64, "four rows of 16 floats per instruction");
+        const int r4 = lane >> 4, q = lane & 15;
+        const bool has_q = q < 13;
+        const float *xp = xpose + (has_q ? 13 * r4 + q : 0);
+        const uint32_t *xg = xgid + r4;
+        uint32_t g[16];
+        float v[16];
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
-            const int f = k * WAVE + lv;
-            const int e = (f * 20165) >> 18;                 // f / 13 for f < 832
-            g[k] = xgid[e];
-            v[k] = xpose[f];
+        for (int k = 0; k < 16; k++) {
+            g[k] = xg[4 * k];
+            v[k] = xp[52 * k];
         }
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
-            const int f = k * WAVE + lv;
-            const int e = (f * 20165) >> 18;
-            const int q = f - 13 * e;
-            if (g[k] != 0xFFFFFFFFu) {
+        for (int k = 0; k < 16; k++) {
+            if (has_q && g[k] != 0xFFFFFFFFu) {
                 if (WIDE) atomicAdd(a.acc64 + (size_t)g[k] * ACC_STRIDE + q, (double)v[k]);
+#ifdef SOAR_EXP_NO_ATOMICS
+                else if (g[k] == 0xFFFFFFFEu) a.acc[q] = v[k];       // (development, results wrong by construction: what the launch costs without them)
+#else
                 else atomicAdd(a.acc + (size_t)g[k] * ACC_STRIDE + q, v[k]);
+#endif
             }
         }
         if (OCC) {
