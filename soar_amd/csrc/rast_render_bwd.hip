@@ -146,8 +146,14 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 // reciprocal instead of a chain of divisions -- inside the gradient tolerance like the shared reciprocal of the other form
 // (the forward's T, n_contrib and final_T are not touched by any of this).
 constexpr int DPP_WAVE_SHR1 = 0x138;
+#ifndef SOAR_BWD_REGION
+#define SOAR_BWD_REGION 2      // (1 / 2 / 4 blocks per wavefront: 245 / 234-237 / 300 us per 4-frame launch at C3)
+#endif
+constexpr int REGION = SOAR_BWD_REGION;              // 4 x 4 blocks a wavefront takes (side by side)
+constexpr int NPIX = 16 * REGION;
+static_assert(REGION == 1 || REGION == 2 || REGION == 4, "one block, a pair side by side, or the four of a quad");
 #ifndef SOAR_BWD_UNIT_GROUPS
-#define SOAR_BWD_UNIT_GROUPS 8     // (16: 4.3 KB of list per wavefront, 17 wavefronts per CU by LDS; 8: 22 -- the registers allow 20)
+#define SOAR_BWD_UNIT_GROUPS 4     // (mask words compacted at a time: 1.3 KB of list; with the 32 pixels' rows 7.7 KB of LDS per wavefront: 21 per CU, the registers allow 20)
 #endif
 constexpr int UNIT_GROUPS = SOAR_BWD_UNIT_GROUPS;    // mask words (64 list positions each) the block walk compacts at a time
 
@@ -294,9 +300,10 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     const uint2 range = make_uint2(orec.y, orec.z);
     if (range.x == range.y) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
+    // (REGION = 2: the wavefront takes two blocks side by side -- 8 x 4 pixels --, REGION = 4: the four of a quad; `blk` names the first)
     const int bx0 = tx * TILE + ((blk >> 2) & 1) * 8 + (blk & 1) * 4, by0 = ty * TILE + (blk >> 3) * 8 + ((blk >> 1) & 1) * 4;
-    const int p_own = lane & 15;                         // lanes 0..15 own the block's pixels (the others hold copies)
-    const int px = bx0 + (p_own & 3), py = by0 + (p_own >> 2);
+    const int p_own = lane & (NPIX - 1);                 // lanes 0..NPIX-1 own the region's pixels (the others hold copies)
+    const int px = bx0 + ((p_own >> 4) & 1) * 4 + (p_own & 3), py = by0 + (p_own >> 5) * 4 + ((p_own >> 2) & 3);
     const bool inside = px < a.W && py < a.H;
 
     // The block's mask words: lane j of the window holds the word of group wb + j.  A list of up to 64 groups (4096 entries: all
@@ -308,7 +315,11 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     uint32_t w_lo = 0u, w_hi = 0u;
     auto load_window = [&]() {
         const uint32_t g = wb + (uint32_t)lane;
-        const unsigned long long word = g <= g_end ? a.masks[(size_t)blk * a.mask_plane + g] : 0ull;
+        unsigned long long word = 0ull;
+        if (g <= g_end) {
+#pragma unroll
+            for (int b = 0; b < REGION; b++) word |= a.masks[(size_t)(blk + b) * a.mask_plane + g];
+        }
         w_lo = (uint32_t)word; w_hi = (uint32_t)(word >> 32);
     };
     if (early) load_window();
@@ -334,7 +345,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     const uint32_t deepest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(vLast));     // back-facing entries: it may outlive the main one)
     if (deepest == 0u) return;
     set_wave_priority_by_length(deepest);
-    if (lane < 16) {
+    if (lane < NPIX) {
         pixc[lane][0] = make_float4(c.fx, c.fy, c.dC0, c.dC1);
         pixc[lane][1] = make_float4(c.dC2, c.dN0, c.dN1, c.dN2);
         pixc[lane][2] = make_float4(c.dD, c.dD_ch, c.norm_depth_k + c.tail, __uint_as_float(c.last));
@@ -513,7 +524,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 
         // ---- one batch: cnt_e entries x the pixels that reach it
         const uint32_t nearest = (uint32_t)__builtin_amdgcn_readlane((int)epos, cnt_e - 1);
-        uint32_t act = (uint32_t)__ballot(vLast > nearest) & 0xFFFFu;
+        unsigned long long act = __ballot(vLast > nearest) & (NPIX == 64 ? ~0ull : (1ull << (NPIX & 63)) - 1ull);
         float acc[13];
 #pragma unroll
         for (int q = 0; q < 13; q++) acc[q] = 0.f;
@@ -522,8 +533,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         float acc_o = 0.f;                       // OCC: sum over the pixels of weight x upstream gradient of this lane's entry
         const float oh = -0.5f * eop;
         while (act) {
-            const int p = __builtin_ctz(act);
-            act &= act - 1u;
+            const int p = (int)__builtin_ctzll(act);
+            act &= act - 1ull;
             const float4 c0 = pixc[p][0], c1 = pixc[p][1], c2 = pixc[p][2];
             const float4 tp = pixc[p][3];
             const uint32_t last_p = __float_as_uint(c2.w);
@@ -620,7 +631,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 template <bool WIDE, bool OCC>
 __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
 {
-    __shared__ float4 pixc[16][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
+    __shared__ float4 pixc[NPIX][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
                                                          //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
     __shared__ uint32_t list[UNIT_GROUPS * WAVE + WAVE]; // compacted list positions of up to UNIT_GROUPS mask words + a batch's worth carried over
@@ -629,8 +640,9 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
     __shared__ float xocc[OCC ? WAVE : 1];               // ... and of the occlusion values' gradient
     __shared__ uint32_t xgid_o[OCC ? WAVE : 1];
     const int xcd = bx & 7, kth = bx >> 3;
-    const int rank0 = (kth >> 4) * 8 + xcd, blk = kth & 15;
-    const int stride = (int)(gridDim.x >> 4);                // ranks per pass of the grid (a multiple of 8)
+    constexpr int PER_TILE = 16 / REGION;                    // wavefronts per tile
+    const int rank0 = (kth / PER_TILE) * 8 + xcd, blk = (kth % PER_TILE) * REGION;
+    const int stride = (int)(gridDim.x / PER_TILE);          // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
     for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, list, xpose, xgid, xocc, xgid_o);
 }
@@ -686,7 +698,7 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     StageTimer timer(ST_RENDER_BWD, stream);
     const int grid_ranks = blend_grid_ranks(a.ntiles);
     a.masks = b.block_masks; a.mask_plane = b.mask_plane;
-    const dim3 grid_blocks(16 * min((a.ntiles + 7) / 8 * 8, grid_ranks));
+    const dim3 grid_blocks((16 / REGION) * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
         if (blend && occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
         else if (blend) SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
