@@ -17,6 +17,8 @@
 // (352 us); this file holds the form that replaced them (298-306 us).
 #include "soar_common.h"
 
+#include <type_traits>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -152,6 +154,10 @@ constexpr int DPP_WAVE_SHR1 = 0x138;
 constexpr int REGION = SOAR_BWD_REGION;              // 4 x 4 blocks a wavefront takes (side by side)
 constexpr int NPIX = 16 * REGION;
 static_assert(REGION == 1 || REGION == 2 || REGION == 4, "one block, a pair side by side, or the four of a quad");
+#ifndef SOAR_BWD_PACKED
+#define SOAR_BWD_PACKED 1
+#endif
+static_assert(!(SOAR_BWD_PACKED && SOAR_BWD_DIV), "the packed pixel steps only carry the default division form");
 #ifndef SOAR_BWD_UNIT_GROUPS
 #define SOAR_BWD_UNIT_GROUPS 4     // (mask words compacted at a time: 1.3 KB of list; with the 32 pixels' rows 7.7 KB of LDS per wavefront: 21 per CU, the registers allow 20)
 #endif
@@ -198,6 +204,117 @@ __device__ __forceinline__ void affine_scan(float &m, float &b)
 // reciprocal of 1 - alpha) instead of s_nop: a scalar instruction between vector ones costs a wavefront far more than its slot
 // (tests/tools/issue_model: ~10 cycles per alternation, whatever the number of resident wavefronts).
 struct PairProducts { float dxdx, dxdy, dydy, gA, gC, r_om; };
+// Segmented forms (round 5): the scan over SEGMENTS of 16 or 32 lanes -- rows of 16 never look across their boundary in the first four
+// steps, the fifth step joins the rows of a half, the sixth the halves; leaving the last one / two steps out is the whole difference.
+template <int S>
+__device__ __forceinline__ PairProducts affine_scan_with_products_seg(float &m, float &b, float dx, float dy, float A, float B, float C)
+{
+    static_assert(S == 16 || S == 32, "segments of rows");
+    PairProducts o;
+    if constexpr (S == 16) {
+        asm volatile(
+            "v_mul_f32 %2, %8, %8\n\t"
+            "v_mul_f32 %3, %8, %9\n\t"
+            "v_rcp_f32 %7, %1\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %4, %9, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %5, %10, %8\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %6, %12, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32 %5, %11, %9\n\t"
+            "v_fmac_f32 %6, %11, %8"
+            : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om)
+            : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    } else {
+        asm volatile(
+            "v_mul_f32 %2, %8, %8\n\t"
+            "v_mul_f32 %3, %8, %9\n\t"
+            "v_rcp_f32 %7, %1\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %4, %9, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %5, %10, %8\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %6, %12, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32 %5, %11, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_fmac_f32 %6, %11, %8"
+            : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om)
+            : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    }
+    return o;
+}
+template <int S>
+__device__ __forceinline__ PairProducts affine_scan_with_products_occ_seg(float &m, float &b, float &mo, float dx, float dy, float A, float B, float C)
+{
+    static_assert(S == 16 || S == 32, "segments of rows");
+    PairProducts o;
+    if constexpr (S == 16) {
+        asm volatile(
+            "v_mul_f32 %2, %9, %9\n\t"
+            "v_mul_f32 %3, %9, %10\n\t"
+            "v_rcp_f32 %7, %1\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %4, %10, %10\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %5, %11, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %6, %13, %10\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32 %5, %12, %10\n\t"
+            "v_fmac_f32 %6, %12, %9"
+            : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om), "+v"(mo)
+            : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    } else {
+        asm volatile(
+            "v_mul_f32 %2, %9, %9\n\t"
+            "v_mul_f32 %3, %9, %10\n\t"
+            "v_rcp_f32 %7, %1\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %4, %10, %10\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %5, %11, %9\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %6, %13, %10\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32 %5, %12, %10\n\t"
+            "v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_mul_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_fmac_f32 %6, %12, %9"
+            : "+v"(b), "+v"(m), "=&v"(o.dxdx), "=&v"(o.dxdy), "=&v"(o.dydy), "=&v"(o.gA), "=&v"(o.gC), "=&v"(o.r_om), "+v"(mo)
+            : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
+    }
+    return o;
+}
 __device__ __forceinline__ PairProducts affine_scan_with_products(float &m, float &b, float dx, float dy, float A, float B, float C)
 {
     PairProducts o;
@@ -444,10 +561,16 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     uint32_t rgid = 0u, rpos = 0xFFFFFFFFu;
     int cnt_e = 0, cnt_r = 0;
 
+    // A batch of at most 16 (32) entries is worked on FOUR (TWO) pixels at a time: every segment of 16 (32) lanes holds a copy of the
+    // batch -- lane = (pixel of the group, entry) -- and the scan runs inside the segments (SOAR_BWD_PACKED, round 5: a pixel step costs
+    // the same ~90 vector instructions whether 5 or 64 of its lanes hold an entry, and 26 % of all pixel steps belong to batches of
+    // at most 32 entries: the last batch of a block's list, or its only one)
+    auto seg_of = [](int cnt) { return SOAR_BWD_PACKED && cnt <= 16 ? 16 : SOAR_BWD_PACKED && cnt <= 32 ? 32 : WAVE; };
     auto fetch_ids = [&](int cnt, uint32_t &gid, uint32_t &pos) {
         pos = 0xFFFFFFFFu;
-        if (lane < cnt) {
-            const uint32_t at = ring[lane];
+        const int li = lane & (seg_of(cnt) - 1);
+        if (li < cnt) {
+            const uint32_t at = ring[li];
             gid = a.point_list[at];
             pos = at - x0;
         }
@@ -466,7 +589,48 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
             if (OCC) rfront = a.front[rgid];
         }
     };
+    int pending_seg = WAVE, pending_cnt = 0;      // how the batch whose sums wait in LDS was laid out (wave-uniform)
+    // a packed batch: every segment holds partial sums of the same (at most S) entries -- added here, segment 0 first
+    auto flush_packed = [&](auto s_tag) {
+        constexpr int S = decltype(s_tag)::value, NS = WAVE / S, KMAX = S / 4;       // four whole rows per instruction, like the other form
+        const int r4 = lane >> 4, q = lane & 15;
+        const bool has_q = q < 13;
+        const float *xp = xpose + (has_q ? 13 * r4 + q : 0);
+        const uint32_t *xg = xgid + r4;
+        uint32_t g[KMAX];
+        float v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            g[k] = 0xFFFFFFFFu; v[k] = 0.f;
+            if (4 * k < pending_cnt) {                       // (wave-uniform: rows 4 k .. 4 k + 3 hold entries)
+                uint32_t gg[NS];
+                float vv[NS];
+#pragma unroll
+                for (int t = 0; t < NS; t++) { gg[t] = xg[4 * k + t * S]; vv[t] = xp[52 * k + t * S * 13]; }
+                g[k] = gg[0]; v[k] = vv[0];
+#pragma unroll
+                for (int t = 1; t < NS; t++) { g[k] = min(g[k], gg[t]); v[k] += vv[t]; }      // (an entry dead in a segment: id 0xFFFFFFFF, sums 0)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            if (has_q && g[k] != 0xFFFFFFFFu) {
+                if (WIDE) atomicAdd(a.acc64 + (size_t)g[k] * ACC_STRIDE + q, (double)v[k]);
+#ifdef SOAR_EXP_NO_ATOMICS
+                else if (g[k] == 0xFFFFFFFEu) a.acc[q] = v[k];
+#else
+                else atomicAdd(a.acc + (size_t)g[k] * ACC_STRIDE + q, v[k]);
+#endif
+            }
+        }
+        if (OCC) {
+            const float vo = xocc[lane];                     // (every segment adds its own part)
+            if (vo != 0.f) atomicAdd(a.g_values + xgid_o[lane], vo);
+        }
+    };
     auto flush_atomics = [&]() {
+        if (pending_seg == 16) { flush_packed(std::integral_constant<int, 16>()); return; }
+        if (pending_seg == 32) { flush_packed(std::integral_constant<int, 32>()); return; }
         // Every instruction adds WHOLE rows: lane = (one of the four rows of the instruction, component), 13 of 16 lanes at work,
         // 16 instructions for the 64 entries.  (Until late in round 5: 13 instructions over the 832 floats as they lie -- a row that
         // straddled two instructions was two requests at the L2, 1.2 per row, and the device-wide float atomics of this path are
@@ -532,6 +696,81 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         float any_live = 0.f;                    // > 0: some pair of this lane's entry was live
         float acc_o = 0.f;                       // OCC: sum over the pixels of weight x upstream gradient of this lane's entry
         const float oh = -0.5f * eop;
+        const int seg = seg_of(cnt_e);           // (wave-uniform)
+        // ---- packed: NS = 64 / S pixels per step, lane = (pixel s = lane / S of the group, entry lane % S)
+        auto packed_pixels = [&](auto s_tag) {
+            constexpr int S = decltype(s_tag)::value, NS = WAVE / S;
+            const int sub = lane / S;
+            const bool seg_first = (lane & (S - 1)) == 0, seg_last = (lane & (S - 1)) == S - 1;
+            while (act) {
+                int pp[NS], np = 1;
+                pp[0] = (int)__builtin_ctzll(act);
+                act &= act - 1ull;
+#pragma unroll
+                for (int k = 1; k < NS; k++) {
+                    pp[k] = pp[0];
+                    if (act) { pp[k] = (int)__builtin_ctzll(act); act &= act - 1ull; np = k + 1; }
+                }
+                int p = pp[0];
+#pragma unroll
+                for (int k = 1; k < NS; k++) p = sub == k ? pp[k] : p;
+                const bool has_pixel = sub < np;             // (a group may end short: its idle segments compute on pixel pp[0] with every pair dead)
+                const float4 c0 = pixc[p][0], c1 = pixc[p][1], c2 = pixc[p][2];
+                const float4 tp = pixc[p][3];
+                const uint32_t last_p = has_pixel ? __float_as_uint(c2.w) : 0u;
+                const float T_in = tp.x, P_in = tp.y;
+                const float dx = ex - c0.x, dy = ey - c0.y;
+                const float power = falloff_power(eA, eB, eC, dx, dy);
+                const float Gx = exp_nonpositive(power);
+                const float alpha = fminf(0.99f, eop * Gx);
+                float a_eff = (power > 0.0f) ? 0.f : alpha;
+                a_eff = (alpha < 1.0f / 255.0f) ? 0.f : a_eff;
+                float a_o = 0.f, m_o = 1.f;
+                if (OCC) {
+                    const uint32_t last_occ = has_pixel ? __float_as_uint(tp.w) : 0u;
+                    a_o = (epos < last_occ) ? a_eff * efront : 0.f;
+                    m_o = 1.f - a_o;
+                }
+                a_eff = (epos < last_p) ? a_eff : 0.f;
+                const bool live = a_eff != 0.f;
+                const float G = live ? Gx : 0.f;
+                const float d_cur = edepth - (dx * epa + dy * epb);
+                const float u = er * c0.z + eg * c0.w + eb * c1.x + enx * c1.y + eny * c1.z + enz * c1.w + d_cur * c2.y;
+                float m = 1.f - a_eff, b = a_eff * u;
+                const PairProducts pp_ = OCC ? affine_scan_with_products_occ_seg<S>(m, b, m_o, dx, dy, eA, eB, eC)
+                                             : affine_scan_with_products_seg<S>(m, b, dx, dy, eA, eB, eC);
+                const float P_front = __builtin_fmaf(m, P_in, b);
+                const float T_mine = T_in * __builtin_amdgcn_rcpf(m);
+                const float r_om = pp_.r_om;
+                float P_mine = dpp_or<DPP_WAVE_SHR1, 0xf>(P_in, P_front);
+                P_mine = seg_first ? P_in : P_mine;          // (the lane in front belongs to another pixel)
+                const float wgt = a_eff * T_mine;
+                acc[6] = __builtin_fmaf(wgt, c0.z, acc[6]); acc[7] = __builtin_fmaf(wgt, c0.w, acc[7]);
+                acc[8] = __builtin_fmaf(wgt, c1.x, acc[8]);
+                acc[9] = __builtin_fmaf(wgt, c1.y, acc[9]); acc[10] = __builtin_fmaf(wgt, c1.z, acc[10]);
+                acc[11] = __builtin_fmaf(wgt, c1.w, acc[11]);
+                acc[12] = __builtin_fmaf(wgt, c2.y, acc[12]);
+                const float dL_dalpha = __builtin_fmaf(u - P_mine, T_mine, c2.z * r_om);
+                const float dL_ddist = dL_dalpha * (oh * G);
+                acc[0] = __builtin_fmaf(dL_ddist, pp_.gA, acc[0]);
+                acc[1] = __builtin_fmaf(dL_ddist, pp_.gC, acc[1]);
+                acc[2] = __builtin_fmaf(dL_ddist, pp_.dxdx, acc[2]);
+                acc[3] = __builtin_fmaf(dL_ddist, pp_.dxdy, acc[3]);
+                acc[4] = __builtin_fmaf(dL_ddist, pp_.dydy, acc[4]);
+                acc[5] = __builtin_fmaf(G, dL_dalpha, acc[5]);
+                sdD += live ? c2.x : 0.f;
+                any_live += a_eff;
+                if (OCC) {
+                    const float To_mine = tp.z * __builtin_amdgcn_rcpf(m_o);
+                    acc_o = __builtin_fmaf(a_o * To_mine, pixc[p][4].x, acc_o);
+                    if (seg_last && has_pixel) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(T_mine, P_front, To_mine, tp.w);
+                } else {
+                    if (seg_last && has_pixel) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
+                }
+            }
+        };
+        if (seg == 16) packed_pixels(std::integral_constant<int, 16>());
+        else if (seg == 32) packed_pixels(std::integral_constant<int, 32>());
         while (act) {
             const int p = (int)__builtin_ctzll(act);
             act &= act - 1ull;
@@ -616,6 +855,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         pending = true;
+        pending_seg = seg;
+        pending_cnt = cnt_e;
     }
     if (pending) flush_atomics();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // the next tile of this wavefront reuses the LDS arrays
