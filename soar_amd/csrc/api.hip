@@ -705,10 +705,10 @@ static int backward_impl(const SoarRastParams *prm, const float *means3D, const 
                          : nullptr;
     {
         // accumulation rows and the camera gradients (atomic sums of the two backward kernels) in one launch
-        const ZeroRange zr[5] = {{wide ? (void *)acc64 : (void *)acc, (wide ? sizeof(double) : sizeof(float)) * ACC_STRIDE * (size_t)prm->P},
-                                 {dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)},
-                                 {dL_docc, sizeof(float) * (size_t)prm->P}};
-        if (launch_zero_ranges(zr, dL_docc ? 5 : 4, stream)) return 1;
+        // (the gradient of the occlusion values travels in slot 13 of the rows and is written, every element, by the geometry backward)
+        const ZeroRange zr[4] = {{wide ? (void *)acc64 : (void *)acc, (wide ? sizeof(double) : sizeof(float)) * ACC_STRIDE * (size_t)prm->P},
+                                 {dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)}};
+        if (launch_zero_ranges(zr, 4, stream)) return 1;
     }
     if (num_rendered > 0 || wide) {
         if (launch_render_backward(*prm, g, b, img, dL_dout_color, dL_dout_normal, dL_dout_depth, dL_dout_opac, grad_scale_dev, acc,
@@ -717,7 +717,7 @@ static int backward_impl(const SoarRastParams *prm, const float *means3D, const 
     }
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
                                  dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat,
-                                 dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/false, stream))
+                                 dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/false, stream, dL_docc))
         return 1;
     return 0;
 }

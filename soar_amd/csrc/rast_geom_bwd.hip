@@ -51,6 +51,7 @@ struct GeomBwdArgs {
     const float *acc;
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
     float *dL_dviewmat, *dL_dprojmat, *dL_dcampos;
+    float *dL_docc;          // != NULL: slot 13 of the rows is the gradient of the Gaussian's occlusion value (soar_rast_backward_occ)
 };
 
 // sum a per-thread value over the wave and let one lane issue the global atomic (camera gradients only)
@@ -77,8 +78,9 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(Batch<GeomBwdArg
         acc[0] = r0.x; acc[1] = r0.y; acc[2] = r0.z; acc[3] = r0.w;
         acc[4] = r1.x; acc[5] = r1.y; acc[6] = r1.z; acc[7] = r1.w;
         acc[8] = r2.x; acc[9] = r2.y; acc[10] = r2.z; acc[11] = r2.w;
-        acc[12] = r3.x;
+        acc[12] = r3.x; acc[13] = r3.y;
     }
+    if (a.dL_docc && in_range) a.dL_docc[idx] = acc[13];      // (every Gaussian: nothing else writes this output)
 
     float g_mean[3] = {0.f, 0.f, 0.f};
     float g_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -350,7 +352,8 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
-                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream)
+                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream,
+                             float *dL_docc)
 {
     GeomBwdArgs a;
     a.P = prm.P; a.D = prm.sh_degree; a.M = prm.M; a.W = prm.W; a.H = prm.H;
@@ -367,6 +370,7 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
     a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity; a.dL_dmeans3D = dL_dmeans3D;
     a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations;
     a.dL_dviewmat = dL_dviewmat; a.dL_dprojmat = dL_dprojmat; a.dL_dcampos = dL_dcampos;
+    a.dL_docc = dL_docc;
     if (zero_camera_grads) {
         const ZeroRange zr[3] = {{dL_dviewmat, 16 * sizeof(float)}, {dL_dprojmat, 16 * sizeof(float)}, {dL_dcampos, 3 * sizeof(float)}};
         if (launch_zero_ranges(zr, 3, stream)) return 1;

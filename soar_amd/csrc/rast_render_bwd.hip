@@ -408,9 +408,10 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 //     batch's gather: the wait for the gather of batch n + 2 then finds the atomics in front of it a whole pixel loop old.
 template <bool WIDE, bool OCC>
 __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
-                                               uint32_t *list, float *xpose, uint32_t *xgid, float *xocc, uint32_t *xgid_o)
+                                               uint32_t *list, float *xpose, uint32_t *xgid)
 {
     const int lane = threadIdx.x & 63;
+    constexpr int NC = OCC ? 14 : 13, XS = OCC ? 15 : 13;       // components of a row that leave; stride of a row in `xpose`
     // tile and list range in ONE load (ImageBuf::order_rec; ranks below n_work are tiles with work)
     const uint4 orec = a.order_rec[rank];
     const int tile = (int)orec.x;
@@ -594,8 +595,8 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     auto flush_packed = [&](auto s_tag) {
         constexpr int S = decltype(s_tag)::value, NS = WAVE / S, KMAX = S / 4;       // four whole rows per instruction, like the other form
         const int r4 = lane >> 4, q = lane & 15;
-        const bool has_q = q < 13;
-        const float *xp = xpose + (has_q ? 13 * r4 + q : 0);
+        const bool has_q = q < NC;
+        const float *xp = xpose + (has_q ? XS * r4 + q : 0);
         const uint32_t *xg = xgid + r4;
         uint32_t g[KMAX];
         float v[KMAX];
@@ -606,7 +607,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 uint32_t gg[NS];
                 float vv[NS];
 #pragma unroll
-                for (int t = 0; t < NS; t++) { gg[t] = xg[4 * k + t * S]; vv[t] = xp[52 * k + t * S * 13]; }
+                for (int t = 0; t < NS; t++) { gg[t] = xg[4 * k + t * S]; vv[t] = xp[4 * XS * k + t * S * XS]; }
                 g[k] = gg[0]; v[k] = vv[0];
 #pragma unroll
                 for (int t = 1; t < NS; t++) { g[k] = min(g[k], gg[t]); v[k] += vv[t]; }      // (an entry dead in a segment: id 0xFFFFFFFF, sums 0)
@@ -623,10 +624,6 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #endif
             }
         }
-        if (OCC) {
-            const float vo = xocc[lane];                     // (every segment adds its own part)
-            if (vo != 0.f) atomicAdd(a.g_values + xgid_o[lane], vo);
-        }
     };
     auto flush_atomics = [&]() {
         if (pending_seg == 16) { flush_packed(std::integral_constant<int, 16>()); return; }
@@ -639,15 +636,15 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         // lane constants now instead of 13 (entry, component) pairs.)
         static_assert(ACC_STRIDE == 16 && WAVE == 64, "four rows of 16 floats per instruction");
         const int r4 = lane >> 4, q = lane & 15;
-        const bool has_q = q < 13;
-        const float *xp = xpose + (has_q ? 13 * r4 + q : 0);
+        const bool has_q = q < NC;
+        const float *xp = xpose + (has_q ? XS * r4 + q : 0);
         const uint32_t *xg = xgid + r4;
         uint32_t g[16];
         float v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             g[k] = xg[4 * k];
-            v[k] = xp[52 * k];
+            v[k] = xp[4 * XS * k];
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -659,10 +656,6 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 else atomicAdd(a.acc + (size_t)g[k] * ACC_STRIDE + q, v[k]);
 #endif
             }
-        }
-        if (OCC) {
-            const float vo = xocc[lane];
-            if (vo != 0.f) atomicAdd(a.g_values + xgid_o[lane], vo);
         }
     };
 
@@ -848,9 +841,9 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         acc[1] = acc[1] * two_ddely - sdD * epb;
         acc[9] *= 10.f; acc[10] *= 10.f; acc[11] *= 10.f;
 #pragma unroll
-        for (int q = 0; q < 13; q++) xpose[lane * 13 + q] = acc[q];
-        xgid[lane] = any_live != 0.f ? egid : 0xFFFFFFFFu;
-        if (OCC) { xocc[lane] = acc_o; xgid_o[lane] = egid; }
+        for (int q = 0; q < 13; q++) xpose[lane * XS + q] = acc[q];
+        if (OCC) xpose[lane * XS + 13] = acc_o;          // (slot 13 of the Gaussian's row: leaves with the same request as the others)
+        xgid[lane] = (any_live != 0.f || (OCC && acc_o != 0.f)) ? egid : 0xFFFFFFFFu;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -876,16 +869,14 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
                                                          //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
     __shared__ uint32_t list[UNIT_GROUPS * WAVE + WAVE]; // compacted list positions of up to UNIT_GROUPS mask words + a batch's worth carried over
-    __shared__ float xpose[WAVE * 13];                   // a batch's sums, [entry][13]
-    __shared__ uint32_t xgid[WAVE];
-    __shared__ float xocc[OCC ? WAVE : 1];               // ... and of the occlusion values' gradient
-    __shared__ uint32_t xgid_o[OCC ? WAVE : 1];
+    __shared__ float xpose[WAVE * (OCC ? 15 : 13)];      // a batch's sums, [entry][13] ([entry][15] with the occlusion value's gradient as
+    __shared__ uint32_t xgid[WAVE];                      // the 14th: an odd stride keeps the lanes' writes on different banks)
     const int xcd = bx & 7, kth = bx >> 3;
     constexpr int PER_TILE = 16 / REGION;                    // wavefronts per tile
     const int rank0 = (kth / PER_TILE) * 8 + xcd, blk = (kth % PER_TILE) * REGION;
     const int stride = (int)(gridDim.x / PER_TILE);          // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
-    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, list, xpose, xgid, xocc, xgid_o);
+    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, list, xpose, xgid);
 }
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)

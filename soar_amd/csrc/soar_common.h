@@ -450,6 +450,7 @@ int launch_geometry_backward(const SoarRastParams &prm, const float *means3D, co
                              const float *scales, const float *rotations, const float *cov3D_precomp, const GeomBuf &g,
                              const float *acc, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
                              float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscales, float *dL_drotations,
-                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream);
+                             float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, bool zero_camera_grads, hipStream_t stream,
+                             float *dL_docc = nullptr);
 
 }  // namespace soar
