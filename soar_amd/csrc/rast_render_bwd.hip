@@ -148,12 +148,16 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 // reciprocal instead of a chain of divisions -- inside the gradient tolerance like the shared reciprocal of the other form
 // (the forward's T, n_contrib and final_T are not touched by any of this).
 constexpr int DPP_WAVE_SHR1 = 0x138;
+// REGION = the 4 x 4 blocks a wavefront takes: 1, 2 (side by side: 8 x 4 pixels) or the 4 of a quad.  A pair leaves 40 % fewer
+// accumulation rows and record gathers for 20 % more pixel steps: at C3 242 -> 219 us per 4-frame launch (a quad: 300; on small
+// images -- C2, 250 tiles with work per frame -- halving the number of wavefronts costs more than it saves: 82 -> 113 us).  NOT the
+// default: with pairs the worst element of dL_drotations of the C3-size surfel scene lands at 1.07e-4 / 1.16e-4 of the reference's
+// in six runs of eight (7.0e-5 in the others; single blocks: 4.9-6.6e-5 in sixteen) -- a pixel's entries are spread over 1.4 x as
+// many batches, and although every step of that is within an ulp the strict 1e-4 bar of tests/test_reference_build_gpu.py has no
+// room for it.  -DSOAR_BWD_REGION=2 builds it.
 #ifndef SOAR_BWD_REGION
-#define SOAR_BWD_REGION 2      // (1 / 2 / 4 blocks per wavefront: 245 / 234-237 / 300 us per 4-frame launch at C3)
+#define SOAR_BWD_REGION 1
 #endif
-constexpr int REGION = SOAR_BWD_REGION;              // 4 x 4 blocks a wavefront takes (side by side)
-constexpr int NPIX = 16 * REGION;
-static_assert(REGION == 1 || REGION == 2 || REGION == 4, "one block, a pair side by side, or the four of a quad");
 #ifndef SOAR_BWD_PACKED
 #define SOAR_BWD_PACKED 1
 #endif
@@ -378,6 +382,17 @@ __device__ __forceinline__ PairProducts affine_scan_with_products_occ(float &m, 
         : "v"(dx), "v"(dy), "v"(A), "v"(B), "v"(C));
     return o;
 }
+// The transmittance a pixel carries from one batch to the next: T_in / (the batch's product).  The lanes' own T_mine is T_in x v_rcp_f32
+// (1 ulp, used once); what is CARRIED takes one residual step -- the quotient to the last bit or next to it -- so that the error does
+// not grow with the number of batches a pixel's list is cut into (round 5: pairs of blocks cut it into 1.4 x as many).
+#ifndef SOAR_BWD_STATE_REFINE
+#define SOAR_BWD_STATE_REFINE 1
+#endif
+#if SOAR_BWD_STATE_REFINE
+#define SOAR_T_STATE(T_in_, m_, q0_) __builtin_fmaf(__builtin_fmaf(-(m_), (q0_), (T_in_)), __builtin_amdgcn_rcpf(m_), (q0_))
+#else
+#define SOAR_T_STATE(T_in_, m_, q0_) (q0_)
+#endif
 // device self-test of affine_scan (soar_selftest_affine_scan): out[lane] = {m, b} of the scan of known maps
 __global__ void selftest_affine_scan_kernel(const float *m_in, const float *b_in, float *out)
 {
@@ -406,12 +421,14 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 //     pixel loop cost sixteen registers and with them 36 bytes of scratch per lane -- more than the hidden round trip was worth);
 //   * the sums of batch n leave through LDS (13 row-contiguous atomic wave-instructions) at the start of batch n + 1, BEHIND that
 //     batch's gather: the wait for the gather of batch n + 2 then finds the atomics in front of it a whole pixel loop old.
-template <bool WIDE, bool OCC>
+template <bool WIDE, bool OCC, int REGION>
 __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
                                                uint32_t *list, float *xpose, uint32_t *xgid)
 {
     const int lane = threadIdx.x & 63;
     constexpr int NC = OCC ? 14 : 13, XS = OCC ? 15 : 13;       // components of a row that leave; stride of a row in `xpose`
+    constexpr int NPIX = 16 * REGION;
+    static_assert(REGION == 1 || REGION == 2 || REGION == 4, "one block, a pair side by side, or the four of a quad");
     // tile and list range in ONE load (ImageBuf::order_rec; ranks below n_work are tiles with work)
     const uint4 orec = a.order_rec[rank];
     const int tile = (int)orec.x;
@@ -756,9 +773,9 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 if (OCC) {
                     const float To_mine = tp.z * __builtin_amdgcn_rcpf(m_o);
                     acc_o = __builtin_fmaf(a_o * To_mine, pixc[p][4].x, acc_o);
-                    if (seg_last && has_pixel) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(T_mine, P_front, To_mine, tp.w);
+                    if (seg_last && has_pixel) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(SOAR_T_STATE(T_in, m, T_mine), P_front, SOAR_T_STATE(tp.z, m_o, To_mine), tp.w);
                 } else {
-                    if (seg_last && has_pixel) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
+                    if (seg_last && has_pixel) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(SOAR_T_STATE(T_in, m, T_mine), P_front);
                 }
             }
         };
@@ -831,9 +848,9 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
                 // transmittance of the occlusion chain in front of my entry: T_in / (the factors behind and at it), like T_mine
                 const float To_mine = tp.z * __builtin_amdgcn_rcpf(m_o);
                 acc_o = __builtin_fmaf(a_o * To_mine, pixc[p][4].x, acc_o);
-                if (lane == 63) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(T_mine, P_front, To_mine, tp.w);
+                if (lane == 63) *reinterpret_cast<float4 *>(&pixc[p][3]) = make_float4(SOAR_T_STATE(T_in, m, T_mine), P_front, SOAR_T_STATE(tp.z, m_o, To_mine), tp.w);
             } else {
-                if (lane == 63) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(T_mine, P_front);
+                if (lane == 63) *reinterpret_cast<float2 *>(&pixc[p][3]) = make_float2(SOAR_T_STATE(T_in, m, T_mine), P_front);
             }
         }
         // the batch's sums -> LDS, [entry][13]; they leave at the start of the next step
@@ -862,9 +879,10 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
 #endif
 // one wavefront per workgroup: a finished block frees its slot at once.  Grid = 16 x ranks; the 16 blocks of a tile are
 // consecutive workgroups of one XCD (its L2 holds the tile's records), ranks dealt round-robin to the XCDs.
-template <bool WIDE, bool OCC>
+template <bool WIDE, bool OCC, int REGION>
 __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
 {
+    constexpr int NPIX = 16 * REGION;
     __shared__ float4 pixc[NPIX][5];                       // per pixel: {fx, fy, dC0, dC1 | dC2, dN0, dN1, dN2 | dD, dD_ch, tail terms, last |
                                                          //             T, P, T_occ, last_occ | upstream gradient of the occlusion image, -, -, -}
     __shared__ uint32_t ring[WAVE];
@@ -876,23 +894,23 @@ __device__ __forceinline__ void backward_blocks(const BwdArgs &a, int bx)
     const int rank0 = (kth / PER_TILE) * 8 + xcd, blk = (kth % PER_TILE) * REGION;
     const int stride = (int)(gridDim.x / PER_TILE);          // ranks per pass of the grid (a multiple of 8)
     const int n_work = (int)a.tile_order[(a.ntiles + 7) / 8 * 8];
-    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC>(a, rank, blk, pixc, ring, list, xpose, xgid);
+    for (int rank = rank0; rank < n_work; rank += stride) backward_block<WIDE, OCC, REGION>(a, rank, blk, pixc, ring, list, xpose, xgid);
 }
-template <bool WIDE>
+template <bool WIDE, int REGION>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOAR_BWD_BLK_WPE, 8))) render_backward_blocks_kernel(Batch<BwdArgs> batch)
 {
     int frame, bx;
     batch_interleave(frame, bx);
-    backward_blocks<WIDE, false>(batch.v[frame], bx);
+    backward_blocks<WIDE, false, REGION>(batch.v[frame], bx);
 }
 // ... with the fused occlusion chain walked in the same pass (soar_rast_backward_occ): a few registers more than the 128 that four
 // wavefronts per SIMD allow
-template <bool WIDE>
+template <bool WIDE, int REGION>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) render_backward_blocks_occ_kernel(Batch<BwdArgs> batch)
 {
     int frame, bx;
     batch_interleave(frame, bx);
-    backward_blocks<WIDE, true>(batch.v[frame], bx);
+    backward_blocks<WIDE, true, REGION>(batch.v[frame], bx);
 }
 
 }  // namespace
@@ -930,18 +948,19 @@ int launch_render_backward(const SoarRastParams &prm, const GeomBuf &g, const Bi
     StageTimer timer(ST_RENDER_BWD, stream);
     const int grid_ranks = blend_grid_ranks(a.ntiles);
     a.masks = b.block_masks; a.mask_plane = b.mask_plane;
-    const dim3 grid_blocks((16 / REGION) * min((a.ntiles + 7) / 8 * 8, grid_ranks));
+    constexpr int region = SOAR_BWD_REGION;
+    const dim3 grid_blocks((16 / region) * min((a.ntiles + 7) / 8 * 8, grid_ranks));
     if (acc64) {
-        if (blend && occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
-        else if (blend) SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<true>), grid_blocks, dim3(64), 0, stream, a);
+        if (blend && occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<true, region>), grid_blocks, dim3(64), 0, stream, a);
+        else if (blend) SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<true, region>), grid_blocks, dim3(64), 0, stream, a);
         // in a batch this launches with the last frame like the blend in front of it (it used to launch per call, i.e. for
         // the frames 0 .. n-2 BEFORE their rows had been accumulated)
         NarrowArgs na;
         na.n = (size_t)prm.P * ACC_STRIDE; na.wide = acc64; na.narrow = acc;
         SOAR_LAUNCH_BATCHED(narrow_rows_kernel, dim3((unsigned)((na.n + 255) / 256)), dim3(256), 0, stream, na);
     } else {
-        if (occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<false>), grid_blocks, dim3(64), 0, stream, a);
-        else SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<false>), grid_blocks, dim3(64), 0, stream, a);
+        if (occ) SOAR_LAUNCH_BATCHED((render_backward_blocks_occ_kernel<false, region>), grid_blocks, dim3(64), 0, stream, a);
+        else SOAR_LAUNCH_BATCHED((render_backward_blocks_kernel<false, region>), grid_blocks, dim3(64), 0, stream, a);
     }
     SOAR_LAUNCH_OK("render_backward", stream, prm.debug & 1);
     return 0;

@@ -207,9 +207,12 @@ def test_c5_frame_matches_the_reference_kernels():
     state, per-pixel contributor counts and final transmittance bit-exact, images within 1e-5, the four accumulator-level gradient tensors
     within the strict 1e-4.  On the three cancellation-prone tensors the reference does not reproduce ITSELF to 1e-4 at this size (two runs
     of its kernels on the same inputs: 1.2e-4 / 1.2e-4 / 1.7e-4 in the max norm, profiles/r05_c5_reference_spread.txt -- hundreds of
-    surfels wider than 48 px, thousands of float atomics each): the test measures that spread and holds the product to max(8e-4, 6 x it)
-    in the max norm and max(2e-4, 4 x it) in L2 (measured: 2.5-3.8 x and 1.6-3.0 x, 6.4e-4 and 1.4e-4 at worst; the float64 rows do not
-    change it: it is not the order of the sums).  Before round 5: L2 <= 3e-4 only."""
+    surfels wider than 48 px, thousands of float atomics each): the test measures that spread and holds the product to max(1.2e-3, 6 x it)
+    in the max norm and max(2.5e-4, 4 x it) in L2.  Measured over 32 runs late in round 5 (the worst element of 1.2 M is a noisy
+    statistic): dL_drotations 5.9e-4 .. 9.5e-4 in the max norm and 1.2e-4 .. 2.0e-4 in L2, dL_dcov3D 2.4e-4 .. 4.4e-4 / 1.0e-4 .. 2.0e-4,
+    dL_dscales 1.5e-4 .. 4.6e-4 / 2.4e-5 .. 4.2e-5 -- the same range with the kernels of the start of the round, whose first three
+    samples (3.0 / 3.0 / 6.4e-4) the floors of 8e-4 / 2e-4 had been set by: one run in seven failed them.  The float64 rows do not
+    change it: it is not the order of the sums.  Before round 5: L2 <= 3e-4 only."""
     ref_r = _ref()
     scene = S.person_scene(P=300_000, W=3840, H=2160, seed=4, config=(1, 1, 1, 0), opacity=None, distance=2.2)
     grads = S.upstream_grads(scene)
@@ -234,4 +237,4 @@ def test_c5_frame_matches_the_reference_kernels():
         assert worst[k][0] <= 1e-4 and worst[k][1] <= 1e-4, (k, worst[k])
     for k in ("dL_dcov3D", "dL_dscales", "dL_drotations"):
         # (the spread of two runs is itself a noisy number: floors at the levels measured over the rounds, a quarter above the worst seen)
-        assert worst[k][0] <= max(8e-4, 6 * spread[k][0]) and worst[k][1] <= max(2e-4, 4 * spread[k][1]), (k, worst[k], spread[k])
+        assert worst[k][0] <= max(1.2e-3, 6 * spread[k][0]) and worst[k][1] <= max(2.5e-4, 4 * spread[k][1]), (k, worst[k], spread[k])
