@@ -7,8 +7,9 @@
 // block of a tile and walks, back to front from the deepest contributor of its pixels, only the list entries the block masks
 // (rast_blockmask.hip) name for it, 64 at a time with lane = entry: the back-to-front recurrences of a pixel become a 64-lane
 // DPP scan, the 13 gradient terms of an entry accumulate over the block's pixels in the lane's own registers and leave as
-// row-contiguous global_atomic_add_f32 wave-instructions into the 64-byte accumulation rows acc[gaussian][16], which
-// geometry_backward_kernel (rast_geom_bwd.hip) consumes.  Same small fixed grid with a rank-stride walk of the longest-first
+// global_atomic_add_f32 wave-instructions of four WHOLE 64-byte accumulation rows acc[gaussian][16] each (this hardware executes
+// them at the memory side, one request per row and instruction: the launch's bound until the rows stopped straddling instructions,
+// round 5), which geometry_backward_kernel (rast_geom_bwd.hip) consumes.  Same small fixed grid with a rank-stride walk of the longest-first
 // tile order as the forward kernel (rast_render_fwd.hip).  Details at the kernel below.
 //
 // Earlier layouts, measured and retired (profiles/README.md, negative results): per-lane entry pointers with ds_add_f32
@@ -142,8 +143,9 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 //     skipped by a scalar loop over the set bits of a ballot -- in the other form their lanes idle.
 // Survivors of the conservative block test are collected across chunk boundaries (a carried, partly filled batch keeps its
 // records in registers) so that batches are full except the last one of a block.  A batch's sums leave through a transposition
-// in LDS as 13 atomic wave-instructions over consecutive floats of the 52-byte row segments (rows of 64 different Gaussians
-// straight from the lanes would be 64 separate 4-byte requests per instruction).
+// in LDS as 16 atomic wave-instructions of four whole rows each (rows of 64 different Gaussians straight from the lanes would be 64
+// separate 4-byte requests per instruction; rounds 3-4: 13 instructions over the consecutive floats of the 52-byte row segments,
+// 1.2 requests per row).
 // About 100 vector instructions per (pixel, 64 entries) against 160 + 28; T in front of an entry is T_in / (product) with one
 // reciprocal instead of a chain of divisions -- inside the gradient tolerance like the shared reciprocal of the other form
 // (the forward's T, n_contrib and final_T are not touched by any of this).
@@ -419,7 +421,7 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 //     set bits are compacted, deepest first, into batches of 64 list positions; list ids are gathered straight into the lanes'
 //     registers one batch ahead, the records at the top of the batch's own turn (round 5: holding the next batch's records across the
 //     pixel loop cost sixteen registers and with them 36 bytes of scratch per lane -- more than the hidden round trip was worth);
-//   * the sums of batch n leave through LDS (13 row-contiguous atomic wave-instructions) at the start of batch n + 1, BEHIND that
+//   * the sums of batch n leave through LDS (16 atomic wave-instructions of four whole rows) at the start of batch n + 1, BEHIND that
 //     batch's gather: the wait for the gather of batch n + 2 then finds the atomics in front of it a whole pixel loop old.
 template <bool WIDE, bool OCC, int REGION>
 __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank, const int blk, float4 (*pixc)[5], uint32_t *ring,
