@@ -210,8 +210,8 @@ def test_c5_frame_matches_the_reference_kernels():
     surfels wider than 48 px, thousands of float atomics each): the test measures that spread and holds the product to max(1.2e-3, 6 x it)
     in the max norm and max(2.5e-4, 4 x it) in L2.  Measured over 32 runs late in round 5 (the worst element of 1.2 M is a noisy
     statistic): dL_drotations 5.9e-4 .. 9.5e-4 in the max norm and 1.2e-4 .. 2.0e-4 in L2, dL_dcov3D 2.4e-4 .. 4.4e-4 / 1.0e-4 .. 2.0e-4,
-    dL_dscales 1.5e-4 .. 4.6e-4 / 2.4e-5 .. 4.2e-5 -- the same range with the kernels of the start of the round, whose first three
-    samples (3.0 / 3.0 / 6.4e-4) the floors of 8e-4 / 2e-4 had been set by: one run in seven failed them.  The float64 rows do not
+    dL_dscales 1.5e-4 .. 4.6e-4 / 2.4e-5 .. 4.2e-5 -- with or without the packed pixel steps of the backward blend (profiles/r05_backward_regions_accuracy.txt).
+    The floors of 8e-4 / 2e-4 of earlier in the round had been set by three samples (3.0 / 3.0 / 6.4e-4): one run in seven failed them.  The float64 rows do not
     change it: it is not the order of the sums.  Before round 5: L2 <= 3e-4 only."""
     ref_r = _ref()
     scene = S.person_scene(P=300_000, W=3840, H=2160, seed=4, config=(1, 1, 1, 0), opacity=None, distance=2.2)
