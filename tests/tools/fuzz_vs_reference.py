@@ -61,8 +61,11 @@ def main():
     bad = 0
     benign = {}
     worst_img, worst_nc = 0.0, 0.0
+    only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]      # replay one scene of a sweep: --only=<its index>
     for it in range(N):
         scene = random_scene(rng)
+        if only and it not in only:
+            continue
         try:
             if scene.shs is not None and scene.sh_degree == 0:
                 pass
