@@ -149,6 +149,9 @@ __device__ __forceinline__ void load_pixel_at_once(const BwdArgs &a, int px, int
 // About 100 vector instructions per (pixel, 64 entries) against 160 + 28; T in front of an entry is T_in / (product) with one
 // reciprocal instead of a chain of divisions -- inside the gradient tolerance like the shared reciprocal of the other form
 // (the forward's T, n_contrib and final_T are not touched by any of this).
+#ifdef SOAR_BWD_HIST
+__device__ unsigned long long g_bwd_hist[16];
+#endif
 constexpr int DPP_WAVE_SHR1 = 0x138;
 // REGION = the 4 x 4 blocks a wavefront takes: 1, 2 (side by side: 8 x 4 pixels) or the 4 of a quad.  A pair leaves 40 % fewer
 // accumulation rows and record gathers for 20 % more pixel steps: at C3 242 -> 219 us per 4-frame launch (a quad: 300; on small
@@ -600,11 +603,7 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
     };
     auto gather = [&]() {                                             // records of (rgid, rpos)
         if (rpos != 0xFFFFFFFFu) {
-#ifdef SOAR_EXP_HOT_GATHER
-            const float4 *src = reinterpret_cast<const float4 *>(a.rec + (rgid & 1023u));       // (development: the records from 64 KB that stay in the caches)
-#else
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + rgid);
-#endif
             r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
             if (OCC) rfront = a.front[rgid];
         }
@@ -701,6 +700,13 @@ __device__ __forceinline__ void backward_block(const BwdArgs &a, const int rank,
         // ---- one batch: cnt_e entries x the pixels that reach it
         const uint32_t nearest = (uint32_t)__builtin_amdgcn_readlane((int)epos, cnt_e - 1);
         unsigned long long act = __ballot(vLast > nearest) & (NPIX == 64 ? ~0ull : (1ull << (NPIX & 63)) - 1ull);
+#ifdef SOAR_BWD_HIST
+        if (lane == 0) {     // development (scripts/bwd_hist.py): pixel steps / batches by the batch's entry count
+            const int bk = cnt_e <= 8 ? 0 : cnt_e <= 16 ? 1 : cnt_e <= 32 ? 2 : cnt_e < 64 ? 3 : 4;
+            atomicAdd(&g_bwd_hist[bk], (unsigned long long)__builtin_popcountll(act));
+            atomicAdd(&g_bwd_hist[8 + bk], 1ull);
+        }
+#endif
         float acc[13];
 #pragma unroll
         for (int q = 0; q < 13; q++) acc[q] = 0.f;
@@ -998,3 +1004,10 @@ extern "C" int soar_selftest_affine_scan(const float *m64_dev, const float *b64_
     SOAR_LAUNCH_OK("selftest_affine_scan", stream, 1);
     return 0;
 }
+
+#ifdef SOAR_BWD_HIST
+extern "C" int soar_debug_bwd_hist(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(soar::g_bwd_hist), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
