@@ -336,6 +336,198 @@ def torch_cpu_baseline(workload, parts, w, A_cano, threads, tg):
     return out
 
 
+def reference_same_box(workload, device):
+    """CONTEXT, not the target and never `value`: the reference's OWN rasterizer kernels (oracle/_ref/libref_rasterizer_fast.so =
+    forward.cu / backward.cu / rasterizer_impl.cu through hipify-perl, -O3 with the compiler's default FMA contraction; built by
+    oracle/ref_build/build_ref.sh where /root/reference exists, travels as a prebuilt checker) timed on THIS box after the timed region:
+    one view of the workload's size, forward and backward, inputs resident, each call bracketed by a device synchronisation (the
+    reference's forward blocks on its num_rendered read-back anyway).  The same rules as the cpu_baseline leg: a checker, outside the
+    timed region, never on the product's path.  None when the library is not there."""
+    here = os.path.join(ROOT, "oracle", "_ref", "libref_rasterizer_fast.so")
+    if not os.path.exists(here):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes as S
+        os.environ["SOAR_REF_LIB"] = "libref_rasterizer_fast.so"
+        from oracle import ref_rasterizer as rr
+        if os.path.basename(rr.LIB_PATH) != "libref_rasterizer_fast.so":
+            return {"fwd_ms": None, "bwd_ms": None, "build": "not measured: another reference library is already loaded in this process"}
+        P, W, H, _F = WORKLOADS[workload]
+        scene = S.person_scene(P=P, W=W, H=H, seed=2, config=(1, 1, 1, 0), opacity=None)      # (one view as the parity tests render it)
+        grads = S.upstream_grads(scene)
+        ref = rr.RefRasterizer(device=str(device))
+        ref.run(scene, grads=grads, state=False, repeat=2)
+        r = ref.run(scene, grads=grads, state=False, repeat=10)
+        # the product's own rasterizer through the same `_C` interface on the same view (NOT the batched step the headline times)
+        from soar_amd.rasterizer import _C
+        st = S.torch_settings(scene, device)
+        t = lambda a: torch.empty(0) if a is None else torch.as_tensor(a, dtype=torch.float32, device=device)
+        means, opac, cols, scl, rot = t(scene.means3D), t(scene.opacities), t(scene.colors), t(scene.scales), t(scene.rotations)
+        cov, sh = t(scene.cov3D), t(scene.shs)
+        g = [torch.as_tensor(x, device=device) for x in grads]
+        fwd = lambda: _C.rasterize_gaussians(st.bg, means, cols, opac, scl, rot, st.scale_modifier, cov, st.viewmatrix, st.projmatrix,
+                                             st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy, st.image_height, st.image_width, sh,
+                                             st.sh_degree, st.campos, st.prefiltered, st.render_front, st.sort_descending, st.debug, st.config)
+
+        def bwd(out):
+            R, _c, _n, _d, _o, radii, geom, binning, img = out
+            return _C.rasterize_gaussians_backward(st.bg, means, radii, cols, scl, rot, st.scale_modifier, cov, st.viewmatrix, st.projmatrix,
+                                                   st.prcppoint, st.patch_bbox, st.tanfovx, st.tanfovy, g[0], g[1], g[2], g[3], sh,
+                                                   st.sh_degree, st.campos, geom, R, binning, img, False, st.config)
+        out = fwd(); bwd(out); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out = fwd()
+            torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / 10 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(10):
+            bwd(out)
+            torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / 10 * 1e3
+        return {"fwd_ms": round(r["ms_forward"], 3), "bwd_ms": round(r["ms_backward"], 3), "num_rendered": int(r["R"]),
+                "product_one_view_fwd_ms": round(tf, 3), "product_one_view_bwd_ms": round(tb, 3),
+                "build": "hipify-perl -O3, context only: the reference's kernels on this box, one synchronous view of the workload's size "
+                         "(tests/scenes.py person_scene, white-noise upstream gradients), mean of 10 calls; product_one_view_*: the "
+                         "product's _C.rasterize_gaussians / _backward on the same view, same bracketing"}
+    except Exception as ex:                  # context must never hide the line
+        return {"fwd_ms": None, "bwd_ms": None, "build": f"failed: {ex!r}"}
+
+
+def rank_diagnostics(flat, stepper, frames_of, args, world, device, local_elapsed, max_rendered):
+    """Several ranks: what a first run on real hardware needs to explain itself.  Per-rank step time (the max is the
+    job's; the spread is the per-frame load imbalance SURVEY 8e expects), instances per rank, and -- from K more steps with events around
+    the stream-side waits -- what of each gradient bucket's flight the step did NOT hide.  Shared by the real ranks and `--dry-run`."""
+    flat.time_waits = True
+    for s in range(args.steps):
+        stepper(frames_of(args.warmup + s))
+    flat.wait_all()
+    waits = flat.wait_stats()
+    flat.time_waits = False
+    mine = torch.tensor([1e3 * local_elapsed / args.steps, max_rendered, waits.get("bucket0_wait_us", 0.0), waits.get("bucket1_wait_us", 0.0)],
+                        dtype=torch.float64, device=device)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = [t.tolist() for t in allr]
+    per_rank_ms = [round(r[0], 4) for r in rows]
+    return {"per_rank_ms_per_step": per_rank_ms,
+            "imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
+            "max_num_rendered_per_rank": [int(r[1]) for r in rows],
+            "bucket_wait_us_per_rank": [[round(r[2], 2), round(r[3], 2)] for r in rows],
+            "buckets": flat.n_buckets,
+            "how": ("per_rank_ms_per_step: each rank's own wall time for the K timed steps up to its device synchronisation, before the "
+                    "closing barrier; bucket_wait_us: mean stall of the waiting stream per gradient bucket (HIP events around the "
+                    f"stream-side wait), {args.steps} more steps after the timed region; buckets: SOAR_DP_BUCKETS")}
+
+
+def timed_region(stepper, frames_of, args, flat, use_dist, sync, before=None, after=None, step_marks=None):
+    """The contract's timed region: W untimed steps have run; barrier + synchronisation on both sides, EXACTLY K steps in between.
+    -> (elapsed with the closing barrier, this rank's own elapsed, the host's issue time).  Shared by the real ranks and `--dry-run`."""
+    flat.wait_all()
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    if before:
+        before()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        stepper(frames_of(args.warmup + s))
+        if step_marks is not None:
+            step_marks.append(time.perf_counter() - t0)
+    host_issue = time.perf_counter() - t0                        # the host is done ISSUING the K steps here; the device may still be working
+    flat.wait_all()                                              # the last step's gradient buckets
+    if after:
+        after()
+    sync()
+    local_elapsed = time.perf_counter() - t0                     # this rank's own K steps (before it waits for the others)
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, local_elapsed, host_issue
+
+
+def job_elapsed(elapsed, use_dist, device):
+    """the MAX over the ranks of the timed region"""
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def dry_run(args, world, rank):
+    """`bench.py --gpus N --dry-run`: the launcher, the rendezvous on 127.0.0.1, the frame sharding, the flat
+    gradient buffer's bucketed all-reduce, the timed region with its barriers, the per-rank / per-bucket aggregation and the one-line
+    contract -- exactly the code the real ranks run -- with gloo on the CPU and stand-in frames (a differentiable function of the shared
+    leaves and the frame id whose cost depends on the frame), so that the first run on an 8-GPU node cannot die in plumbing.  The line
+    says what it is (`data`: dry-run); its value is not a measurement of anything."""
+    from soar_amd import frame_dp
+    from soar_amd.frame_dp import FlatGradBuffer, global_batch, shard_frames
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    use_dist = world > 1 or os.environ.get("SOAR_BENCH_FORCE_DIST", "0") == "1"
+    device = torch.device("cpu")
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame_dp.FORCE_COLLECTIVES = use_dist and world == 1
+    torch.set_num_threads(1)
+    P, F = 4096, 400
+    gen = torch.Generator().manual_seed(0)                       # replicated parameters: the same seed on every rank
+    leaves = {n: torch.randn(P, w, generator=gen).requires_grad_(True) for n, w in frame_dp.LEAVES[:4]}
+    flat = FlatGradBuffer(leaves)
+    fps_per_rank = max(1, args.frames_per_step)
+    frames_of = lambda step: shard_frames(global_batch(step, fps_per_rank, world, F), rank, world)
+
+    def stepper(frames):
+        flat.wait_all()                                          # the previous step's reduction, then its (stand-in) update
+        with torch.no_grad():
+            for t in leaves.values():
+                t.add_(t.grad, alpha=-1e-3)
+        flat.flat.zero_()
+        for f in frames:
+            g = torch.Generator().manual_seed(1000 + f)
+            for _ in range(1 + f % 3):                           # frames of unequal cost
+                sum((torch.sin(t * (1 + 0.01 * f)) * torch.randn(t.shape, generator=g)).sum() for t in leaves.values()).backward()
+        flat.all_reduce_buckets()
+
+    for s in range(max(args.warmup, 1)):
+        stepper(frames_of(s))
+    elapsed, local_elapsed, host_issue = timed_region(stepper, frames_of, args, flat, use_dist, lambda: None)
+    dist_diag = rank_diagnostics(flat, stepper, frames_of, args, world, device, local_elapsed, 0.0) if use_dist else None
+    elapsed = job_elapsed(elapsed, use_dist, device)
+    # every rank ends with the same parameters (the same sums applied in the same order): the property frame-DP rests on
+    digest = torch.stack([t.detach().double().sum() for t in leaves.values()])
+    same = True
+    if use_dist:
+        flat.wait_all()
+        all_d = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(all_d, digest)
+        same = all(torch.equal(d, all_d[0]) for d in all_d)
+    total_frames = args.steps * fps_per_rank * world
+    result = {"metric": "fwd+bwd frames/sec @100k Gaussians, 1080p; achieved HBM GB/s vs roofline",
+              "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(1e3 * elapsed / args.steps, 3), "repeats_ms_per_step": [], "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f32",
+              "data": "dry-run: CPU stand-in frames over gloo -- launcher / rendezvous / sharding / all-reduce / aggregation plumbing only, NOT a measurement",
+              "config": {"workload": f"dry-run: {P} stand-in Gaussians, {F}-frame sequence, batch={fps_per_rank} frames/rank/step", "parallelism": f"frame-dp{world}",
+                         "mode": "dry-run", "collectives": (f"gloo: {flat.n_buckets} all-reduce bucket(s) per step" if use_dist else "none"),
+                         "replicas_identical": bool(same), "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3)},
+              "roofline": None, "cpu_baseline": None}
+    if dist_diag is not None:
+        result["ranks"] = dist_diag
+    if use_dist:
+        dist.destroy_process_group()
+    if not same:
+        raise SystemExit("dry-run: the ranks' parameters differ after the same steps")
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+
+
 def visible_gpu_count():
     """GPUs this job can use, found WITHOUT any torch.cuda / HIP call in this process (the parent of the ranks must never
     initialise the GPU: its children are fresh processes, but a parent that touched HIP may not exec or fork safely on this
@@ -369,7 +561,7 @@ def launch_ranks(n):
     rendezvous on 127.0.0.1) from a parent that has not initialised the GPU, print rank 0's JSON line, return the exit code."""
     import socket
     import subprocess
-    have = visible_gpu_count()                    # sysfs / environment only: no HIP call in this process
+    have = n if "--dry-run" in sys.argv else visible_gpu_count()     # sysfs / environment only: no HIP call in this process
     if have < n:
         print(f"[bench] --gpus {n} but only {have} GPU(s) visible: not running (a line with n_gpus != --gpus would be wrong)",
               file=sys.stderr)
@@ -426,6 +618,9 @@ def main():
                          "renderer's post-ops, loss_occ through the occlusion image's backward "
                          "(TS/system/gaussian_surfel_mvdream.py:305-338, 412-417) -- a second line, same units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: N gloo ranks on the CPU with stand-in frames through the same launcher, rendezvous, frame sharding, flat gradient "
+                         "all-reduce, timed region, per-rank aggregation and one-line contract (plumbing check for a multi-GPU node; not a measurement)")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--pmc-json", default=None,
                     help="rocprofv3 counter summary (scripts/make_traffic_json.py) whose FETCH_SIZE + WRITE_SIZE become roofline.traffic; "
@@ -454,6 +649,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     # SOAR_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, all-reduces, default mode) with
     # a single rank too -- the only way to exercise it on a one-GPU box
     use_dist = world > 1 or os.environ.get("SOAR_BENCH_FORCE_DIST", "0") == "1"
@@ -599,44 +796,39 @@ def main():
     # profiles/r05_bench_spread_20steps.txt).  The untimed steps that precede the timed region are issued HERE, right in front of it.
     for s in range(max(args.warmup, 2)):
         stepper(frames_of(s))
-    flat.wait_all()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
     step_marks = [] if os.environ.get("SOAR_BENCH_STEP_TIMES", "0") == "1" else None      # (diagnostic: when the host issued every step)
     # the same region on the device's clock: a HIP event pair on the stream the steps are issued on (every step of the plan ends on
     # it) -- `value` stays the host's wall clock between the synchronisations, as the contract says; both are in the line
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev_begin.record()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        stepper(frames_of(args.warmup + s))
-        if step_marks is not None:
-            step_marks.append(time.perf_counter() - t0)
-    host_issue = time.perf_counter() - t0                        # the host is done ISSUING the K steps here; the device may still be working
+    elapsed, local_elapsed, host_issue = timed_region(stepper, frames_of, args, flat, use_dist, torch.cuda.synchronize,
+                                                      before=ev_begin.record, after=ev_end.record, step_marks=step_marks)
     if step_marks is not None:
         per = [1e3 * (b - a) for a, b in zip([0.0] + step_marks[:-1], step_marks)]
         print("[bench] host issue per step (ms): " + " ".join(f"{v:.2f}" for v in per), file=sys.stderr)
-    flat.wait_all()                                              # the last step's gradient buckets
-    ev_end.record()
-    torch.cuda.synchronize()
-    local_elapsed = time.perf_counter() - t0                     # this rank's own K steps (before it waits for the others)
     device_ms_per_step = ev_begin.elapsed_time(ev_end) / args.steps
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # SOAR_BENCH_REPEAT=n (diagnostic): n more timed regions of the same K steps in this process, one line each on stderr -- tells a
-    # per-process spread (placement of the buffers, clocks at start) from a spread in time (other tenants of the node)
-    for rep in range(int(os.environ.get("SOAR_BENCH_REPEAT", "0"))):
+    # The spread of the number, in the line itself: SOAR_BENCH_REPEAT (default 4) more timed regions of the SAME K
+    # steps over the same frames in this process, bracketed like the contract's region (barrier + synchronisation on both sides, the max
+    # over the ranks).  `value` stays the FIRST region's; these are `repeats_ms_per_step`.  With a 17 ms region one collector pause or
+    # clock ramp is several per cent: the list says whether the first region was typical.
+    repeats_ms = []
+    for rep in range(int(os.environ.get("SOAR_BENCH_REPEAT", "4"))):
         torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
         r0 = time.perf_counter()
         for s in range(args.steps):
             stepper(frames_of(args.warmup + s))
         r_issue = time.perf_counter() - r0
         flat.wait_all()
         torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
         r_all = time.perf_counter() - r0
+        if use_dist:
+            t_rep = torch.tensor([r_all], dtype=torch.float64, device=device)
+            dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
+            r_all = float(t_rep.item())
+        repeats_ms.append(round(1e3 * r_all / args.steps, 4))
         print(f"[bench] repeat {rep}: {1e3 * r_all / args.steps:.3f} ms/step, host issue {1e3 * r_issue / args.steps:.3f} ms/step", file=sys.stderr)
     binning_status = None
     if plan is not None:
@@ -648,26 +840,8 @@ def main():
     #      steps with HIP events around the stream-side waits -- what of each gradient bucket's flight the step did NOT hide.
     dist_diag = None
     if use_dist:
-        flat.time_waits = True
-        for s in range(args.steps):
-            stepper(frames_of(args.warmup + s))
-        flat.wait_all()
-        waits = flat.wait_stats()
-        flat.time_waits = False
-        mine = torch.tensor([1e3 * local_elapsed / args.steps, float(max((n for n, _ in binning_status), default=0)) if binning_status else 0.0,
-                             waits.get("bucket0_wait_us", 0.0), waits.get("bucket1_wait_us", 0.0)], dtype=torch.float64, device=device)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rows = [t.tolist() for t in allr]
-        per_rank_ms = [round(r[0], 4) for r in rows]
-        dist_diag = {"per_rank_ms_per_step": per_rank_ms,
-                     "imbalance_max_over_mean": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
-                     "max_num_rendered_per_rank": [int(r[1]) for r in rows],
-                     "bucket_wait_us_per_rank": [[round(r[2], 2), round(r[3], 2)] for r in rows],
-                     "buckets": flat.n_buckets,
-                     "how": ("per_rank_ms_per_step: each rank's own wall time for the K timed steps up to its device synchronisation, before the "
-                             "closing barrier; bucket_wait_us: mean stall of the waiting stream per gradient bucket (HIP events around the "
-                             f"stream-side wait), {args.steps} more steps after the timed region; buckets: SOAR_DP_BUCKETS")}
+        dist_diag = rank_diagnostics(flat, stepper, frames_of, args, world, device, local_elapsed,
+                                     float(max((n for n, _ in binning_status), default=0)) if binning_status else 0.0)
     stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
     # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
     #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views
@@ -701,10 +875,7 @@ def main():
     else:
         for k, v in stats_timed.items():
             rasterizer.stats[k] = v
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job_elapsed(elapsed, use_dist, device)
 
     total_frames = args.steps * fps_per_rank * world
     value = total_frames / elapsed
@@ -777,7 +948,7 @@ def main():
     result = {
         "metric": "fwd+bwd frames/sec @100k Gaussians, 1080p; achieved HBM GB/s vs roofline",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "repeats_ms_per_step": repeats_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {P} Gaussians, {H}x{W}, {seq.num_frames}-frame sequence, "
                                f"batch={fps_per_rank} frames/GPU/step; frame = LBS warp + main rasterize fwd+bwd + "
@@ -832,6 +1003,8 @@ def main():
                                           "sample": f"failed: {ex!r}"}
         else:
             result["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            result["reference_same_box"] = reference_same_box(args.workload, device)
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -48,6 +48,9 @@ def lib():
         L.ref_rast_backward.restype = C.c_int
         L.ref_rast_backward.argtypes = ([_vp, C.c_int, C.c_int] + [_vp] * 5 + [C.c_float] + [_vp] * 7 + [C.c_float, C.c_float]
                                         + [_vp] * 19 + [C.c_int, _vp])
+        if hasattr(L, "ref_rast_backward_wide"):
+            L.ref_rast_backward_wide.restype = C.c_int
+            L.ref_rast_backward_wide.argtypes = [_vp, C.c_int] + list(L.ref_rast_backward.argtypes[1:])
         L.ref_rast_mark_visible.restype = C.c_int
         L.ref_rast_mark_visible.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
         L.ref_rast_state.restype = C.c_int
@@ -75,8 +78,11 @@ class RefRasterizer:
         except Exception:
             pass
 
-    def run(self, scene, grads=None, state=True, repeat=1):
-        """repeat > 1: the forward (and backward) calls are repeated on the resident inputs and the mean wall time per call
+    def run(self, scene, grads=None, state=True, repeat=1, wide=0):
+        """wide = 1 / 2: the backward blend's formulas evaluated by ref_shim.hip's wide kernel over the reference's own forward state --
+        per-Gaussian sums in float64, per-pixel arithmetic in the reference's float (1: order-free) or in float64 too (2: the value
+        the formulas define) -- followed by the reference's own per-Gaussian backward (ref_rast_backward_wide).
+        repeat > 1: the forward (and backward) calls are repeated on the resident inputs and the mean wall time per call
         (each call ends with a device synchronisation inside the shim) is returned as res["ms_forward"/"ms_backward"]."""
         import time
         import torch
@@ -138,7 +144,8 @@ class RefRasterizer:
                 if repeat > 1:
                     for v in outs.values():
                         v.zero_()                # the binding hands the kernels zeroed gradient tensors every call
-                rc = L.ref_rast_backward(self.h, scene.sh_degree, M, _ptr(bg), _ptr(means), _ptr(sh), _ptr(cols), _ptr(scl),
+                call = L.ref_rast_backward if not wide else (lambda h, *a: L.ref_rast_backward_wide(h, int(wide), *a))
+                rc = call(self.h, scene.sh_degree, M, _ptr(bg), _ptr(means), _ptr(sh), _ptr(cols), _ptr(scl),
                                          scene.scale_modifier, _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(prcp), _ptr(patch), cam.tanfovx, cam.tanfovy, _ptr(radii), *[_ptr(x) for x in g],
                                          *[v.data_ptr() for v in outs.values()], 0, _ptr(config))

@@ -427,7 +427,8 @@ int step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_
         b.Gx = poses[p].grad_scratch; b.Gr = b.Gx + 3 * nP; b.Gc = b.Gr + 4 * nP; b.Gs = b.Gc + 3 * nP; b.Go = b.Gs + 3 * nP; b.Gjunk = b.Go + nP;
         b.Gcam = b.Gjunk + 7 * nP;
         b.Gsum_s = b.Gcam + 35 * (size_t)views_per_pose[p];         // + [P][3]: the scales3 gradient summed over the views
-        b.Gocc3 = b.Gsum_s + 3 * P;                                  // + [P][16]: a back view's occlusion-pass backward
+        b.Gocc3 = b.Gsum_s + 3 * P;                                  // + [n][P][16]: a back view's occlusion-pass backward (a block per view:
+                                                                     //   two back views of a pose run on streams of their own)
     }
     ViewBuf vb[MAX_BATCH];
     bool live[MAX_BATCH], fused_occ[MAX_BATCH];
@@ -502,7 +503,7 @@ int step_views_backward(int32_t n_poses, const SoarPoseArgs *poses, const int32_
             const size_t pix = (size_t)a.rast.W * a.rast.H;
             SOAR_HIP_OK(hipMemsetAsync(vb[v].zero4, 0, sizeof(float) * 4 * pix, st_));
             float *junk = b.Gjunk + 7 * k * P, *cam = b.Gcam + 35 * k;
-            float *gc3 = b.Gocc3;                            // [P][3] + the throw-away blocks of a backward
+            float *gc3 = b.Gocc3 + 16 * k * P;               // this view's [P][3] + the throw-away blocks of a backward
             if (soar_rast_backward(&po, xyz_p, vb[v].radii_o, nullptr, pose->occ3, scales3, rot_p, nullptr, vb[v].geom_o, vb[v].binning_o,
                                    vb[v].img_o, a.capacity, a.g_occ, vb[v].zero4, vb[v].zero4 + 3 * pix, vb[v].zero4 + 3 * pix,
                                    gc3 + 3 * P, gc3, junk, gc3 + 6 * P, junk + P, nullptr, gc3 + 9 * P,
@@ -610,7 +611,7 @@ int soar_cameras_from_c2w(int32_t n, const float *c2w_dev, const float *c2w_host
 int soar_views_grad_scratch_floats(int32_t P, int32_t n_views, size_t *floats)
 {
     if (!floats || P < 0 || n_views < 1 || n_views > MAX_BATCH) { set_error("soar_views_grad_scratch_floats: bad arguments"); return 1; }
-    *floats = (size_t)n_views * P * (3 + 4 + 3 + 3 + 1 + 7) + 35 * (size_t)n_views + 3 * (size_t)P + 16 * (size_t)P;
+    *floats = (size_t)n_views * P * (3 + 4 + 3 + 3 + 1 + 7 + 16) + 35 * (size_t)n_views + 3 * (size_t)P;
     return 0;
 }
 

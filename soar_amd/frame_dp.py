@@ -147,7 +147,12 @@ class FlatGradBuffer:
 
     def wait_bucket(self, k: int):
         if k < len(self.pending) and self.pending[k] is not None:
-            if self.time_waits:
+            if self.time_waits and self.flat.device.type == "cpu":     # (gloo on the host: bench.py --dry-run, the CPU tests)
+                import time
+                t0 = time.perf_counter()
+                self.pending[k].wait()
+                self._wait_events.append((k, None, 1e6 * (time.perf_counter() - t0)))
+            elif self.time_waits:
                 dev = self.flat.device
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(dev))
@@ -161,10 +166,11 @@ class FlatGradBuffer:
     def wait_stats(self) -> Dict[str, float]:
         """Mean time (us) the waiting stream stalled for each bucket since ``time_waits`` was switched on (synchronises): what of a
         collective's flight the step did NOT hide.  {"bucket0_wait_us": .., "bucket1_wait_us": .., "waits": n}"""
-        torch.cuda.synchronize(self.flat.device)
+        if self.flat.device.type != "cpu":
+            torch.cuda.synchronize(self.flat.device)
         tot, cnt = {}, {}
         for k, e0, e1 in self._wait_events:
-            tot[k] = tot.get(k, 0.0) + e0.elapsed_time(e1) * 1e3
+            tot[k] = tot.get(k, 0.0) + (e1 if e0 is None else e0.elapsed_time(e1) * 1e3)
             cnt[k] = cnt.get(k, 0) + 1
         self._wait_events = []
         out = {f"bucket{k}_wait_us": round(tot[k] / cnt[k], 2) for k in sorted(tot)}

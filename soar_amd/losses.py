@@ -185,8 +185,6 @@ class _CosLossViews(torch.autograd.Function):
             raise RuntimeError("cos_loss runs on HIP devices only (torch device type 'cuda' on ROCm); there is no CPU fallback")
         dev = output.device
         B, Cn, H, W = output.shape
-        if B > 8:
-            raise ValueError("cos_loss: at most 8 views per call")
         inner = lambda t: t.stride()[1:] == (H * W, W, 1) and t.dtype == torch.float32 and t.stride(0) >= Cn * H * W
         a = output.detach()
         a = a if inner(a) else a.to(torch.float32).contiguous()
@@ -206,15 +204,17 @@ class _CosLossViews(torch.autograd.Function):
         es = a.element_size()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            check(L.soar_batch_begin(B), "soar_batch_begin")
-            try:
-                for v in range(B):
-                    check(L.soar_batch_frame(v), "soar_batch_frame")
-                    check(L.soar_cos_loss(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
-                                          None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
-                                          scratch.data_ptr() + 4 * k * v, stream), "soar_cos_loss")
-            finally:
-                L.soar_batch_end()
+            for v0 in range(0, B, 8):                            # (a batch of launches holds at most 8 views; the reference takes any B)
+                nb = min(8, B - v0)
+                check(L.soar_batch_begin(nb), "soar_batch_begin")
+                try:
+                    for v in range(v0, v0 + nb):
+                        check(L.soar_batch_frame(v - v0), "soar_batch_frame")
+                        check(L.soar_cos_loss(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
+                                              None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
+                                              scratch.data_ptr() + 4 * k * v, stream), "soar_cos_loss")
+                finally:
+                    L.soar_batch_end()
         cnt = stats[:, 1]
         total = cnt.sum()
         ctx.saved = (a, b, m, stats, ct, wt, total)
@@ -229,20 +229,24 @@ class _CosLossViews(torch.autograd.Function):
         B, Cn, H, W = a.shape
         L = hip_lib.lib()
         grad = torch.empty((B, Cn, H, W), dtype=torch.float32, device=dev)
-        # the kernel scales a view's gradient by upstream / count(view): upstream_v = g count_v / total gives g / total everywhere
+        # the kernel scales a view's gradient by upstream / max(count(view), 1): upstream_v = g count_v / total gives g / total everywhere.
+        # (A view without a selected pixel: upstream_v = 0 -- or NaN when no view has one -- and every gradient of it is the kernel's
+        # SELECTED zero, not a product with that factor.)
         up = (g.detach().to(device=dev, dtype=torch.float32).reshape(1) * stats[:, 1] / total).contiguous()
         es = a.element_size()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            check(L.soar_batch_begin(B), "soar_batch_begin")
-            try:
-                for v in range(B):
-                    check(L.soar_batch_frame(v), "soar_batch_frame")
-                    check(L.soar_cos_loss_backward(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
-                                                   None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
-                                                   up.data_ptr() + 4 * v, grad.data_ptr() + 4 * v * Cn * H * W, stream), "soar_cos_loss_backward")
-            finally:
-                L.soar_batch_end()
+            for v0 in range(0, B, 8):
+                nb = min(8, B - v0)
+                check(L.soar_batch_begin(nb), "soar_batch_begin")
+                try:
+                    for v in range(v0, v0 + nb):
+                        check(L.soar_batch_frame(v - v0), "soar_batch_frame")
+                        check(L.soar_cos_loss_backward(Cn, H, W, a.data_ptr() + v * a.stride(0) * es, b.data_ptr() + v * b.stride(0) * es,
+                                                       None if m is None else m.data_ptr() + v * H * W, ct, wt, stats.data_ptr() + 8 * v,
+                                                       up.data_ptr() + 4 * v, grad.data_ptr() + 4 * v * Cn * H * W, stream), "soar_cos_loss_backward")
+                finally:
+                    L.soar_batch_end()
         return grad, None, None, None, None
 
 
@@ -255,7 +259,7 @@ def masked_l1(img: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] 
 def cos_loss(output: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None, thrsh: float = 0.0,
              weight: float = 1.0) -> torch.Tensor:
     """``cos_loss`` of the reference (TS/system/gaussian_surfel_mvdream.py:622-630) for channel-first [3,H,W] normal images
-    in [0,1]: mean of 1 - cos over the masked pixels whose cosine is below cos(thrsh).  A batch [B,3,H,W] (B <= 8; the views may be
+    in [0,1]: mean of 1 - cos over the masked pixels whose cosine is below cos(thrsh).  A batch [B,3,H,W] (any B; the views may be
     slices of a larger allocation at a fixed stride) gives the reference's single mean over the selected pixels of all views, as
     one launch each way."""
     if output.dim() == 4:
@@ -328,7 +332,8 @@ class _AvatarStageLoss(torch.autograd.Function):
         # background (opt-in, the one-pass form only): `render` / `mask_out` / `normal` are the plugin's images of a rasterization over
         # this background colour; the gradients of pixels nothing contributed to (mask <= 1e-5) -- which the rasterizer's backward never
         # reads -- are then not computed: the SSIM gradient only on the tiles with a rendered pixel, the per-pixel terms without reading
-        # the images or writing gradients there.  Same loss value; what such a pixel's gradient holds afterwards is unspecified.
+        # the images or writing gradients there.  Same loss value; such a pixel's gradient comes back as 0 from this node (the planes are
+        # zeroed first; soar_avatar_pixel_losses itself leaves them untouched, as include/soar_hip.h says).
         bg = _as_f32(background, dev).reshape(-1) if (background is not None and fused) else None
         if bg is not None and bg.numel() != 3:
             raise ValueError("avatar_stage_loss: background must hold 3 values")
@@ -376,7 +381,10 @@ class _AvatarStageLoss(torch.autograd.Function):
         Cn, H, W = r.shape
         back = ctx.back
         up = _as_f32(g, dev).reshape(1) * _coef_tensor(back, dev)            # upstream scalar of every term (device side)
-        g_r, g_mo, g_n = torch.empty_like(r), torch.empty_like(mo), torch.empty_like(n)
+        # with `background` the kernels skip the pixels nothing contributed to: what autograd hands on for them must still be a number
+        # (retain_grad on an image, a gradient-norm check, detect_anomaly) -- zeros, which is also their value's limit under the promise
+        alloc = torch.zeros_like if ctx.bg_keep is not None else torch.empty_like
+        g_r, g_mo, g_n = alloc(r), alloc(mo), alloc(n)
         stream = torch.cuda.current_stream(dev).cuda_stream
         at = lambda t, i: t.data_ptr() + 4 * i
         with torch.cuda.device(dev):

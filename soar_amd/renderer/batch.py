@@ -17,6 +17,29 @@ from .fused_view import stack_views
 _KEYMAP = (("depth", "depths"), ("mask", "masks"), ("occ", "occs"), ("curv", "curvs"), ("comp_bg", "comp_bgs"))
 
 
+class _PinnedRing:
+    """Eight page-locked 3-float buffers handed out in turn (a pageable copy of three floats would drain the stream; a fresh pinned
+    allocation per step is a call into the host allocator).  A buffer is handed out again only when the copy that read it has completed."""
+
+    def __init__(self, n=8):
+        self.n, self.bufs, self.events, self.k = n, [None] * n, [None] * n, 0
+
+    def rand3_to(self, device):
+        i, self.k = self.k, (self.k + 1) % self.n
+        if self.bufs[i] is None:
+            self.bufs[i] = torch.empty(3).pin_memory()
+        elif self.events[i] is not None:
+            self.events[i].synchronize()
+        torch.rand(3, out=self.bufs[i])                          # the CPU generator's next three numbers, as torch.rand(3) draws them
+        out = self.bufs[i].to(device, non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record(torch.cuda.current_stream(device))
+        return out
+
+
+_rand_bg_ring = _PinnedRing()
+
+
 def _stack_hwc(xs: List[torch.Tensor]) -> torch.Tensor:
     return stack_views(xs).permute(0, 2, 3, 1)          # (no copy when the views' images lie behind each other: fused_view.stack_views)
 
@@ -115,11 +138,12 @@ class GaussianBatchRenderer:
         gt_pkgs = None
         one_node = with_gt and hasattr(self, "forward_step_views")
         if with_gt:
-            # (drawn where the reference draws it: behind the SDS views' cameras.  Through page-locked memory: a pageable copy of three
-            # floats would drain the stream)
-            rand_bg_color = torch.rand(3)
-            batch["rand_bg_color"] = rand_bg_color.pin_memory().to(batch["gt_rgb"].device, non_blocking=True) if batch["gt_rgb"].is_cuda \
-                else rand_bg_color.to(batch["gt_rgb"].device)
+            # The reference draws it BEHIND the renders of the SDS views (TS/renderer/gaussian_batch_renderer.py:387); here it is drawn in
+            # front of them, because the one-node path renders the video frame's views in the same call.  The same numbers for a given
+            # seed: nothing between this line and the reference's place draws from torch's CPU generator (the renders, the KNN follower and
+            # the background module are deterministic; `sample_camera` above is where the reference has it too).
+            batch["rand_bg_color"] = _rand_bg_ring.rand3_to(batch["gt_rgb"].device) if batch["gt_rgb"].is_cuda \
+                else torch.rand(3).to(batch["gt_rgb"].device)
         with torch.autocast("cuda", enabled=False):
             if one_node:
                 # the SDS views show one pose (zeroed root, one gt_index), the video frame's three another: ONE autograd node, one C

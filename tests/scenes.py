@@ -145,6 +145,17 @@ def upstream_grads(scene: Scene, seed_offset=0):
             rng.normal(0, 1, (1, H, W)).astype(np.float32), rng.normal(0, 1, (1, H, W)).astype(np.float32))
 
 
+def loss_grads(scene: Scene, images):
+    """The upstream gradients the headline workload produces: those of
+    L = mean|color - target| + mean|opac - mask| + 0.1 mean(normal . n_t) + 0.01 mean(depth) at the rendered images
+    `images` = {"color", "normal", "depth", "opac"} (of ONE evaluation -- the sign() of a difference near zero must not depend on whose
+    forward it is), with the seeded targets of soar_amd.synthetic.make_loss_targets."""
+    tg = syn.make_loss_targets(scene.H, scene.W, scene.seed)
+    _, dC, dN, dD, dO = syn.loss_and_pixel_grads(*[torch.from_numpy(np.asarray(images[k], np.float32).reshape(-1, scene.H, scene.W))
+                                                   for k in ("color", "normal", "depth", "opac")], tg)
+    return tuple(np.ascontiguousarray(x.numpy(), dtype=np.float32) for x in (dC, dN, dD, dO))
+
+
 def oracle_settings(scene: Scene):
     from oracle import cpu_oracle as co
     cam = scene.cam

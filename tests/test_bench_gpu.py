@@ -34,6 +34,13 @@ def test_bench_line_schema(mode):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
+    # the spread of the number and the same-box context are in the line itself
+    rep = d["repeats_ms_per_step"]
+    assert len(rep) == 4 and all(v > 0 for v in rep)
+    assert "reference_same_box" in d
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_rasterizer_fast.so")):
+        rb = d["reference_same_box"]
+        assert rb["fwd_ms"] > 0 and rb["bwd_ms"] > 0 and rb["product_one_view_fwd_ms"] > 0 and "context only" in rb["build"], rb
 
 
 def test_bench_avatar_loss_line():

@@ -156,7 +156,11 @@ def _worker8(rank, world, port, P, steps, buckets, out_dir):
                 for n in ("rot", "scales", "colors"):
                     leaves[n] -= 1e-3 * buf.views[n]                                # ... the rest behind the second
         frame_dp.all_reduce_densifier_stats(acc5, rad)                                # (what SurfelDensifier.sync_stats does before it plans)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), acc5=acc5.numpy(), rad=rad.numpy(), seen=np.array(seen),
+        # SurfelDensifier(spatial_order=True) re-orders the model after every densification by a permutation that is a pure function of
+        # the replicated positions (densify.spatial_permutation: Morton keys, stable sort): every rank must arrive at the SAME one
+        from soar_amd.densify import spatial_permutation
+        perm = spatial_permutation(leaves["xyz"] * 0.05)                              # (several points per 2 cm cell: ties, kept in row order)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), acc5=acc5.numpy(), rad=rad.numpy(), seen=np.array(seen), perm=perm.numpy(),
                  **{n: t.detach().numpy() for n, t in leaves.items()})
     finally:
         dist.destroy_process_group()
@@ -195,6 +199,58 @@ def test_eight_rank_gloo_training_steps_equal_single_process(tmp_path, buckets):
     for r in ranks:                                                                 # densifier statistics: sum and max over the ranks
         np.testing.assert_allclose(r["acc5"], acc5.numpy(), rtol=1e-6)
         np.testing.assert_array_equal(r["rad"], rad.numpy())
+        # the spatial re-ordering a densifying job applies: one permutation, the same on every rank
+        np.testing.assert_array_equal(r["perm"], ranks[0]["perm"])
+        assert sorted(r["perm"].tolist()) == list(range(P))
+
+
+def _bench_line(cmd, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("buckets", ["1", "2"])
+def test_bench_dry_run_with_eight_ranks_keeps_the_one_line_contract(buckets):
+    """`bench.py --gpus 8 --dry-run`: bench.py's OWN launcher, rendezvous, frame sharding, flat-buffer all-reduce,
+    timed region, per-rank / per-bucket aggregation and one-line contract with eight gloo ranks on the CPU and stand-in frames -- the
+    functions the real ranks run (bench.timed_region / rank_diagnostics / job_elapsed / launch_ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SOAR_DP_BUCKETS"] = buckets
+    d = _bench_line(["bench.py", "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1"], env)
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["data"].startswith("dry-run") and d["config"]["parallelism"] == "frame-dp8" and d["config"]["replicas_identical"] is True
+    assert abs(d["value"] - 8 * 4 * 1000.0 / d["ms_per_step"]) <= d["value"] * (0.00051 / d["ms_per_step"] + 1e-6)
+    rk = d["ranks"]
+    assert len(rk["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in rk["per_rank_ms_per_step"]) and rk["imbalance_max_over_mean"] >= 1.0
+    assert len(rk["bucket_wait_us_per_rank"]) == 8 and rk["buckets"] == int(buckets)
+    assert max(rk["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001           # the job's step is the slowest rank's (plus the barrier)
+    if buckets == "2":
+        assert all(w[1] > 0 for w in rk["bucket_wait_us_per_rank"])
+
+
+def test_bench_dry_run_under_the_drivers_launcher():
+    """... and started the way the driver starts N > 1: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                     "bench.py", "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], env)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "frame-dp2" and len(d["ranks"]["per_rank_ms_per_step"]) == 2
+    # --gpus must describe the job: a mismatch prints no line
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, cwd=root,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == ""
 
 
 def test_flat_buffer_refuses_stale_views():

@@ -489,6 +489,51 @@ def test_plugin_back_view_descending_and_unfused_occ(world):
     assert np.abs(out["occ"].cpu().numpy() - occ_fw.out_color).mean() < 1e-5
 
 
+def test_two_back_views_of_a_pose_keep_their_occlusion_gradients_apart(world):
+    """every back view of a pose runs its occlusion-pass backward on a side stream of its own; each needs its own [P][16]
+    block of the gradient scratch (they shared one).  A front view and TWO back views of one pose as one node, `_occ` trained through all
+    three occlusion images, against one forward() call per view -- over several repetitions (a race shows in some of them)."""
+    from soar_amd.renderer import cameras
+    w = world
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    spec2 = syn.make_camera(W, H, distance=2.6, elevation=-0.2, azimuth=2.1)
+    cam2 = cameras.Camera(FoVx=spec2.fovx, FoVy=spec2.fovy, camera_center=spec2.camera_center.to(DEV), image_width=W, image_height=H,
+                          world_view_transform=spec2.world_view_transform.to(DEV), full_proj_transform=spec2.full_proj_transform.to(DEV),
+                          prcppoint=spec2.prcppoint.to(DEV))
+    views = [{"camera": w.cam, "bg_color": bg, "render_front": True}, {"camera": w.cam, "bg_color": bg, "render_front": False},
+             {"camera": cam2, "bg_color": bg, "render_front": False}]
+    gen = torch.Generator().manual_seed(11)
+    wt = [torch.rand(3, H, W, generator=gen).to(DEV) for _ in views]
+    occ0 = w.pc._occ
+    leaves = (w.pc._xyz, w.pc._rot, w.pc._scale, w.pc._color)
+    try:
+        def grads_of(outs):
+            sum((o["occ"] * k).sum() + o["render"].square().mean() for o, k in zip(outs, wt)).backward()
+            g = [w.pc._occ.grad.clone()] + [t.grad.clone() for t in leaves]
+            return g
+        w.pc._occ = occ0.clone().requires_grad_(True)
+        w.renderer.forward_views(views, gt=True, gt_index=2)           # (teaches the capacity book: the next call is the one-call form)
+        ref = None
+        for rep in range(4):
+            for t in leaves:
+                t.grad = None
+            w.pc._occ = occ0.clone().requires_grad_(True)
+            one = grads_of(w.renderer.forward_views(views, gt=True, gt_index=2))
+            if ref is None:
+                for t in leaves:
+                    t.grad = None
+                w.pc._occ = occ0.clone().requires_grad_(True)
+                ref = grads_of([w.renderer(v["camera"], bg, gt=True, gt_index=2, render_front=v["render_front"]) for v in views])
+                assert ref[0].abs().sum() > 0
+            for a, b in zip(one, ref):
+                assert torch.isfinite(a).all()
+                assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), rep
+    finally:
+        w.pc._occ = occ0
+        for t in leaves:
+            t.grad = None
+
+
 def test_gt_forward_renders_the_three_views_of_a_video_frame(world):
     """GaussianBatchRenderer.gt_forward (TS/renderer/gaussian_batch_renderer.py:96-220): the frame at video resolution plus the
     normal view and the back normal view (render_front=False) at gt_normal_res, stacked channel-last under the reference's keys."""
@@ -1071,14 +1116,16 @@ def test_ssim_kernel_matches_oracle_and_reference_goldens(shape):
         ssim(a, b)
 
 
+@pytest.mark.parametrize("B", [3, 11])
 @pytest.mark.parametrize("masked", [False, True])
-def test_cos_loss_over_a_batch_of_views_is_the_references_single_mean(masked):
+def test_cos_loss_over_a_batch_of_views_is_the_references_single_mean(masked, B):
     """cos_loss on [B,3,H,W] (how the reference calls it on its stacked normal images, TS/system/gaussian_surfel_mvdream.py:412-432):
     one mean over the selected pixels of all views == oracle/loss_oracle.py's cos_loss on the [B,H,W,3] batch, value and gradient;
-    the views may be slices of a larger allocation (what the one-node step leaves behind: no copy)."""
+    the views may be slices of a larger allocation (what the one-node step leaves behind: no copy).  Any B, like the reference's function
+    (more than 8 views leave as several batches of launches); a view without a selected pixel gives zeros, value and gradient."""
     from oracle import loss_oracle as lo
     from soar_amd.losses import cos_loss
-    B, H, W = 3, 40, 52
+    H, W = 40, 52
     g = torch.Generator().manual_seed(17)
     t = torch.nn.functional.normalize(torch.randn(B, H, W, 3, generator=g), dim=-1) * 0.5 + 0.5
     o = (0.5 * torch.rand(B, H, W, 3, generator=g) + 0.5 * t).clamp(0, 1)
@@ -1200,6 +1247,7 @@ def test_avatar_stage_loss_with_the_background_promise_gives_the_same_step(world
     for k in g0:
         sel = m0.expand_as(g0[k])
         assert torch.equal(g0[k][sel], g1[k][sel]), k           # wherever something was rendered: the same gradient
+        assert torch.isfinite(g1[k]).all() and float(g1[k][~sel].abs().max()) == 0.0, k    # elsewhere: zeros, not whatever the allocator left
     for a, b in zip(p0, p1):
         assert b.abs().max() > 0 and (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()     # (float atomics of the backward blend)
 

@@ -202,39 +202,89 @@ def test_surfel_scenes_meet_the_strict_gradient_bar(name):
     print(name, {k: f"{v[0]:.1e}" for k, v in worst.items()})
 
 
-def test_c5_frame_matches_the_reference_kernels():
-    """BASELINE config C5 size (300k densified surfels, 3840x2160): the product against the reference's kernels -- binning
-    state, per-pixel contributor counts and final transmittance bit-exact, images within 1e-5, the four accumulator-level gradient tensors
-    within the strict 1e-4.  On the three cancellation-prone tensors the reference does not reproduce ITSELF to 1e-4 at this size (two runs
-    of its kernels on the same inputs: 1.2e-4 / 1.2e-4 / 1.7e-4 in the max norm, profiles/r05_c5_reference_spread.txt -- hundreds of
-    surfels wider than 48 px, thousands of float atomics each): the test measures that spread and holds the product to max(1.2e-3, 6 x it)
-    in the max norm and max(2.5e-4, 4 x it) in L2.  Measured over 32 runs late in round 5 (the worst element of 1.2 M is a noisy
-    statistic): dL_drotations 5.9e-4 .. 9.5e-4 in the max norm and 1.2e-4 .. 2.0e-4 in L2, dL_dcov3D 2.4e-4 .. 4.4e-4 / 1.0e-4 .. 2.0e-4,
-    dL_dscales 1.5e-4 .. 4.6e-4 / 2.4e-5 .. 4.2e-5 -- with or without the packed pixel steps of the backward blend (profiles/r05_backward_regions_accuracy.txt).
-    The floors of 8e-4 / 2e-4 of earlier in the round had been set by three samples (3.0 / 3.0 / 6.4e-4): one run in seven failed them.  The float64 rows do not
-    change it: it is not the order of the sums.  Before round 5: L2 <= 3e-4 only."""
+def _f64_dist(a, b, truth):
+    """(max-norm, L2) distance of two evaluations, relative to the f64 tensor's largest value / norm (float64 throughout: the white-noise
+    gradients make elements of 1e25 whose squares do not fit a float)."""
+    a, b, t = (np.asarray(x, np.float64).reshape(truth.shape) for x in (a, b, truth))
+    return float(np.abs(a - b).max() / max(np.abs(t).max(), 1e-300)), float(np.linalg.norm(a - b) / max(np.linalg.norm(t), 1e-300))
+
+
+ACCUMULATOR_LEVEL = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D")
+CANCELLATION_PRONE = ("dL_dcov3D", "dL_dscales", "dL_drotations")
+TRIANGLE_L2, TRIANGLE_MAX = 1.5, 2.0
+
+
+def _c5_triangle(grads_kind):
+    """BASELINE config C5 size (300k densified surfels, 3840x2160): binning state, per-pixel contributor counts and final transmittance
+    bit-exact against the reference's kernels, images within 1e-5, the four accumulator-level gradient tensors within the strict 1e-4 of the
+    reference's.  The three cancellation-prone tensors (conic -> covariance -> scale / rotation, condition number ~1e3) are held to the
+    TRUTH, not to one noisy sample of the reference: at this size two runs of the reference's own kernels differ by 1.2 .. 4.9e-4 (max
+    norm, five measurements over two rounds) and each of them lies 6 .. 7e-4 from the float64 evaluation of the reference's formulas over
+    the reference's own forward state (ref_rast_backward_wide mode 2: per-pixel recurrences and per-Gaussian sums in float64, the skip
+    decisions the float ones of the forward) -- 2e-4 of it the float arithmetic per pixel, the rest the order of its float atomics
+    (profiles/r06_c5_triangle.txt).  No implementation can be closer to such a sample than the sample is to the truth; what can be asked,
+    and is: the product is as close to the truth as the reference is --
+        L2:        |product - f64| <= max(1e-4, 1.5 x |reference - f64|)     (a norm over 1-2 M elements: a stable statistic)
+        max norm:  |product - f64| <= max(1e-4, 2.0 x |reference - f64|)     (the worst element of 1-2 M: a noisy one)
+    with |reference - f64| the larger of two runs.  Measured (r06_c5_triangle.txt): product 3.9 .. 9.2e-4, reference 6.0 .. 7.0e-4
+    (dL_drotations, white-noise upstream gradients); with the workload's own loss-derived gradients the product is the closer one
+    (1.1 .. 1.3e-4 against 2.5 .. 3.0e-4).  Rounds 4-5 held these tensors to max(1.2e-3, 6 x the reference's two-run spread) against the sample."""
     ref_r = _ref()
     scene = S.person_scene(P=300_000, W=3840, H=2160, seed=4, config=(1, 1, 1, 0), opacity=None, distance=2.2)
-    grads = S.upstream_grads(scene)
+    if grads_kind == "noise":
+        grads = S.upstream_grads(scene)
+    else:
+        grads = S.loss_grads(scene, ref_r.run(scene, grads=None, state=False))
     hip = run_hip(scene, grads=grads)
     ref = ref_r.run(scene, grads=grads)
     ref2 = ref_r.run(scene, grads=grads, state=False)
+    f64 = ref_r.run(scene, grads=grads, state=False, wide=2)
     assert hip["R"] == ref["R"] and ref["R"] > 3_000_000
     for k in ("radii", "tiles_touched", "point_offsets", "keys_sorted", "point_list", "n_contrib", "final_T"):
         np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(hip["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
     for name in ("color", "normal", "depth", "opac"):
         assert rel_err(hip[name], ref[name]) <= 1e-5, name
-    worst, spread = {}, {}
-    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
-        a, b, b2 = hip[k].reshape(ref[k].shape), ref[k], ref2[k].reshape(ref[k].shape)
+    for k in ACCUMULATOR_LEVEL:
+        a, b = hip[k].reshape(ref[k].shape), ref[k]
         assert np.isfinite(a).all(), k
-        worst[k] = (rel_err(a, b), l2_err(a, b))
-        spread[k] = (rel_err(b2, b), l2_err(b2, b))
-    print("C5 product vs reference", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
-    print("C5 reference vs itself ", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in spread.items()})
-    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D"):
-        assert worst[k][0] <= 1e-4 and worst[k][1] <= 1e-4, (k, worst[k])
-    for k in ("dL_dcov3D", "dL_dscales", "dL_drotations"):
-        # (the spread of two runs is itself a noisy number: floors at the levels measured over the rounds, a quarter above the worst seen)
-        assert worst[k][0] <= max(1.2e-3, 6 * spread[k][0]) and worst[k][1] <= max(2.5e-4, 4 * spread[k][1]), (k, worst[k], spread[k])
+        assert rel_err(a, b) <= 1e-4 and l2_err(a, b) <= 1e-4, (k, rel_err(a, b), l2_err(a, b))
+    rows = {}
+    for k in CANCELLATION_PRONE:
+        assert np.isfinite(hip[k]).all(), k
+        rows[k] = dict(prod=_f64_dist(hip[k], f64[k], f64[k]), ref=_f64_dist(ref[k], f64[k], f64[k]), ref2=_f64_dist(ref2[k], f64[k], f64[k]),
+                       prod_ref=_f64_dist(hip[k], ref[k], f64[k]), spread=_f64_dist(ref2[k], ref[k], f64[k]))
+    fmt = lambda d: "%.1e/%.1e" % d
+    for k, r in rows.items():
+        print(f"C5 {grads_kind} {k}: product-f64 {fmt(r['prod'])}  ref-f64 {fmt(r['ref'])} {fmt(r['ref2'])}  product-ref {fmt(r['prod_ref'])}  "
+              f"ref-ref {fmt(r['spread'])}")
+    for k, r in rows.items():
+        e_ref = tuple(max(r["ref"][i], r["ref2"][i]) for i in (0, 1))
+        assert r["prod"][1] <= max(1e-4, TRIANGLE_L2 * e_ref[1]), (k, "L2", r)
+        assert r["prod"][0] <= max(1e-4, TRIANGLE_MAX * e_ref[0]), (k, "max norm", r)
+
+
+def test_c5_frame_matches_the_reference_kernels():
+    _c5_triangle("noise")
+
+
+def test_c5_frame_with_the_workloads_own_upstream_gradients():
+    """... and with the gradients the headline workload produces (L = mean|color - target| + mean|opac - mask| +
+    0.1 mean(normal . n_t) + 0.01 mean(depth), tests/scenes.py::loss_grads) instead of white noise."""
+    _c5_triangle("loss")
+
+
+def test_c3_frame_with_the_workloads_own_upstream_gradients_meets_the_strict_bar():
+    """BASELINE config C3's frame with the loss-derived upstream gradients of BASELINE.md section 3 (what bench.py times) instead of the
+    white noise of every other gradient test (the worst case for cancellation): all tensors within the strict 1e-4 of the reference's
+    kernels, element by element and norm-wise."""
+    ref_r = _ref()
+    scene = SURFEL_SCENES["C3_100k_1080p"]()
+    grads = S.loss_grads(scene, ref_r.run(scene, grads=None, state=False))
+    ref = ref_r.run(scene, grads=grads)
+    hip = run_hip(scene, grads=grads)
+    assert hip["R"] == ref["R"] and ref["R"] > 500_000
+    for k in ("radii", "point_list", "n_contrib", "final_T"):
+        np.testing.assert_array_equal(hip[k], ref[k], err_msg=k)
+    worst = check_backward(scene, hip, _AsOracle(ref, scene), rel=REL, strict=True)
+    print("C3 loss-derived gradients", {k: f"{v[0]:.1e}" for k, v in worst.items()})
