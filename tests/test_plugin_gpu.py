@@ -1247,7 +1247,12 @@ def test_avatar_stage_loss_with_the_background_promise_gives_the_same_step(world
     for k in g0:
         sel = m0.expand_as(g0[k])
         assert torch.equal(g0[k][sel], g1[k][sel]), k           # wherever something was rendered: the same gradient
-        assert torch.isfinite(g1[k]).all() and float(g1[k][~sel].abs().max()) == 0.0, k    # elsewhere: zeros, not whatever the allocator left
+        # elsewhere: what the full evaluation gives (a pixel whose group of four or whose SSIM tile holds a rendered one is still
+        # computed) or 0 (skipped) -- never whatever the allocator left (the planes are zeroed first)
+        rest = ~sel
+        assert torch.isfinite(g1[k]).all(), k
+        assert bool(((g1[k][rest] == 0) | ((g1[k][rest] - g0[k][rest]).abs() <= 1e-6 * g0[k].abs().max())).all()), k
+        assert float((g1[k][rest] == 0).float().mean()) > 0.5, k
     for a, b in zip(p0, p1):
         assert b.abs().max() > 0 and (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()     # (float atomics of the backward blend)
 
