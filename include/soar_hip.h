@@ -62,7 +62,10 @@ typedef struct SoarRastParams {
                                   the previous forward call with this image_buffer, untouched since: tiles without Gaussians in both calls
                                   are not written again (their pixels already hold the background values; a background colour or
                                   normalize-depth switch that differs from the previous call's is noticed on the device and every tile is
-                                  written).  Never set it on the first call with an image_buffer. */
+                                  written).  Never set it on the first call with an image_buffer;
+                                  bit 3 (backward only): the call stops behind the backward blend -- the accumulation rows stay in the
+                                  workspace and NO gradient output is written; the caller finishes all frames of the step with ONE
+                                  soar_frames_geometry_warp_backward (the per-Gaussian stage and the warp's backward in one kernel). */
     /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
     int32_t cfg_surface;       /* config[0] */
     int32_t cfg_normalize_depth; /* config[1] */
@@ -337,6 +340,37 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
                            const float *axis_perm, int32_t P, int32_t J,
                            const float *dL_dxyz_out, const float *dL_drot_out,
                            float *dL_dxyz, float *dL_drot, void *stream);
+
+/* The per-Gaussian stage of the backward ALONE (BACKWARD::preprocess, backward.cu:437-526 with :163-322 and :326-432), over the
+ * accumulation rows that a soar_rast_backward* call with SoarRastParams.debug bit 3 left at the start of its workspace: together the two
+ * calls are soar_rast_backward.  Outputs as soar_rast_backward's (all fully written; dL_dsh / dL_docc may be NULL). */
+int soar_rast_backward_rows(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs, const float *scales,
+                            const float *rotations, const float *cov3D_precomp, const void *geom_buffer, const void *workspace,
+                            float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+                            float *dL_dscales, float *dL_drotations, float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc,
+                            void *stream);
+
+/* The tail of the backward pass of the n frames of one optimizer step in ONE kernel (round 6; no reference counterpart: the reference
+ * runs BACKWARD::preprocess per frame, backward.cu:437-526 + :163-322 + :326-432, and autograd carries dL_dmeans3D / dL_drotations
+ * through the torch ops of the warp, TS/renderer/diff_gaussian_rasterizer.py:103-114).  Every frame's soar_rast_backward /
+ * soar_rast_backward_occ ran with SoarRastParams.debug bit 3: its accumulation rows wait in `workspace`.  Per frame and Gaussian the
+ * per-Gaussian backward of the rasterizer, then the warp's backward through that frame's joint transforms, in registers; the frames'
+ * gradients are added in frame order.  Explicit colours (M == 0), scales + quaternions (no precomputed covariance), cfg_lrn_cam == 0.
+ * Writes dL_dmeans2D of every frame ([P,3]: what the densifier's statistics read) and the sums over the frames dL_dxyz [P,3],
+ * dL_drot [P,4] (canonical), dL_dscales [P,3], dL_dcolors [P,3] and -- when the frames ran soar_rast_backward_occ -- dL_docc [P].
+ * Bit for bit what soar_rast_backward* (without bit 3) + soar_lbs_warp_backward_sum (+ soar_sum_frames) leave in those outputs. */
+typedef struct SoarFrameTail {
+    const SoarRastParams *prm;
+    const float *means3D;        /* [P,3] posed (what the forward was given) */
+    const float *rotations;      /* [P,4] posed */
+    const int32_t *radii;
+    const void *geom_buffer;
+    const void *workspace;       /* the backward call's workspace: accumulation rows [P][16] at its start */
+    float *dL_dmeans2D;          /* [P,3] */
+} SoarFrameTail;
+int soar_frames_geometry_warp_backward(int32_t n, const SoarFrameTail *frames, const float *xyz, const float *rot, const float *weights,
+                                       const float *joint_mats, int32_t P, int32_t J, const float *scales, float *dL_dxyz, float *dL_drot,
+                                       float *dL_dscales, float *dL_dcolors, float *dL_docc, void *stream);
 
 /* The warps of the n frames of one optimizer step, one launch each way (no reference counterpart: the reference warps frame by
  * frame).  The canonical model (xyz, rot) and the blend weights are shared; joint_mats [n][J][16]; xyz_out / dL_dxyz_out

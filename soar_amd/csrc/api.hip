@@ -651,6 +651,30 @@ int soar_rast_backward(const SoarRastParams *prm, const float *means3D, const in
                                      stream_);
 }
 
+// The per-Gaussian stage alone, over the accumulation rows a soar_rast_backward* call with SoarRastParams.debug bit 3 left in `workspace`:
+// the second half of that call (and what soar_frames_geometry_warp_backward fuses with the warp's backward).
+int soar_rast_backward_rows(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs, const float *scales,
+                            const float *rotations, const float *cov3D_precomp, const void *geom_buffer, const void *workspace,
+                            float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+                            float *dL_dscales, float *dL_drotations, float *dL_dviewmat, float *dL_dprojmat, float *dL_dcampos, float *dL_docc,
+                            void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (check_params(prm)) return 1;
+    if (prm->P == 0) return 0;
+    if (check_aligned(geom_buffer, "geom_buffer") || check_aligned(workspace, "workspace")) return 1;
+    if (!means3D || !radii || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations ||
+        !dL_dviewmat || !dL_dprojmat || !dL_dcampos) {
+        set_error("soar_rast_backward_rows: a required pointer is NULL");
+        return 1;
+    }
+    GeomBuf g;
+    carve_geom(const_cast<void *>(geom_buffer), prm->P, prm->M, &g);
+    return launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, static_cast<const float *>(workspace),
+                                    dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+                                    dL_dviewmat, dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/true, stream, dL_docc);
+}
+
 }  // extern "C"
 
 static int backward_impl(const SoarRastParams *prm, const float *means3D, const int32_t *radii, const float *shs,
@@ -715,6 +739,10 @@ static int backward_impl(const SoarRastParams *prm, const float *means3D, const 
                                    acc64, num_rendered > 0, dL_dout_occ, dL_docc, normal_scale_dev, occ_planes, stream))
             return 1;
     }
+    // SoarRastParams.debug bit 3: the rows stay in the workspace for soar_frames_geometry_warp_backward (lbs.hip), which runs the
+    // per-Gaussian stage of every frame of the step and the warp's backward in one kernel
+    // (with bit 1 the float64 rows have been narrowed into the float32 ones behind the blend: the same rows either way)
+    if ((prm->debug & 8) != 0) return 0;
     if (launch_geometry_backward(*prm, means3D, radii, shs, scales, rotations, cov3D_precomp, g, acc, dL_dmeans2D, dL_dcolors,
                                  dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dviewmat,
                                  dL_dprojmat, dL_dcampos, /*zero_camera_grads=*/false, stream, dL_docc))

@@ -8,10 +8,15 @@
 //  * warp_backward_kernel : analytic gradient w.r.t. canonical xyz and quaternion.
 //  * dist2_knn3_kernel    : simple-knn distCUDA2 semantics (mean of the 3 smallest squared distances, self excluded).
 #include "soar_common.h"
+#include "geom_bwd_point.h"
 
 // Products and sums contract to FMAs within one expression only, as written: the same point has to come out bit-identical
 // from the single-frame kernels and from the all-frames ones, whatever each kernel's surroundings let the backend fuse.
 #pragma clang fp contract(on)
+
+#ifndef SOAR_LBS_SKIP_UNUSED_JOINTS
+#define SOAR_LBS_SKIP_UNUSED_JOINTS 1
+#endif
 
 namespace soar {
 
@@ -182,12 +187,11 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
 }
 
 // gradient of one Gaussian's canonical position / quaternion given its blended 3x4 transform M and the upstream gradients
-__device__ __forceinline__ void backward_point(const WarpArgs &a, int p, const float M[12], const float *g_xyz_out, const float *g_rot_out,
-                                              float dxyz[3], float4 &drot)
+__device__ __forceinline__ void backward_point_vals(const WarpArgs &a, int p, const float M[12], float gx, float gy, float gz, const float4 gq,
+                                                   float dxyz[3], float4 &drot)
 {
     const float *T = a.axis_perm;
     // ---- position: dL/dp = M3^T (T g)
-    float gx = g_xyz_out[3 * p], gy = g_xyz_out[3 * p + 1], gz = g_xyz_out[3 * p + 2];
     if (T) {
         const float tx = T[0] * gx + T[1] * gy + T[2] * gz;
         const float ty = T[3] * gx + T[4] * gy + T[5] * gz;
@@ -221,7 +225,6 @@ __device__ __forceinline__ void backward_point(const WarpArgs &a, int p, const f
     const float sgn = (o[0] < 0.f) ? -1.f : 1.f;
     float u[4] = {sgn * o[0], sgn * o[1], sgn * o[2], sgn * o[3]};
     const float un = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
-    const float4 gq = reinterpret_cast<const float4 *>(g_rot_out)[p];
     float g[4] = {gq.x, gq.y, gq.z, gq.w};
     // through F.normalize: g_u = (g - (g.n) n) / |u|   (eps branch: plain scale)
     float gu[4];
@@ -287,6 +290,13 @@ __device__ __forceinline__ void backward_point(const WarpArgs &a, int p, const f
         make_float4(s * dr - s * s * r * GQ, s * di - s * s * i * GQ, s * dj - s * s * j * GQ, s * dk - s * s * k * GQ);
 }
 
+__device__ __forceinline__ void backward_point(const WarpArgs &a, int p, const float M[12], const float *g_xyz_out, const float *g_rot_out,
+                                              float dxyz[3], float4 &drot)
+{
+    backward_point_vals(a, p, M, g_xyz_out[3 * p], g_xyz_out[3 * p + 1], g_xyz_out[3 * p + 2], reinterpret_cast<const float4 *>(g_rot_out)[p],
+                        dxyz, drot);
+}
+
 __global__ void __launch_bounds__(WARP_THREADS) warp_backward_kernel(WarpArgs a)
 {
     extern __shared__ float wtile[];
@@ -332,6 +342,13 @@ __device__ __forceinline__ void blend_frame_matrix(const float *wrow, const floa
     for (int c = 0; c < 12; c++) M[c] = 0.f;
     for (int j = 0; j < J; j++) {
         const float w = wrow[j];
+        // Skinning weights are sparse -- a vertex follows at most a handful of the 55 joints, a Gaussian the union of its 30 nearest
+        // vertices' joints, and the 64 Gaussians of a wavefront (neighbours in space when the model is in spatial order) share most of
+        // them: a joint NO lane of the wavefront follows is left out (round 6).  Exact: its terms are w A = +-0 added to sums that
+        // started at +0 -- M does not change by a bit, whatever the lanes left out of the test hold.
+#if SOAR_LBS_SKIP_UNUSED_JOINTS
+        if (__ballot(w != 0.f) == 0ull) continue;
+#endif
         const float *A = mats + 16 * j;                // wavefront-uniform address -> scalar loads
 #pragma unroll
         for (int c = 0; c < 12; c++) M[c] += w * A[c];
@@ -409,6 +426,79 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_frames_kernel(Warp
                 for (int f = WARP_NF; f < n; f++) s += src[(size_t)f * count + c0 + c];
                 dst[c0 + c] = s;
             }
+        }
+    }
+}
+
+// ---- the per-Gaussian backward of the rasterizer and the warp's backward in ONE kernel (round 6) ----------------------------------
+// geometry_backward_kernel wrote, per frame and Gaussian, the gradients of the posed position / quaternion / scales / colours (52
+// bytes, plus 28 nobody reads) and warp_backward_frames_kernel read them back one launch later: 99 us of four launches per 4-frame
+// step at C3 for 53 us worth of bytes.  Here wavefront k of a workgroup takes frame k of 64 Gaussians: the accumulation row of the
+// backward blend -> geometry_backward_point (geom_bwd_point.h: the same function, the same un-contracted arithmetic) -> the blended
+// joint transform -> backward_point, all in registers; the frames' results are added in frame order through LDS exactly like the
+// unfused kernel's, the scale / colour / occlusion gradients on the way.  Explicit colours, scales + quaternions, no camera gradients
+// (what the per-frame training path uses; the general entry points keep the two kernels).
+constexpr int TAIL_C = 14;        // xyz 3 | quaternion 4 | scales 3 | colours 3 | occlusion value 1
+struct TailOut {
+    float *dL_dmeans2D[MAX_BATCH];   // per frame [P,3]
+    float *dL_dscales, *dL_dcolors, *dL_docc;      // sums over the frames: [P,3], [P,3], [P] or NULL
+};
+#ifndef SOAR_TAIL_WPE
+#define SOAR_TAIL_WPE 4
+#endif
+__global__ void __launch_bounds__(WARP_THREADS) __attribute__((amdgpu_waves_per_eu(SOAR_TAIL_WPE, 8))) geom_warp_backward_frames_kernel(WarpArgs a, int n, Batch<GeomBwdArgs> fr, TailOut out)
+{
+    extern __shared__ float wtile[];
+    float *red = wtile + WAVE * a.J;                             // [WARP_NF][TAIL_C][WAVE]
+    const int tid = threadIdx.x, k = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE;
+    const int p0 = blockIdx.x * WAVE, p = p0 + lane;
+    stage_weight_rows(a, wtile, tid, p0);
+    constexpr int PER = (TAIL_C * WAVE + WARP_THREADS - 1) / WARP_THREADS;       // outputs per thread: o = tid + h * WARP_THREADS
+    float acc[PER];
+#pragma unroll
+    for (int h = 0; h < PER; h++) acc[h] = 0.f;
+    for (int f0 = 0; f0 < n; f0 += WARP_NF) {
+        const int f = f0 + k;
+        float d[TAIL_C];
+#pragma unroll
+        for (int c = 0; c < TAIL_C; c++) d[c] = 0.f;
+        if (p < a.P && f < n) {
+            const GeomBwdArgs &g = fr.v[f];
+            GeomBwdPoint o;
+            geometry_backward_point<false>(g, p, g.radii[p] > 0, o, nullptr, nullptr, nullptr);
+            float *m2 = out.dL_dmeans2D[f];
+            m2[3 * p + 0] = o.acc[0]; m2[3 * p + 1] = o.acc[1]; m2[3 * p + 2] = 0.f;        // (z is never written by the reference)
+            float M[12], dx[3];
+            float4 dq;
+            blend_frame_matrix(wtile + lane * a.J, a.joint_mats + (size_t)f * a.mats_stride, a.J, M);
+            backward_point_vals(a, p, M, o.g_mean[0], o.g_mean[1], o.g_mean[2], make_float4(o.g_rot[0], o.g_rot[1], o.g_rot[2], o.g_rot[3]), dx, dq);
+            d[0] = dx[0]; d[1] = dx[1]; d[2] = dx[2]; d[3] = dq.x; d[4] = dq.y; d[5] = dq.z; d[6] = dq.w;
+            d[7] = o.g_scale[0]; d[8] = o.g_scale[1]; d[9] = o.g_scale[2];
+            d[10] = o.acc[6]; d[11] = o.acc[7]; d[12] = o.acc[8];
+            d[13] = o.acc[13];
+        }
+        if (f0) __syncthreads();                                 // the previous group's sums have been read
+#pragma unroll
+        for (int c = 0; c < TAIL_C; c++) red[(k * TAIL_C + c) * WAVE + lane] = d[c];
+        __syncthreads();
+        // frame order: (((acc + g_f0) + g_f0+1) + g_f0+2) + g_f0+3 (frames past n contribute exact zeros)
+#pragma unroll
+        for (int h = 0; h < PER; h++) {
+            const int o = tid + h * WARP_THREADS;
+            if (o < TAIL_C * WAVE)
+#pragma unroll
+                for (int kk = 0; kk < WARP_NF; kk++) acc[h] += red[kk * TAIL_C * WAVE + o];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < PER; h++) {
+        const int o = tid + h * WARP_THREADS, c = o / WAVE, q = p0 + o % WAVE;
+        if (o < TAIL_C * WAVE && q < a.P) {
+            if (c < 3) a.g_xyz[3 * q + c] = acc[h];
+            else if (c < 7) a.g_rot[4 * q + c - 3] = acc[h];
+            else if (c < 10) out.dL_dscales[3 * q + c - 7] = acc[h];
+            else if (c < 13) out.dL_dcolors[3 * q + c - 10] = acc[h];
+            else if (out.dL_docc) out.dL_docc[q] = acc[h];
         }
     }
 }
@@ -573,6 +663,46 @@ static int warp_backward_frames(const float *xyz, const float *rot, const float 
     StageTimer timer(ST_LBS_WARP_BWD, stream);
     hipLaunchKernelGGL(warp_backward_frames_kernel, dim3((P + WAVE - 1) / WAVE), dim3(WARP_THREADS), lds, stream, a, (int)n, fs);
     SOAR_LAUNCH_OK("lbs_warp_backward_sum", stream, 0);
+    return 0;
+}
+
+int soar_frames_geometry_warp_backward(int32_t n, const SoarFrameTail *frames, const float *xyz, const float *rot, const float *weights,
+                                       const float *joint_mats, int32_t P, int32_t J, const float *scales, float *dL_dxyz, float *dL_drot,
+                                       float *dL_dscales, float *dL_dcolors, float *dL_docc, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const char *who = "soar_frames_geometry_warp_backward";
+    if (n < 1 || n > MAX_BATCH || !frames) { set_error("%s: 1 <= n <= %d frames", who, MAX_BATCH); return 1; }
+    if (!weights) { set_error("%s: needs the blend weights", who); return 1; }
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!scales || !dL_dxyz || !dL_drot || !dL_dscales || !dL_dcolors) { set_error("%s: a required pointer is NULL", who); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats;
+    a.g_xyz = dL_dxyz; a.g_rot = dL_drot;
+    a.mats_stride = (size_t)J * 16;
+    Batch<GeomBwdArgs> fr{};
+    TailOut out{};
+    out.dL_dscales = dL_dscales; out.dL_dcolors = dL_dcolors; out.dL_docc = dL_docc;
+    for (int f = 0; f < n; f++) {
+        const SoarFrameTail &t = frames[f];
+        if (!t.prm || !t.means3D || !t.rotations || !t.radii || !t.geom_buffer || !t.workspace || !t.dL_dmeans2D) {
+            set_error("%s: frame %d: a pointer is NULL", who, f);
+            return 1;
+        }
+        if (t.prm->P != P || t.prm->M != 0 || t.prm->cfg_lrn_cam != 0) {
+            set_error("%s: frame %d: needs P = %d Gaussians with explicit colours (M = 0) and cfg_lrn_cam = 0", who, f, P);
+            return 1;
+        }
+        GeomBuf g;
+        carve_geom(const_cast<void *>(t.geom_buffer), P, 0, &g);
+        fill_geom_bwd_args(fr.v[f], *t.prm, t.means3D, t.radii, nullptr, scales, t.rotations, nullptr, g, static_cast<const float *>(t.workspace));
+        out.dL_dmeans2D[f] = t.dL_dmeans2D;
+    }
+    const size_t lds = sizeof(float) * (WAVE * (size_t)J + WARP_NF * TAIL_C * WAVE);
+    StageTimer timer(ST_LBS_WARP_BWD, stream);
+    hipLaunchKernelGGL(geom_warp_backward_frames_kernel, dim3((P + WAVE - 1) / WAVE), dim3(WARP_THREADS), lds, stream, a, (int)n, fr, out);
+    SOAR_LAUNCH_OK("frames_geometry_warp_backward", stream, 0);
     return 0;
 }
 

@@ -37,9 +37,6 @@ namespace soar {
 
 namespace {
 
-#ifndef SOAR_EXP_FWD_EMIT_BEHIND
-#define SOAR_EXP_FWD_EMIT_BEHIND 0
-#endif
 #ifndef SOAR_FWD_CHUNK
 #define SOAR_FWD_CHUNK 256
 #endif
@@ -225,8 +222,8 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     int emit_n = 0;                                  // survivor words waiting in wmask[wave][..] (wave-uniform)
     uint32_t emit_base = 0;                          // list position of bit 0 of the first one
     auto emit_masks = [&]() {
-#ifdef SOAR_EXP_FWD_NO_MASK_EMIT       // (development, the backward's input wrong by construction: what the forward costs without the masks' atomics)
-        emit_n = 0;
+#ifdef SOAR_EXP_FWD_NO_MASK_EMIT       // (development, the backward's input wrong by construction: what the forward costs without leaving the
+        emit_n = 0;                    // masks behind -- 209.5-214 us against 237 per 4-frame launch at C3, profiles/README.md round 6)
         return;
 #endif
         if (a.masks && lane < emit_n) {
@@ -242,10 +239,8 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
     };
     for (uint32_t base = range.x; base < range.y; base += CHUNK, parity ^= 1) {
         const int n = min((uint32_t)CHUNK, range.y - base);
-#if !SOAR_EXP_FWD_EMIT_BEHIND
         emit_masks();                                // (the chunk before)
         emit_base = base;
-#endif
         if (tid < n) {
             const uint32_t id = id_next;
             const float4 *src = reinterpret_cast<const float4 *>(a.rec + id);
@@ -254,10 +249,6 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         }
         if (base + CHUNK + tid < range.y) id_next = a.point_list[base + CHUNK + tid];
         lds_barrier();
-#if SOAR_EXP_FWD_EMIT_BEHIND           // (development: the words leave behind the gather's wait and the barrier instead of in front of the gather)
-        emit_masks();
-        emit_base = base;
-#endif
         if (LOG && base == range.x) t_ready = wall_clock64();
 
         if (!wave_done) {
@@ -422,9 +413,7 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
         lds_barrier();
         if ((wave_alive[parity][0] | wave_alive[parity][1] | wave_alive[parity][2] | wave_alive[parity][3]) == 0) break;
     }
-#if !SOAR_EXP_FWD_EMIT_BEHIND
     emit_masks();                                    // (the last chunk this wavefront tested)
-#endif
 
     if (LOG) t_blended = wall_clock64();
     // fold the four slots of every pixel
@@ -470,9 +459,6 @@ __device__ __forceinline__ void blend_quad(const FwdArgs &a, const int rank, con
             a.out_occ[2 * hw + pix] = Co + T_o * a.bg[2];
         }
     }
-#if SOAR_EXP_FWD_EMIT_BEHIND
-    emit_masks();                                    // (the last chunk this wavefront tested: behind the epilogue, nothing waits for it)
-#endif
     if (LOG && lane == 0) {
         unsigned long long *w = a.wave_log + ((size_t)seq * 4 + wave) * 4;
         // (w[2]: list length | time to the first staged chunk << 24 | time from the end of the blending to here << 44, in 10 ns)

@@ -59,6 +59,12 @@ class SoarCameraSpec(C.Structure):
                 ("cy", C.c_double), ("img_w", C.c_double), ("img_h", C.c_double), ("has_cxcy", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SoarFrameTail(C.Structure):
+    """Mirror of ``struct SoarFrameTail`` (include/soar_hip.h): one frame of soar_frames_geometry_warp_backward."""
+    _fields_ = [("prm", _vp), ("means3D", _vp), ("rotations", _vp), ("radii", _vp), ("geom_buffer", _vp), ("workspace", _vp),
+                ("dL_dmeans2D", _vp)]
+
+
 class SoarViewArgs(C.Structure):
     """Mirror of ``struct SoarViewArgs`` (include/soar_hip.h)."""
     _fields_ = [("rast", SoarRastParams), ("focal_k00", C.c_float), ("focal_k11", C.c_float), ("back", C.c_int32), ("pad_", C.c_int32),
@@ -122,6 +128,8 @@ SIGNATURES = {
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_lbs_warp_forward_batch": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 3),
     "soar_lbs_warp_backward_sum": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp, _vp, _vp, _vp]),
+    "soar_rast_backward_rows": (C.c_int, [_vp] * 22),
+    "soar_frames_geometry_warp_backward": (C.c_int, [C.c_int32, _vp] + [_vp] * 4 + [C.c_int32, C.c_int32] + [_vp] * 7),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
     "soar_depth2normal": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     "soar_depth2normal_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp,

@@ -115,6 +115,19 @@ class FrameStepPlan:
                 g_campos=torch.empty((3,), **f))
             v["geom"][:256].zero_()          # (the header's running maxima of `check()` start from zero)
             self.views.append(v)
+        # The tail of the backward pass as ONE kernel (soar_frames_geometry_warp_backward, round 6): every frame's rasterizer backward
+        # stops behind its blend (SoarRastParams.debug bit 3; the forward calls share the block and do not look at that bit), the
+        # epilogue runs the per-Gaussian stage of all frames and the warp's backward together.  SOAR_PLAN_FUSED_TAIL=0: the two kernels
+        # of rounds 1-5 (geometry_backward per frame, then soar_lbs_warp_backward_sum).
+        self.fused_tail = os.environ.get("SOAR_PLAN_FUSED_TAIL", "1") != "0"
+        if self.fused_tail:
+            self.ctx.params.debug |= 8
+            self._tail_frames = (hip_lib.SoarFrameTail * self.n)()
+            for i, v in enumerate(self.views):
+                t = self._tail_frames[i]
+                t.prm = C.addressof(self.ctx.params)
+                t.means3D, t.rotations, t.radii = v["xyz_p"].data_ptr(), v["rot_p"].data_ptr(), v["radii"].data_ptr()
+                t.geom_buffer, t.workspace, t.dL_dmeans2D = v["geom"].data_ptr(), v["work"].data_ptr(), v["g_means2D"].data_ptr()
         # per-frame gradients of the leaves, frame-major so that one reduction per leaf sums them
         self.g_xyz = torch.empty((self.n, P, 3), **f)
         self.g_rot = torch.empty((self.n, P, 4), **f)
@@ -463,6 +476,15 @@ class FrameStepPlan:
         src = (C.c_void_p * 2)(ptr(self.g_scales), ptr(self.g_colors))
         dst = (C.c_void_p * 2)(ptr(fv["scales"]), ptr(fv["colors"]))
         width = (C.c_int32 * 2)(3, 3)
+        if self.fused_tail:
+            # the per-Gaussian stage of every frame's rasterizer backward and the warp's backward in ONE kernel: the frames' backward
+            # calls stopped behind their blends (SoarRastParams.debug bit 3), their accumulation rows wait in the workspaces
+            occ = ptr(fv["occ"]) if (self.loss_kind == "avatar" and "occ" in fv) else None
+            check(L.soar_frames_geometry_warp_backward(self.n, self._tail_frames, ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights),
+                                                       ptr(self.mats), self.P, J, ptr(s.scales.detach()), ptr(fv["xyz"]), ptr(fv["rot"]),
+                                                       ptr(fv["scales"]), ptr(fv["colors"]), occ, stream), "frames_geometry_warp_backward")
+            self._stamp(2 * self.n + 3, stream)
+            return
         check(L.soar_lbs_warp_backward_sum(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
                                            self.P, J, ptr(self.g_means3D_all), ptr(self.g_rot_p_all), ptr(fv["xyz"]), ptr(fv["rot"]),
                                            2, src, dst, width, stream), "warp_backward_sum")

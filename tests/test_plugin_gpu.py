@@ -916,6 +916,83 @@ def test_step_plan_matches_autograd(use_graphs, pooled):
         assert _rel(flat.flat.cpu().numpy(), want.cpu().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("loss", ["synthetic", "avatar"])
+def test_step_plan_fused_tail_equals_the_two_kernels_bit_for_bit(loss, monkeypatch):
+    """soar_frames_geometry_warp_backward (round 6: the per-Gaussian stage of the rasterizer backward of every frame + the warp's
+    backward + the sums over the frames as ONE kernel, geometry_backward_point inlined next to backward_point) against the kernels it
+    replaces, on the SAME accumulation rows (the frames' backward calls stop behind their blends, SoarRastParams.debug bit 3; float
+    atomics make two blends differ in their last bits, one blend feeds both tails): soar_rast_backward_rows per frame ->
+    soar_lbs_warp_backward_sum (-> soar_sum_frames): every output bit for bit -- dL_dmeans2D per frame, and the sums dL_dxyz,
+    dL_drot, dL_dscales, dL_dcolors (, dL_docc).  Then the plan with SOAR_PLAN_FUSED_TAIL=0 gives the same step to float-atomic order."""
+    import ctypes as C
+    import bench
+    from soar_amd import hip_lib, rasterizer
+    from soar_amd.frame_dp import FlatGradBuffer
+    from soar_amd.hip_lib import check, ptr
+    from soar_amd.step_plan import FrameStepPlan
+    seq, pool, _ = bench.build_sequence("tiny", DEV)
+    leaves = seq.leaves()
+    if loss == "avatar":
+        seq.occ.requires_grad_(True)
+        leaves = dict(leaves, occ=seq.occ)
+    flats = [FlatGradBuffer(leaves) for _ in range(2)]
+    bg = torch.tensor([0.2, 0.5, 0.7], device=DEV)
+    bench.run_step(seq, pool, flats[0], [0, 1, 2, 3], bg)
+    cap = 2 * rasterizer.last_num_rendered
+    plan = FrameStepPlan(seq, 4, pool, bg, cap, flats[0], use_graphs=False, loss=loss)
+    assert plan.fused_tail
+    monkeypatch.setenv("SOAR_PLAN_FUSED_TAIL", "0")
+    plan_two = FrameStepPlan(seq, 4, pool, bg, cap, flats[1], use_graphs=False, loss=loss)
+    assert not plan_two.fused_tail
+    L = hip_lib.lib()
+    P, n = plan.P, plan.n
+    f32 = dict(dtype=torch.float32, device=DEV)
+    for frames in ([5, 2, 7, 1], [3, 3, 0, 6]):
+        losses = plan.run(frames)
+        torch.cuda.synchronize()
+        plan.check()
+        fused = flats[0].flat.clone()
+        m2_fused = [v["g_means2D"].clone() for v in plan.views]
+        # the same rows through the two kernels of rounds 1-5
+        stream = torch.cuda.current_stream(DEV).cuda_stream
+        g_m3, g_rot = torch.empty((n, P, 3), **f32), torch.empty((n, P, 4), **f32)
+        g_scl, g_col, g_occ = torch.empty((n, P, 3), **f32), torch.empty((n, P, 3), **f32), torch.empty((n, P), **f32)
+        junk = torch.empty((P, 7), **f32)
+        cam = torch.empty((35,), **f32)
+        s = seq
+        for i, v in enumerate(plan.views):
+            m2 = torch.empty((P, 3), **f32)
+            check(L.soar_rast_backward_rows(C.byref(plan.ctx.params), ptr(v["xyz_p"]), ptr(v["radii"]), None, ptr(s.scales.detach()),
+                                            ptr(v["rot_p"]), None, ptr(v["geom"]), ptr(v["work"]), ptr(m2), ptr(g_col[i]), ptr(junk),
+                                            ptr(g_m3[i]), junk.data_ptr() + 4 * P, None, ptr(g_scl[i]), ptr(g_rot[i]), ptr(cam),
+                                            cam.data_ptr() + 64, cam.data_ptr() + 128, ptr(g_occ[i]) if loss == "avatar" else None, stream), "rows")
+            assert torch.equal(m2, m2_fused[i]), i
+        two = torch.zeros_like(flats[0].flat)
+        views = {}
+        start = 0
+        from soar_amd.frame_dp import LEAVES
+        for name, width in LEAVES:
+            views[name] = two[start:start + P * width].view(P, width)
+            start += P * width
+        src = (C.c_void_p * 2)(ptr(g_scl), ptr(g_col))
+        dst = (C.c_void_p * 2)(ptr(views["scales"]), ptr(views["colors"]))
+        width = (C.c_int32 * 2)(3, 3)
+        check(L.soar_lbs_warp_backward_sum(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(plan.blend_weights), ptr(plan.mats), n, P,
+                                           int(plan.blend_weights.shape[1]), ptr(g_m3), ptr(g_rot), ptr(views["xyz"]), ptr(views["rot"]),
+                                           2, src, dst, width, stream), "warp_backward_sum")
+        if loss == "avatar":
+            check(L.soar_sum_frames(n, P, ptr(g_occ), ptr(views["occ"]), stream), "sum_frames")
+        torch.cuda.synchronize()
+        for name in flats[0].leaves:
+            assert torch.equal(flats[0].views[name], views[name]), name
+            assert float(views[name].abs().sum()) > 0, name
+        # ... and the whole step of the plan that keeps the two kernels: the same to float-atomic order
+        losses_two = plan_two.run(frames)
+        torch.cuda.synchronize()
+        assert torch.equal(losses, losses_two)
+        assert _rel(flats[1].flat.cpu().numpy(), fused.cpu().numpy()) < 1e-5
+
+
 def test_step_plan_batched_launches_equal_the_per_frame_chains():
     """FrameStepPlan(batched=True): one stream, every stage of the chain as one launch for all frames (soar_batch_begin / _frame /
     _end, frame = blockIdx.y) against the frames' chains on streams of their own: same images bit for bit, same losses, gradients
