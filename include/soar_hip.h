@@ -65,7 +65,10 @@ typedef struct SoarRastParams {
                                   written).  Never set it on the first call with an image_buffer;
                                   bit 3 (backward only): the call stops behind the backward blend -- the accumulation rows stay in the
                                   workspace and NO gradient output is written; the caller finishes all frames of the step with ONE
-                                  soar_frames_geometry_warp_backward (the per-Gaussian stage and the warp's backward in one kernel). */
+                                  soar_frames_geometry_warp_backward (the per-Gaussian stage and the warp's backward in one kernel);
+                                  bit 4 (soar_rast_forward_geometry only): the preprocess stage of this frame has been run by
+                                  soar_frames_warp_preprocess (the warp and the per-Gaussian forward stage in one kernel): the call goes
+                                  straight to what follows it. */
     /* `config` tensor of the reference (TS/geometry/surfel_base.py:166,675-679), as host flags (config[i] > 0) */
     int32_t cfg_surface;       /* config[0] */
     int32_t cfg_normalize_depth; /* config[1] */
@@ -340,6 +343,22 @@ int soar_lbs_warp_backward(const float *xyz, const float *rot, const float *weig
                            const float *axis_perm, int32_t P, int32_t J,
                            const float *dL_dxyz_out, const float *dL_drot_out,
                            float *dL_dxyz, float *dL_drot, void *stream);
+
+/* The head of the forward pass of the n frames of one optimizer step in ONE kernel (round 6; no reference counterpart: the reference
+ * warps with torch ops, TS/renderer/diff_gaussian_rasterizer.py:103-114 / :138-149, and runs FORWARD::preprocess per frame,
+ * forward.cu:205-385): per frame and Gaussian the warp through that frame's joint transforms, then the per-Gaussian forward stage of the
+ * rasterizer on the posed values, in registers.  Writes what soar_lbs_warp_forward_batch writes (xyz_out [n][P][3], rot_out [n][P][4])
+ * and, into every frame's geom_buffer / radii, what the preprocess stage of soar_rast_forward_geometry writes -- bit for bit.  Every
+ * frame's soar_rast_forward_geometry then runs with SoarRastParams.debug bit 4 (its preprocess stage has been done: the depth buckets
+ * follow).  Explicit colours [P,3] (M == 0), opacities [P], scales [P,3] shared by the frames; not prefiltered. */
+typedef struct SoarFrameHead {
+    const SoarRastParams *prm;
+    void *geom_buffer;
+    int32_t *radii;              /* [P] */
+} SoarFrameHead;
+int soar_frames_warp_preprocess(int32_t n, const SoarFrameHead *frames, const float *xyz, const float *rot, const float *weights,
+                                const float *joint_mats, int32_t P, int32_t J, const float *colors, const float *opacities, const float *scales,
+                                float *xyz_out, float *rot_out, void *stream);
 
 /* The per-Gaussian stage of the backward ALONE (BACKWARD::preprocess, backward.cu:437-526 with :163-322 and :326-432), over the
  * accumulation rows that a soar_rast_backward* call with SoarRastParams.debug bit 3 left at the start of its workspace: together the two

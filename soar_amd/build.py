@@ -45,7 +45,7 @@ EXTRA_FLAGS = {
 }
 SOURCES = ["api.hip", "rast_preprocess.hip", "rast_binning.hip", "rast_tilebin.hip", "rast_blockmask.hip", "rast_render_fwd.hip", "rast_render_bwd.hip",
            "rast_geom_bwd.hip", "lbs.hip", "lbs_knn.hip", "frame_loss.hip", "postops.hip", "ssim.hip", "image_losses.hip", "smplx_joints.hip", "densify.hip", "optim.hip", "view.hip"]
-HEADERS = [os.path.join(CSRC, "soar_common.h"), os.path.join(_HERE, "..", "include", "soar_hip.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(_HERE, "..", "include", "soar_hip.h")]
 
 
 def _digest(paths: List[str], flags: List[str]) -> str:

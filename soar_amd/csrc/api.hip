@@ -196,7 +196,7 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->ids_sorted, n);
     take(p, out->bucket_mat, (size_t)(BKT_MAX + BKT_MAX / 1024) * ((n + 16383) / 16384));
     take(p, out->bucket_base, BKT_MAX + 1);
-    take(p, out->blk_stats, ((n + 255) / 256) * BLK_STATS);
+    take(p, out->blk_stats, ((n + 63) / 64) * BLK_STATS);          // one row per 64 Gaussians (a wavefront of preprocess)
     take(p, out->band_cnt, 64 * ((n + 1023) / 1024));
     take(p, out->band_info, 128);
     out->scan_temp_bytes = scan_temp_bytes(P);
@@ -402,7 +402,9 @@ int soar_rast_forward_geometry(const SoarRastParams *prm, const float *means3D, 
         const ZeroRange zr[1] = {{g.header, 12 * sizeof(uint32_t)}};          // (not the running maxima behind them: H_STICKY_*)
         if (launch_zero_ranges(zr, 1, stream)) return 1;
     }
-    if (launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
+    // (SoarRastParams.debug bit 4: soar_frames_warp_preprocess, lbs.hip, has run this stage for all frames of the step)
+    if ((prm->debug & 16) == 0 &&
+        launch_preprocess(*prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii_out, stream))
         return 1;
     if (prm->prefiltered && (prm->debug & 1)) {
         // debug mode is synchronous (CHECK_CUDA semantics): report what the reference's kernel would have trapped on

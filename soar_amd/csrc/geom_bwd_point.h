@@ -11,34 +11,11 @@
 // function is inlined.
 #pragma once
 #include "soar_common.h"
+#include "soar_m3.h"
 
 namespace soar {
 
 namespace {
-
-struct M3 {
-    float e[3][3];   // [column][row]
-};
-__device__ __forceinline__ M3 m3mul(const M3 &a, const M3 &b)
-{
-#pragma clang fp contract(off)
-    M3 r;
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) r.e[c][k] = a.e[0][k] * b.e[c][0] + a.e[1][k] * b.e[c][1] + a.e[2][k] * b.e[c][2];
-    return r;
-}
-__device__ __forceinline__ M3 m3t(const M3 &a)
-{
-#pragma clang fp contract(off)
-    M3 r;
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) r.e[c][k] = a.e[k][c];
-    return r;
-}
 
 __constant__ float bSH_C0 = 0.28209479177387814f;
 __constant__ float bSH_C1 = 0.4886025119029199f;

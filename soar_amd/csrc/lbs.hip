@@ -9,6 +9,7 @@
 //  * dist2_knn3_kernel    : simple-knn distCUDA2 semantics (mean of the 3 smallest squared distances, self excluded).
 #include "soar_common.h"
 #include "geom_bwd_point.h"
+#include "preprocess_point.h"
 
 // Products and sums contract to FMAs within one expression only, as written: the same point has to come out bit-identical
 // from the single-frame kernels and from the all-frames ones, whatever each kernel's surroundings let the backend fuse.
@@ -111,7 +112,7 @@ __device__ __forceinline__ void blend_matrix(const WarpArgs &a, float *wtile, in
 }
 
 // the warp of one Gaussian given its blended 3x4 transform M
-__device__ __forceinline__ void forward_point(const WarpArgs &a, int p, const float M[12], float *xyz_out, float *rot_out)
+__device__ __forceinline__ void forward_point_vals(const WarpArgs &a, int p, const float M[12], float pos[3], float4 &quat)
 {
     // position: p' = M3 p + t (+ offsets), then optional axis permutation p' <- p' T
     const float x = a.xyz[3 * p], y = a.xyz[3 * p + 1], z = a.xyz[3 * p + 2];
@@ -144,7 +145,7 @@ __device__ __forceinline__ void forward_point(const WarpArgs &a, int p, const fl
 #pragma unroll
         for (int k = 0; k < 9; k++) Rp[k] = Rt[k];
     }
-    xyz_out[3 * p] = px; xyz_out[3 * p + 1] = py; xyz_out[3 * p + 2] = pz;
+    pos[0] = px; pos[1] = py; pos[2] = pz;
 
     // q' = normalize(standardize(matrix_to_quaternion(R')))
     float cand[4], a_best, x_best;
@@ -153,7 +154,15 @@ __device__ __forceinline__ void forward_point(const WarpArgs &a, int p, const fl
     float o[4] = {cand[0] * inv, cand[1] * inv, cand[2] * inv, cand[3] * inv};
     if (o[0] < 0.f) { o[0] = -o[0]; o[1] = -o[1]; o[2] = -o[2]; o[3] = -o[3]; }
     const float nrm = fmaxf(sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]), 1e-12f);
-    reinterpret_cast<float4 *>(rot_out)[p] = make_float4(o[0] / nrm, o[1] / nrm, o[2] / nrm, o[3] / nrm);
+    quat = make_float4(o[0] / nrm, o[1] / nrm, o[2] / nrm, o[3] / nrm);
+}
+__device__ __forceinline__ void forward_point(const WarpArgs &a, int p, const float M[12], float *xyz_out, float *rot_out)
+{
+    float pos[3];
+    float4 quat;
+    forward_point_vals(a, p, M, pos, quat);
+    xyz_out[3 * p] = pos[0]; xyz_out[3 * p + 1] = pos[1]; xyz_out[3 * p + 2] = pos[2];
+    reinterpret_cast<float4 *>(rot_out)[p] = quat;
 }
 
 __global__ void __launch_bounds__(WARP_THREADS) warp_forward_kernel(WarpArgs a)
@@ -430,6 +439,36 @@ __global__ void __launch_bounds__(WARP_THREADS) warp_backward_frames_kernel(Warp
     }
 }
 
+// ---- the warp and the per-Gaussian forward stage of the rasterizer in ONE kernel (round 6) ------------------------------------------
+// warp_forward_frames_kernel wrote the posed position and quaternion of every (frame, Gaussian) and preprocess_kernel read them
+// back one launch later.  Here wavefront k of a workgroup takes frame k of 64 Gaussians: blended joint transform -> forward_point ->
+// preprocess_point (preprocess_point.h: the same function, the same un-contracted arithmetic -- radii, tile rectangles and depth
+// keys bit for bit those of the two kernels) in registers.  The posed values are still written (the backward's tail reads them).
+__global__ void __launch_bounds__(WARP_THREADS) warp_preprocess_frames_kernel(WarpArgs a, int n, Batch<PreArgs> fr)
+{
+    extern __shared__ float wtile[];
+    const int tid = threadIdx.x, k = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE;
+    const int p0 = blockIdx.x * WAVE, p_raw = p0 + lane;
+    stage_weight_rows(a, wtile, tid, p0);
+    const int f = blockIdx.y * WARP_NF + k;
+    if (f >= n) return;
+    // lanes past the end redo the last Gaussian (identical stores) so that the whole wavefront reaches the statistics' reduction
+    const bool in_range = p_raw < a.P;
+    const int p = in_range ? p_raw : a.P - 1;
+    float M[12], pos[3];
+    float4 quat;
+    blend_frame_matrix(wtile + (p - p0) * a.J, a.joint_mats + (size_t)f * a.mats_stride, a.J, M);
+    forward_point_vals(a, p, M, pos, quat);
+    float *xyz_out = a.xyz_out + (size_t)f * a.xyz_stride, *rot_out = a.rot_out + (size_t)f * a.rot_stride;
+    xyz_out[3 * p] = pos[0]; xyz_out[3 * p + 1] = pos[1]; xyz_out[3 * p + 2] = pos[2];
+    reinterpret_cast<float4 *>(rot_out)[p] = quat;
+    const PreArgs &g = fr.v[f];
+    PrePoint o;
+    preprocess_point(g, p, in_range, pos[0], pos[1], pos[2], true, quat, o);
+    preprocess_store(g, p, in_range, blockIdx.x, o);
+    if (!g.prefiltered && blockIdx.x == 0 && lane == 0) g.header[H_PREFILTER_VIOLATIONS] = 0u;
+}
+
 // ---- the per-Gaussian backward of the rasterizer and the warp's backward in ONE kernel (round 6) ----------------------------------
 // geometry_backward_kernel wrote, per frame and Gaussian, the gradients of the posed position / quaternion / scales / colours (52
 // bytes, plus 28 nobody reads) and warp_backward_frames_kernel read them back one launch later: 99 us of four launches per 4-frame
@@ -663,6 +702,42 @@ static int warp_backward_frames(const float *xyz, const float *rot, const float 
     StageTimer timer(ST_LBS_WARP_BWD, stream);
     hipLaunchKernelGGL(warp_backward_frames_kernel, dim3((P + WAVE - 1) / WAVE), dim3(WARP_THREADS), lds, stream, a, (int)n, fs);
     SOAR_LAUNCH_OK("lbs_warp_backward_sum", stream, 0);
+    return 0;
+}
+
+int soar_frames_warp_preprocess(int32_t n, const SoarFrameHead *frames, const float *xyz, const float *rot, const float *weights,
+                                const float *joint_mats, int32_t P, int32_t J, const float *colors, const float *opacities, const float *scales,
+                                float *xyz_out, float *rot_out, void *stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const char *who = "soar_frames_warp_preprocess";
+    if (n < 1 || n > MAX_BATCH || !frames) { set_error("%s: 1 <= n <= %d frames", who, MAX_BATCH); return 1; }
+    if (!weights) { set_error("%s: needs the blend weights", who); return 1; }
+    if (warp_check(xyz, rot, weights, joint_mats, P, J)) return 1;
+    if (P == 0) return 0;
+    if (!colors || !opacities || !scales || !xyz_out || !rot_out) { set_error("%s: a required pointer is NULL", who); return 1; }
+    WarpArgs a{};
+    a.P = P; a.J = J; a.xyz = xyz; a.rot = rot; a.weights = weights; a.joint_mats = joint_mats;
+    a.xyz_out = xyz_out; a.rot_out = rot_out;
+    a.mats_stride = (size_t)J * 16; a.xyz_stride = (size_t)P * 3; a.rot_stride = (size_t)P * 4;
+    Batch<PreArgs> fr{};
+    for (int f = 0; f < n; f++) {
+        const SoarFrameHead &t = frames[f];
+        if (!t.prm || !t.geom_buffer || !t.radii) { set_error("%s: frame %d: a pointer is NULL", who, f); return 1; }
+        if (t.prm->P != P || t.prm->M != 0 || t.prm->prefiltered != 0) {
+            set_error("%s: frame %d: needs P = %d Gaussians with explicit colours (M = 0), not prefiltered", who, f, P);
+            return 1;
+        }
+        GeomBuf g;
+        carve_geom(t.geom_buffer, P, 0, &g);
+        fill_pre_args(fr.v[f], *t.prm, xyz_out + (size_t)f * a.xyz_stride, nullptr, colors, opacities, scales, rot_out + (size_t)f * a.rot_stride,
+                      nullptr, g, t.radii);
+    }
+    const size_t lds = sizeof(float) * WAVE * (size_t)J;
+    StageTimer timer(ST_LBS_WARP_FWD, stream);
+    hipLaunchKernelGGL(warp_preprocess_frames_kernel, dim3((P + WAVE - 1) / WAVE, (n + WARP_NF - 1) / WARP_NF), dim3(WARP_THREADS), lds, stream,
+                       a, (int)n, fr);
+    SOAR_LAUNCH_OK("frames_warp_preprocess", stream, 0);
     return 0;
 }
 

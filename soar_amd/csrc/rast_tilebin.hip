@@ -817,14 +817,14 @@ static int bucket_count_for(int32_t P)
 int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stream)
 {
     const int B = bucket_count_for(prm.P);
-    const int nblk = (prm.P + 255) / 256;               // = preprocess grid: one statistics row per block
+    const int nblk = (prm.P + 63) / 64;                 // one statistics row per wavefront of preprocess (64 Gaussians)
     const int nw = (prm.P + BKT_CHUNK - 1) / BKT_CHUNK;
     StageTimer timer(ST_SORT, stream);
     const BucketCountArgs ca = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot};
     SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nw), dim3(1024), 0, stream, ca);
     SOAR_LAUNCH_BATCHED(bucket_scan_kernel, dim3((B + 1023) / 1024), dim3(1024), 0, stream, ca);
     const BucketScatterArgs sa = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.header, g.bucket_mat, g.sort_slot, g.sort_pairs};
-    SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, stream, sa);
+    SOAR_LAUNCH_BATCHED(bucket_scatter_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream, sa);
     SOAR_LAUNCH_OK("depth_buckets", stream, prm.debug);
     return 0;
 }

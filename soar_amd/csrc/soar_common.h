@@ -147,7 +147,7 @@ struct GeomBuf {
     uint32_t *bucket_mat;    // [W = ceil(P / 16384)][B <= BKT_MAX] depth buckets: members per counting workgroup, then where they start;
                              // behind it [W][BKT_MAX / 1024]: members per group of 1024 buckets
     uint32_t *bucket_base;   // [BKT_MAX + 1]
-    uint32_t *blk_stats;     // [ceil(P/256)][BLK_STATS] per-block maxima written by preprocess
+    uint32_t *blk_stats;     // [ceil(P/64)][BLK_STATS] per-wavefront maxima written by preprocess
     uint32_t *band_cnt;      // [64][ceil(P/1024)] entries per (band of tile rows, chunk of the depth order) (rast_tilebin.hip)
     uint32_t *band_info;     // [128] start / length of every band's list
     void *scan_temp;
@@ -296,7 +296,10 @@ __device__ __forceinline__ bool splat_may_touch_rect(float gx, float gy, float A
 }
 __device__ __forceinline__ float splat_cull_threshold(float opacity)
 {
-    return (255.f * opacity < 0.999f) ? -3.0e38f : 2.f * __logf(255.f * opacity) + 2.0e-3f;
+#pragma clang fp contract(off)          // (the same threshold bits whichever kernel the per-Gaussian forward stage is inlined in)
+    // (__builtin_logf here, not __logf: the header's wrapper is a function of its own, compiled under the TRANSLATION UNIT's contraction
+    // mode, and the backend expands the logarithm differently with and without it -- 11.084526 against 11.084527 for opacity 1)
+    return (255.f * opacity < 0.999f) ? -3.0e38f : 2.f * __builtin_logf(255.f * opacity) + 2.0e-3f;
 }
 __device__ __forceinline__ bool splat_may_touch_quad(float gx, float gy, float A, float B, float Cc, float opacity,
                                                      float x0, float y0)

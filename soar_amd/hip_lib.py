@@ -59,6 +59,11 @@ class SoarCameraSpec(C.Structure):
                 ("cy", C.c_double), ("img_w", C.c_double), ("img_h", C.c_double), ("has_cxcy", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SoarFrameHead(C.Structure):
+    """Mirror of ``struct SoarFrameHead`` (include/soar_hip.h): one frame of soar_frames_warp_preprocess."""
+    _fields_ = [("prm", _vp), ("geom_buffer", _vp), ("radii", _vp)]
+
+
 class SoarFrameTail(C.Structure):
     """Mirror of ``struct SoarFrameTail`` (include/soar_hip.h): one frame of soar_frames_geometry_warp_backward."""
     _fields_ = [("prm", _vp), ("means3D", _vp), ("rotations", _vp), ("radii", _vp), ("geom_buffer", _vp), ("workspace", _vp),
@@ -128,6 +133,7 @@ SIGNATURES = {
     "soar_lbs_warp_backward": (C.c_int, [_vp] * 5 + [C.c_int32, C.c_int32] + [_vp] * 5),
     "soar_lbs_warp_forward_batch": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 3),
     "soar_lbs_warp_backward_sum": (C.c_int, [_vp] * 4 + [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp, _vp, _vp, _vp]),
+    "soar_frames_warp_preprocess": (C.c_int, [C.c_int32, _vp] + [_vp] * 4 + [C.c_int32, C.c_int32] + [_vp] * 6),
     "soar_rast_backward_rows": (C.c_int, [_vp] * 22),
     "soar_frames_geometry_warp_backward": (C.c_int, [C.c_int32, _vp] + [_vp] * 4 + [C.c_int32, C.c_int32] + [_vp] * 7),
     "soar_dist2_knn3": (C.c_int, [_vp, C.c_int32, _vp, _vp]),

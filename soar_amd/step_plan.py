@@ -128,6 +128,14 @@ class FrameStepPlan:
                 t.prm = C.addressof(self.ctx.params)
                 t.means3D, t.rotations, t.radii = v["xyz_p"].data_ptr(), v["rot_p"].data_ptr(), v["radii"].data_ptr()
                 t.geom_buffer, t.workspace, t.dL_dmeans2D = v["geom"].data_ptr(), v["work"].data_ptr(), v["g_means2D"].data_ptr()
+        # ... and the head of the forward pass likewise (soar_frames_warp_preprocess; SOAR_PLAN_FUSED_HEAD=0: warp, then preprocess)
+        self.fused_head = os.environ.get("SOAR_PLAN_FUSED_HEAD", "1") != "0"
+        if self.fused_head:
+            self.ctx.params.debug |= 16
+            self._head_frames = (hip_lib.SoarFrameHead * self.n)()
+            for i, v in enumerate(self.views):
+                h = self._head_frames[i]
+                h.prm, h.geom_buffer, h.radii = C.addressof(self.ctx.params), v["geom"].data_ptr(), v["radii"].data_ptr()
         # per-frame gradients of the leaves, frame-major so that one reduction per leaf sums them
         self.g_xyz = torch.empty((self.n, P, 3), **f)
         self.g_rot = torch.empty((self.n, P, 4), **f)
@@ -345,6 +353,13 @@ class FrameStepPlan:
         -- the KNN prologue in front of it only needs the positions."""
         L, s = self.L, self.seq
         J = int(self.blend_weights.shape[1])
+        if self.fused_head:
+            # the warp AND the per-Gaussian forward stage of every frame (soar_frames_warp_preprocess): the frames' geometry calls go
+            # straight to their depth buckets (SoarRastParams.debug bit 4)
+            check(L.soar_frames_warp_preprocess(self.n, self._head_frames, ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights),
+                                                ptr(self.mats), self.P, J, ptr(s.colors.detach()), ptr(self.ones), ptr(s.scales.detach()),
+                                                ptr(self.xyz_p_all), ptr(self.rot_p_all), stream), "frames_warp_preprocess")
+            return
         check(L.soar_lbs_warp_forward_batch(ptr(s.xyz.detach()), ptr(s.rot.detach()), ptr(self.blend_weights), ptr(self.mats), self.n,
                                             self.P, J, ptr(self.xyz_p_all), ptr(self.rot_p_all), stream), "warp_forward_batch")
 
