@@ -64,8 +64,10 @@ STAGE_KERNELS = {
     "geometry_backward": ["geometry_backward_kernel"],
     "lbs_knn_weights": ["knn_blend_search_kernel", "knn_certify_kernel", "knn_cell_kernel + query sort + item order (the full search, every 1024th step)"],
     "optimizer": ["adam_update_kernel", "adam_tick_kernel"],
-    "lbs_warp_forward": ["warp_forward_frames_kernel", "warp_forward_kernel"],
-    "lbs_warp_backward": ["warp_backward_frames_kernel", "warp_backward_kernel"],
+    # (round 6: the plan's warps carry the per-Gaussian stages of the rasterizer with them -- soar_frames_warp_preprocess /
+    # soar_frames_geometry_warp_backward; SOAR_PLAN_FUSED_HEAD / _TAIL = 0 bring the stages "preprocess" / "geometry_backward" back)
+    "lbs_warp_forward": ["warp_preprocess_frames_kernel", "warp_forward_frames_kernel", "warp_forward_kernel"],
+    "lbs_warp_backward": ["geom_warp_backward_frames_kernel", "warp_backward_frames_kernel", "warp_backward_kernel"],
     "frame_loss": ["frame_loss_kernel", "frame_loss_finish_kernel",
                    "(--loss avatar: ssim_forward_kernel, ssim_backward_kernel, avatar_pixel_kernel + their finish kernels)"],
     "postops": ["view_finish_kernel"],
@@ -99,12 +101,11 @@ def measured_traffic(stage):
 
 
 # kernels of the plan's timed step (default loss) by how often they run: once per FRAME of the step, or once per STEP
-STEP_KERNELS_PER_FRAME = ["preprocess_kernel", "zero_ranges_kernel", "bucket_count_kernel", "bucket_scan_kernel", "bucket_scatter_kernel",
+STEP_KERNELS_PER_FRAME = ["zero_ranges_kernel", "bucket_count_kernel", "bucket_scan_kernel", "bucket_scatter_kernel",
                           "bucket_sort_kernel", "band_count_kernel", "band_place_kernel", "bin_tiles_kernel", "tile_order_binned_kernel",
-                          "render_forward_kernel", "frame_loss_kernel", "frame_loss_finish_kernel", "render_backward_blocks_kernel",
-                          "geometry_backward_kernel"]
+                          "render_forward_kernel", "frame_loss_kernel", "frame_loss_finish_kernel", "render_backward_blocks_kernel"]
 STEP_KERNELS_PER_STEP = ["adam_update_kernel", "knn_certify_kernel", "knn_blend_search_kernel", "gather_step_inputs_ids_kernel",
-                         "warp_forward_frames_kernel", "warp_backward_frames_kernel"]
+                         "warp_preprocess_frames_kernel", "geom_warp_backward_frames_kernel"]
 
 
 def measured_step_traffic(frames_per_step):
@@ -141,6 +142,8 @@ def algorithmic_bytes(P, R, W, H, R_occ=None):
         "preprocess": 160 * P, "scan": 8 * P, "depth_order": 44 * P, "tile_ranges": 8 * P + 12 * T,
         "tile_lists": 12 * P + 4 * R + 8 * T, "render_forward": 8 * T + 96 * R + 44 * pix + fused_occ,
         "render_backward": 44 * pix + 96 * R + 60 * P, "geometry_backward": (92 + 148) * P,
+        # (the fused head / tail of the plan move the bytes of "preprocess" / "geometry_backward" of every frame of the step as well:
+        # these two rows are per launch of the WHOLE step's kernel only when that kernel dominates, which it does not)
         "lbs_warp_forward": 276 * P, "lbs_warp_backward": 304 * P,
         "lbs_knn_weights": 232 * P + 232 * 10475,
         "frame_loss": 92 * pix,

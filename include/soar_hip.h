@@ -40,8 +40,12 @@ extern "C" {
  * soar_rast_forward_render_status, soar_lbs_warp_backward_views, soar_rast_binning_status_sticky, soar_avatar_pixel_losses, soar_rast_backward_occ (the image
  * buffer grew by two planes: ask soar_rast_image_bytes), soar_gather_step_inputs_ids;
  * soar_selftest_wave_reduce is gone with the backward form it tested.  7 (round 5): soar_step_views_forward / _backward (several poses
- * behind one call each way), soar_cameras_from_c2w, soar_ssim_rendered, SoarAvatarLossArgs::background. */
-#define SOAR_HIP_ABI_VERSION 7
+ * behind one call each way), soar_cameras_from_c2w, soar_ssim_rendered, SoarAvatarLossArgs::background.  8 (round 6):
+ * soar_frames_warp_preprocess (+ SoarFrameHead; SoarRastParams.debug bit 4) and soar_frames_geometry_warp_backward (+ SoarFrameTail;
+ * debug bit 3): the head of the forward pass and the tail of the backward pass of all frames of a step as one kernel each;
+ * soar_rast_backward_rows; the geometry buffer grew (one statistics row per 64 Gaussians: ask soar_rast_geometry_bytes) and so did
+ * soar_views_grad_scratch_floats (a block per back view). */
+#define SOAR_HIP_ABI_VERSION 8
 
 /* Mirrors GaussianRasterizationSettings (DGR/diff_gaussian_rasterization/__init__.py:267-284) and the
  * scalar arguments of RasterizeGaussiansCUDA (DGR/rasterize_points.h:17-31). */

@@ -16,7 +16,7 @@ if os.environ.get("SOAR_HIP_LIB"):
     print(f"[soar_amd] SOAR_HIP_LIB is set: loading {LIB_PATH} instead of the in-tree build (development A/B runs only)", file=_sys.stderr)
 
 FRAME_LOSS_SCRATCH_FLOATS = 4 * 2048   # SOAR_FRAME_LOSS_SCRATCH_FLOATS: the scratch argument of soar_frame_loss[_pooled]
-ABI_VERSION = 7          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
+ABI_VERSION = 8          # SOAR_HIP_ABI_VERSION of include/soar_hip.h this binding was written for
 c_f32p = C.c_void_p
 _vp = C.c_void_p
 

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in soar_hip.h but not exported"
     assert sorted(hip_lib.SIGNATURES) == declared, "ctypes binding and header disagree"
-    assert lib.soar_abi_version() == hip_lib.ABI_VERSION == 7
+    assert lib.soar_abi_version() == hip_lib.ABI_VERSION == 8
 
 
 def test_sizing_functions(lib):
