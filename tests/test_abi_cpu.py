@@ -141,3 +141,30 @@ def test_debug_snapshot_protocol_forward(tmp_path, monkeypatch):
         GaussianRasterizer(st._replace(debug=False))(means, torch.zeros(4, 3), torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
                                                      scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
     assert not (tmp_path / "snapshot_fw.dump").exists()
+
+
+def test_the_fused_ends_of_a_step_refuse_bad_arguments_before_any_launch(lib):
+    """soar_frames_warp_preprocess / soar_frames_geometry_warp_backward (ABI 8): frame counts, NULL blocks and parameter blocks that do
+    not describe the per-frame training path (SH colours, camera gradients, another P) come back as errors -- nothing is launched."""
+    from soar_amd import hip_lib
+    one = C.c_float(0.0)
+    p = C.cast(C.pointer(one), C.c_void_p)           # any non-NULL address: nothing reads it before the checks fail
+    heads = (hip_lib.SoarFrameHead * 9)()
+    tails = (hip_lib.SoarFrameTail * 9)()
+    assert lib.soar_frames_warp_preprocess(0, heads, p, p, p, p, 10, 55, p, p, p, p, p, None) != 0 and "frames" in hip_lib.last_error()
+    assert lib.soar_frames_warp_preprocess(9, heads, p, p, p, p, 10, 55, p, p, p, p, p, None) != 0
+    assert lib.soar_frames_warp_preprocess(1, heads, p, p, None, p, 10, 55, p, p, p, p, p, None) != 0 and "weights" in hip_lib.last_error()
+    assert lib.soar_frames_warp_preprocess(1, heads, p, p, p, p, 10, 55, p, p, p, p, p, None) != 0 and "frame 0" in hip_lib.last_error()
+    prm = hip_lib.SoarRastParams()
+    prm.P, prm.W, prm.H, prm.M = 10, 64, 64, 16
+    heads[0].prm, heads[0].geom_buffer, heads[0].radii = C.addressof(prm), p, p
+    assert lib.soar_frames_warp_preprocess(1, heads, p, p, p, p, 10, 55, p, p, p, p, p, None) != 0 and "explicit colours" in hip_lib.last_error()
+    assert lib.soar_frames_geometry_warp_backward(0, tails, p, p, p, p, 10, 55, p, p, p, p, p, None, None) != 0
+    assert lib.soar_frames_geometry_warp_backward(1, tails, p, p, p, p, 10, 55, None, p, p, p, p, None, None) != 0 and "NULL" in hip_lib.last_error()
+    assert lib.soar_frames_geometry_warp_backward(1, tails, p, p, p, p, 10, 55, p, p, p, p, p, None, None) != 0 and "frame 0" in hip_lib.last_error()
+    prm.M, prm.cfg_lrn_cam = 0, 1
+    t = tails[0]
+    t.prm, t.means3D, t.rotations, t.radii, t.geom_buffer, t.workspace, t.dL_dmeans2D = C.addressof(prm), p, p, p, p, p, p
+    assert lib.soar_frames_geometry_warp_backward(1, tails, p, p, p, p, 10, 55, p, p, p, p, p, None, None) != 0 and "cfg_lrn_cam" in hip_lib.last_error()
+    # P == 0: nothing to do, no error
+    assert lib.soar_frames_geometry_warp_backward(1, tails, p, p, p, p, 0, 55, p, p, p, p, p, None, None) == 0
