@@ -119,7 +119,7 @@ class FrameStepPlan:
         # stops behind its blend (SoarRastParams.debug bit 3; the forward calls share the block and do not look at that bit), the
         # epilogue runs the per-Gaussian stage of all frames and the warp's backward together.  SOAR_PLAN_FUSED_TAIL=0: the two kernels
         # of rounds 1-5 (geometry_backward per frame, then soar_lbs_warp_backward_sum).
-        self.fused_tail = os.environ.get("SOAR_PLAN_FUSED_TAIL", "1") != "0"
+        self.fused_tail = os.environ.get("SOAR_PLAN_FUSED_TAIL", "1") != "0" and self.n <= 8      # (the entry takes at most 8 frames)
         if self.fused_tail:
             self.ctx.params.debug |= 8
             self._tail_frames = (hip_lib.SoarFrameTail * self.n)()
@@ -129,7 +129,7 @@ class FrameStepPlan:
                 t.means3D, t.rotations, t.radii = v["xyz_p"].data_ptr(), v["rot_p"].data_ptr(), v["radii"].data_ptr()
                 t.geom_buffer, t.workspace, t.dL_dmeans2D = v["geom"].data_ptr(), v["work"].data_ptr(), v["g_means2D"].data_ptr()
         # ... and the head of the forward pass likewise (soar_frames_warp_preprocess; SOAR_PLAN_FUSED_HEAD=0: warp, then preprocess)
-        self.fused_head = os.environ.get("SOAR_PLAN_FUSED_HEAD", "1") != "0"
+        self.fused_head = os.environ.get("SOAR_PLAN_FUSED_HEAD", "1") != "0" and self.n <= 8
         if self.fused_head:
             self.ctx.params.debug |= 16
             self._head_frames = (hip_lib.SoarFrameHead * self.n)()
