@@ -198,7 +198,7 @@ int carve_geom(void *base, int32_t P, int32_t M, GeomBuf *out)
     take(p, out->bucket_base, BKT_MAX + 1);
     take(p, out->blk_stats, ((n + 63) / 64) * BLK_STATS);          // one row per 64 Gaussians (a wavefront of preprocess)
     take(p, out->band_cnt, 64 * ((n + 1023) / 1024));
-    take(p, out->band_info, 128);
+    take(p, out->band_info, 256);
     out->scan_temp_bytes = scan_temp_bytes(P);
     char *tmp;
     take(p, tmp, out->scan_temp_bytes);

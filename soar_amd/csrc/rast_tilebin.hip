@@ -42,6 +42,7 @@ __device__ __forceinline__ int prefix_in_mask(unsigned long long m)
 // preprocess); a bucket holds a few dozen pairs and is sorted by one wavefront in registers.  Larger buckets are sorted by
 // the whole workgroup in LDS, and the (pathological: thousands of equal depths) ones beyond that in global memory.
 constexpr int BKT_LDS = 2048;            // pairs one workgroup sorts in LDS
+constexpr int BAND_MAX = 64;            // bands of tile rows (upper bound: one lane per band in the per-wavefront counts)
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float scale, int B)
 {
@@ -72,6 +73,7 @@ struct BucketCountArgs {
     uint32_t *bucket_mat;    // [ceil(P / BKT_CHUNK)][B]: counts, then starts
     uint32_t *bucket_base;   // [B + 1]: start of every bucket
     uint32_t *slot;          // [P] place among the workgroup's members of the bucket
+    uint32_t *band_info;     // (the scan launch resets the bands' column extents for band_count)
 };
 __global__ void __launch_bounds__(1024) bucket_count_kernel(Batch<BucketCountArgs> batch)
 {
@@ -196,6 +198,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(Batch<BucketCountArgs
         }
     }
     if (grp == 0 && tid == 0) { a.bucket_base[B] = all_s; a.header[H_NVIS] = all_s; }
+    if (grp == 0 && tid < BAND_MAX) { a.band_info[2 * BAND_MAX + tid] = 0xFFFFFFFFu; a.band_info[3 * BAND_MAX + tid] = 0u; }
 }
 
 struct BucketScatterArgs {
@@ -350,7 +353,6 @@ __global__ void __launch_bounds__(256) bucket_sort_kernel(Batch<BucketSortArgs> 
 // band b = tile rows [b * band_rows, (b + 1) * band_rows).  band_count: per (band, 1024-chunk of the depth order) the number of
 // rectangles that reach into the band; band_place: exclusive scan of that matrix in (band, chunk) order = where every chunk's
 // entries of every band go, then the same ballots again to place them.  Both keep the depth order inside a band.
-constexpr int BAND_MAX = 64;            // bands (upper bound: one lane per band in the per-wavefront counts)
 constexpr int BAND_THREADS = 1024;
 constexpr int BAND_WAVES = BAND_THREADS / WAVE;
 
@@ -361,7 +363,7 @@ struct BandArgs {
     const uint2 *rect_sorted;
     const uint32_t *ids_sorted;
     uint32_t *band_cnt;                 // [nb][nchunk]
-    uint32_t *band_info;                // [2 * BAND_MAX]: start, length of every band's list
+    uint32_t *band_info;                // [4 * BAND_MAX]: start, length of every band's list; first / one past the last tile column it reaches
     uint2 *band_rect;
     uint32_t *band_id;
 };
@@ -392,15 +394,25 @@ __global__ void __launch_bounds__(BAND_THREADS) band_count_kernel(Batch<BandArgs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nvis = (int)a.header[H_NVIS];
     const int k = blockIdx.x * BAND_THREADS + tid;
+    // (and the tile columns every band's rectangles reach: a super-tile outside its band's extent leaves bin_tiles at once)
+    __shared__ uint32_t col0[BAND_MAX], col1[BAND_MAX];
+    if (tid < BAND_MAX) { col0[tid] = 0xFFFFFFFFu; col1[tid] = 0u; }
     int b0 = 0, b1 = -1;
-    if (k < nvis) band_span(a.rect_sorted[k], a.band_rows, b0, b1);
+    uint2 rc = make_uint2(0u, 0u);
+    if (k < nvis) { rc = a.rect_sorted[k]; band_span(rc, a.band_rows, b0, b1); }
     band_wave_counts(a.nb, b0, b1, lane, wcnt, wave);
     __syncthreads();
+    for (int b = b0; b <= b1; b++) { atomicMin(&col0[b], rc.x & 0xFFFFu); atomicMax(&col1[b], rc.x >> 16); }
     if (tid < a.nb) {
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < BAND_WAVES; w++) t += wcnt[w][tid];
         a.band_cnt[(size_t)tid * a.nchunk + blockIdx.x] = t;
+    }
+    __syncthreads();
+    if (tid < a.nb && col1[tid] > col0[tid]) {
+        atomicMin(&a.band_info[2 * BAND_MAX + tid], col0[tid]);
+        atomicMax(&a.band_info[3 * BAND_MAX + tid], col1[tid]);
     }
 }
 
@@ -796,11 +808,336 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
         w[3] = ((dbg_t1 - dbg_t0) << 32) | (unsigned long long)P;
     }
 }
-__global__ void __launch_bounds__(BIN_THREADS) bin_tiles_kernel(Batch<BinTilesArgs> batch)
+
+// Round 6: the same lists with no barrier inside either walk and no shared survivor buffers (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us
+// per 4-frame launch at C3).  Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
+// leaves the sizes of the 16 lists per wavefront, an exclusive scan of those over the wavefronts (per tile) says where every
+// wavefront's entries of every tile start -- slice after slice = depth order -- and every wavefront then appends straight to the 16
+// lists at 16 running cursors in scalar registers.
+//   * These launches are bound by vector instructions: a wavefront instruction occupies its SIMD for four cycles, and the log
+//     (SOAR_BIN_LOG) of every variant tried fits  time = vector instructions of the workgroup's wavefronts / 2400 per us  + ~9 us of
+//     fixed latencies (first loads, three barriers, the reservation's atomic).  A slab of 64 rectangles none of which touches the
+//     super-tile costs its loads and ~12 instructions (most slabs of most workgroups: 30 super-tiles walk every band; the test itself is
+//     two packed 16-bit multiply-adds and a sign mask), one with a hit ~45 more (cover mask, compaction).
+//   * The rectangles that do touch it are compacted -- (id, 16-bit cover mask), in order -- into a ring of CAP entries PRIVATE to the
+//     wavefront (no barrier: the LDS executes one wavefront's operations in order), and both the counting and the placing work on DENSE
+//     slabs of 64 kept entries: one ballot-prefix compaction per (dense slab, tile) -- 6 vector instructions and two stores; the ballot
+//     itself is the stores' lane mask.
+//   * A wavefront whose kept entries all fit the ring never walks the band a second time: the first walk captured them.
+//     The others walk their slice again, streaming through the ring.
+//   * A super-tile outside the columns its band's rectangles reach (band_count leaves the extent) has nothing to list.  In a band of
+//     more than SPLIT_AT rectangles its workgroup HELPS instead: it takes the lower two rows of tiles of a super-tile inside the extent,
+//     whose own workgroup keeps the upper two (the launch waits for its heaviest workgroup: 72k list entries from a band of 26k, 49 us
+//     alone; halved 40 us).
+//   Tried and dropped, all with `point_list` bit-exact (same file): placing straight from the walk's slabs (74 us: 16 compactions per
+//   slab with ANY hit); a pool of kept-entry blocks in LDS that wavefront t goes through for tile t (balanced whichever wavefronts found
+//   the entries -- a patch of surface is a narrow range of depths, so a super-tile's hits cluster in a few slices -- but 16 wavefronts x
+//   ~30 instructions per block: 65 us), the same with a tile's entries merged across blocks by a cross-lane permute into full 64-lane
+//   stores (71 us: the stores were not what the placing waited for); two workgroups per super-tile in the grid (+13 us for DISPATCHING
+//   2040 more idle 16-wavefront workgroups, whatever they then do); four helpers' rows instead of two (55 us: three more walks of the
+//   band per heavy super-tile); workgroups of 8 wavefronts (58-62 us); sizes counted by 16 ballots per slab (57 us).
+#ifndef SOAR_BIN_DIRECT
+#define SOAR_BIN_DIRECT 1
+#endif
+#ifndef SOAR_BIN_DIRECT_UNROLL
+#define SOAR_BIN_DIRECT_UNROLL 4
+#endif
+#ifndef SOAR_BIN_SPLIT_AT
+#define SOAR_BIN_SPLIT_AT 12288      // rectangles in a band from which its super-tiles are shared by two workgroups
+#endif
+#ifndef SOAR_BIN_DIRECT_WAVES
+#define SOAR_BIN_DIRECT_WAVES 16     // (8: 58-62 us against 51)
+#endif
+constexpr int BD_WAVES = SOAR_BIN_DIRECT_WAVES, BD_THREADS = BD_WAVES * WAVE;
+#ifndef SOAR_BIN_MAX_PARTS
+#define SOAR_BIN_MAX_PARTS 2         // (4: a row of tiles per workgroup where three helpers are free -- 55 us against 52)
+#endif
+#ifndef SOAR_BIN_CAPTURE
+#define SOAR_BIN_CAPTURE 512         // kept entries a wavefront's ring holds (power of two >= 128): 4 KB per wavefront, 64 KB per workgroup
+                                     // (128 / 256 / 512: 57.0 / 52.4 / 50.9 us)
+#endif
+__device__ __forceinline__ void wave_lds_order()
+{
+    // the wavefront's own LDS writes before its own LDS reads: ordering for the compiler only (the hardware keeps one wavefront's
+    // LDS operations in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// does the rectangle touch the super-tile?  x0 < tx1 && x1 > tx0 as the signs of (tx1 - 1 - x0, x1 - tx0 - 1), two 16-bit halves of one
+// packed multiply-add (coordinates are tile indices: < 2^15), likewise y
+struct SuperTileTest {
+    uint32_t cx, cy;
+};
+__device__ __forceinline__ SuperTileTest super_tile_test(const SuperTile &s)
+{
+    SuperTileTest t;
+    t.cx = ((uint32_t)(s.tx1 - 1) & 0xFFFFu) | ((uint32_t)(-s.tx0 - 1) << 16);
+    t.cy = ((uint32_t)(s.ty1 - 1) & 0xFFFFu) | ((uint32_t)(-s.ty0 - 1) << 16);
+    return t;
+}
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool rect_hits_packed(uint2 rc, const SuperTileTest &t)
+{
+    // low half: -x0 + (tx1 - 1), high half: +x1 + (-tx0 - 1); both >= 0 <=> hit
+    const uint32_t sign = 0x0001FFFFu;                 // (-1, +1) as two int16: low half first
+    short2v a, b, c;
+    uint32_t dx, dy;
+    __builtin_memcpy(&a, &rc.x, 4); __builtin_memcpy(&b, &sign, 4); __builtin_memcpy(&c, &t.cx, 4);
+    short2v rx = a * b + c;
+    __builtin_memcpy(&a, &rc.y, 4); __builtin_memcpy(&c, &t.cy, 4);
+    short2v ry = a * b + c;
+    __builtin_memcpy(&dx, &rx, 4); __builtin_memcpy(&dy, &ry, 4);
+    return ((dx | dy) & 0x80008000u) == 0u;
+}
+__device__ __forceinline__ void bin_tiles_direct_body(const int bx, const BinTilesArgs &a)
+{
+    const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
+    constexpr int NT = BIN_SUPER * BIN_SUPER, U = SOAR_BIN_DIRECT_UNROLL, CAP = SOAR_BIN_CAPTURE;
+    static_assert(BIN_SUPER == 4 && BD_WAVES * WAVE >= NT, "16 tiles: a cover mask has 16 bits");
+    static_assert(CAP >= 2 * WAVE && (CAP & (CAP - 1)) == 0, "a ring holds a dense slab plus what one slab of the band can add");
+    __shared__ uint2 ring[BD_WAVES][CAP];             // kept entries of one wavefront: (id, cover mask)
+    __shared__ uint32_t wave_tile[BD_WAVES][NT];      // sizes per (wavefront, tile); then: entries of the wavefronts before it
+    __shared__ uint32_t tile_cnt[NT], tile_base[NT];
+    __shared__ int fits_s;
+    const uint32_t *__restrict__ header = a.header;
+    const int gx = a.gx, gy = a.gy;
+    const int band = band_of_block(bx, gx, a.band_rows);
+    const uint2 *__restrict__ rect_sorted = a.band_rect + a.band_info[band];
+    const uint32_t *__restrict__ ids_sorted = a.band_id + a.band_info[band];
+    const int P = header[H_NVIS] ? (int)a.band_info[BAND_MAX + band] : 0;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (scalar: uniform loop bounds)
+    char *__restrict__ point_list = reinterpret_cast<char *>(a.point_list);
+    char *__restrict__ tile_xy = reinterpret_cast<char *>(a.tile_xy);
+    // The super-tile columns the band's rectangles reach (band_count): the workgroups of the other columns have nothing to list.
+    // In a band of more than SPLIT_AT rectangles they HELP instead: the h-th of them takes the lower two rows of tiles of the h-th
+    // column inside the extent (its own walk, its own reservation), whose own workgroup then only takes the upper two -- the launch
+    // waits for its heaviest workgroup (72k list entries from a band of 26k at C3: 49 us alone), and a launch with two workgroups per
+    // super-tile pays more for dispatching the idle ones than the split wins (+13 us for 2040 more of them).
+    const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, scol = bx % nsx;
+    const int ex0 = (int)(a.band_info[2 * BAND_MAX + band] & 0xFFFFu), ex1 = (int)a.band_info[3 * BAND_MAX + band];
+    const int se0 = ex0 / BIN_SUPER, se1 = (ex1 + BIN_SUPER - 1) / BIN_SUPER, width = se1 - se0;
+    const bool inside = P > 0 && scol >= se0 && scol < se1, split = P > SOAR_BIN_SPLIT_AT;
+    SuperTile st = super_tile_of(bx, gx, gy);
+    // the idle columns are dealt to the columns inside the extent in turn: column j gets the helpers j, j + width, j + 2 width, ...
+    // and is shared by 2 workgroups (two rows of tiles each) with one helper, by 4 (a row each) with three
+    const int helpers = nsx - width;
+    auto parts_of = [&](int j) {
+        const int q = helpers / width + (j < helpers % width ? 1 : 0);
+        return !split ? 1 : (q >= 3 && SOAR_BIN_MAX_PARTS >= 4) ? 4 : q >= 1 ? 2 : 1;
+    };
+    int sub = 0, parts = 1;
+    if (!inside) {
+        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + ((tid >> 2) & 3);
+        if (tid < NT && tx < st.tx1 && ty < st.ty1) { a.tile_count[ty * gx + tx] = 0u; a.ranges[ty * gx + tx] = make_uint2(0u, 0u); }
+        const int h = scol < se0 ? scol : scol - width;                 // its number among the columns outside the extent
+        const int j = width > 0 ? h % width : 0;
+        if (split && width > 0) { parts = parts_of(j); sub = h / width + 1; }
+        if (sub == 0 || sub >= parts) {
+            if (a.dbg && tid == 0) { a.dbg[(size_t)bx * 4] = 1ull; a.dbg[(size_t)bx * 4 + 1] = dbg_t0; }
+            return;
+        }
+        st = super_tile_of(bx - scol + se0 + j, gx, gy);
+    } else {
+        parts = parts_of(scol - se0);
+    }
+    {
+        const int rows = BIN_SUPER / parts;
+        st.ty0 += sub * rows;
+        st.ty1 = min(st.ty1, st.ty0 + rows);
+        if (st.ty0 >= st.ty1) return;                  // (a last row of super-tiles with fewer rows of tiles)
+    }
+    const int my_tx = st.tx0 + (tid & 3), my_ty = st.ty0 + ((tid >> 2) & 3);          // thread t < 16 reports tile t
+    const bool my_tile = tid < NT && my_tx < st.tx1 && my_ty < st.ty1;
+    // this wavefront's slabs (64 rectangles each) of the band
+    const int nslab = (P + WAVE - 1) / WAVE, per = (nslab + BD_WAVES - 1) / BD_WAVES;
+    const int s0 = wave * per, s1 = min(nslab, s0 + per);
+    uint2 *__restrict__ my_ring = ring[wave];
+    const SuperTileTest stt = super_tile_test(st);
+
+    // The walk of the slice: `keep(hit ballot, hit, id, mask)` for every slab with a rectangle that touches the super-tile.
+    // (loads behind the end of the list are clamped, not skipped: see the note in bin_tiles_kernel_body)
+    const char *__restrict__ rect_bytes = reinterpret_cast<const char *>(rect_sorted);
+    const char *__restrict__ id_bytes = reinterpret_cast<const char *>(ids_sorted);
+    const int in_slice = min(P, s1 * WAVE);            // rectangles behind this are not this wavefront's
+    auto walk = [&](auto &&keep) {
+        uint2 rc[U];
+        uint32_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = (uint32_t)min((s0 + u) * WAVE + lane, P - 1);       // (32-bit byte offsets: P < 2^28)
+            rc[u] = *reinterpret_cast<const uint2 *>(rect_bytes + (k << 3));
+            id[u] = *reinterpret_cast<const uint32_t *>(id_bytes + (k << 2));
+        }
+        for (int s = s0; s < s1; s += U) {
+            uint2 nrc[U];
+            uint32_t nid[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t k = (uint32_t)min((s + U + u) * WAVE + lane, P - 1);
+                nrc[u] = *reinterpret_cast<const uint2 *>(rect_bytes + (k << 3));
+                nid[u] = *reinterpret_cast<const uint32_t *>(id_bytes + (k << 2));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool hit = rect_hits_packed(rc[u], stt) & ((s + u) * WAVE + lane < in_slice);
+                const unsigned long long hb = __builtin_amdgcn_ballot_w64(hit);
+                if (hb != 0ull) keep(hb, hit, id[u], hit ? cover_mask(rc[u], st) : 0u);
+                rc[u] = nrc[u];
+                id[u] = nid[u];
+            }
+        }
+    };
+
+    // walk 1: the kept entries into the ring while they fit, and the sizes of the 16 lists: 16 byte-wide counters per lane (the cover
+    // mask spread over four registers), folded over the wavefront before a byte could overflow and at the end -- lane t < 16 then holds
+    // the wavefront's number of entries of tile t.  The masks are counted from the ring's DENSE slabs of 64 kept entries (16 instructions
+    // per dense slab instead of per slab of the band with a hit in it); from the slab that no longer fits, the ring's content is
+    // counted and the rest slab by slab.
+    uint32_t mine = 0u;
+    int nkept = 0;                                     // kept entries of this wavefront (scalar)
+    {
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};
+        int since = 0;
+        auto fold = [&]() {
+            uint32_t part[8];
+#pragma unroll
+            for (int d = 0; d < 4; d++) { part[2 * d] = acc[d] & 0x00FF00FFu; part[2 * d + 1] = (acc[d] >> 8) & 0x00FF00FFu; acc[d] = 0u; }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) part[q] += (uint32_t)__shfl_xor((int)part[q], d);
+            // part[2d] = tiles 4d (low half) and 4d+2 (high half), part[2d+1] = tiles 4d+1 and 4d+3
+            const int d = (lane >> 2) & 3, k = lane & 3;
+            const uint32_t w = (k & 1) ? (d == 0 ? part[1] : d == 1 ? part[3] : d == 2 ? part[5] : part[7])
+                                       : (d == 0 ? part[0] : d == 1 ? part[2] : d == 2 ? part[4] : part[6]);
+            mine += (k & 2) ? w >> 16 : w & 0xFFFFu;
+            since = 0;
+        };
+        auto count_masks = [&](uint32_t m) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) acc[d] += (((m >> (4 * d)) & 15u) * 0x00204081u) & 0x01010101u;
+            if (++since == 255) fold();
+        };
+        auto count_ring = [&](int n) {
+            wave_lds_order();
+            for (int h = 0; h < n; h += WAVE) count_masks(h + lane < n ? my_ring[h + lane].y : 0u);
+        };
+        bool full = false;
+        walk([&](unsigned long long hb, bool hit, uint32_t id, uint32_t m) {
+            const int n = __builtin_popcountll(hb);
+            if (!full && nkept + n > CAP) { count_ring(nkept); full = true; }
+            if (full) count_masks(m);
+            else if (hit) my_ring[nkept + prefix_in_mask(hb)] = make_uint2(id, m);
+            nkept += n;
+        });
+        if (!full) count_ring(nkept);
+        if (since) fold();
+    }
+    if (lane < NT) wave_tile[wave][lane] = mine;
+    lds_barrier();
+    const unsigned long long dbg_t1 = a.dbg ? wall_clock64() : 0ull;
+    {   // thread (w, t): the entries of tile t in the wavefronts before w, and in all of them
+        const int w = (tid >> 4) & (BD_WAVES - 1), t = tid & (NT - 1);
+        uint32_t before = 0u, all = 0u;
+        if (tid < BD_WAVES * NT) {
+#pragma unroll
+            for (int v = 0; v < BD_WAVES; v++) {
+                const uint32_t c = wave_tile[v][t];
+                before += v < w ? c : 0u;
+                all += c;
+            }
+        }
+        lds_barrier();
+        if (tid < BD_WAVES * NT) wave_tile[w][t] = before;
+        if (tid < NT) tile_cnt[tid] = all;
+    }
+    lds_barrier();
+    if (tid == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) { tile_base[t] = sum; sum += tile_cnt[t]; }
+        uint32_t start = 0;
+        bool fits = true;
+        if (sum) {
+            start = atomicAdd(&a.header[H_TOTAL], sum);
+            fits = (uint64_t)start + sum <= (uint64_t)a.capacity;
+            if (!fits) atomicMax(&a.header[H_OVERFLOW], start + sum);     // the last one to get here leaves the number needed
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) tile_base[t] += start;
+        fits_s = fits ? 1 : 0;
+    }
+    lds_barrier();
+    const bool fits = fits_s != 0;
+    {
+        const uint32_t cnt = tile_cnt[tid & (NT - 1)], first = tile_base[tid & (NT - 1)];
+        if (my_tile) {
+            a.tile_count[my_ty * gx + my_tx] = cnt;
+            a.ranges[my_ty * gx + my_tx] = (cnt && fits) ? make_uint2(first, first + cnt) : make_uint2(0u, 0u);
+        }
+    }
+    // placing: the wavefronts that kept something append their entries, dense slab by dense slab; cursors in scalar registers
+    if (fits && nkept > 0) {
+        const uint32_t curv = lane < NT ? tile_base[lane] + wave_tile[wave][lane] : 0u;
+        uint32_t cur[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) cur[t] = (uint32_t)__builtin_amdgcn_readlane((int)curv, t);
+        const uint32_t xy0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)st.ty0 << 16) | (uint32_t)st.tx0));
+        auto place = [&](int head, int cnt) {          // the ring's entries [head, head + cnt), cnt <= 64
+            wave_lds_order();
+            const uint2 e = my_ring[(head + lane) & (CAP - 1)];
+            const uint32_t m = lane < cnt ? e.y : 0u;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64((m & (1u << t)) != 0u);
+                if (bal != 0ull) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(bal)) {     // (the ballot IS the stores' lane mask: no second compare)
+                        const uint32_t at = (cur[t] + (uint32_t)prefix_in_mask(bal)) << 2;        // byte offset: capacity < 2^30 entries
+                        *reinterpret_cast<uint32_t *>(point_list + at) = e.x;
+                        uint32_t xy = xy0;                 // (a scalar, and kept out of 16 loop-invariant vector registers: two
+                        asm volatile("" : "+s"(xy));       //  workgroups per CU need <= 64)
+                        *reinterpret_cast<uint32_t *>(tile_xy + at) = xy + (((uint32_t)(t >> 2) << 16) | (uint32_t)(t & 3));
+                    }
+                    cur[t] += (uint32_t)__builtin_popcountll(bal);
+                }
+            }
+            wave_lds_order();                           // (the slots are free for the walk's next entries only now)
+        };
+        if (nkept <= CAP) {
+            for (int h = 0; h < nkept; h += WAVE) place(h, min(WAVE, nkept - h));
+        } else {
+            int head = 0, n = 0;
+            walk([&](unsigned long long hb, bool hit, uint32_t id, uint32_t m) {
+                if (hit) my_ring[(head + n + prefix_in_mask(hb)) & (CAP - 1)] = make_uint2(id, m);
+                n += __builtin_popcountll(hb);
+                if (n >= WAVE) { place(head, WAVE); head = (head + WAVE) & (CAP - 1); n -= WAVE; }
+            });
+            if (n) place(head, n);
+        }
+    }
+    if (a.dbg) lds_barrier();                          // (the log's end of the workgroup: its last wavefront's)
+    if (a.dbg && tid == 0) {
+        unsigned long long *w = a.dbg + (size_t)bx * 4;
+        uint32_t kept = 0;
+        for (int t = 0; t < NT; t++) kept += tile_cnt[t];
+        w[0] = wall_clock64() - dbg_t0; w[1] = dbg_t0; w[2] = (unsigned long long)kept;
+        w[3] = ((dbg_t1 - dbg_t0) << 32) | (unsigned long long)P;
+    }
+}
+
+#ifndef SOAR_BIN_WPE
+#define SOAR_BIN_WPE 8        // two workgroups per CU
+#endif
+__global__ void __launch_bounds__(SOAR_BIN_DIRECT ? BD_THREADS : BIN_THREADS) __attribute__((amdgpu_waves_per_eu(SOAR_BIN_WPE, 8))) bin_tiles_kernel(Batch<BinTilesArgs> batch)
 {
     int frame, bx;
     batch_interleave1(frame, bx);
+#if SOAR_BIN_DIRECT
+    bin_tiles_direct_body(bx, batch.v[frame]);
+#else
     bin_tiles_kernel_body(bx, batch.v[frame]);
+#endif
 }
 
 
@@ -820,7 +1157,7 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
     const int nblk = (prm.P + 63) / 64;                 // one statistics row per wavefront of preprocess (64 Gaussians)
     const int nw = (prm.P + BKT_CHUNK - 1) / BKT_CHUNK;
     StageTimer timer(ST_SORT, stream);
-    const BucketCountArgs ca = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot};
+    const BucketCountArgs ca = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.blk_stats, nblk, g.header, g.bucket_mat, g.bucket_base, g.sort_slot, g.band_info};
     SOAR_LAUNCH_BATCHED(bucket_count_kernel, dim3(nw), dim3(1024), 0, stream, ca);
     SOAR_LAUNCH_BATCHED(bucket_scan_kernel, dim3((B + 1023) / 1024), dim3(1024), 0, stream, ca);
     const BucketScatterArgs sa = {prm.P, B, prm.sort_descending ? 1 : 0, g.depth_key, g.header, g.bucket_mat, g.sort_slot, g.sort_pairs};
@@ -832,6 +1169,7 @@ int launch_depth_buckets(const SoarRastParams &prm, GeomBuf &g, hipStream_t stre
 int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageBuf &img, int64_t capacity, hipStream_t stream)
 {
     if (prm.P >= (1 << 28)) { set_error("tile binning packs a Gaussian's index into 28 bits: P = %d is too large", prm.P); return 1; }
+    if (capacity >= (1ll << 30)) { set_error("tile binning addresses the lists with 32-bit byte offsets: a capacity of %lld instances is too large", (long long)capacity); return 1; }
     const int gx = (prm.W + TILE - 1) / TILE, gy = (prm.H + TILE - 1) / TILE;
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, nsy = (gy + BIN_SUPER - 1) / BIN_SUPER;
     {
@@ -872,16 +1210,29 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         }
         const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted,
                                  img.tile_count, ba.capacity, dbg, b.tile_xy};
-        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bt);
+        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(SOAR_BIN_DIRECT ? BD_THREADS : BIN_THREADS), 0, stream, bt);
         if (log_now) {
-            const size_t nw = (size_t)(nsx * nsy) * 4;
+            const int nwg = nsx * nsy;
+            const size_t nw = (size_t)nwg * 4;
             SOAR_HIP_OK(hipStreamSynchronize(stream));
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
             SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
             (void)hipFree(dbg);
+#if SOAR_BIN_DIRECT
+            {   // when the workgroups started and ended, relative to the first one's start (100 MHz clock)
+                unsigned long long first = ~0ull, last = 0ull;
+                for (int i = 0; i < nwg; i++) if (h[i * 4]) { first = h[i * 4 + 1] < first ? h[i * 4 + 1] : first; }
+                for (int i = 0; i < nwg; i++) if (h[i * 4]) { const unsigned long long e = h[i * 4 + 1] + h[i * 4]; last = e > last ? e : last; }
+                fprintf(stderr, "[bin_tiles] %d workgroups: first start to last end %.1f us; starts (us after the first) of workgroups 0, 1/4, 1/2, 3/4, last: %.1f %.1f %.1f %.1f %.1f\n",
+                        nwg, (last - first) / 100.0, (h[1] - first) / 100.0, (h[(nwg / 4) * 4 + 1] - first) / 100.0,
+                        (h[(nwg / 2) * 4 + 1] - first) / 100.0, (h[(3 * nwg / 4) * 4 + 1] - first) / 100.0, (h[(nwg - 1) * 4 + 1] - first) / 100.0);
+                for (int i = 0; i < nwg; i++) if (h[i * 4] > 1500) fprintf(stderr, "[bin_tiles]   WG %d: start %.1f, %.1f us (walk %.1f), %llu kept of %llu%s\n", i, (h[i * 4 + 1] - first) / 100.0,
+                        h[i * 4] / 100.0, (h[i * 4 + 3] >> 32) / 100.0, h[i * 4 + 2] & 0xFFFFFFFFull, h[i * 4 + 3] & 0xFFFFFFFFull, (h[i * 4 + 2] >> 32) ? " (two walks)" : "");
+            }
+#endif
             for (int rep = 0; rep < 5; rep++) {             // the five slowest workgroups
                 int best = -1;
-                for (int i = 0; i < nsx * nsy; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
+                for (int i = 0; i < nwg; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
                 fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, first walk %.1f us, %.1f us in %llu flushes, %llu kept entries of %llu band entries\n",
                         best, h[best * 4] / 100.0, (h[best * 4 + 3] >> 32) / 100.0, h[best * 4 + 1] / 100.0, h[best * 4 + 2] >> 32,
                         h[best * 4 + 2] & 0xFFFFFFFFull, h[best * 4 + 3] & 0xFFFFFFFFull);

@@ -149,7 +149,7 @@ struct GeomBuf {
     uint32_t *bucket_base;   // [BKT_MAX + 1]
     uint32_t *blk_stats;     // [ceil(P/64)][BLK_STATS] per-wavefront maxima written by preprocess
     uint32_t *band_cnt;      // [64][ceil(P/1024)] entries per (band of tile rows, chunk of the depth order) (rast_tilebin.hip)
-    uint32_t *band_info;     // [128] start / length of every band's list
+    uint32_t *band_info;     // [256] start / length of every band's list, first / one past the last tile column its rectangles reach
     void *scan_temp;
     size_t scan_temp_bytes;
     size_t total_bytes;
