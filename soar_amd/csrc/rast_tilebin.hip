@@ -14,14 +14,15 @@
 //   2. band_count / band_place: the depth-ordered rectangles are split -- stably, by ballot-prefix compaction, no atomics --
 //      into one list per BAND of tile rows (a band = the rows of one super-tile row, or a few of them on very tall images).
 //      A super-tile only has to look at its own band's list (~1/10 of the Gaussians at 1080p) instead of all of them.
-//   3. bin_tiles: one workgroup per super-tile (4x4 tiles) walks its band list twice.  First pass: the sizes of its 16 lists, in
-//      byte-wide counters in registers; then ONE atomic add reserves room for the 16 lists (ranges, capacity check).  Second pass:
-//      the rectangles that touch the super-tile are kept (in order, per row of tiles) and appended to each covered tile's list with
+//   3. bin_tiles: one workgroup per super-tile (4x4 tiles) walks its band list: every wavefront a contiguous slice of it, keeping
+//      the rectangles that touch the super-tile (in order) in a ring of its own and counting them per tile; ONE atomic add reserves room
+//      for the 16 lists (ranges, capacity check); then every wavefront appends its kept entries to each covered tile's list with
 //      ballot-prefix compaction: every list comes out in depth order with no per-tile sort and no atomics on the lists.
 //      (Rounds 1-2: a counting launch on an LDS difference grid, a one-workgroup scan of the tile counts, then the placing launch.)
 //   The longest-list-first tile order of the blend kernels needs every tile's count: one workgroup of the NEXT launch builds it
 //   (block_mask_kernel, rast_blockmask.hip).
-// The descending sort (back views) keeps the library path (rast_binning.hip).
+// Back views (descending sort) take the same path with flipped keys; the 64-bit key sort (rast_binning.hip) only serves the key export
+// and the empty case.
 #include "soar_common.h"
 
 #include <cstdio>
@@ -489,13 +490,7 @@ __global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs
     }
 }
 
-constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile: one tile per wavefront
-constexpr int BIN_THREADS = 1024;
-constexpr int BIN_WAVES = BIN_THREADS / WAVE;
-constexpr int BIN_UNROLL = 4;           // rectangles per thread and trip (independent loads in flight)
-constexpr int BIN_CHUNK = BIN_THREADS * BIN_UNROLL;
-constexpr int BIN_CAP = BIN_CHUNK;      // survivors buffered per ROW of tiles between two flushes: a whole trip's hits always fit
-                                        // (4 rows x 4096 entries x 4 bytes = 64 KB of LDS)
+constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile
 
 struct SuperTile {
     int tx0, ty0, tx1, ty1;
@@ -510,12 +505,6 @@ __device__ __forceinline__ SuperTile super_tile_of(int block, int gx, int gy)
     s.ty1 = min(gy, s.ty0 + BIN_SUPER);
     return s;
 }
-__device__ __forceinline__ bool rect_hits(uint2 rc, const SuperTile &s)
-{
-    const int x0 = (int)(rc.x & 0xFFFFu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xFFFFu), y1 = (int)(rc.y >> 16);
-    return x0 < s.tx1 && x1 > s.tx0 && y0 < s.ty1 && y1 > s.ty0;       // empty rectangles are never stored in the sorted list
-}
-
 // band of a super-tile: its row of super-tiles, or several rows per band on very tall images
 __device__ __forceinline__ int band_of_block(int block, int gx, int band_rows)
 {
@@ -533,14 +522,13 @@ __device__ __forceinline__ uint32_t cover_mask(uint2 rc, const SuperTile &s)
     return row * spread;                       // row < 16: no carries between the nibbles
 }
 
-// The lists.  One workgroup per 4x4 tiles walks its band's depth-ordered rectangles; those that touch the 16 tiles are kept (in order)
-// in LDS with the mask of the tiles they cover.  Wavefront t owns tile t: it counts the kept entries that cover its tile, the
-// workgroup reserves room for its 16 lists behind whatever has been reserved so far (ONE atomic add on header[H_TOTAL] per
-// workgroup: the lists of a tile are contiguous and in depth order, the tiles of a frame lie in the order the workgroups got there --
-// `ranges` says where; nothing downstream assumes tile order), and every wavefront appends its tile's entries by ballot-prefix
-// compaction at its own cursor: no per-tile sort, no atomics on the lists.  Rounds 1-2 had a counting launch, a one-workgroup scan of
-// the tile counts and this launch: two walks of every band list and a serial kernel between them, 100 us per 4-frame step at C3.
-// A super-tile with more kept entries than the LDS buffer holds (8192) counts buffer by buffer and walks its band a second time.
+// The lists.  One workgroup per 4x4 tiles walks its band's depth-ordered rectangles and keeps those that touch its 16 tiles (in
+// order) with the mask of the tiles they cover; it counts them per tile, reserves room for its 16 lists behind whatever has been
+// reserved so far (ONE atomic add on header[H_TOTAL] per workgroup: the list of a tile is contiguous and in depth order, the tiles of
+// a frame lie in the order the workgroups got there -- `ranges` says where; nothing downstream assumes tile order), and appends
+// every tile's entries by ballot-prefix compaction: no per-tile sort, no atomics on the lists.  (Rounds 1-2 had a counting launch, a
+// one-workgroup scan of the tile counts and this launch, 100 us per 4-frame step at C3; rounds 3-5 one launch with the kept entries
+// in row buffers shared by the workgroup, a barrier per trip of 4096 rectangles, 66 us.)
 // When the lists do not fit the caller's buffer (`capacity`) the workgroup writes no list; header[H_OVERFLOW] ends up as the number
 // of instances needed, and the workgroup that builds the tile order one launch later (block_mask_kernel) empties every range.
 struct BinTilesArgs {
@@ -558,259 +546,8 @@ struct BinTilesArgs {
     unsigned long long *dbg;
     uint32_t *tile_xy;       // BinBuf::tile_xy
 };
-__device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTilesArgs &a)
-{
-    const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
-    unsigned long long dbg_flush = 0;
-    int dbg_nflush = 0, dbg_hits = 0;
-    constexpr int NT = BIN_SUPER * BIN_SUPER;
-    static_assert(BIN_WAVES == NT && BIN_SUPER == 4, "one wavefront per tile of the 4x4 super-tile");
-    // The kept entries are buffered per ROW of tiles (an entry that spans rows is kept once per row): id << 4 | the columns of the
-    // row it covers.  A wavefront then only walks its own row's buffer -- a third of the entries of a dense super-tile, where a
-    // splat covers one or two tiles: the walks of the buffers are what the slowest workgroups of this launch spend their time on.
-    __shared__ uint32_t surv[BIN_SUPER][BIN_CAP];
-    __shared__ uint32_t tile_cnt[NT], tile_base[NT];
-    __shared__ uint32_t wave_cnt[2][BIN_WAVES * BIN_SUPER];
-    __shared__ int fits_s;
-    const uint32_t *__restrict__ header = a.header;
-    const int gx = a.gx, gy = a.gy;
-    const int band = band_of_block(bx, gx, a.band_rows);
-    const uint2 *__restrict__ rect_sorted = a.band_rect + a.band_info[band];      // this band's rectangles / ids, depth order
-    const uint32_t *__restrict__ ids_sorted = a.band_id + a.band_info[band];
-    const int P = header[H_NVIS] ? (int)a.band_info[BAND_MAX + band] : 0;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int my_row = wave >> 2, my_col = wave & 3;
-    const SuperTile st = super_tile_of(bx, gx, gy);
-    const int my_tx = st.tx0 + my_col, my_ty = st.ty0 + my_row;
-    const bool my_tile = my_tx < st.tx1 && my_ty < st.ty1;
-    uint32_t *__restrict__ point_list = a.point_list;
-    uint32_t *__restrict__ tile_xy = a.tile_xy;
-
-    // super-tiles outside the bounding box of all rectangles leave at once
-    const int bx0 = (int)~header[H_NOT_X0], by0 = (int)~header[H_NOT_Y0], bx1 = (int)header[H_X1], by1 = (int)header[H_Y1];
-    if (!(P > 0 && st.tx0 < bx1 && st.tx1 > bx0 && st.ty0 < by1 && st.ty1 > by0)) {
-        if (lane == 0 && my_tile) { a.tile_count[my_ty * gx + my_tx] = 0u; a.ranges[my_ty * gx + my_tx] = make_uint2(0u, 0u); }
-        return;
-    }
-
-    int nbuf[BIN_SUPER] = {0, 0, 0, 0};           // entries buffered per row (the same in every wavefront)
-    uint32_t cnt = 0;                             // entries of this wavefront's tile
-    uint32_t cursor = 0;                          // next free position of this wavefront's tile list
-    const uint32_t my_xy = ((uint32_t)my_ty << 16) | (uint32_t)my_tx;           // whose list it is (block masks)
-    constexpr int FU = 8;                         // slabs per round: their LDS reads are in flight together
-    auto my_nbuf = [&]() { return my_row == 0 ? nbuf[0] : my_row == 1 ? nbuf[1] : my_row == 2 ? nbuf[2] : nbuf[3]; };
-    // The buffered entries that cover this wavefront's tile are appended to the tile's list, slab by slab, at the wavefront's own
-    // running cursor -- one pass, no barrier between slabs; lists stay in depth order
-    auto flush = [&]() {
-        const unsigned long long f0 = a.dbg ? wall_clock64() : 0ull;
-        dbg_nflush++; dbg_hits += nbuf[0] + nbuf[1] + nbuf[2] + nbuf[3];
-        lds_barrier();
-        const int n = my_nbuf(), nslab = (n + WAVE - 1) / WAVE;
-        for (int sl = 0; sl < nslab; sl += FU) {
-            uint32_t m[FU];
-#pragma unroll
-            for (int u = 0; u < FU; u++) {
-                const int e = (sl + u) * WAVE + lane;
-                m[u] = e < n ? surv[my_row][e] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < FU; u++) {
-                const bool h = (m[u] >> my_col) & 1u;
-                const unsigned long long bal = __ballot(h);
-                if (h) {
-                    const uint32_t at = cursor + (uint32_t)prefix_in_mask(bal);
-                    point_list[at] = m[u] >> 4;
-                    tile_xy[at] = my_xy;
-                }
-                cursor += (uint32_t)__builtin_popcountll(bal);
-            }
-        }
-        if (a.dbg) dbg_flush += wall_clock64() - f0;
-    };
-
-    // The walk: wavefront w scans the contiguous slice [base + w*256, base + (w+1)*256) of every trip: survivors stay in depth
-    // order when the wavefronts append one after the other.  The next trip's loads are issued before this one is used.  `drain`
-    // empties the buffers when the next trip's survivors would not fit.
-    auto walk = [&](auto &&drain) {
-        // (loads behind the end of the list are clamped, not skipped: a load under a branch makes the compiler wait for ALL loads
-        // in flight at the next use of any of them -- s_waitcnt vmcnt(1) right behind the prefetch -- and the prefetch hides nothing)
-        uint2 rc[BIN_UNROLL];
-        uint32_t id[BIN_UNROLL];
-        {
-            const int k0 = wave * (WAVE * BIN_UNROLL) + lane;
-#pragma unroll
-            for (int j = 0; j < BIN_UNROLL; j++) {
-                const int k = min(k0 + j * WAVE, P - 1);
-                rc[j] = rect_sorted[k];
-                id[j] = ids_sorted[k];
-            }
-        }
-        int parity = 0;
-        for (int base = 0; base < P; base += BIN_CHUNK, parity ^= 1) {
-            uint2 nrc[BIN_UNROLL];
-            uint32_t nid[BIN_UNROLL];
-            {
-                const int k0 = base + BIN_CHUNK + wave * (WAVE * BIN_UNROLL) + lane;
-#pragma unroll
-                for (int j = 0; j < BIN_UNROLL; j++) {
-                    const int k = min(k0 + j * WAVE, P - 1);
-                    nrc[j] = rect_sorted[k];
-                    nid[j] = ids_sorted[k];
-                }
-            }
-            // rows / columns of the super-tile a rectangle covers (0 when it misses the super-tile)
-            uint32_t rows[BIN_UNROLL], cols[BIN_UNROLL];
-            unsigned long long hits[BIN_UNROLL][BIN_SUPER];
-            uint32_t mine[BIN_SUPER] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int j = 0; j < BIN_UNROLL; j++) {
-                const bool hit = base + wave * (WAVE * BIN_UNROLL) + j * WAVE + lane < P && rect_hits(rc[j], st);
-                const int x0 = max((int)(rc[j].x & 0xFFFFu), st.tx0) - st.tx0, x1 = min((int)(rc[j].x >> 16), st.tx1) - st.tx0;
-                const int y0 = max((int)(rc[j].y & 0xFFFFu), st.ty0) - st.ty0, y1 = min((int)(rc[j].y >> 16), st.ty1) - st.ty0;
-                rows[j] = hit ? ((1u << y1) - (1u << y0)) : 0u;
-                cols[j] = (1u << x1) - (1u << x0);
-#pragma unroll
-                for (int r = 0; r < BIN_SUPER; r++) {
-                    hits[j][r] = __ballot((rows[j] >> r) & 1u);
-                    mine[r] += (uint32_t)__builtin_popcountll(hits[j][r]);
-                }
-            }
-            if (lane < BIN_SUPER) wave_cnt[parity][wave * BIN_SUPER + lane] = lane == 0 ? mine[0] : lane == 1 ? mine[1] : lane == 2 ? mine[2] : mine[3];
-            lds_barrier();
-            // lane (w, r) holds wavefront w's count of row r: sums over the wavefronts before this one / over all of them
-            uint32_t before, all;
-            {
-                const uint32_t c = wave_cnt[parity][lane];
-                before = (lane >> 2) < wave ? c : 0u;
-                all = c;
-#pragma unroll
-                for (int d = 4; d < WAVE; d <<= 1) {
-                    before += (uint32_t)__shfl_xor((int)before, d);
-                    all += (uint32_t)__shfl_xor((int)all, d);
-                }
-            }
-            uint32_t off[BIN_SUPER], total[BIN_SUPER];
-            bool any = false, room = true;
-#pragma unroll
-            for (int r = 0; r < BIN_SUPER; r++) {
-                off[r] = (uint32_t)__builtin_amdgcn_readlane((int)before, r);
-                total[r] = (uint32_t)__builtin_amdgcn_readlane((int)all, r);
-                any = any || total[r] != 0u;
-                room = room && nbuf[r] + (int)total[r] <= BIN_CAP;
-            }
-            if (any) {
-                if (!room) drain();                                  // total <= BIN_CHUNK = BIN_CAP: after a drain a trip always fits
-#pragma unroll
-                for (int r = 0; r < BIN_SUPER; r++) {
-                    uint32_t at = (uint32_t)nbuf[r] + off[r];
-#pragma unroll
-                    for (int j = 0; j < BIN_UNROLL; j++) {
-                        if ((hits[j][r] >> lane) & 1ull) surv[r][at + (uint32_t)prefix_in_mask(hits[j][r])] = (id[j] << 4) | cols[j];
-                        at += (uint32_t)__builtin_popcountll(hits[j][r]);
-                    }
-                    nbuf[r] += (int)total[r];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < BIN_UNROLL; j++) { rc[j] = nrc[j]; id[j] = nid[j]; }
-        }
-    };
-    auto clear = [&]() {
-        lds_barrier();
-#pragma unroll
-        for (int r = 0; r < BIN_SUPER; r++) nbuf[r] = 0;
-    };
-
-    // Pass 1, the sizes of the 16 lists: every wavefront walks its share of the band with 16 byte-wide counters per lane (the cover
-    // mask of a rectangle spread over four registers, one add each) -- no LDS, no ballots, no barriers; the counters are folded
-    // (wavefront sum, then 16 LDS atomics per wavefront) before a byte could overflow and at the end.
-    if (tid < NT) tile_cnt[tid] = 0u;
-    lds_barrier();
-    {
-        uint32_t acc[4] = {0u, 0u, 0u, 0u};
-        auto fold = [&]() {
-            uint32_t part[8];
-#pragma unroll
-            for (int d = 0; d < 4; d++) { part[2 * d] = acc[d] & 0x00FF00FFu; part[2 * d + 1] = (acc[d] >> 8) & 0x00FF00FFu; acc[d] = 0u; }
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) part[q] += (uint32_t)__shfl_xor((int)part[q], d);
-            // part[2d] = tiles 4d (low half) and 4d+2 (high half), part[2d+1] = tiles 4d+1 and 4d+3
-            if (lane < NT) {
-                const int d = lane >> 2, k = lane & 3;
-                const uint32_t w = (k & 1) ? (d == 0 ? part[1] : d == 1 ? part[3] : d == 2 ? part[5] : part[7])
-                                           : (d == 0 ? part[0] : d == 1 ? part[2] : d == 2 ? part[4] : part[6]);
-                const uint32_t c = (k & 2) ? w >> 16 : w & 0xFFFFu;
-                if (c) atomicAdd(&tile_cnt[lane], c);
-            }
-        };
-#ifndef SOAR_BIN_COUNT_UNROLL
-#define SOAR_BIN_COUNT_UNROLL 4   // (2 / 4 / 8 / 16: 66.0 / 65.3 / 67.1 / 71.2 us for the tile lists)
-#endif
-        constexpr int CU_ = SOAR_BIN_COUNT_UNROLL;   // rectangles per lane and trip of this pass
-        constexpr int CCHUNK = BIN_THREADS * CU_;
-        int since = 0;
-        uint2 rc[CU_];
-#pragma unroll
-        for (int j = 0; j < CU_; j++) rc[j] = rect_sorted[min(wave * (WAVE * CU_) + j * WAVE + lane, P - 1)];
-        for (int base = 0; base < P; base += CCHUNK) {
-            uint2 nrc[CU_];
-#pragma unroll
-            for (int j = 0; j < CU_; j++) nrc[j] = rect_sorted[min(base + CCHUNK + wave * (WAVE * CU_) + j * WAVE + lane, P - 1)];
-#pragma unroll
-            for (int j = 0; j < CU_; j++) {
-                const bool hit = base + wave * (WAVE * CU_) + j * WAVE + lane < P && rect_hits(rc[j], st);
-                const uint32_t m = hit ? cover_mask(rc[j], st) : 0u;
-#pragma unroll
-                for (int d = 0; d < 4; d++) acc[d] += (((m >> (4 * d)) & 15u) * 0x00204081u) & 0x01010101u;
-                rc[j] = nrc[j];
-            }
-            since += CU_;
-            if (since > 255 - CU_) { fold(); since = 0; }
-        }
-        fold();
-    }
-    lds_barrier();
-    cnt = tile_cnt[wave];
-    const unsigned long long dbg_t1 = a.dbg ? wall_clock64() : 0ull;
-    lds_barrier();
-    if (tid == 0) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int t = 0; t < NT; t++) { tile_base[t] = sum; sum += tile_cnt[t]; }
-        uint32_t start = 0;
-        bool fits = true;
-        if (sum) {
-            start = atomicAdd(&a.header[H_TOTAL], sum);
-            fits = (uint64_t)start + sum <= (uint64_t)a.capacity;
-            if (!fits) atomicMax(&a.header[H_OVERFLOW], start + sum);     // the last one to get here leaves the number needed
-        }
-#pragma unroll
-        for (int t = 0; t < NT; t++) tile_base[t] += start;
-        fits_s = (fits ? 1 : 0) | (sum ? 2 : 0);
-    }
-    lds_barrier();
-    const bool fits = (fits_s & 1) != 0, cnt_total_nonzero = (fits_s & 2) != 0;
-    cursor = tile_base[wave];
-    if (lane == 0 && my_tile) {
-        a.tile_count[my_ty * gx + my_tx] = cnt;
-        a.ranges[my_ty * gx + my_tx] = (cnt && fits) ? make_uint2(cursor, cursor + cnt) : make_uint2(0u, 0u);
-    }
-    if (fits && cnt_total_nonzero) {
-        // Pass 2: the walk that keeps the entries, flushing the buffers whenever the next trip's entries would not fit
-        walk([&]() { flush(); clear(); });
-        flush();
-    }
-    if (a.dbg && tid == 0) {
-        unsigned long long *w = a.dbg + (size_t)bx * 4;
-        w[0] = wall_clock64() - dbg_t0; w[1] = dbg_flush; w[2] = ((unsigned long long)dbg_nflush << 32) | (unsigned)dbg_hits;
-        w[3] = ((dbg_t1 - dbg_t0) << 32) | (unsigned long long)P;
-    }
-}
-
-// Round 6: the same lists with no barrier inside either walk and no shared survivor buffers (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us
-// per 4-frame launch at C3).  Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
+// Round 6 (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us per 4-frame launch at C3): no barrier inside a walk, no shared buffers.
+// Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
 // leaves the sizes of the 16 lists per wavefront, an exclusive scan of those over the wavefronts (per tile) says where every
 // wavefront's entries of every tile start -- slice after slice = depth order -- and every wavefront then appends straight to the 16
 // lists at 16 running cursors in scalar registers.
@@ -836,19 +573,16 @@ __device__ __forceinline__ void bin_tiles_kernel_body(const int bx, const BinTil
 //   stores (71 us: the stores were not what the placing waited for); two workgroups per super-tile in the grid (+13 us for DISPATCHING
 //   2040 more idle 16-wavefront workgroups, whatever they then do); four helpers' rows instead of two (55 us: three more walks of the
 //   band per heavy super-tile); workgroups of 8 wavefronts (58-62 us); sizes counted by 16 ballots per slab (57 us).
-#ifndef SOAR_BIN_DIRECT
-#define SOAR_BIN_DIRECT 1
-#endif
-#ifndef SOAR_BIN_DIRECT_UNROLL
-#define SOAR_BIN_DIRECT_UNROLL 4
+#ifndef SOAR_BIN_UNROLL
+#define SOAR_BIN_UNROLL 4
 #endif
 #ifndef SOAR_BIN_SPLIT_AT
 #define SOAR_BIN_SPLIT_AT 12288      // rectangles in a band from which its super-tiles are shared by two workgroups
 #endif
-#ifndef SOAR_BIN_DIRECT_WAVES
-#define SOAR_BIN_DIRECT_WAVES 16     // (8: 58-62 us against 51)
+#ifndef SOAR_BIN_WAVES
+#define SOAR_BIN_WAVES 16     // (8: 58-62 us against 51)
 #endif
-constexpr int BD_WAVES = SOAR_BIN_DIRECT_WAVES, BD_THREADS = BD_WAVES * WAVE;
+constexpr int BIN_WAVES = SOAR_BIN_WAVES, BIN_THREADS = BIN_WAVES * WAVE;
 #ifndef SOAR_BIN_MAX_PARTS
 #define SOAR_BIN_MAX_PARTS 2         // (4: a row of tiles per workgroup where three helpers are free -- 55 us against 52)
 #endif
@@ -890,14 +624,14 @@ __device__ __forceinline__ bool rect_hits_packed(uint2 rc, const SuperTileTest &
     __builtin_memcpy(&dx, &rx, 4); __builtin_memcpy(&dy, &ry, 4);
     return ((dx | dy) & 0x80008000u) == 0u;
 }
-__device__ __forceinline__ void bin_tiles_direct_body(const int bx, const BinTilesArgs &a)
+__device__ __forceinline__ void bin_tiles_body(const int bx, const BinTilesArgs &a)
 {
     const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
-    constexpr int NT = BIN_SUPER * BIN_SUPER, U = SOAR_BIN_DIRECT_UNROLL, CAP = SOAR_BIN_CAPTURE;
-    static_assert(BIN_SUPER == 4 && BD_WAVES * WAVE >= NT, "16 tiles: a cover mask has 16 bits");
+    constexpr int NT = BIN_SUPER * BIN_SUPER, U = SOAR_BIN_UNROLL, CAP = SOAR_BIN_CAPTURE;
+    static_assert(BIN_SUPER == 4 && BIN_WAVES * WAVE >= NT, "16 tiles: a cover mask has 16 bits");
     static_assert(CAP >= 2 * WAVE && (CAP & (CAP - 1)) == 0, "a ring holds a dense slab plus what one slab of the band can add");
-    __shared__ uint2 ring[BD_WAVES][CAP];             // kept entries of one wavefront: (id, cover mask)
-    __shared__ uint32_t wave_tile[BD_WAVES][NT];      // sizes per (wavefront, tile); then: entries of the wavefronts before it
+    __shared__ uint2 ring[BIN_WAVES][CAP];             // kept entries of one wavefront: (id, cover mask)
+    __shared__ uint32_t wave_tile[BIN_WAVES][NT];      // sizes per (wavefront, tile); then: entries of the wavefronts before it
     __shared__ uint32_t tile_cnt[NT], tile_base[NT];
     __shared__ int fits_s;
     const uint32_t *__restrict__ header = a.header;
@@ -950,13 +684,14 @@ __device__ __forceinline__ void bin_tiles_direct_body(const int bx, const BinTil
     const int my_tx = st.tx0 + (tid & 3), my_ty = st.ty0 + ((tid >> 2) & 3);          // thread t < 16 reports tile t
     const bool my_tile = tid < NT && my_tx < st.tx1 && my_ty < st.ty1;
     // this wavefront's slabs (64 rectangles each) of the band
-    const int nslab = (P + WAVE - 1) / WAVE, per = (nslab + BD_WAVES - 1) / BD_WAVES;
+    const int nslab = (P + WAVE - 1) / WAVE, per = (nslab + BIN_WAVES - 1) / BIN_WAVES;
     const int s0 = wave * per, s1 = min(nslab, s0 + per);
     uint2 *__restrict__ my_ring = ring[wave];
     const SuperTileTest stt = super_tile_test(st);
 
     // The walk of the slice: `keep(hit ballot, hit, id, mask)` for every slab with a rectangle that touches the super-tile.
-    // (loads behind the end of the list are clamped, not skipped: see the note in bin_tiles_kernel_body)
+    // (loads behind the end of the list are clamped, not skipped: a load under a branch makes the compiler wait for ALL loads in
+    // flight at the next use of any of them, and the prefetch of the next trip hides nothing)
     const char *__restrict__ rect_bytes = reinterpret_cast<const char *>(rect_sorted);
     const char *__restrict__ id_bytes = reinterpret_cast<const char *>(ids_sorted);
     const int in_slice = min(P, s1 * WAVE);            // rectangles behind this are not this wavefront's
@@ -1038,18 +773,18 @@ __device__ __forceinline__ void bin_tiles_direct_body(const int bx, const BinTil
     lds_barrier();
     const unsigned long long dbg_t1 = a.dbg ? wall_clock64() : 0ull;
     {   // thread (w, t): the entries of tile t in the wavefronts before w, and in all of them
-        const int w = (tid >> 4) & (BD_WAVES - 1), t = tid & (NT - 1);
+        const int w = (tid >> 4) & (BIN_WAVES - 1), t = tid & (NT - 1);
         uint32_t before = 0u, all = 0u;
-        if (tid < BD_WAVES * NT) {
+        if (tid < BIN_WAVES * NT) {
 #pragma unroll
-            for (int v = 0; v < BD_WAVES; v++) {
+            for (int v = 0; v < BIN_WAVES; v++) {
                 const uint32_t c = wave_tile[v][t];
                 before += v < w ? c : 0u;
                 all += c;
             }
         }
         lds_barrier();
-        if (tid < BD_WAVES * NT) wave_tile[w][t] = before;
+        if (tid < BIN_WAVES * NT) wave_tile[w][t] = before;
         if (tid < NT) tile_cnt[tid] = all;
     }
     lds_barrier();
@@ -1129,15 +864,11 @@ __device__ __forceinline__ void bin_tiles_direct_body(const int bx, const BinTil
 #ifndef SOAR_BIN_WPE
 #define SOAR_BIN_WPE 8        // two workgroups per CU
 #endif
-__global__ void __launch_bounds__(SOAR_BIN_DIRECT ? BD_THREADS : BIN_THREADS) __attribute__((amdgpu_waves_per_eu(SOAR_BIN_WPE, 8))) bin_tiles_kernel(Batch<BinTilesArgs> batch)
+__global__ void __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(SOAR_BIN_WPE, 8))) bin_tiles_kernel(Batch<BinTilesArgs> batch)
 {
     int frame, bx;
     batch_interleave1(frame, bx);
-#if SOAR_BIN_DIRECT
-    bin_tiles_direct_body(bx, batch.v[frame]);
-#else
-    bin_tiles_kernel_body(bx, batch.v[frame]);
-#endif
+    bin_tiles_body(bx, batch.v[frame]);
 }
 
 
@@ -1210,7 +941,7 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
         }
         const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted,
                                  img.tile_count, ba.capacity, dbg, b.tile_xy};
-        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(SOAR_BIN_DIRECT ? BD_THREADS : BIN_THREADS), 0, stream, bt);
+        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bt);
         if (log_now) {
             const int nwg = nsx * nsy;
             const size_t nw = (size_t)nwg * 4;
@@ -1218,25 +949,16 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             unsigned long long *h = (unsigned long long *)malloc(8 * nw);
             SOAR_HIP_OK(hipMemcpy(h, dbg, 8 * nw, hipMemcpyDeviceToHost));
             (void)hipFree(dbg);
-#if SOAR_BIN_DIRECT
-            {   // when the workgroups started and ended, relative to the first one's start (100 MHz clock)
+            {   // when the workgroups started and ended, relative to the first one's start (100 MHz clock); the busy ones one by one
                 unsigned long long first = ~0ull, last = 0ull;
                 for (int i = 0; i < nwg; i++) if (h[i * 4]) { first = h[i * 4 + 1] < first ? h[i * 4 + 1] : first; }
                 for (int i = 0; i < nwg; i++) if (h[i * 4]) { const unsigned long long e = h[i * 4 + 1] + h[i * 4]; last = e > last ? e : last; }
-                fprintf(stderr, "[bin_tiles] %d workgroups: first start to last end %.1f us; starts (us after the first) of workgroups 0, 1/4, 1/2, 3/4, last: %.1f %.1f %.1f %.1f %.1f\n",
-                        nwg, (last - first) / 100.0, (h[1] - first) / 100.0, (h[(nwg / 4) * 4 + 1] - first) / 100.0,
-                        (h[(nwg / 2) * 4 + 1] - first) / 100.0, (h[(3 * nwg / 4) * 4 + 1] - first) / 100.0, (h[(nwg - 1) * 4 + 1] - first) / 100.0);
-                for (int i = 0; i < nwg; i++) if (h[i * 4] > 1500) fprintf(stderr, "[bin_tiles]   WG %d: start %.1f, %.1f us (walk %.1f), %llu kept of %llu%s\n", i, (h[i * 4 + 1] - first) / 100.0,
-                        h[i * 4] / 100.0, (h[i * 4 + 3] >> 32) / 100.0, h[i * 4 + 2] & 0xFFFFFFFFull, h[i * 4 + 3] & 0xFFFFFFFFull, (h[i * 4 + 2] >> 32) ? " (two walks)" : "");
-            }
-#endif
-            for (int rep = 0; rep < 5; rep++) {             // the five slowest workgroups
-                int best = -1;
-                for (int i = 0; i < nwg; i++) if (best < 0 || h[i * 4] > h[best * 4]) best = i;
-                fprintf(stderr, "[bin_tiles] WG %d: %.1f us total, first walk %.1f us, %.1f us in %llu flushes, %llu kept entries of %llu band entries\n",
-                        best, h[best * 4] / 100.0, (h[best * 4 + 3] >> 32) / 100.0, h[best * 4 + 1] / 100.0, h[best * 4 + 2] >> 32,
-                        h[best * 4 + 2] & 0xFFFFFFFFull, h[best * 4 + 3] & 0xFFFFFFFFull);
-                h[best * 4] = 0;
+                fprintf(stderr, "[bin_tiles] %d workgroups: first start to last end %.1f us\n", nwg, (last - first) / 100.0);
+                for (int i = 0; i < nwg; i++)
+                    if (h[i * 4] > 1500)
+                        fprintf(stderr, "[bin_tiles]   WG %d: start %.1f, %.1f us (walk %.1f), %llu list entries from a band of %llu\n", i,
+                                (h[i * 4 + 1] - first) / 100.0, h[i * 4] / 100.0, (h[i * 4 + 3] >> 32) / 100.0, h[i * 4 + 2] & 0xFFFFFFFFull,
+                                h[i * 4 + 3] & 0xFFFFFFFFull);
             }
             free(h);
         }
