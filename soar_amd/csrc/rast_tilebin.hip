@@ -545,6 +545,7 @@ struct BinTilesArgs {
     uint32_t capacity;
     unsigned long long *dbg;
     uint32_t *tile_xy;       // BinBuf::tile_xy
+    int split_at;            // rectangles in a band from which idle columns help (SOAR_BIN_SPLIT_AT)
 };
 // Round 6 (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us per 4-frame launch at C3): no barrier inside a walk, no shared buffers.
 // Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
@@ -651,7 +652,7 @@ __device__ __forceinline__ void bin_tiles_body(const int bx, const BinTilesArgs 
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, scol = bx % nsx;
     const int ex0 = (int)(a.band_info[2 * BAND_MAX + band] & 0xFFFFu), ex1 = (int)a.band_info[3 * BAND_MAX + band];
     const int se0 = ex0 / BIN_SUPER, se1 = (ex1 + BIN_SUPER - 1) / BIN_SUPER, width = se1 - se0;
-    const bool inside = P > 0 && scol >= se0 && scol < se1, split = P > SOAR_BIN_SPLIT_AT;
+    const bool inside = P > 0 && scol >= se0 && scol < se1, split = P > a.split_at;
     SuperTile st = super_tile_of(bx, gx, gy);
     // the idle columns are dealt to the columns inside the extent in turn: column j gets the helpers j, j + width, j + 2 width, ...
     // and is shared by 2 workgroups (two rows of tiles each) with one helper, by 4 (a row each) with three
@@ -939,8 +940,10 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             SOAR_HIP_OK(hipMalloc(&dbg, 8 * (size_t)(nsx * nsy) * 4));
             SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * (size_t)(nsx * nsy) * 4, stream));
         }
+        // (the environment variable of the same name: a test's way to reach the helpers' code on scenes the CPU oracle finishes in seconds)
+        static const int split_at = getenv("SOAR_BIN_SPLIT_AT") ? atoi(getenv("SOAR_BIN_SPLIT_AT")) : SOAR_BIN_SPLIT_AT;
         const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted,
-                                 img.tile_count, ba.capacity, dbg, b.tile_xy};
+                                 img.tile_count, ba.capacity, dbg, b.tile_xy, split_at};
         SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bt);
         if (log_now) {
             const int nwg = nsx * nsy;

@@ -5,6 +5,7 @@ ranges); images and gradients within 1e-4 relative.  The oracle is a restatement
 (tests/test_reference_build_gpu.py, oracle/rasterizer_oracle.h).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -245,6 +246,36 @@ def test_binning_band_lists_on_a_very_tall_image():
     rows = np.nonzero(fw.ranges[:, 1] > fw.ranges[:, 0])[0] // 3           # 3 tiles per row
     assert rows.max() - rows.min() > 80                                     # the lists span many bands
     check_forward(scene, run_hip(scene), fw)
+
+
+_HELPERS_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
+import scenes as S
+from test_rasterizer_gpu import run_hip, check_forward
+for name, scene in (("wide", S.person_scene(P=6000, W=640, H=360, seed=3, config=(1, 1, 1, 0), opacity=None)),
+                    ("tall", S.person_scene(P=9000, W=320, H=4300, seed=12, config=(1, 1, 1, 0), opacity=None, distance=0.5)),
+                    ("back view", S.person_scene(P=6000, W=640, H=360, seed=5, config=(1, 1, 1, 0), opacity=None, render_front=False, sort_descending=True))):
+    fw, _ = S.run_oracle(scene, n_threads=8)
+    assert fw.num_rendered > 3000, name
+    check_forward(scene, run_hip(scene), fw)
+    print("ok", name, fw.num_rendered)
+"""
+
+
+def test_binning_idle_columns_help_the_long_bands():
+    """bin_tiles: in a band of more than SOAR_BIN_SPLIT_AT rectangles the workgroups of the super-tile columns the band does not reach
+    take the lower two rows of tiles of the columns it does reach (rast_tilebin.hip).  The default threshold (12288) is only crossed by
+    scenes the CPU oracle needs minutes for (the C3 / C5 parity tests against the reference's kernels do cross it); here a fresh process
+    with the threshold at 32 runs the helpers' code on small scenes -- a wide one, one with two rows of super-tiles per band (H = 4300)
+    and a back view -- against the oracle: lists, ranges, contributor counts bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAR_BIN_SPLIT_AT="32")
+    r = subprocess.run([sys.executable, "-c", _HELPERS_CHILD.format(tests=os.path.join(root, "tests"), root=root)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok ") == 3, r.stdout
 
 
 def test_camera_gradients_when_lrn_cam():
