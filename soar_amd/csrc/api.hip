@@ -219,6 +219,7 @@ int carve_image(void *base, int32_t W, int32_t H, ImageBuf *out)
     take(p, out->tile_order, (tiles + 7) / 8 * 8 + 8);
     take(p, out->order_rec, (tiles + 7) / 8 * 8 + 8);
     take(p, out->tile_count, tiles > 0 ? tiles : 1);
+    take(p, out->bin_work, (size_t)(((W + TILE - 1) / TILE + 3) / 4) * (size_t)(((H + TILE - 1) / TILE + 3) / 4) + 1);
     take(p, out->bg_state, 8);
     take(p, out->bg_tiles, tiles > 0 ? tiles : 1);
     take(p, out->final_To, pix > 0 ? pix : 1);

@@ -44,6 +44,7 @@ __device__ __forceinline__ int prefix_in_mask(unsigned long long m)
 // the whole workgroup in LDS, and the (pathological: thousands of equal depths) ones beyond that in global memory.
 constexpr int BKT_LDS = 2048;            // pairs one workgroup sorts in LDS
 constexpr int BAND_MAX = 64;            // bands of tile rows (upper bound: one lane per band in the per-wavefront counts)
+constexpr int BIN_SUPER = 4;            // tiles per side of a super-tile, the unit of bin_tiles_kernel's work
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, float scale, int B)
 {
@@ -367,6 +368,11 @@ struct BandArgs {
     uint32_t *band_info;                // [4 * BAND_MAX]: start, length of every band's list; first / one past the last tile column it reaches
     uint2 *band_rect;
     uint32_t *band_id;
+    // what bin_tiles_kernel starts from: every tile's range and count cleared, and the list of the super-tiles with work
+    int T, nsx, nsy, split_at;
+    uint2 *ranges;
+    uint32_t *tile_count;
+    uint32_t *work;
 };
 
 // bands [b0, b1] a rectangle reaches into (b1 < b0: none)
@@ -461,17 +467,52 @@ __global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs
     __syncthreads();
     const uint32_t total = total_s;
     const bool fits = total <= a.capacity;
+    // (bin_tiles only visits the super-tiles with work: every tile starts empty)
+    for (int t = (int)blockIdx.x * BAND_THREADS + tid; t < a.T; t += (int)gridDim.x * BAND_THREADS) {
+        a.tile_count[t] = 0u;
+        a.ranges[t] = make_uint2(0u, 0u);
+    }
     if (blockIdx.x == 0) {
         // a band list that does not fit the caller's buffer: every band is left empty, the overflow is reported like a
         // tile-list overflow (tile_scan_kernel keeps the flag)
+        uint32_t len = 0u;                                  // lane b of wavefront 0: entries of band b
         if (tid < a.nb) {
             const uint32_t st = a.band_info[tid], en = a.band_info[BAND_MAX + tid];
-            a.band_info[BAND_MAX + tid] = fits ? en - st : 0u;
+            len = fits ? en - st : 0u;
+            a.band_info[BAND_MAX + tid] = len;
         }
         if (tid == 0) {
             a.header[H_BAND_OVERFLOW] = fits ? 0u : total;
             a.header[H_TOTAL] = 0u;                         // bin_tiles adds up the instances ...
             a.header[H_OVERFLOW] = fits ? 0u : total;       // ... and raises this when the lists do not fit either
+        }
+        if (wave == 0) {
+            // The super-tiles bin_tiles has work for, the longest bands' first (they hold its heaviest workgroups; the launch is a
+            // grid of at most SOAR_BIN_GRID workgroups per frame that takes the list in turns: a workgroup of sixteen wavefronts and
+            // 64 KB of LDS that only finds out that it has nothing to do still has to wait for a slot of its size behind the busy
+            // ones -- 2040 launched for ~700 with work cost the launch a quarter of its time).  Of a band: the columns its
+            // rectangles reach, or every column when it is long enough for the others to help (bin_tiles_body).
+            const int b = lane, rows_per_band = a.band_rows / BIN_SUPER, srow0 = b * rows_per_band;
+            const int nrows = b < a.nb ? max(0, min(rows_per_band, a.nsy - srow0)) : 0;
+            int c0 = 0, ncols = 0;
+            if (len > 0u) {
+                const int ex0 = (int)(a.band_info[2 * BAND_MAX + b] & 0xFFFFu), ex1 = (int)a.band_info[3 * BAND_MAX + b];
+                const int se0 = ex0 / BIN_SUPER, se1 = min(a.nsx, (ex1 + BIN_SUPER - 1) / BIN_SUPER);
+                const bool split = len > (uint32_t)a.split_at;
+                c0 = split ? 0 : se0;
+                ncols = split ? a.nsx : max(0, se1 - se0);
+            }
+            const uint32_t items = (uint32_t)(ncols * nrows);
+            uint32_t before = 0u, all = 0u;
+            for (int o = 0; o < a.nb; o++) {
+                const uint32_t len_o = (uint32_t)__shfl((int)len, o), items_o = (uint32_t)__shfl((int)items, o);
+                before += (len_o > len || (len_o == len && o < b)) ? items_o : 0u;
+                all += items_o;
+            }
+            uint32_t at = before;
+            for (int r = 0; r < nrows; r++)
+                for (int c = 0; c < ncols; c++) a.work[at++] = (uint32_t)((srow0 + r) * a.nsx + c0 + c);
+            if (lane == 0) a.header[H_BIN_WORK] = all;
         }
     }
     if (!fits) return;
@@ -489,8 +530,6 @@ __global__ void __launch_bounds__(BAND_THREADS) band_place_kernel(Batch<BandArgs
         }
     }
 }
-
-constexpr int BIN_SUPER = 4;            // tiles per side of a workgroup's super-tile
 
 struct SuperTile {
     int tx0, ty0, tx1, ty1;
@@ -546,6 +585,7 @@ struct BinTilesArgs {
     unsigned long long *dbg;
     uint32_t *tile_xy;       // BinBuf::tile_xy
     int split_at;            // rectangles in a band from which idle columns help (SOAR_BIN_SPLIT_AT)
+    const uint32_t *work;    // ImageBuf::bin_work: header[H_BIN_WORK] super-tiles
 };
 // Round 6 (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us per 4-frame launch at C3): no barrier inside a walk, no shared buffers.
 // Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
@@ -584,6 +624,10 @@ struct BinTilesArgs {
 #define SOAR_BIN_WAVES 16     // (8: 58-62 us against 51)
 #endif
 constexpr int BIN_WAVES = SOAR_BIN_WAVES, BIN_THREADS = BIN_WAVES * WAVE;
+#ifndef SOAR_BIN_GRID
+#define SOAR_BIN_GRID 512           // workgroups of a frame's launch (the slots of the chip): they take the list of super-tiles with work in turns
+                                    // (128 / 192 / 256 / 384 / 512 at C3, four frames per launch: 60.3 / 52.2 / 47.3 / 47.2 / 47.3 us)
+#endif
 #ifndef SOAR_BIN_MAX_PARTS
 #define SOAR_BIN_MAX_PARTS 2         // (4: a row of tiles per workgroup where three helpers are free -- 55 us against 52)
 #endif
@@ -663,8 +707,6 @@ __device__ __forceinline__ void bin_tiles_body(const int bx, const BinTilesArgs 
     };
     int sub = 0, parts = 1;
     if (!inside) {
-        const int tx = st.tx0 + (tid & 3), ty = st.ty0 + ((tid >> 2) & 3);
-        if (tid < NT && tx < st.tx1 && ty < st.ty1) { a.tile_count[ty * gx + tx] = 0u; a.ranges[ty * gx + tx] = make_uint2(0u, 0u); }
         const int h = scol < se0 ? scol : scol - width;                 // its number among the columns outside the extent
         const int j = width > 0 ? h % width : 0;
         if (split && width > 0) { parts = parts_of(j); sub = h / width + 1; }
@@ -869,7 +911,12 @@ __global__ void __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_e
 {
     int frame, bx;
     batch_interleave1(frame, bx);
-    bin_tiles_body(bx, batch.v[frame]);
+    const BinTilesArgs &a = batch.v[frame];
+    const uint32_t n_work = a.header[H_BIN_WORK];
+    for (uint32_t i = (uint32_t)bx; i < n_work; i += gridDim.x) {
+        bin_tiles_body((int)a.work[i], a);
+        lds_barrier();                                      // (the next super-tile's rings overwrite this one's)
+    }
 }
 
 
@@ -924,6 +971,10 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
     ba.header = g.header; ba.rect_sorted = g.rect_sorted; ba.ids_sorted = g.ids_sorted; ba.band_cnt = g.band_cnt;
     ba.band_info = g.band_info;
     ba.band_rect = reinterpret_cast<uint2 *>(b.keys_unsorted); ba.band_id = b.vals_unsorted;
+    // (the environment variable of the same name: a test's way to reach the helpers' code on scenes the CPU oracle finishes in seconds)
+    static const int split_at = getenv("SOAR_BIN_SPLIT_AT") ? atoi(getenv("SOAR_BIN_SPLIT_AT")) : SOAR_BIN_SPLIT_AT;
+    ba.T = gx * gy; ba.nsx = nsx; ba.nsy = nsy; ba.split_at = split_at;
+    ba.ranges = img.ranges; ba.tile_count = img.tile_count; ba.work = img.bin_work;
     {
         StageTimer timer(ST_RANGES, stream);
         SOAR_LAUNCH_BATCHED(band_count_kernel, dim3(ba.nchunk), dim3(BAND_THREADS), 0, stream, ba);
@@ -940,11 +991,9 @@ int launch_tile_binning(const SoarRastParams &prm, GeomBuf &g, BinBuf &b, ImageB
             SOAR_HIP_OK(hipMalloc(&dbg, 8 * (size_t)(nsx * nsy) * 4));
             SOAR_HIP_OK(hipMemsetAsync(dbg, 0, 8 * (size_t)(nsx * nsy) * 4, stream));
         }
-        // (the environment variable of the same name: a test's way to reach the helpers' code on scenes the CPU oracle finishes in seconds)
-        static const int split_at = getenv("SOAR_BIN_SPLIT_AT") ? atoi(getenv("SOAR_BIN_SPLIT_AT")) : SOAR_BIN_SPLIT_AT;
         const BinTilesArgs bt = {g.header, gx, gy, band_rows, g.band_info, ba.band_rect, ba.band_id, img.ranges, b.vals_sorted,
-                                 img.tile_count, ba.capacity, dbg, b.tile_xy, split_at};
-        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(nsx * nsy), dim3(BIN_THREADS), 0, stream, bt);
+                                 img.tile_count, ba.capacity, dbg, b.tile_xy, split_at, img.bin_work};
+        SOAR_LAUNCH_BATCHED(bin_tiles_kernel, dim3(min(nsx * nsy, SOAR_BIN_GRID)), dim3(BIN_THREADS), 0, stream, bt);
         if (log_now) {
             const int nwg = nsx * nsy;
             const size_t nw = (size_t)nwg * 4;

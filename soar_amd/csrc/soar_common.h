@@ -168,6 +168,7 @@ constexpr int H_BAND_OVERFLOW = 10;   // 0, or the entries the band lists needed
 constexpr int H_PREFILTER_VIOLATIONS = 11;   // Gaussians culled although SoarRastParams.prefiltered was set (auxiliary.h:163-167, 195-199)
 constexpr int H_STICKY_TOTAL = 12;      // max of H_TOTAL / of H_OVERFLOW | H_BAND_OVERFLOW over the frames since the caller cleared them
 constexpr int H_STICKY_OVERFLOW = 13;   //   (soar_rast_binning_status_sticky; only meaningful in a geometry buffer kept between frames)
+constexpr int H_BIN_WORK = 14;          // super-tiles with work in ImageBuf::bin_work (band_place_kernel -> bin_tiles_kernel)
 constexpr int BKT_MAX = 16384;  // depth buckets (upper bound; the counters of a counting workgroup live in LDS: 64 KB)
 constexpr int BLK_STATS = 6;    // words per preprocess block in GeomBuf::blk_stats
 struct ImageBuf {
@@ -180,6 +181,7 @@ struct ImageBuf {
     uint4 *order_rec;        // [Tpad] {tile, range.x, range.y, 0} of the same order: what a blend wavefront needs of its tile in ONE load
                              // (tile_order -> ranges is two dependent round trips at the start of every wavefront)
     uint32_t *tile_count;    // [T] instances per tile (rast_tilebin.hip)
+    uint32_t *bin_work;      // [super-tiles] the super-tiles bin_tiles_kernel has to visit, those of the longest bands first
     uint32_t *bg_state;      // [8] {background bits x3, normalize_depth} of the last forward, [4]: they differ from the one before
     uint32_t *bg_tiles;      // [T] 1: every output plane of the tile holds the background values of the last forward blend.
                              // One 32-bit word per tile, written with agent-scope stores: workgroups on different XCDs (one L2
