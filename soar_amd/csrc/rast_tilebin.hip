@@ -587,7 +587,7 @@ struct BinTilesArgs {
     int split_at;            // rectangles in a band from which idle columns help (SOAR_BIN_SPLIT_AT)
     const uint32_t *work;    // ImageBuf::bin_work: header[H_BIN_WORK] super-tiles
 };
-// Round 6 (profiles/r06_ab_bin_tiles.txt: 67 -> 51 us per 4-frame launch at C3): no barrier inside a walk, no shared buffers.
+// Round 6 (profiles/r06_ab_bin_tiles.txt: 67 -> 47 us per 4-frame launch at C3): no barrier inside a walk, no shared buffers.
 // Wavefront w takes the CONTIGUOUS slice [w * len, (w + 1) * len) of the band's depth order: its walk
 // leaves the sizes of the 16 lists per wavefront, an exclusive scan of those over the wavefronts (per tile) says where every
 // wavefront's entries of every tile start -- slice after slice = depth order -- and every wavefront then appends straight to the 16
@@ -603,10 +603,12 @@ struct BinTilesArgs {
 //     itself is the stores' lane mask.
 //   * A wavefront whose kept entries all fit the ring never walks the band a second time: the first walk captured them.
 //     The others walk their slice again, streaming through the ring.
-//   * A super-tile outside the columns its band's rectangles reach (band_count leaves the extent) has nothing to list.  In a band of
-//     more than SPLIT_AT rectangles its workgroup HELPS instead: it takes the lower two rows of tiles of a super-tile inside the extent,
-//     whose own workgroup keeps the upper two (the launch waits for its heaviest workgroup: 72k list entries from a band of 26k, 49 us
-//     alone; halved 40 us).
+//   * The launch is a grid of at most SOAR_BIN_GRID workgroups per frame over the LIST of super-tiles with work that band_place_kernel
+//     leaves (the columns every band's rectangles reach -- band_count's extents --, the longest bands first): a sixteen-wavefront
+//     workgroup with 64 KB of LDS that only finds out that it has nothing to do still queues for a slot of its size behind the busy ones.
+//   * In a band of more than SPLIT_AT rectangles the list holds EVERY column, and the ones outside the extent HELP: the h-th of them
+//     takes the lower two rows of tiles of the h-th column inside, whose own workgroup keeps the upper two (the launch waits for its
+//     heaviest workgroup: 72k list entries from a band of 26k, 49 us alone; halved 40 us).
 //   Tried and dropped, all with `point_list` bit-exact (same file): placing straight from the walk's slabs (74 us: 16 compactions per
 //   slab with ANY hit); a pool of kept-entry blocks in LDS that wavefront t goes through for tile t (balanced whichever wavefronts found
 //   the entries -- a patch of surface is a narrow range of depths, so a super-tile's hits cluster in a few slices -- but 16 wavefronts x
@@ -688,11 +690,10 @@ __device__ __forceinline__ void bin_tiles_body(const int bx, const BinTilesArgs 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (scalar: uniform loop bounds)
     char *__restrict__ point_list = reinterpret_cast<char *>(a.point_list);
     char *__restrict__ tile_xy = reinterpret_cast<char *>(a.tile_xy);
-    // The super-tile columns the band's rectangles reach (band_count): the workgroups of the other columns have nothing to list.
-    // In a band of more than SPLIT_AT rectangles they HELP instead: the h-th of them takes the lower two rows of tiles of the h-th
-    // column inside the extent (its own walk, its own reservation), whose own workgroup then only takes the upper two -- the launch
-    // waits for its heaviest workgroup (72k list entries from a band of 26k at C3: 49 us alone), and a launch with two workgroups per
-    // super-tile pays more for dispatching the idle ones than the split wins (+13 us for 2040 more of them).
+    // The super-tile columns the band's rectangles reach (band_count).  In a band of more than SPLIT_AT rectangles the other columns are
+    // on the work list too and HELP: the h-th of them takes the lower two rows of tiles of the h-th column inside the extent (its own
+    // walk, its own reservation), whose own workgroup then only takes the upper two -- the launch waits for its heaviest workgroup
+    // (72k list entries from a band of 26k at C3: 49 us alone).
     const int nsx = (gx + BIN_SUPER - 1) / BIN_SUPER, scol = bx % nsx;
     const int ex0 = (int)(a.band_info[2 * BAND_MAX + band] & 0xFFFFu), ex1 = (int)a.band_info[3 * BAND_MAX + band];
     const int se0 = ex0 / BIN_SUPER, se1 = (ex1 + BIN_SUPER - 1) / BIN_SUPER, width = se1 - se0;
