@@ -345,22 +345,35 @@ __device__ __forceinline__ void stage_weight_rows(const WarpArgs &a, float *wtil
     if (tid < count % 4) wtile[count - 1 - tid] = src[count - 1 - tid];
     __syncthreads();
 }
+#ifndef SOAR_LBS_WCHUNK
+#define SOAR_LBS_WCHUNK 8
+#endif
 __device__ __forceinline__ void blend_frame_matrix(const float *wrow, const float *mats, int J, float M[12])
 {
 #pragma unroll
     for (int c = 0; c < 12; c++) M[c] = 0.f;
-    for (int j = 0; j < J; j++) {
-        const float w = wrow[j];
-        // Skinning weights are sparse -- a vertex follows at most a handful of the 55 joints, a Gaussian the union of its 30 nearest
-        // vertices' joints, and the 64 Gaussians of a wavefront (neighbours in space when the model is in spatial order) share most of
-        // them: a joint NO lane of the wavefront follows is left out (round 6).  Exact: its terms are w A = +-0 added to sums that
-        // started at +0 -- M does not change by a bit, whatever the lanes left out of the test hold.
-#if SOAR_LBS_SKIP_UNUSED_JOINTS
-        if (__ballot(w != 0.f) == 0ull) continue;
-#endif
-        const float *A = mats + 16 * j;                // wavefront-uniform address -> scalar loads
+    // Skinning weights are sparse -- a vertex follows at most a handful of the 55 joints, a Gaussian the union of its 30 nearest
+    // vertices' joints, and the 64 Gaussians of a wavefront (neighbours in space when the model is in spatial order) share most of
+    // them: a joint NO lane of the wavefront follows is left out (round 6).  Exact: its terms are w A = +-0 added to sums that
+    // started at +0 -- M does not change by a bit, whatever the lanes left out of the test hold.
+    // (the weights of SOAR_LBS_WCHUNK joints are read together: one LDS round trip per chunk instead of one per joint in front of
+    // every test; the joints are still taken in ascending order)
+    constexpr int WC = SOAR_LBS_WCHUNK;
+    for (int j0 = 0; j0 < J; j0 += WC) {
+        float w[WC];
 #pragma unroll
-        for (int c = 0; c < 12; c++) M[c] += w * A[c];
+        for (int u = 0; u < WC; u++) w[u] = j0 + u < J ? wrow[j0 + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < WC; u++) {
+#if SOAR_LBS_SKIP_UNUSED_JOINTS
+            if (__ballot(w[u] != 0.f) == 0ull) continue;
+#else
+            if (j0 + u >= J) continue;
+#endif
+            const float *A = mats + 16 * (j0 + u);     // wavefront-uniform address -> scalar loads
+#pragma unroll
+            for (int c = 0; c < 12; c++) M[c] += w[u] * A[c];
+        }
     }
 }
 __global__ void __launch_bounds__(WARP_THREADS) warp_forward_frames_kernel(WarpArgs a, int n)
