@@ -809,6 +809,42 @@ def main():
         per = [1e3 * (b - a) for a, b in zip([0.0] + step_marks[:-1], step_marks)]
         print("[bench] host issue per step (ms): " + " ".join(f"{v:.2f}" for v in per), file=sys.stderr)
     device_ms_per_step = ev_begin.elapsed_time(ev_end) / args.steps
+    stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
+    # (this pass comes right behind the contract's timed region, in FRONT of the repeated regions: after half a second more of full load
+    # the chip's clock has given back 3-6 % -- `repeats_ms_per_step` drifts by that much -- and the durations priced against the
+    # roofline are the timed region's, not a warmer chip's)
+    # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
+    #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views
+    #      of a step overlap on separate streams and share the GPU).  Not part of `value`.
+    frames_per_launch = 1
+    batched_plan = plan is not None and plan.graphs is None and plan.batched and not use_dist
+    if not args.no_stage_timers and batched_plan:
+        # the timed region's own launches: every stage of the chain is ONE launch for the frames of a step, on one stream -- a
+        # launch has a duration of its own, so the same plan runs the same K steps again with the event pairs switched on
+        frames_per_launch = fps_per_rank
+        L.soar_prof_reset()
+        L.soar_prof_enable(1)
+        for s in range(args.steps):
+            stepper(frames_of(args.warmup + s))
+        torch.cuda.synchronize()
+        L.soar_prof_enable(0)
+        for k, v in stats_timed.items():
+            rasterizer.stats[k] = v
+    elif not args.no_stage_timers:
+        streams_timed = rasterizer.NUM_STREAMS
+        rasterizer.NUM_STREAMS = 1
+        L.soar_prof_reset()
+        L.soar_prof_enable(1)
+        for k in rasterizer.stats:                               # the instance counts of exactly these frames price the bytes
+            rasterizer.stats[k] = 0
+        for s in range(args.steps):
+            run_step(seq, targets, flat, frames_of(args.warmup + s), bg)
+        torch.cuda.synchronize()
+        L.soar_prof_enable(0)
+        rasterizer.NUM_STREAMS = streams_timed
+    else:
+        for k, v in stats_timed.items():
+            rasterizer.stats[k] = v
     # The spread of the number, in the line itself: SOAR_BENCH_REPEAT (default 4) more timed regions of the SAME K
     # steps over the same frames in this process, bracketed like the contract's region (barrier + synchronisation on both sides, the max
     # over the ranks).  `value` stays the FIRST region's; these are `repeats_ms_per_step`.  With a 17 ms region one collector pause or
@@ -845,39 +881,6 @@ def main():
     if use_dist:
         dist_diag = rank_diagnostics(flat, stepper, frames_of, args, world, device, local_elapsed,
                                      float(max((n for n, _ in binning_status), default=0)) if binning_status else 0.0)
-    stats_timed = stats_warm                                     # real num_rendered per launch, from the synchronous warm-up
-    # ---- per-kernel pass: the same K steps again with a pair of HIP events around every stage, the views of a step
-    #      serialised on ONE stream so that a launch duration is the kernel's own (in the timed region above the views
-    #      of a step overlap on separate streams and share the GPU).  Not part of `value`.
-    frames_per_launch = 1
-    batched_plan = plan is not None and plan.graphs is None and plan.batched and not use_dist
-    if not args.no_stage_timers and batched_plan:
-        # the timed region's own launches: every stage of the chain is ONE launch for the frames of a step, on one stream -- a
-        # launch has a duration of its own, so the same plan runs the same K steps again with the event pairs switched on
-        frames_per_launch = fps_per_rank
-        L.soar_prof_reset()
-        L.soar_prof_enable(1)
-        for s in range(args.steps):
-            stepper(frames_of(args.warmup + s))
-        torch.cuda.synchronize()
-        L.soar_prof_enable(0)
-        for k, v in stats_timed.items():
-            rasterizer.stats[k] = v
-    elif not args.no_stage_timers:
-        streams_timed = rasterizer.NUM_STREAMS
-        rasterizer.NUM_STREAMS = 1
-        L.soar_prof_reset()
-        L.soar_prof_enable(1)
-        for k in rasterizer.stats:                               # the instance counts of exactly these frames price the bytes
-            rasterizer.stats[k] = 0
-        for s in range(args.steps):
-            run_step(seq, targets, flat, frames_of(args.warmup + s), bg)
-        torch.cuda.synchronize()
-        L.soar_prof_enable(0)
-        rasterizer.NUM_STREAMS = streams_timed
-    else:
-        for k, v in stats_timed.items():
-            rasterizer.stats[k] = v
     elapsed = job_elapsed(elapsed, use_dist, device)
 
     total_frames = args.steps * fps_per_rank * world
